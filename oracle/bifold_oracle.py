@@ -1,0 +1,451 @@
+"""Functional fp32 CPU restatement of BiFold's VLM training-step hot path.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``): the product package
+never imports this file.
+
+Style: every function is a pure function of a flat ``state`` mapping
+(reference state-dict key -> tensor) plus inputs.  There is no nn.Module tree;
+the reference's state-dict key names ARE the interface, which is what lets the
+same checkpoint feed the reference, this oracle and the HIP path.
+
+Each function cites the reference lines it restates (paths relative to
+/root/reference/bifold/).  Layout here is batch-first ``[B, L, W]`` throughout;
+the reference runs its CLIP towers sequence-first, which only permutes memory.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+State = Mapping[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def layer_norm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-5):
+    """nn.LayerNorm over the last dim, biased variance, fp32
+    (models/clip/model.py:178-184; models/modules.py:11)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
+
+
+def quick_gelu(x: torch.Tensor):
+    """x * sigmoid(1.702 x) (models/clip/model.py:187-189)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def erf_gelu(x: torch.Tensor):
+    """nn.GELU() default = exact erf form (models/modules.py:23)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def split_heads(t: torch.Tensor, heads: int):
+    b, l, w = t.shape
+    return t.reshape(b, l, heads, w // heads).permute(0, 2, 1, 3)  # [B,h,L,d]
+
+
+def merge_heads(t: torch.Tensor):
+    b, h, l, d = t.shape
+    return t.permute(0, 2, 1, 3).reshape(b, l, h * d)
+
+
+def attention_core(q, k, v, scale: float, causal: bool = False,
+                   query_row_mask: Optional[torch.Tensor] = None):
+    """softmax(q k^T * scale [+mask]) v on [B,h,L,d] tensors.
+
+    * causal: additive -inf above the diagonal (models/clip/model.py:414-420).
+    * query_row_mask [B,L] (0 = masked): the reference fills the WHOLE score row
+      of a masked *query* with -1e5, not the key column
+      (models/transformer.py:33-35) -> that row's softmax becomes uniform.
+    """
+    s = torch.matmul(q, k.transpose(-1, -2)) * scale
+    if causal:
+        l = s.shape[-1]
+        upper = torch.ones(l, l, dtype=torch.bool, device=s.device).triu(1)
+        s = s.masked_fill(upper, float("-inf"))
+    if query_row_mask is not None:
+        s = s.masked_fill(query_row_mask[:, None, :, None] == 0, -100000.0)
+    p = torch.softmax(s, dim=-1)
+    return torch.matmul(p, v)
+
+
+# --------------------------------------------------------------------------
+# CLIP towers (frozen)
+# --------------------------------------------------------------------------
+def clip_resblock(state: State, pfx: str, x: torch.Tensor, heads: int, causal: bool):
+    """ResidualAttentionBlock (models/clip/model.py:192-219):
+    x += MHA(ln_1 x); x += c_proj(QuickGELU(c_fc(ln_2 x)))."""
+    w = x.shape[-1]
+    h = layer_norm(x, state[pfx + "ln_1.weight"], state[pfx + "ln_1.bias"])
+    qkv = F.linear(h, state[pfx + "attn.in_proj_weight"], state[pfx + "attn.in_proj_bias"])
+    q, k, v = (split_heads(t, heads) for t in qkv.split(w, dim=-1))
+    o = attention_core(q, k, v, scale=(w // heads) ** -0.5, causal=causal)
+    o = F.linear(merge_heads(o), state[pfx + "attn.out_proj.weight"],
+                 state[pfx + "attn.out_proj.bias"])
+    x = x + o
+    h = layer_norm(x, state[pfx + "ln_2.weight"], state[pfx + "ln_2.bias"])
+    h = quick_gelu(F.linear(h, state[pfx + "mlp.c_fc.weight"], state[pfx + "mlp.c_fc.bias"]))
+    h = F.linear(h, state[pfx + "mlp.c_proj.weight"], state[pfx + "mlp.c_proj.bias"])
+    return x + h
+
+
+def count_blocks(state: State, pfx: str) -> int:
+    n = 0
+    while f"{pfx}{n}.ln_1.weight" in state:
+        n += 1
+    return n
+
+
+def clip_vision_tokens(state: State, img: torch.Tensor, pfx: str = "clip_encoder.visual."):
+    """VisionTransformer.forward_with_embeddings (models/clip/model.py:296-317):
+    patchify conv (no bias) -> prepend class token -> + pos -> ln_pre -> blocks ->
+    ln_post on ALL tokens, no output projection.  [B,3,S,S] -> [B,g*g+1,W]."""
+    wconv = state[pfx + "conv1.weight"]
+    width, _, p, _ = wconv.shape
+    x = F.conv2d(img, wconv, bias=None, stride=p)           # [B,W,g,g]
+    x = x.flatten(2).transpose(1, 2)                        # [B,g*g,W] row-major patches
+    cls = state[pfx + "class_embedding"].expand(x.shape[0], 1, width)
+    x = torch.cat([cls, x], dim=1) + state[pfx + "positional_embedding"]
+    x = layer_norm(x, state[pfx + "ln_pre.weight"], state[pfx + "ln_pre.bias"])
+    heads = width // 64                                      # models/clip/model.py:351
+    for i in range(count_blocks(state, pfx + "transformer.resblocks.")):
+        x = clip_resblock(state, f"{pfx}transformer.resblocks.{i}.", x, heads, causal=False)
+    return layer_norm(x, state[pfx + "ln_post.weight"], state[pfx + "ln_post.bias"])
+
+
+def clip_text_tokens(state: State, tokens: torch.Tensor, pfx: str = "clip_encoder."):
+    """CLIP.encode_text_with_embeddings (models/clip/model.py:447-461):
+    embedding gather + pos -> causal blocks -> ln_final; no EOT pooling,
+    no text_projection.  [B,77] int -> [B,77,W]."""
+    emb = state[pfx + "token_embedding.weight"]
+    x = emb[tokens.long()] + state[pfx + "positional_embedding"]
+    heads = emb.shape[1] // 64                               # models/clip/model.py:532
+    for i in range(count_blocks(state, pfx + "transformer.resblocks.")):
+        x = clip_resblock(state, f"{pfx}transformer.resblocks.{i}.", x, heads, causal=True)
+    return layer_norm(x, state[pfx + "ln_final.weight"], state[pfx + "ln_final.bias"])
+
+
+# --------------------------------------------------------------------------
+# trainable tail: fusion transformer + heatmap decoders
+# --------------------------------------------------------------------------
+def fusion_layer(state: State, pfx: str, x: torch.Tensor, heads: int,
+                 query_row_mask: Optional[torch.Tensor] = None):
+    """One Transformer layer (models/transformer.py:44-64, modules.py:8-30):
+    x = Attn(LN x) + x ; x = FF(LN x) + x.  to_qkv has NO bias, scale = d_h^-0.5,
+    FF = Linear -> erf-GELU -> Linear, dropout p = 0."""
+    w = x.shape[-1]
+    h = layer_norm(x, state[pfx + "0.norm.weight"], state[pfx + "0.norm.bias"])
+    qkv = F.linear(h, state[pfx + "0.fn.to_qkv.weight"])
+    q, k, v = (split_heads(t, heads) for t in qkv.chunk(3, dim=-1))
+    o = attention_core(q, k, v, scale=(w // heads) ** -0.5, query_row_mask=query_row_mask)
+    o = F.linear(merge_heads(o), state[pfx + "0.fn.to_out.0.weight"],
+                 state[pfx + "0.fn.to_out.0.bias"])
+    x = o + x
+    h = layer_norm(x, state[pfx + "1.norm.weight"], state[pfx + "1.norm.bias"])
+    h = erf_gelu(F.linear(h, state[pfx + "1.fn.net.0.weight"], state[pfx + "1.fn.net.0.bias"]))
+    h = F.linear(h, state[pfx + "1.fn.net.3.weight"], state[pfx + "1.fn.net.3.bias"])
+    return h + x
+
+
+def concat_transformer(state: State, inputs: Sequence[torch.Tensor], heads: int,
+                       modalities: Optional[Sequence[int]] = None,
+                       attention_masks: Optional[torch.Tensor] = None,
+                       pfx: str = "pick_place.fusion."):
+    """ConcatTransformer.forward (models/fusion.py:35-64): add the modality's
+    type embedding to each input, concatenate along the sequence, run the
+    pre-norm transformer (no final norm), return the last input's tokens."""
+    if modalities is None:
+        modalities = range(len(inputs))
+    type_emb = state[pfx + "token_type_embeddings.weight"]
+    x = torch.cat([inp + type_emb[m] for m, inp in zip(modalities, inputs)], dim=1)
+    depth = 0
+    while f"{pfx}transformer_encoder.layers.{depth}.0.norm.weight" in state:
+        x = fusion_layer(state, f"{pfx}transformer_encoder.layers.{depth}.", x, heads,
+                         attention_masks)
+        depth += 1
+    return x[:, -inputs[-1].shape[1]:, :]
+
+
+def conv_decoder_logits(state: State, pfx: str, feat: torch.Tensor):
+    """ConvDecoder as written (models/modules.py:33-74): five 1x1 convs (with
+    bias, NO activation) interleaved with four bilinear x2 upsamples
+    (align_corners=False).  [B,D,g,g] -> [B,1,16g,16g]."""
+    x = feat
+    for i in (0, 2, 4, 6, 8):
+        x = F.conv2d(x, state[f"{pfx}decoder_net.{i}.weight"], state[f"{pfx}decoder_net.{i}.bias"])
+        if i != 8:
+            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    return x
+
+
+def decoder_heads(is_bimanual: bool):
+    """Head order of PickPlaceConvDecoder (models/pickplace.py:34-47)."""
+    if is_bimanual:
+        return ["left_pick", "right_pick", "left_place", "right_place"]
+    return ["pick", "place"]
+
+
+def pick_place_convdecoder(state: State, inputs: Sequence[torch.Tensor], heads: int,
+                           is_bimanual: bool, pfx: str = "pick_place.", **fusion_kw):
+    """PickPlaceConvDecoder.forward with compute_mask=False
+    (models/pickplace.py:59-124): fuse, drop token 0, view tokens as a row-major
+    g x g grid -> [B,D,g,g], one ConvDecoder per head, squeeze, sigmoid."""
+    fused = concat_transformer(state, inputs, heads, pfx=pfx + "fusion.", **fusion_kw)
+    tok = fused[:, 1:, :]
+    b, n, d = tok.shape
+    g = int(math.isqrt(n))
+    feat = tok.reshape(b, g, g, d).permute(0, 3, 1, 2)
+    out: Dict[str, Optional[torch.Tensor]] = {"attn_weights": None}
+    for name in decoder_heads(is_bimanual):
+        logits = conv_decoder_logits(state, f"{pfx}{name}_decoder.", feat)
+        out[f"{name}_heatmap"] = torch.sigmoid(logits.squeeze(1))
+    return out
+
+
+def upsample_operator(g: int, levels: int = 4, dtype=torch.float64) -> torch.Tensor:
+    """The fixed [g*2^levels, g] matrix U such that `levels` successive bilinear x2
+    upsamples (align_corners=False) of a g-vector v equal U @ v.  Used by the
+    collapsed form of the decoder (the decoder is affine: SURVEY.md K9)."""
+    eye = torch.eye(g, dtype=dtype).reshape(g, 1, g)         # g signals of length g
+    x = eye
+    for _ in range(levels):
+        x = F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
+    return x.reshape(g, -1).t().contiguous()                 # [S, g]
+
+
+def collapse_decoder(state: State, pfx: str):
+    """Fold the five affine 1x1 convs into (w_eff [D], b_eff scalar).  Bilinear rows
+    sum to 1, so biases commute with the upsamples exactly (in real arithmetic)."""
+    w_eff = None
+    b_eff = None
+    for i in (0, 2, 4, 6, 8):
+        w = state[f"{pfx}decoder_net.{i}.weight"].flatten(1).double()   # [Cout,Cin]
+        b = state[f"{pfx}decoder_net.{i}.bias"].double()
+        if w_eff is None:
+            w_eff, b_eff = w, b
+        else:
+            w_eff, b_eff = w @ w_eff, w @ b_eff + b
+    return w_eff.reshape(-1), b_eff.reshape(())
+
+
+# --------------------------------------------------------------------------
+# model, loss, optimiser
+# --------------------------------------------------------------------------
+def rgb_clip_forward(state: State, sample: Mapping[str, torch.Tensor], heads: int,
+                     is_bimanual: bool = False):
+    """RGBOnly.forward (models/rgb_clip.py:52-73)."""
+    t = clip_text_tokens(state, sample["instruction"])
+    b = t.shape[0]
+    t = torch.cat([state["text_token"].expand(b, 1, -1), t], dim=1)
+    x_text = t + state["text_pos_embedding"][:, : t.shape[1]]
+    v = clip_vision_tokens(state, sample["rgb"])
+    x_rgb = F.linear(v, state["project.weight"], state["project.bias"]) + state["rgb_pos_embedding"]
+    return pick_place_convdecoder(state, [x_text, x_rgb], heads, is_bimanual)
+
+
+def bce_mean(p: torch.Tensor, t: torch.Tensor):
+    """nn.BCELoss(reduction='mean') incl. PyTorch's clamp of each log at -100."""
+    lp = torch.log(p).clamp_min(-100.0)
+    l1p = torch.log(1.0 - p).clamp_min(-100.0)
+    return -(t * lp + (1.0 - t) * l1p).mean()
+
+
+def bce_gaussmap(output: Mapping[str, torch.Tensor], sample: Mapping[str, torch.Tensor],
+                 is_bimanual: bool, mask_pick_heatmap: bool = False):
+    """BCEGaussMap (losses/__init__.py:54-109): per-head mean BCE, summed over heads;
+    optional target*mask on pick heads."""
+    names = ([f"{a}_{k}" for a in ("left", "right") for k in ("pick", "place")]
+             if is_bimanual else ["pick", "place"])
+    parts = {}
+    total = None
+    for n in names:
+        tgt = sample[f"{n}_heatmap"]
+        if mask_pick_heatmap and n.endswith("pick"):
+            tgt = tgt * sample["mask"].squeeze(1)
+        cur = bce_mean(output[f"{n}_heatmap"], tgt)
+        parts[n] = cur
+        total = cur if total is None else total + cur
+    return total, parts
+
+
+def adam_update(p, g, m, v, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-8,
+                weight_decay=0.0, decoupled=False):
+    """torch.optim.Adam / AdamW single-tensor math (optim/__init__.py:4-14 selects
+    them; formula = PyTorch's _single_tensor_adam, `step` is 1-based).  Returns
+    new (p, m, v)."""
+    if weight_decay != 0.0:
+        if decoupled:
+            p = p * (1.0 - lr * weight_decay)
+        else:
+            g = g + weight_decay * p
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * (m / denom)
+    return p, m, v
+
+
+def linear_warmup_lrs(base_lr: float, max_iters: int, n_steps: int, warmup_portion=0.1,
+                      warmup_start_lr=0.0, use_cosine_decay=True):
+    """LR seen by optimizer.step() number 0,1,2,... under LinearWarmup
+    (optim/__init__.py:28-92).  Quirk kept: last_step starts at -1 and step() runs
+    in __init__, so the first LR is start + (base-start)*(-1/warmup) (negative for
+    start 0); warm-up runs while last_step <= warmup_steps, then CosineAnnealingLR
+    (T_max = max_iters - warmup_steps, eta_min 0) takes over from base."""
+    warm = int(warmup_portion * max_iters)
+    lrs = []
+    last = -1
+    lr = base_lr
+    cos_t = 0
+    t_max = max_iters - warm
+
+    def sched_step():
+        nonlocal last, lr, cos_t
+        if last <= warm:
+            lr = warmup_start_lr + (base_lr - warmup_start_lr) * (last / warm)
+            last += 1
+        elif use_cosine_decay:
+            # closed form of CosineAnnealingLR's recursion, eta_min = 0
+            cos_t += 1
+            lr = base_lr * (1.0 + math.cos(math.pi * cos_t / t_max)) / 2.0
+
+    sched_step()                       # the call in __init__
+    for _ in range(n_steps):
+        lrs.append(lr)                 # LR used by this optimizer.step()
+        sched_step()
+    return lrs
+
+
+# --------------------------------------------------------------------------
+# parameter construction (same keys / shapes / init family as the reference)
+# --------------------------------------------------------------------------
+def make_clip_state(gen: torch.Generator, *, image_resolution=224, vision_layers=12,
+                    vision_width=768, vision_patch_size=16, context_length=77,
+                    vocab_size=49408, transformer_width=512, transformer_layers=12,
+                    embed_dim=512, pfx="clip_encoder.") -> Dict[str, torch.Tensor]:
+    """Random CLIP weights with the reference's key names and init scales
+    (models/clip/model.py:250-262, 367-412).  Values come from this generator,
+    not from the reference's RNG stream: fixtures store the weights explicitly."""
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=gen) * std
+
+    s: Dict[str, torch.Tensor] = {}
+    vw, tw = vision_width, transformer_width
+    g = image_resolution // vision_patch_size
+    v = pfx + "visual."
+    s[v + "conv1.weight"] = rn(vw, 3, vision_patch_size, vision_patch_size,
+                               std=(3 * vision_patch_size ** 2) ** -0.5)
+    s[v + "class_embedding"] = rn(vw, std=vw ** -0.5)
+    s[v + "positional_embedding"] = rn(g * g + 1, vw, std=vw ** -0.5)
+    s[v + "proj"] = rn(vw, embed_dim, std=vw ** -0.5)
+    for ln in ("ln_pre", "ln_post"):
+        s[v + ln + ".weight"] = 1.0 + 0.1 * rn(vw)
+        s[v + ln + ".bias"] = 0.1 * rn(vw)
+
+    def blocks(prefix, width, layers):
+        proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+        for i in range(layers):
+            b = f"{prefix}transformer.resblocks.{i}."
+            s[b + "attn.in_proj_weight"] = rn(3 * width, width, std=width ** -0.5)
+            s[b + "attn.in_proj_bias"] = 0.02 * rn(3 * width)
+            s[b + "attn.out_proj.weight"] = rn(width, width, std=proj_std)
+            s[b + "attn.out_proj.bias"] = 0.02 * rn(width)
+            for ln in ("ln_1", "ln_2"):
+                s[b + ln + ".weight"] = 1.0 + 0.1 * rn(width)
+                s[b + ln + ".bias"] = 0.1 * rn(width)
+            s[b + "mlp.c_fc.weight"] = rn(4 * width, width, std=(2 * width) ** -0.5)
+            s[b + "mlp.c_fc.bias"] = 0.02 * rn(4 * width)
+            s[b + "mlp.c_proj.weight"] = rn(width, 4 * width, std=proj_std)
+            s[b + "mlp.c_proj.bias"] = 0.02 * rn(width)
+
+    blocks(v, vw, vision_layers)
+    blocks(pfx, tw, transformer_layers)
+    s[pfx + "token_embedding.weight"] = rn(vocab_size, tw, std=0.02)
+    s[pfx + "positional_embedding"] = rn(context_length, tw, std=0.01)
+    s[pfx + "ln_final.weight"] = 1.0 + 0.1 * rn(tw)
+    s[pfx + "ln_final.bias"] = 0.1 * rn(tw)
+    s[pfx + "text_projection"] = rn(tw, embed_dim, std=tw ** -0.5)
+    s[pfx + "logit_scale"] = torch.tensor(math.log(1 / 0.07))
+    return s
+
+
+def make_tail_state(gen: torch.Generator, *, dim=512, vision_width=768, n_text=78, n_rgb=197,
+                    depth=8, mlp_ratio=4, is_bimanual=False, num_modalities=2
+                    ) -> Dict[str, torch.Tensor]:
+    """Random trainable-tail weights, reference keys (models/rgb_clip.py:34-50,
+    fusion.py:8-33, transformer.py:8-58, modules.py:33-74)."""
+    def rn(*shape, std=1.0):
+        return torch.randn(*shape, generator=gen) * std
+
+    def lin(prefix, out_f, in_f, bias=True):
+        bound = in_f ** -0.5
+        s[prefix + ".weight"] = (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * bound
+        if bias:
+            s[prefix + ".bias"] = (torch.rand(out_f, generator=gen) * 2 - 1) * bound
+
+    s: Dict[str, torch.Tensor] = {}
+    s["text_token"] = rn(1, 1, dim)
+    s["text_pos_embedding"] = rn(1, n_text, dim)
+    s["rgb_pos_embedding"] = rn(1, n_rgb, dim)
+    lin("project", dim, vision_width)
+    f = "pick_place.fusion."
+    s[f + "token_type_embeddings.weight"] = rn(num_modalities, dim, std=0.02)
+    for i in range(depth):
+        b = f"{f}transformer_encoder.layers.{i}."
+        for n in ("0.norm", "1.norm"):
+            s[b + n + ".weight"] = 1.0 + 0.1 * rn(dim)
+            s[b + n + ".bias"] = 0.1 * rn(dim)
+        lin(b + "0.fn.to_qkv", 3 * dim, dim, bias=False)
+        lin(b + "0.fn.to_out.0", dim, dim)
+        lin(b + "1.fn.net.0", dim * mlp_ratio, dim)
+        lin(b + "1.fn.net.3", dim, dim * mlp_ratio)
+    chans = [dim, dim // 2, dim // 2, dim // 4, dim // 4, 1]
+    for name in decoder_heads(is_bimanual):
+        for j, i in enumerate((0, 2, 4, 6, 8)):
+            cin, cout = chans[j], chans[j + 1]
+            bound = cin ** -0.5
+            s[f"pick_place.{name}_decoder.decoder_net.{i}.weight"] = (
+                (torch.rand(cout, cin, 1, 1, generator=gen) * 2 - 1) * bound)
+            s[f"pick_place.{name}_decoder.decoder_net.{i}.bias"] = (
+                (torch.rand(cout, generator=gen) * 2 - 1) * bound)
+    return s
+
+
+def is_trainable_key(key: str) -> bool:
+    """RGBOnly freezes every parameter whose name contains 'clip_encoder'
+    (models/rgb_clip.py:31, models/__init__.py:70-73)."""
+    return "clip_encoder" not in key
+
+
+# --------------------------------------------------------------------------
+# synthetic inputs
+# --------------------------------------------------------------------------
+def gaussian_heatmaps(centres: torch.Tensor, size: int, sigma: float = 5.0):
+    """One peak-1.0 Gaussian per map; centres [B,2] as (x, y) pixels."""
+    ys = torch.arange(size, dtype=torch.float32).view(1, size, 1)
+    xs = torch.arange(size, dtype=torch.float32).view(1, 1, size)
+    cx = centres[:, 0].float().view(-1, 1, 1)
+    cy = centres[:, 1].float().view(-1, 1, 1)
+    return torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2.0 * sigma ** 2))
+
+
+def synthetic_sample(batch: int, gen: torch.Generator, *, size=224, context=77, vocab=49408,
+                     real_tokens=32, is_bimanual=False) -> Dict[str, torch.Tensor]:
+    rgb = torch.randn(batch, 3, size, size, generator=gen)
+    instr = torch.zeros(batch, context, dtype=torch.int32)
+    instr[:, 0] = vocab - 2                                   # <|startoftext|> 49406
+    body = torch.randint(1, vocab - 2, (batch, real_tokens - 2), generator=gen)
+    instr[:, 1:real_tokens - 1] = body.int()
+    instr[:, real_tokens - 1] = vocab - 1                     # <|endoftext|> 49407
+    sample = {"rgb": rgb, "instruction": instr}
+    for n in decoder_heads(is_bimanual):
+        c = torch.randint(0, size, (batch, 2), generator=gen)
+        sample[f"{n}_heatmap"] = gaussian_heatmaps(c, size)
+    return sample

@@ -1,0 +1,406 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF (import from
+/root/reference) and cross-check the oracle restatement against it.
+
+Runs only in the build container (needs /root/reference); the GPU box and the
+test-suite only ever see the resulting fixtures.  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [--skip-full]
+
+What is stubbed, and why it is not on the arithmetic: `timm`
+(import-time symbol for the out-of-scope TransformerDecoder), `torchvision.
+transforms` and `ftfy` (CLIP image preprocessing factory / tokenizer text
+cleaning).  Pretrained weights cannot be downloaded, so `load` is replaced by a
+random-init CLIP of the requested hyper-parameters: parity is a property of the
+arithmetic, not of the weights, and the fixtures carry the weights explicitly.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+import transformers  # noqa: F401,E402  (its lazy loader probes timm; import before stubbing)
+
+for _name in ("timm", "timm.models", "timm.models.vision_transformer", "ftfy", "torchvision",
+              "torchvision.transforms"):
+    if _name not in sys.modules:
+        try:
+            __import__(_name)
+        except Exception:
+            sys.modules[_name] = types.ModuleType(_name)
+if not hasattr(sys.modules["timm.models.vision_transformer"], "Block"):
+    sys.modules["timm.models.vision_transformer"].Block = object
+_tv = sys.modules["torchvision.transforms"]
+for _n in ("CenterCrop", "Compose", "Normalize", "Resize", "ToTensor", "InterpolationMode"):
+    if not hasattr(_tv, _n):
+        setattr(_tv, _n, type(_n, (), {"BICUBIC": 3}))
+
+import bifold.models.rgb_clip as ref_rgb_clip  # noqa: E402
+from bifold.losses import Losses as RefLosses  # noqa: E402
+from bifold.models import Components as RefComponents  # noqa: E402
+from bifold.models.clip.model import CLIP as RefCLIP  # noqa: E402
+from bifold.models.modules import ConvDecoder as RefConvDecoder  # noqa: E402
+from bifold.optim import Optimizers as RefOptimizers  # noqa: E402
+from bifold.optim import Schedulers as RefSchedulers  # noqa: E402
+
+from oracle import bifold_oracle as O  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+class Cfg(dict):
+    """Attribute-style dict standing in for an OmegaConf node (factories do
+    `cfg.name`, `del cfg.name`, `**cfg`)."""
+    __getattr__ = dict.__getitem__
+    __delattr__ = dict.__delitem__
+
+
+def np_state(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def check(name, a, b, rtol=2e-5, atol=2e-6):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    ok = err <= atol + rtol * ref
+    print(f"  [{'ok' if ok else 'FAIL'}] {name}: max|d|={err:.3e} ref max={ref:.3e}")
+    if not ok:
+        raise SystemExit(f"oracle != reference for {name}")
+
+
+# --------------------------------------------------------------------------
+def build_ref_rgbonly(clip_kwargs, model_kwargs, seed):
+    torch.manual_seed(seed)
+
+    def fake_load(name, device="cpu", **_):
+        return RefCLIP(**clip_kwargs).float().eval(), None
+
+    ref_rgb_clip.load = fake_load
+    model = ref_rgb_clip.RGBOnly(device=torch.device("cpu"), **model_kwargs)
+    # the reference inits LayerNorm to (1, 0) and CLIP biases to default; perturb so that
+    # scale/shift parameters are exercised by the fixtures
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if ("ln_" in k or ".norm." in k) and k.endswith("weight"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+            elif ("ln_" in k or ".norm." in k) and k.endswith("bias"):
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    return model
+
+
+def run_reference_training(model, sample, is_bimanual, steps, lr=1e-4):
+    """Trainer.prepare_train + train_epoch semantics (bifold/__main__.py:112-163)
+    driven through the reference's own factories."""
+    loss_fn = RefLosses.get_by_name(cfg=Cfg(name="bce_gaussmap", is_bimanual=is_bimanual,
+                                            mask_pick_heatmap=False))
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = RefOptimizers.get_by_name(cfg=Cfg(name="adam", lr=lr, betas=[0.9, 0.999], eps=1e-8,
+                                            weight_decay=0), params=params)
+    model.train()
+    rec = {}
+    for it in range(steps):
+        out = model({k: v.clone() for k, v in sample.items()})
+        loss, parts = loss_fn(out, sample)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            rec["out"] = {k: v.detach().clone() for k, v in out.items() if v is not None}
+            rec["loss"] = loss.detach().clone()
+            rec["parts"] = {k: v.detach().clone() for k, v in parts.items()}
+            rec["grads"] = {k: p.grad.detach().clone() for k, p in model.named_parameters()
+                            if p.requires_grad}
+        rec.setdefault("losses", []).append(float(loss))
+        opt.step()
+    rec["params_after"] = {k: p.detach().clone() for k, p in model.named_parameters()
+                           if p.requires_grad}
+    return rec
+
+
+def oracle_training(state0, sample, heads, is_bimanual, steps, lr=1e-4):
+    state = {k: v.clone() for k, v in state0.items()}
+    train_keys = [k for k in state if O.is_trainable_key(k)]
+    m = {k: torch.zeros_like(state[k]) for k in train_keys}
+    v = {k: torch.zeros_like(state[k]) for k in train_keys}
+    rec = {"losses": []}
+    for it in range(steps):
+        for k in train_keys:
+            state[k] = state[k].detach().requires_grad_(True)
+        out = O.rgb_clip_forward(state, sample, heads, is_bimanual)
+        loss, parts = O.bce_gaussmap(out, sample, is_bimanual)
+        grads = torch.autograd.grad(loss, [state[k] for k in train_keys])
+        if it == 0:
+            rec["out"] = {k: t.detach() for k, t in out.items() if t is not None}
+            rec["loss"] = loss.detach()
+            rec["grads"] = dict(zip(train_keys, grads))
+        rec["losses"].append(float(loss))
+        with torch.no_grad():
+            for k, g in zip(train_keys, grads):
+                state[k], m[k], v[k] = O.adam_update(state[k].detach(), g, m[k], v[k], it + 1, lr)
+    rec["params_after"] = {k: state[k].detach() for k in train_keys}
+    return rec
+
+
+TINY_CLIP = dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_width=128,
+                 vision_patch_size=16, context_length=77, vocab_size=512, transformer_width=64,
+                 transformer_heads=1, transformer_layers=2)
+TINY_MODEL = dict(image_size=64, is_bimanual=False, requires_graph=False, text_encoder="ViT-B/16",
+                  patch_size=16, depth=2, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0,
+                  rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
+                  fusion_model="concat_transformer")
+
+
+def tiny_end_to_end(is_bimanual: bool, fname: str, seed: int):
+    print(f"== tiny end-to-end, bimanual={is_bimanual}")
+    mk = dict(TINY_MODEL, is_bimanual=is_bimanual)
+    model = build_ref_rgbonly(TINY_CLIP, mk, seed)
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(seed + 7)
+    sample = O.synthetic_sample(3, gen, size=64, vocab=512, is_bimanual=is_bimanual)
+
+    # intermediates from the reference
+    with torch.no_grad():
+        x_text = model.encode_text(sample["instruction"]).clone()
+        x_rgb = model.encode_rgb(sample["rgb"]).clone()
+        vis = model.clip_encoder.encode_image_with_embeddings(sample["rgb"]).clone()
+        txt = model.clip_encoder.encode_text_with_embeddings(sample["instruction"]).clone()
+        fused, _ = model.pick_place.fusion(x_text.clone(), x_rgb.clone())
+    rec = run_reference_training(model, sample, is_bimanual, steps=3)
+
+    # oracle vs reference
+    with torch.no_grad():
+        check("clip vision tokens", O.clip_vision_tokens(state0, sample["rgb"]), vis)
+        check("clip text tokens", O.clip_text_tokens(state0, sample["instruction"]), txt)
+    orec = oracle_training(state0, sample, heads=mk["heads"], is_bimanual=is_bimanual, steps=3)
+    for k, t in rec["out"].items():
+        check(f"out[{k}]", orec["out"][k], t)
+    check("loss", orec["loss"], rec["loss"], rtol=1e-6)
+    for k, g in rec["grads"].items():
+        check(f"grad[{k}]", orec["grads"][k], g, rtol=1e-4, atol=1e-7)
+    for k, p in rec["params_after"].items():
+        check(f"param3[{k}]", orec["params_after"][k], p, rtol=1e-5, atol=1e-6)
+
+    blob = {}
+    for k, t in np_state(state0).items():
+        blob["state/" + k] = t
+    for k, t in sample.items():
+        blob["sample/" + k] = t.numpy()
+    blob["mid/clip_vision"] = vis.numpy()
+    blob["mid/clip_text"] = txt.numpy()
+    blob["mid/x_text"] = x_text.numpy()
+    blob["mid/x_rgb"] = x_rgb.numpy()
+    blob["mid/fused"] = fused.numpy()
+    for k, t in rec["out"].items():
+        blob["out/" + k] = t.numpy()
+    blob["loss"] = rec["loss"].numpy()
+    blob["losses3"] = np.array(rec["losses"], dtype=np.float64)
+    for k, t in rec["parts"].items():
+        blob["loss_part/" + k] = t.numpy()
+    for k, t in rec["grads"].items():
+        blob["grad/" + k] = t.numpy()
+    for k, t in rec["params_after"].items():
+        blob["param3/" + k] = t.numpy()
+    blob["meta/heads"] = np.array(mk["heads"])
+    blob["meta/is_bimanual"] = np.array(int(is_bimanual))
+    np.savez_compressed(os.path.join(GOLD, fname), **blob)
+    print(f"  wrote {fname}")
+
+
+def masked_fusion_fixture(seed: int):
+    """PickPlaceConvDecoder driven the way SiglipSequential drives it
+    (models/siglip.py:118-137): three inputs, modalities [0,1,1], a query-row
+    attention mask with zeros, bimanual (4 decoders)."""
+    print("== masked 3-input fusion + 4 decoders")
+    torch.manual_seed(seed)
+    dim, heads, depth, g = 96, 2, 2, 3                      # d_head = 48 like the Q config
+    pp = RefComponents.get_by_name("pick_place_convdecoder", dim=dim, is_bimanual=True,
+                                   fusion_model="concat_transformer", num_patches=g * g,
+                                   patch_size=16, heads=heads, depth=depth, dropout=0.0,
+                                   mlp_ratio=4)
+    gen = torch.Generator().manual_seed(seed + 3)
+    B, T = 2, 2
+    n_img = g * g + 1
+    x_text = torch.randn(B, 5, dim, generator=gen)
+    x_ctx = torch.randn(B, T * n_img, dim, generator=gen)
+    x_img = torch.randn(B, n_img, dim, generator=gen)
+    ctx_mask = torch.tensor([[1, 0], [0, 0]], dtype=torch.int64)
+    mask = torch.cat([torch.ones(B, 5, dtype=torch.int64),
+                      ctx_mask.repeat_interleave(n_img, dim=1),
+                      torch.ones(B, n_img, dtype=torch.int64)], dim=1)
+    out = pp(x_text.clone(), x_ctx.clone(), x_img.clone(), attention_masks=mask,
+             modalities=[0, 1, 1])
+    state = {"pick_place." + k: v.detach() for k, v in pp.state_dict().items()}
+    with torch.no_grad():
+        oo = O.pick_place_convdecoder(state, [x_text, x_ctx, x_img], heads, True,
+                                      modalities=[0, 1, 1], attention_masks=mask)
+    blob = {"in/x_text": x_text.numpy(), "in/x_ctx": x_ctx.numpy(), "in/x_img": x_img.numpy(),
+            "in/mask": mask.numpy(), "meta/heads": np.array(heads)}
+    for k, t in out.items():
+        if t is not None:
+            check(f"masked out[{k}]", oo[k], t)
+            blob["out/" + k] = t.detach().numpy()
+    for k, t in np_state(state).items():
+        blob["state/" + k] = t
+    np.savez_compressed(os.path.join(GOLD, "fusion_masked_bimanual.npz"), **blob)
+    print("  wrote fusion_masked_bimanual.npz")
+
+
+def per_op_fixture(seed: int):
+    print("== per-op vectors")
+    gen = torch.Generator().manual_seed(seed)
+    blob = {}
+    # LayerNorm at the real widths
+    for w in (512, 768):
+        ln = torch.nn.LayerNorm(w)
+        with torch.no_grad():
+            ln.weight.copy_(1 + 0.2 * torch.randn(w, generator=gen))
+            ln.bias.copy_(0.2 * torch.randn(w, generator=gen))
+        x = 3.0 * torch.randn(5, w, generator=gen) + 0.5
+        y = ln(x).detach()
+        check(f"layernorm {w}", O.layer_norm(x, ln.weight.detach(), ln.bias.detach()), y)
+        blob[f"ln{w}/x"], blob[f"ln{w}/w"], blob[f"ln{w}/b"], blob[f"ln{w}/y"] = (
+            x.numpy(), ln.weight.detach().numpy(), ln.bias.detach().numpy(), y.numpy())
+    # activations
+    from bifold.models.clip.model import QuickGELU as RefQuickGELU
+    x = torch.linspace(-8, 8, 257)
+    blob["act/x"] = x.numpy()
+    blob["act/quick_gelu"] = RefQuickGELU()(x).numpy()
+    blob["act/erf_gelu"] = torch.nn.GELU()(x).numpy()
+    check("quick_gelu", O.quick_gelu(x), blob["act/quick_gelu"])
+    check("erf_gelu", O.erf_gelu(x), blob["act/erf_gelu"])
+    # one CLIP text block (causal MHA, 77 tokens, width 128 -> 2 heads of 64)
+    from bifold.models.clip.model import ResidualAttentionBlock as RefBlock
+    torch.manual_seed(seed)
+    mask = torch.empty(77, 77).fill_(float("-inf")).triu_(1)
+    blk = RefBlock(128, 2, mask).eval()
+    x = torch.randn(2, 77, 128, generator=gen)
+    with torch.no_grad():
+        y = blk(x.permute(1, 0, 2)).permute(1, 0, 2).contiguous()
+    st = {"b." + k: v.detach() for k, v in blk.state_dict().items()}
+    with torch.no_grad():
+        check("clip causal block", O.clip_resblock(st, "b.", x, 2, causal=True), y)
+    blob["clipblock/x"], blob["clipblock/y"] = x.numpy(), y.numpy()
+    for k, v in st.items():
+        blob["clipblock/state/" + k] = v.numpy()
+    # ConvDecoder at D=512, g=14 (full size), B=1: as-written vs collapsed form
+    torch.manual_seed(seed + 1)
+    dec = RefConvDecoder(512).eval()
+    feat = torch.randn(1, 512, 14, 14, generator=gen)
+    with torch.no_grad():
+        logits = dec(feat)
+    st = {"d." + k: v.detach() for k, v in dec.state_dict().items()}
+    with torch.no_grad():
+        check("conv decoder as written", O.conv_decoder_logits(st, "d.", feat), logits)
+    w_eff, b_eff = O.collapse_decoder(st, "d.")
+    U = O.upsample_operator(14)
+    low = torch.einsum("d,bdij->bij", w_eff, feat.double()) + b_eff
+    coll = torch.einsum("yi,bij,xj->byx", U, low, U)
+    check("conv decoder collapsed", coll, logits.squeeze(1), rtol=1e-5, atol=1e-6)
+    blob["decoder/feat"], blob["decoder/logits"] = feat.numpy(), logits.numpy()
+    blob["decoder/upsample_operator_14"] = U.numpy()
+    for k, v in st.items():
+        blob["decoder/state/" + k] = v.numpy()
+    # BCE incl. the clamp edge (p exactly 0 / 1)
+    p = torch.tensor([0.0, 1.0, 1e-30, 0.5, 0.999999, 0.25, 1.0, 0.0])
+    t = torch.tensor([1.0, 0.0, 1.0, 0.3, 1.0, 0.0, 1.0, 0.0])
+    l = torch.nn.BCELoss()(p, t)
+    check("bce clamp", O.bce_mean(p, t), l)
+    blob["bce/p"], blob["bce/t"], blob["bce/loss"] = p.numpy(), t.numpy(), l.numpy()
+    # LinearWarmup LR trace (15 optimiser steps, 100 iters, base 1e-4)
+    prm = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.Adam(prm, lr=1e-4)
+    sch = RefSchedulers.get_by_name(Cfg(name="linear_warmup", warmup_portion=0.1, warmup_start_lr=0,
+                                        use_cosine_decay=True), optimizer=opt, max_iters=100)
+    trace = []
+    for _ in range(30):
+        trace.append(opt.param_groups[0]["lr"])
+        prm[0].grad = torch.ones(1)
+        opt.step()
+        sch.step()
+    mine = O.linear_warmup_lrs(1e-4, 100, 30)
+    check("linear_warmup trace", torch.tensor(mine), torch.tensor(trace), rtol=1e-9, atol=1e-15)
+    blob["warmup/lrs"] = np.array(trace, dtype=np.float64)
+    # Adam: 4 steps on a fixed gradient sequence
+    pa = torch.nn.Parameter(torch.randn(64, generator=gen))
+    p0 = pa.detach().clone()
+    opt = torch.optim.Adam([pa], lr=1e-3)
+    gs = torch.randn(4, 64, generator=gen)
+    for i in range(4):
+        pa.grad = gs[i].clone()
+        opt.step()
+    q, m, v = p0.clone(), torch.zeros(64), torch.zeros(64)
+    for i in range(4):
+        q, m, v = O.adam_update(q, gs[i], m, v, i + 1, 1e-3)
+    check("adam 4 steps", q, pa.detach(), rtol=1e-6, atol=1e-7)
+    blob["adam/p0"], blob["adam/grads"], blob["adam/p4"] = p0.numpy(), gs.numpy(), pa.detach().numpy()
+    np.savez_compressed(os.path.join(GOLD, "per_op.npz"), **blob)
+    print("  wrote per_op.npz")
+
+
+def stats(t: torch.Tensor):
+    t = t.detach().double().flatten()
+    return np.concatenate([[t.mean().item(), t.std().item(), t.abs().max().item()],
+                           t[:8].numpy()])
+
+
+def full_size_summary(seed: int, batch: int):
+    """Config A (ViT-B/16 @224, fusion 512/16 heads/8 layers, unimanual) at small batch:
+    weights come from the ORACLE's seeded constructors (reproducible on any host
+    from the seed alone), are loaded into the reference model, and the reference's
+    loss / output / gradient summaries are frozen."""
+    print(f"== full-size summary, config A, B={batch}")
+    gen = torch.Generator().manual_seed(seed)
+    state = {**O.make_clip_state(gen), **O.make_tail_state(gen)}
+    clip_kwargs = dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768,
+                       vision_patch_size=16, context_length=77, vocab_size=49408,
+                       transformer_width=512, transformer_heads=8, transformer_layers=12)
+    mk = dict(TINY_MODEL, image_size=224, depth=8, heads=16)
+    model = build_ref_rgbonly(clip_kwargs, mk, seed)
+    missing, unexpected = model.load_state_dict(state, strict=False)
+    assert not unexpected, unexpected
+    assert all("attn_mask" in k or k == "" for k in missing), missing
+    sample = O.synthetic_sample(batch, torch.Generator().manual_seed(seed + 11))
+    rec = run_reference_training(model, sample, False, steps=1)
+    with torch.no_grad():
+        oo = O.rgb_clip_forward(state, sample, 16)
+    blob = {"meta/seed": np.array(seed), "meta/batch": np.array(batch),
+            "loss": rec["loss"].numpy()}
+    for k, t in rec["out"].items():
+        check(f"full out[{k}]", oo[k], t, rtol=1e-4, atol=1e-6)
+        blob["out_stats/" + k] = stats(t)
+        blob["out_head/" + k] = t[0, 100:108, 100:108].numpy()
+    for k, t in rec["grads"].items():
+        blob["grad_stats/" + k] = stats(t)
+    np.savez_compressed(os.path.join(GOLD, "config_a_summary.npz"), **blob)
+    print("  wrote config_a_summary.npz; loss =", float(rec["loss"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    tiny_end_to_end(False, "tiny_unimanual.npz", seed=3407)
+    tiny_end_to_end(True, "tiny_bimanual.npz", seed=3408)
+    masked_fusion_fixture(seed=3409)
+    per_op_fixture(seed=3410)
+    if not args.skip_full:
+        full_size_summary(seed=3407, batch=2)
+
+
+if __name__ == "__main__":
+    main()
