@@ -1,0 +1,466 @@
+// Multi-head attention on the packed QKV buffer [B, L, 3, H, D].
+//
+//  * attn_fwd_mfma_kernel (bf16): flash-style, one wave per 32 query rows, K / V^T tiles of
+//    64 keys staged in LDS and shared by up to 8 waves.  Scores are computed "swapped"
+//    (S^T = K Q^T with v_mfma_f32_32x32x16_bf16) so that a query's scores sit in ONE lane
+//    column: the row max / row sum are in-register reductions plus a single exchange with
+//    lane^32, and the bf16-packed P^T accumulator registers are directly the B operand of
+//    O^T += V^T P^T (no LDS round trip for P).
+//  * attn_fwd_simple_kernel / attn_bwd_* (fp32 math, fp32 or bf16 I/O): one thread per
+//    query (or key) row with K/V (or Q/dO) tiles broadcast from LDS.  These are the exact
+//    (parity) mode, and the first-correct backward for the bf16 mode.
+#include "common.h"
+
+#define KT 64                                 // keys per LDS tile
+
+__device__ __forceinline__ size_t qkv_off(int b, int i, int which, int h, int L, int H, int D) {
+    return (((size_t)b * L + i) * 3 + which) * (size_t)H * D + (size_t)h * D;
+}
+
+// =====================================================================================
+//                      simple kernels (fp32 math; T = storage dtype)
+// =====================================================================================
+template <typename T, int D>
+__device__ __forceinline__ void load_row(float (&dst)[D], const T* src) {
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+        const float4 v = Vec4<T>::load(src + d);
+        dst[d] = v.x; dst[d + 1] = v.y; dst[d + 2] = v.z; dst[d + 3] = v.w;
+    }
+}
+
+// stage rows [j0, j0+KT) of operand `which` (and optionally a second operand) into LDS fp32
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(float* lds, const T* __restrict__ base, int b, int h,
+                                           int which, int j0, int L, int H, int nthreads) {
+    for (int idx = threadIdx.x; idx < KT * (D / 4); idx += nthreads) {
+        const int j = idx / (D / 4), c = idx - j * (D / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j0 + j < L) v = Vec4<T>::load(base + qkv_off(b, j0 + j, which, h, L, H, D) + c * 4);
+        *(float4*)(lds + j * D + c * 4) = v;
+    }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_simple_kernel(
+    const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int mask_mode) {
+    __shared__ __attribute__((aligned(16))) float ks[KT * D];
+    __shared__ __attribute__((aligned(16))) float vs[KT * D];
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    const bool live = i < L;
+    float q[D], o[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { q[d] = 0.f; o[d] = 0.f; }
+    if (live) load_row<T, D>(q, qkv + qkv_off(b, i, 0, h, L, H, D));
+    const bool row_masked = live && mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + i] == 0;
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < L; j0 += KT) {
+        __syncthreads();
+        stage_rows<T, D>(ks, qkv, b, h, 1, j0, L, H, 256);
+        stage_rows<T, D>(vs, qkv, b, h, 2, j0, L, H, 256);
+        __syncthreads();
+        if (!live) continue;
+        const int jn = min(KT, L - j0);
+        for (int j = 0; j < jn; ++j) {
+            if (mask_mode == BF_MASK_CAUSAL && j0 + j > i) break;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s = fmaf(q[d], ks[j * D + d], s);
+            s = row_masked ? -100000.0f : s * scale;
+            if (s > m) {
+                const float a = expf(m - s);
+                l *= a;
+#pragma unroll
+                for (int d = 0; d < D; ++d) o[d] *= a;
+                m = s;
+            }
+            const float p = expf(s - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[d] = fmaf(p, vs[j * D + d], o[d]);
+        }
+    }
+    if (live) {
+        const float inv = 1.0f / l;
+        T* op = out + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4)
+            Vec4<T>::store(op + d, make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv));
+        if (lse) lse[((size_t)b * H + h) * L + i] = m + logf(l);
+    }
+}
+
+// dQ (thread per query) + delta = rowsum(dO * O)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, T* __restrict__ dqkv,
+    float* __restrict__ delta_ws, int L, int H, float scale, int mask_mode) {
+    __shared__ __attribute__((aligned(16))) float ks[KT * D];
+    __shared__ __attribute__((aligned(16))) float vs[KT * D];
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    const bool live = i < L;
+    float q[D], dO[D], dq[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { q[d] = 0.f; dO[d] = 0.f; dq[d] = 0.f; }
+    float delta = 0.f, lse_i = 0.f;
+    if (live) {
+        load_row<T, D>(q, qkv + qkv_off(b, i, 0, h, L, H, D));
+        const size_t oo = ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D;
+        load_row<T, D>(dO, dout + oo);
+        float ov[D];
+        load_row<T, D>(ov, out + oo);
+#pragma unroll
+        for (int d = 0; d < D; ++d) delta = fmaf(dO[d], ov[d], delta);
+        lse_i = lse[((size_t)b * H + h) * L + i];
+        delta_ws[((size_t)b * H + h) * L + i] = delta;
+    }
+    const bool row_masked = live && mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + i] == 0;
+    for (int j0 = 0; j0 < L; j0 += KT) {
+        __syncthreads();
+        stage_rows<T, D>(ks, qkv, b, h, 1, j0, L, H, 256);
+        stage_rows<T, D>(vs, qkv, b, h, 2, j0, L, H, 256);
+        __syncthreads();
+        if (!live || row_masked) continue;       // masked rows: scores are constants, no dQ
+        const int jn = min(KT, L - j0);
+        for (int j = 0; j < jn; ++j) {
+            if (mask_mode == BF_MASK_CAUSAL && j0 + j > i) break;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                s = fmaf(q[d], ks[j * D + d], s);
+                dp = fmaf(dO[d], vs[j * D + d], dp);
+            }
+            const float p = expf(s * scale - lse_i);
+            const float ds = p * (dp - delta) * scale;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, ks[j * D + d], dq[d]);
+        }
+    }
+    if (live) {
+        T* dst = dqkv + qkv_off(b, i, 0, h, L, H, D);
+#pragma unroll
+        for (int d = 0; d < D; d += 4)
+            Vec4<T>::store(dst + d, make_float4(dq[d], dq[d + 1], dq[d + 2], dq[d + 3]));
+    }
+}
+
+// dK, dV (thread per key)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
+    const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, T* __restrict__ dqkv,
+    int L, int H, float scale, int mask_mode) {
+    __shared__ __attribute__((aligned(16))) float qs[KT * D];
+    __shared__ __attribute__((aligned(16))) float dos[KT * D];
+    __shared__ float lses[KT], dels[KT];
+    __shared__ int msk[KT];
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    const bool live = j < L;
+    const float inv_len = 1.0f / (float)L;
+    float k[D], v[D], dk[D], dv[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { k[d] = 0.f; v[d] = 0.f; dk[d] = 0.f; dv[d] = 0.f; }
+    if (live) {
+        load_row<T, D>(k, qkv + qkv_off(b, j, 1, h, L, H, D));
+        load_row<T, D>(v, qkv + qkv_off(b, j, 2, h, L, H, D));
+    }
+    for (int i0 = 0; i0 < L; i0 += KT) {
+        __syncthreads();
+        stage_rows<T, D>(qs, qkv, b, h, 0, i0, L, H, 256);
+        for (int idx = threadIdx.x; idx < KT * (D / 4); idx += 256) {
+            const int r = idx / (D / 4), c = idx - r * (D / 4);
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 + r < L)
+                t = Vec4<T>::load(dout + ((size_t)b * L + i0 + r) * (size_t)H * D + (size_t)h * D + c * 4);
+            *(float4*)(dos + r * D + c * 4) = t;
+        }
+        if (threadIdx.x < KT) {
+            const int i = i0 + threadIdx.x;
+            lses[threadIdx.x] = i < L ? lse[((size_t)b * H + h) * L + i] : 0.f;
+            dels[threadIdx.x] = i < L ? delta_ws[((size_t)b * H + h) * L + i] : 0.f;
+            msk[threadIdx.x] = (i < L && mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int in = min(KT, L - i0);
+        for (int r = 0; r < in; ++r) {
+            if (mask_mode == BF_MASK_CAUSAL && j > i0 + r) continue;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                s = fmaf(qs[r * D + d], k[d], s);
+                dp = fmaf(dos[r * D + d], v[d], dp);
+            }
+            const bool rm = msk[r] != 0;
+            // a masked query row is exactly uniform over the L keys (all scores equal -1e5);
+            // exp(-1e5 - lse) would lose ~2^-7 absolute precision at that magnitude
+            const float p = rm ? inv_len : expf(s * scale - lses[r]);
+            const float ds = rm ? 0.f : p * (dp - dels[r]) * scale;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                dv[d] = fmaf(p, dos[r * D + d], dv[d]);
+                dk[d] = fmaf(ds, qs[r * D + d], dk[d]);
+            }
+        }
+    }
+    if (live) {
+        T* dkp = dqkv + qkv_off(b, j, 1, h, L, H, D);
+        T* dvp = dqkv + qkv_off(b, j, 2, h, L, H, D);
+#pragma unroll
+        for (int d = 0; d < D; d += 4) {
+            Vec4<T>::store(dkp + d, make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]));
+            Vec4<T>::store(dvp + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+        }
+    }
+}
+
+// =====================================================================================
+//                               bf16 MFMA flash forward
+// =====================================================================================
+// LDS: K tile  [KT keys][D] bf16, row stride D*2+16 bytes (conflict-free b128 rows)
+//      V^T tile [DP][KT keys'] bf16, row stride KT*2+16 bytes; DP = D rounded up to 32;
+//      within every 16-key group the key index has bits 2 and 3 swapped, which is the k
+//      order of an accumulator tile reused as an MFMA operand (guide §3).
+template <int D>
+__global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int mask_mode,
+    int waves_per_block) {
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = D / 16;                // k-steps of Q K^T
+    constexpr int DB = DP / 32;               // 32-row blocks of O^T
+    constexpr int KROW = D * 2 + 16;          // bytes
+    constexpr int VROW = KT * 2 + 16;         // bytes
+    __shared__ __attribute__((aligned(16))) char k_lds[KT * KROW];
+    __shared__ __attribute__((aligned(16))) char v_lds[DP * VROW];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int q0 = (blockIdx.y * waves_per_block + wave) * 32;   // first query of this wave
+    const int nthreads = blockDim.x;
+    const int qi = q0 + r;                                        // this lane's query
+    const bool q_live = qi < L;
+
+    // Q fragments (B operand): B[k = 8hh + j][col r] = Q[qi][16 ks + 8 hh + j]
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (q_live) qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
+        }
+    }
+    const bool row_masked = q_live && mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
+
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[db][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float sl2 = scale * 1.44269504088896340736f;           // scores in log2 units
+
+    // zero the V^T pad rows once (D = 48 -> rows 48..63)
+    if (DP != D) {
+        for (int idx = threadIdx.x; idx < (DP - D) * (VROW / 4); idx += nthreads)
+            ((uint32_t*)(v_lds + D * VROW))[idx] = 0u;
+    }
+    // causal: keys beyond the block's last query are never needed
+    const int q_hi = min(L, (int)(blockIdx.y + 1) * waves_per_block * 32);
+    const int key_end = (mask_mode == BF_MASK_CAUSAL) ? q_hi : L;
+
+    for (int j0 = 0; j0 < key_end; j0 += KT) {
+        __syncthreads();
+        // ---- stage K (row-major) and V (transposed, permuted) -------------------------
+        for (int idx = threadIdx.x; idx < KT * (D / 8); idx += nthreads) {
+            const int j = idx / (D / 8), c = idx - j * (D / 8);
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (j0 + j < L) {
+                kv = *(const uint4*)(qkv + qkv_off(b, j0 + j, 1, h, L, H, D) + c * 8);
+                vv = *(const uint4*)(qkv + qkv_off(b, j0 + j, 2, h, L, H, D) + c * 8);
+            }
+            *(uint4*)(k_lds + j * KROW + c * 16) = kv;
+            const int pos = (j & ~12) | ((j & 4) << 1) | ((j & 8) >> 1);   // swap bits 2 and 3
+            const uint16_t* ve = (const uint16_t*)&vv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *(uint16_t*)(v_lds + (c * 8 + e) * VROW + pos * 2) = ve[e];
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T for the two 32-key blocks of this tile -------------------------
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(k_lds + (kb * 32 + r) * KROW + ks * 32 + hh * 16);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---- masks + online softmax (log2 domain) --------------------------------------
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                float s = row_masked ? -100000.0f * 1.44269504088896340736f : sacc[kb][e] * sl2;
+                if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) s = -INFINITY;
+                sacc[kb][e] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);
+        // m_new is finite for every live query: tile 0 always holds an unmasked key
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = exp2f(sacc[kb][e] - m_use);
+                sacc[kb][e] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+
+        // ---- O^T += V^T P^T : P^T accumulator registers are the B operand ---------------
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[kb][8 * s + e];
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const bf16x8 vf =
+                        *(const bf16x8*)(v_lds + (db * 32 + r) * VROW + (kb * 32 + s * 16 + hh * 8) * 2);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+    }
+
+    if (q_live) {
+        const float inv = 1.0f / l;
+        bf16_t* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)(oacc[db][4 * g + e] * inv);
+                    *(bf16x4*)(op + d0) = o4;
+                }
+            }
+        if (lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
+    }
+}
+
+// =====================================================================================
+//                                        host
+// =====================================================================================
+static int attn_check(const char* who, const void* qkv, int batch, int seq, int heads, int head_dim,
+                      int mask_mode, const int32_t* row_mask, int cdt) {
+    BF_REQUIRE(batch > 0 && seq > 0 && heads > 0, BF_EINVAL, "%s: bad shape", who);
+    BF_REQUIRE(head_dim == 32 || head_dim == 48 || head_dim == 64, BF_EINVAL,
+               "%s: head_dim must be 32, 48 or 64 (got %d)", who, head_dim);
+    BF_REQUIRE(mask_mode >= BF_MASK_NONE && mask_mode <= BF_MASK_QUERY_ROW, BF_EINVAL, "%s: bad mask_mode", who);
+    BF_REQUIRE(mask_mode != BF_MASK_QUERY_ROW || row_mask, BF_EINVAL, "%s: row_mask is NULL", who);
+    BF_REQUIRE(cdt == BF_F32 || cdt == BF_BF16, BF_EINVAL, "%s: bad cdt", who);
+    BF_REQUIRE(bf_aligned16(qkv), BF_EALIGN, "%s: unaligned qkv", who);
+    BF_REQUIRE((long)batch * heads < 65536L * 32768L, BF_EINVAL, "%s: batch*heads too large", who);
+    return BF_OK;
+}
+
+extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const int32_t* row_mask,
+                                int batch, int seq, int heads, int head_dim, float scale, int mask_mode,
+                                int cdt, bf_stream_t stream) {
+    int rc = attn_check("bf_attention_fwd", qkv, batch, seq, heads, head_dim, mask_mode, row_mask, cdt);
+    if (rc) return rc;
+    BF_REQUIRE(bf_aligned16(out), BF_EALIGN, "bf_attention_fwd: unaligned out");
+    hipStream_t s = (hipStream_t)stream;
+    if (cdt == BF_BF16) {
+        const int nq32 = bf_cdiv(seq, 32);
+        const int chunks = bf_cdiv(nq32, 8);
+        const int wpb = bf_cdiv(nq32, chunks);
+        dim3 grid(batch * heads, chunks), block(wpb * 64);
+#define FWD_MFMA(DD)                                                                              \
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel<DD>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, \
+                       lse, row_mask, seq, heads, scale, mask_mode, wpb)
+        if (head_dim == 32) FWD_MFMA(32);
+        else if (head_dim == 48) FWD_MFMA(48);
+        else FWD_MFMA(64);
+#undef FWD_MFMA
+    } else {
+        dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
+#define FWD_SIMPLE(DD)                                                                            \
+    hipLaunchKernelGGL((attn_fwd_simple_kernel<float, DD>), grid, block, 0, s, (const float*)qkv,  \
+                       (float*)out, lse, row_mask, seq, heads, scale, mask_mode)
+        if (head_dim == 32) FWD_SIMPLE(32);
+        else if (head_dim == 48) FWD_SIMPLE(48);
+        else FWD_SIMPLE(64);
+#undef FWD_SIMPLE
+    }
+    BF_CHECK_LAUNCH("bf_attention_fwd");
+    return BF_OK;
+}
+
+template <typename T>
+static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse,
+                           const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq,
+                           int heads, int head_dim, float scale, int mask_mode, hipStream_t s) {
+    dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
+#define BWD(DD)                                                                                     \
+    do {                                                                                            \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD>), grid, block, 0, s, (const T*)qkv, (const T*)out, \
+                           (const T*)dout, lse, row_mask, (T*)dqkv, delta_ws, seq, heads, scale, mask_mode); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD>), grid, block, 0, s, (const T*)qkv, (const T*)dout, \
+                           lse, delta_ws, row_mask, (T*)dqkv, seq, heads, scale, mask_mode);         \
+    } while (0)
+    if (head_dim == 32) BWD(32);
+    else if (head_dim == 48) BWD(48);
+    else BWD(64);
+#undef BWD
+    return 0;
+}
+
+extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                                const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq,
+                                int heads, int head_dim, float scale, int mask_mode, int cdt,
+                                bf_stream_t stream) {
+    int rc = attn_check("bf_attention_bwd", qkv, batch, seq, heads, head_dim, mask_mode, row_mask, cdt);
+    if (rc) return rc;
+    BF_REQUIRE(lse && delta_ws, BF_EINVAL, "bf_attention_bwd: lse and delta_ws are required");
+    BF_REQUIRE(bf_aligned16(out) && bf_aligned16(dout) && bf_aligned16(dqkv), BF_EALIGN,
+               "bf_attention_bwd: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (cdt == BF_BF16)
+        attn_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
+                                head_dim, scale, mask_mode, s);
+    else
+        attn_bwd_launch<float>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
+                               head_dim, scale, mask_mode, s);
+    BF_CHECK_LAUNCH("bf_attention_bwd");
+    return BF_OK;
+}

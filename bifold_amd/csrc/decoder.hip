@@ -1,0 +1,525 @@
+// Heatmap decoder (collapsed affine form) + sigmoid + BCE, forward and backward.
+//
+// ConvDecoder (reference models/modules.py:33-74) is five 1x1 convs with no activation,
+// interleaved with four bilinear x2 upsamples.  Both commute: the convs fold into one
+// vector w_eff[D] and scalar b_eff, the upsamples into one separable operator U [S, g]
+// whose rows sum to 1.  logits = U (tok . w_eff + b_eff) U^T.  The reference materialises
+// ~60 MB of fp32 intermediates per sample and head; this form reads the tokens once and
+// writes the heatmap once.  Everything here is HBM-bound and fp32.
+#include "common.h"
+
+struct Ptr5 { const float* p[5]; };
+struct MPtr5 { float* p[5]; };
+
+// out[c] = sum_k r[k] * W[k*cols + c]   (r in LDS), all threads of the block
+__device__ __forceinline__ void vecmat(const float* r, const float* __restrict__ W, int rows, int cols,
+                                       float* out_lds, float* out_glb) {
+    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+        float acc = 0.f;
+        for (int k = 0; k < rows; ++k) acc = fmaf(r[k], W[(size_t)k * cols + c], acc);
+        if (out_lds) out_lds[c] = acc;
+        if (out_glb) out_glb[c] = acc;
+    }
+}
+__device__ __forceinline__ float block_dot(const float* a, const float* __restrict__ b, int n, float* red) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s = fmaf(a[i], b[i], s);
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void collapse_fwd_kernel(Ptr5 w, Ptr5 b, float* __restrict__ w_eff,
+                                                           float* __restrict__ b_eff,
+                                                           float* __restrict__ rows_ws, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C1 = D / 2, C3 = D / 4;
+    float* r2 = sm;             // [C1]
+    float* r3 = r2 + C1;        // [C1]
+    float* r4 = r3 + C1;        // [C3]
+    float* r5 = r4 + C3;        // [C3]
+    float* red = r5 + C3;       // [4]
+    for (int i = threadIdx.x; i < C3; i += 256) { r5[i] = w.p[4][i]; rows_ws[2 * C1 + C3 + i] = w.p[4][i]; }
+    __syncthreads();
+    vecmat(r5, w.p[3], C3, C3, r4, rows_ws + 2 * C1);
+    __syncthreads();
+    vecmat(r4, w.p[2], C3, C1, r3, rows_ws + C1);
+    __syncthreads();
+    vecmat(r3, w.p[1], C1, C1, r2, rows_ws);
+    __syncthreads();
+    vecmat(r2, w.p[0], C1, D, nullptr, w_eff);
+    const float t4 = block_dot(r5, b.p[3], C3, red);
+    const float t3 = block_dot(r4, b.p[2], C3, red);
+    const float t2 = block_dot(r3, b.p[1], C1, red);
+    const float t1 = block_dot(r2, b.p[0], C1, red);
+    if (threadIdx.x == 0) b_eff[0] = b.p[4][0] + t4 + t3 + t2 + t1;
+}
+
+extern "C" int bf_decoder_collapse_fwd(const float* const* w, const float* const* b, float* w_eff,
+                                       float* b_eff, float* rows_ws, int dim, bf_stream_t stream) {
+    BF_REQUIRE(w && b && dim > 0 && (dim & 3) == 0, BF_EINVAL, "bf_decoder_collapse_fwd: bad dim %d", dim);
+    Ptr5 pw, pb;
+    for (int i = 0; i < 5; ++i) { pw.p[i] = w[i]; pb.p[i] = b[i]; }
+    const size_t lds = (size_t)(dim + dim / 2 + 8) * sizeof(float);
+    hipLaunchKernelGGL(collapse_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, pw, pb, w_eff,
+                       b_eff, rows_ws, dim);
+    BF_CHECK_LAUNCH("bf_decoder_collapse_fwd");
+    return BF_OK;
+}
+
+// dr_prev[k] = sum_c W[k][c] * g[c] + gb * bias[k]  (wave per row);  dW[k][c] = r[k] * g[c]
+__device__ __forceinline__ void back_step(const float* __restrict__ W, const float* __restrict__ bias,
+                                          const float* r_glb, const float* g_lds, float gb, int rows,
+                                          int cols, float* dW, float* dbias, float* dr_lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < rows; k += 4) {
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) s = fmaf(W[(size_t)k * cols + c], g_lds[c], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            dr_lds[k] = s + gb * bias[k];
+            dbias[k] = gb * r_glb[k];
+        }
+    }
+    for (int i = threadIdx.x; i < rows * cols; i += 256) {
+        const int k = i / cols, c = i - k * cols;
+        dW[i] = r_glb[k] * g_lds[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void collapse_bwd_kernel(Ptr5 w, Ptr5 b, const float* __restrict__ rows_ws,
+                                                           const float* __restrict__ g_w_eff,
+                                                           const float* __restrict__ g_b_eff, MPtr5 dw,
+                                                           MPtr5 db, int D) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C1 = D / 2, C3 = D / 4;
+    float* ga = sm;          // [D]
+    float* gbuf = ga + D;    // [D]
+    const float gb = g_b_eff[0];
+    for (int i = threadIdx.x; i < D; i += 256) ga[i] = g_w_eff[i];
+    __syncthreads();
+    const float* r2 = rows_ws;
+    const float* r3 = rows_ws + C1;
+    const float* r4 = rows_ws + 2 * C1;
+    const float* r5 = rows_ws + 2 * C1 + C3;
+    back_step(w.p[0], b.p[0], r2, ga, gb, C1, D, dw.p[0], db.p[0], gbuf);     // -> dr2 in gbuf
+    __syncthreads();
+    back_step(w.p[1], b.p[1], r3, gbuf, gb, C1, C1, dw.p[1], db.p[1], ga);    // -> dr3 in ga
+    __syncthreads();
+    back_step(w.p[2], b.p[2], r4, ga, gb, C3, C1, dw.p[2], db.p[2], gbuf);    // -> dr4 in gbuf
+    __syncthreads();
+    back_step(w.p[3], b.p[3], r5, gbuf, gb, C3, C3, dw.p[3], db.p[3], ga);    // -> dr5 in ga
+    __syncthreads();
+    for (int i = threadIdx.x; i < C3; i += 256) dw.p[4][i] = ga[i];
+    if (threadIdx.x == 0) db.p[4][0] = gb;
+}
+
+extern "C" int bf_decoder_collapse_bwd(const float* const* w, const float* const* b, const float* rows_ws,
+                                       const float* g_w_eff, const float* g_b_eff, float* const* dw,
+                                       float* const* db, int dim, bf_stream_t stream) {
+    BF_REQUIRE(w && b && dw && db && dim > 0 && (dim & 3) == 0, BF_EINVAL, "bf_decoder_collapse_bwd: bad args");
+    Ptr5 pw, pb;
+    MPtr5 pdw, pdb;
+    for (int i = 0; i < 5; ++i) { pw.p[i] = w[i]; pb.p[i] = b[i]; pdw.p[i] = dw[i]; pdb.p[i] = db[i]; }
+    const size_t lds = (size_t)2 * dim * sizeof(float);
+    hipLaunchKernelGGL(collapse_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, pw, pb, rows_ws,
+                       g_w_eff, g_b_eff, pdw, pdb, dim);
+    BF_CHECK_LAUNCH("bf_decoder_collapse_bwd");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ token projection
+#define DEC_MAXH 4
+#define DEC_MAXC 4        // float4 chunks per lane -> dim <= 1024
+
+__global__ __launch_bounds__(256) void decoder_project_kernel(const float* __restrict__ tok,
+                                                              const float* __restrict__ w_eff,
+                                                              const float* __restrict__ b_eff,
+                                                              float* __restrict__ low, int batch,
+                                                              int n_heads, int n_patch, int dim,
+                                                              long tok_bstride) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= batch * n_patch) return;
+    const int b = t / n_patch, p = t - b * n_patch;
+    const float* row = tok + (size_t)b * tok_bstride + (size_t)(1 + p) * dim;
+    const int nvec = dim >> 2;
+    float acc[DEC_MAXH];
+#pragma unroll
+    for (int h = 0; h < DEC_MAXH; ++h) acc[h] = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEC_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float4 x = *(const float4*)(row + c * 4);
+#pragma unroll
+            for (int h = 0; h < DEC_MAXH; ++h)
+                if (h < n_heads) {
+                    const float4 w = *(const float4*)(w_eff + (size_t)h * dim + c * 4);
+                    acc[h] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+                }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < DEC_MAXH; ++h)
+        if (h < n_heads) {
+            const float s = wave_sum(acc[h]);
+            if (lane == 0) low[((size_t)h * batch + b) * n_patch + p] = s + b_eff[h];
+        }
+}
+
+extern "C" int bf_decoder_project(const float* tok, long tok_bstride, const float* w_eff, const float* b_eff,
+                                  float* low, int batch, int n_heads, int n_patch, int dim, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_heads >= 1 && n_heads <= DEC_MAXH && n_patch > 0 && (dim & 3) == 0 &&
+                   dim <= DEC_MAXC * 256, BF_EINVAL, "bf_decoder_project: bad shape (heads=%d dim=%d)", n_heads, dim);
+    BF_REQUIRE(bf_aligned16(tok) && bf_aligned16(w_eff) && (tok_bstride & 3) == 0, BF_EALIGN,
+               "bf_decoder_project: unaligned pointer or stride");
+    hipLaunchKernelGGL(decoder_project_kernel, dim3(bf_cdiv((long)batch * n_patch, 4)), dim3(256), 0,
+                       (hipStream_t)stream, tok, w_eff, b_eff, low, batch, n_heads, n_patch, dim, tok_bstride);
+    BF_CHECK_LAUNCH("bf_decoder_project");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ upsample + sigmoid
+#define DEC_MAXG 24
+__global__ __launch_bounds__(256) void upsample_sigmoid_kernel(const float* __restrict__ low,
+                                                               const float* __restrict__ U,
+                                                               float* __restrict__ heat, int g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int S = g * 16;
+    float* Us = sm;               // [S][g]
+    float* lw = Us + S * g;       // [g][g]
+    float* T = lw + g * g;        // [g][S]   T[i][x] = sum_j low[i][j] U[x][j]
+    const size_t bh = blockIdx.x;
+    for (int i = threadIdx.x; i < S * g; i += 256) Us[i] = U[i];
+    for (int i = threadIdx.x; i < g * g; i += 256) lw[i] = low[bh * g * g + i];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < g * S; idx += 256) {
+        const int i = idx / S, x = idx - i * S;
+        float a = 0.f;
+        for (int j = 0; j < g; ++j) a = fmaf(lw[i * g + j], Us[x * g + j], a);
+        T[idx] = a;
+    }
+    __syncthreads();
+    float* dst = heat + bh * (size_t)S * S;
+    const int S4 = S >> 2;
+    for (int idx = threadIdx.x; idx < S * S4; idx += 256) {
+        const int y = idx / S4, x4 = (idx - y * S4) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < g; ++i) {
+            const float u = Us[y * g + i];
+            const float4 t = *(const float4*)(T + i * S + x4);
+            a.x = fmaf(u, t.x, a.x); a.y = fmaf(u, t.y, a.y); a.z = fmaf(u, t.z, a.z); a.w = fmaf(u, t.w, a.w);
+        }
+        a.x = 1.0f / (1.0f + expf(-a.x)); a.y = 1.0f / (1.0f + expf(-a.y));
+        a.z = 1.0f / (1.0f + expf(-a.z)); a.w = 1.0f / (1.0f + expf(-a.w));
+        *(float4*)(dst + (size_t)y * S + x4) = a;
+    }
+}
+
+extern "C" int bf_decoder_upsample_sigmoid(const float* low, const float* U, float* heat, int n_maps,
+                                           int grid, bf_stream_t stream) {
+    BF_REQUIRE(n_maps > 0 && grid > 0 && grid <= DEC_MAXG, BF_EINVAL,
+               "bf_decoder_upsample_sigmoid: grid must be in 1..%d (got %d)", DEC_MAXG, grid);
+    BF_REQUIRE(bf_aligned16(heat), BF_EALIGN, "bf_decoder_upsample_sigmoid: unaligned heat");
+    const int S = grid * 16;
+    const size_t lds = (size_t)(S * grid + grid * grid + grid * S) * sizeof(float);
+    hipLaunchKernelGGL(upsample_sigmoid_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream,
+                       low, U, heat, grid);
+    BF_CHECK_LAUNCH("bf_decoder_upsample_sigmoid");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ BCE forward
+extern "C" int bf_bce_parts(int batch) {
+    int p = batch * 8;
+    return p > 1024 ? 1024 : (p < 1 ? 1 : p);
+}
+
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ heat,
+                                                      const float* __restrict__ target,
+                                                      float* __restrict__ loss_part, int batch, int pixels,
+                                                      long hb, long hh, long tb, long th) {
+    __shared__ float red[4];
+    const int h = blockIdx.y;
+    const int p4n = pixels >> 2;
+    const size_t total = (size_t)batch * p4n;
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int b = (int)(i / p4n);
+        const int p = (int)(i - (size_t)b * p4n) * 4;
+        const float4 pv = *(const float4*)(heat + b * hb + h * hh + p);
+        const float4 tv = *(const float4*)(target + b * tb + h * th + p);
+        const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+        const float tt[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lp = fmaxf(logf(pp[e]), -100.0f);
+            const float l1 = fmaxf(logf(1.0f - pp[e]), -100.0f);
+            acc -= tt[e] * lp + (1.0f - tt[e]) * l1;
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[(size_t)h * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int bf_bce_fwd(const float* heat, const float* target, float* loss_part, int batch, int n_heads,
+                          int pixels, long heat_bstride, long heat_hstride, long tgt_bstride,
+                          long tgt_hstride, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_heads > 0 && pixels > 0 && (pixels & 3) == 0, BF_EINVAL, "bf_bce_fwd: bad shape");
+    BF_REQUIRE((heat_bstride & 3) == 0 && (heat_hstride & 3) == 0 && (tgt_bstride & 3) == 0 &&
+                   (tgt_hstride & 3) == 0 && bf_aligned16(heat) && bf_aligned16(target),
+               BF_EALIGN, "bf_bce_fwd: strides must be multiples of 4 elements, pointers 16-byte aligned");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(bf_bce_parts(batch), n_heads), dim3(256), 0, (hipStream_t)stream,
+                       heat, target, loss_part, batch, pixels, heat_bstride, heat_hstride, tgt_bstride,
+                       tgt_hstride);
+    BF_CHECK_LAUNCH("bf_bce_fwd");
+    return BF_OK;
+}
+
+__global__ __launch_bounds__(64) void bce_finish_kernel(const float* __restrict__ loss_part,
+                                                        float* __restrict__ loss, int n_part, float inv_count) {
+    const int h = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_part; i += 64) acc += loss_part[(size_t)h * n_part + i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[h] = acc * inv_count;
+}
+
+extern "C" int bf_bce_finish(const float* loss_part, float* loss, int n_heads, int n_part, float inv_count,
+                             bf_stream_t stream) {
+    BF_REQUIRE(n_heads > 0 && n_part > 0, BF_EINVAL, "bf_bce_finish: bad shape");
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(n_heads), dim3(64), 0, (hipStream_t)stream, loss_part, loss,
+                       n_part, inv_count);
+    BF_CHECK_LAUNCH("bf_bce_finish");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ BCE backward (elementwise)
+// d_heat = gscale[0] * inv_count * (p - t) / max(p (1 - p), 1e-12)     (torch's BCELoss backward)
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ heat,
+                                                      const float* __restrict__ target,
+                                                      const float* __restrict__ gscale,
+                                                      float* __restrict__ d_heat, size_t n4, float inv_count) {
+    const float gs = gscale[0] * inv_count;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 p = ((const float4*)heat)[i];
+        const float4 t = ((const float4*)target)[i];
+        float4 d;
+        d.x = gs * (p.x - t.x) / fmaxf(p.x * (1.0f - p.x), 1e-12f);
+        d.y = gs * (p.y - t.y) / fmaxf(p.y * (1.0f - p.y), 1e-12f);
+        d.z = gs * (p.z - t.z) / fmaxf(p.z * (1.0f - p.z), 1e-12f);
+        d.w = gs * (p.w - t.w) / fmaxf(p.w * (1.0f - p.w), 1e-12f);
+        ((float4*)d_heat)[i] = d;
+    }
+}
+
+extern "C" int bf_bce_bwd(const float* heat, const float* target, const float* gscale, float* d_heat,
+                          size_t count, float inv_count, bf_stream_t stream) {
+    BF_REQUIRE(count > 0 && (count & 3) == 0, BF_EINVAL, "bf_bce_bwd: count must be a positive multiple of 4");
+    BF_REQUIRE(bf_aligned16(heat) && bf_aligned16(target) && bf_aligned16(d_heat), BF_EALIGN,
+               "bf_bce_bwd: unaligned pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, heat, target,
+                       gscale, d_heat, n4, inv_count);
+    BF_CHECK_LAUNCH("bf_bce_bwd");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ sigmoid o upsample backward
+// per map: dlogit = d_heat * p (1 - p);  g_low = U^T dlogit U      (adjoint of the separable upsample)
+__global__ __launch_bounds__(256) void upsample_sigmoid_bwd_kernel(const float* __restrict__ heat,
+                                                                   const float* __restrict__ d_heat,
+                                                                   const float* __restrict__ U,
+                                                                   float* __restrict__ g_low, int g) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int S = g * 16;
+    float* Us = sm;                 // [S][g]
+    float* Rw = Us + S * g;         // [4 waves][DEC_MAXG]
+    float* Gw = Rw + 4 * DEC_MAXG;  // [4 waves][g*g]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t bh = blockIdx.x;
+    for (int i = threadIdx.x; i < S * g; i += 256) Us[i] = U[i];
+    __syncthreads();
+    const float* hp = heat + bh * (size_t)S * S;
+    const float* dp = d_heat + bh * (size_t)S * S;
+    const int gg = g * g;
+    constexpr int NE = (DEC_MAXG * DEC_MAXG + 63) / 64;
+    float gacc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) gacc[e] = 0.f;
+    for (int y = wave; y < S; y += 4) {
+        float rj[DEC_MAXG];
+#pragma unroll
+        for (int j = 0; j < DEC_MAXG; ++j) rj[j] = 0.f;
+        for (int x = lane; x < S; x += 64) {
+            const float p = hp[(size_t)y * S + x];
+            const float dl = dp[(size_t)y * S + x] * (p * (1.0f - p));
+#pragma unroll
+            for (int j = 0; j < DEC_MAXG; ++j)
+                if (j < g) rj[j] = fmaf(dl, Us[x * g + j], rj[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < DEC_MAXG; ++j)
+            if (j < g) {
+                const float s = wave_sum(rj[j]);
+                if (lane == 0) Rw[wave * DEC_MAXG + j] = s;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int ij = lane + e * 64;
+            if (ij < gg) {
+                const int i = ij / g, j = ij - i * g;
+                gacc[e] = fmaf(Us[y * g + i], Rw[wave * DEC_MAXG + j], gacc[e]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int ij = lane + e * 64;
+        if (ij < gg) Gw[wave * gg + ij] = gacc[e];
+    }
+    __syncthreads();
+    for (int ij = threadIdx.x; ij < gg; ij += 256)
+        g_low[bh * gg + ij] = (Gw[ij] + Gw[gg + ij]) + (Gw[2 * gg + ij] + Gw[3 * gg + ij]);
+}
+
+extern "C" int bf_decoder_upsample_sigmoid_bwd(const float* heat, const float* d_heat, const float* U,
+                                               float* g_low, int n_maps, int grid, bf_stream_t stream) {
+    BF_REQUIRE(n_maps > 0 && grid > 0 && grid <= DEC_MAXG, BF_EINVAL,
+               "bf_decoder_upsample_sigmoid_bwd: grid must be in 1..%d", DEC_MAXG);
+    const int S = grid * 16;
+    const size_t lds = (size_t)(S * grid + 4 * DEC_MAXG + 4 * grid * grid) * sizeof(float);
+    hipLaunchKernelGGL(upsample_sigmoid_bwd_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream, heat,
+                       d_heat, U, g_low, grid);
+    BF_CHECK_LAUNCH("bf_decoder_upsample_sigmoid_bwd");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ token projection backward
+#define PB_BLOCKS 256
+extern "C" size_t bf_decoder_project_bwd_ws(int batch, int n_heads, int dim) {
+    (void)batch;
+    return (size_t)PB_BLOCKS * n_heads * (dim + 4);
+}
+
+// stage 1: wave per token; d_tok rows written; per-block partial G / gb
+__global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
+    const float* __restrict__ tok, const float* __restrict__ w_eff, const float* __restrict__ g_low,
+    float* __restrict__ d_tok, float* __restrict__ part, int batch, int n_heads, int n_patch, int dim,
+    long tok_bstride, long dtok_bstride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][n_heads][dim+4]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = dim >> 2;
+    const int L = n_patch + 1;
+    float4 G[DEC_MAXH][DEC_MAXC];
+    float gb[DEC_MAXH];
+#pragma unroll
+    for (int h = 0; h < DEC_MAXH; ++h) {
+        gb[h] = 0.f;
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i) G[h][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int rows = batch * L;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const int b = row / L, t = row - b * L;
+        float* dr = d_tok + (size_t)b * dtok_bstride + (size_t)t * dim;
+        if (t == 0) {
+            for (int c = lane; c < nvec; c += 64) *(float4*)(dr + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        float gl[DEC_MAXH];
+#pragma unroll
+        for (int h = 0; h < DEC_MAXH; ++h)
+            gl[h] = h < n_heads ? g_low[((size_t)h * batch + b) * n_patch + (t - 1)] : 0.f;
+        const float* xr = tok + (size_t)b * tok_bstride + (size_t)t * dim;
+#pragma unroll
+        for (int i = 0; i < DEC_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                const float4 x = *(const float4*)(xr + c * 4);
+                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int h = 0; h < DEC_MAXH; ++h)
+                    if (h < n_heads) {
+                        const float4 w = *(const float4*)(w_eff + (size_t)h * dim + c * 4);
+                        d.x = fmaf(gl[h], w.x, d.x); d.y = fmaf(gl[h], w.y, d.y);
+                        d.z = fmaf(gl[h], w.z, d.z); d.w = fmaf(gl[h], w.w, d.w);
+                        G[h][i].x = fmaf(gl[h], x.x, G[h][i].x); G[h][i].y = fmaf(gl[h], x.y, G[h][i].y);
+                        G[h][i].z = fmaf(gl[h], x.z, G[h][i].z); G[h][i].w = fmaf(gl[h], x.w, G[h][i].w);
+                    }
+                *(float4*)(dr + c * 4) = d;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < DEC_MAXH; ++h) gb[h] += gl[h];
+    }
+    const int stride = dim + 4;
+#pragma unroll
+    for (int h = 0; h < DEC_MAXH; ++h)
+        if (h < n_heads) {
+#pragma unroll
+            for (int i = 0; i < DEC_MAXC; ++i) {
+                const int c = lane + i * 64;
+                if (c < nvec) *(float4*)(sm + ((size_t)wave * n_heads + h) * stride + c * 4) = G[h][i];
+            }
+            if (lane == 0) sm[((size_t)wave * n_heads + h) * stride + dim] = gb[h];
+        }
+    __syncthreads();
+    const int per = n_heads * stride;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int c = i % stride;
+        if (c <= dim)
+            part[(size_t)blockIdx.x * per + i] = (sm[i] + sm[per + i]) + (sm[2 * per + i] + sm[3 * per + i]);
+    }
+}
+__global__ __launch_bounds__(256) void decoder_project_bwd2_kernel(const float* __restrict__ part,
+                                                                   float* __restrict__ g_w_eff,
+                                                                   float* __restrict__ g_b_eff, int nblocks,
+                                                                   int n_heads, int dim) {
+    const int stride = dim + 4, per = n_heads * stride;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= per) return;
+    const int h = i / stride, c = i - h * stride;
+    if (c > dim) return;
+    float acc = 0.f;
+    for (int k = 0; k < nblocks; ++k) acc += part[(size_t)k * per + i];
+    if (c < dim) g_w_eff[(size_t)h * dim + c] = acc;
+    else g_b_eff[h] = acc;
+}
+
+extern "C" int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_eff,
+                                      const float* g_low, float* d_tok, long dtok_bstride, float* g_w_eff,
+                                      float* g_b_eff, float* part_ws, int batch, int n_heads, int n_patch,
+                                      int dim, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_heads >= 1 && n_heads <= DEC_MAXH && n_patch > 0 && (dim & 3) == 0 &&
+                   dim <= DEC_MAXC * 256, BF_EINVAL, "bf_decoder_project_bwd: bad shape");
+    BF_REQUIRE(bf_aligned16(tok) && bf_aligned16(w_eff) && bf_aligned16(d_tok) && bf_aligned16(part_ws) &&
+                   (tok_bstride & 3) == 0 && (dtok_bstride & 3) == 0,
+               BF_EALIGN, "bf_decoder_project_bwd: unaligned pointer or stride");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = batch * (n_patch + 1);
+    int nblocks = bf_cdiv(rows, 4);
+    if (nblocks > PB_BLOCKS) nblocks = PB_BLOCKS;
+    const size_t lds = (size_t)4 * n_heads * (dim + 4) * sizeof(float);
+    hipLaunchKernelGGL(decoder_project_bwd_kernel, dim3(nblocks), dim3(256), lds, s, tok, w_eff, g_low, d_tok,
+                       part_ws, batch, n_heads, n_patch, dim, tok_bstride, dtok_bstride);
+    BF_CHECK_LAUNCH("bf_decoder_project_bwd/1");
+    hipLaunchKernelGGL(decoder_project_bwd2_kernel, dim3(bf_cdiv(n_heads * (dim + 4), 256)), dim3(256), 0, s,
+                       part_ws, g_w_eff, g_b_eff, nblocks, n_heads, dim);
+    BF_CHECK_LAUNCH("bf_decoder_project_bwd/2");
+    return BF_OK;
+}

@@ -1,0 +1,536 @@
+// GEMM with fused epilogue for gfx950.
+//
+//   C = epilogue(alpha * op(A) * op(B))        (see include/bifold_hip.h)
+//
+// Two kernels share one LDS-staged, fully coalesced epilogue:
+//   * gemm_bf16_kernel : bf16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+//       128x128x64 tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
+//       K-contiguous operands ([M,K] / [N,K]) sit in LDS as 128-byte rows with an
+//       XOR-swizzled 16-byte chunk index and are read with ds_read_b128;
+//       K-strided operands ([K,M] / [K,N]) keep their memory order in LDS and are
+//       read with ds_read_b64_tr_b16 (the hardware transposed read), so dX = dY W and
+//       dW = dY^T X need no transposed copies in HBM.
+//   * gemm_f32_kernel  : fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+//       128x128x16 tile.  This is the parity ("exact") mode.
+// Register-staged double buffering: the global loads of tile t+1 are issued before the
+// MFMAs of tile t and written to the other LDS buffer afterwards.
+// Block -> tile mapping is XCD-aware: the 8 XCDs (private L2s) each get a contiguous
+// range of output tiles with the N index fastest, so the blocks that share an A row
+// panel run on one XCD back to back.
+#include "common.h"
+
+struct EpiParams {
+    void* c;
+    void* c2;
+    void* pre;
+    const void* aux;
+    const float* bias;
+    const float* residual;
+    int m, n;
+    int ldc, ld_aux, ld_res;
+    int resid_mod;
+    int rows_in, rows_out, row_off;
+    int act;
+    int accumulate;
+    float alpha;
+};
+
+template <typename TC, typename TD>
+__device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int n, float4 v) {
+    v.x *= ep.alpha; v.y *= ep.alpha; v.z *= ep.alpha; v.w *= ep.alpha;
+    if (ep.bias) {
+        const float4 b = *(const float4*)(ep.bias + n);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    size_t orow = (size_t)m;
+    if (ep.rows_in > 0) orow = (size_t)(m / ep.rows_in) * ep.rows_out + ep.row_off + (m % ep.rows_in);
+    if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU) {
+        if (ep.pre) Vec4<TD>::store((TD*)ep.pre + orow * ep.ldc + n, v);
+        if (ep.act == BF_ACT_QUICK_GELU) {
+            v.x = quick_gelu_f(v.x); v.y = quick_gelu_f(v.y); v.z = quick_gelu_f(v.z); v.w = quick_gelu_f(v.w);
+        } else {
+            v.x = erf_gelu_f(v.x); v.y = erf_gelu_f(v.y); v.z = erf_gelu_f(v.z); v.w = erf_gelu_f(v.w);
+        }
+    } else if (ep.act == BF_ACT_ERF_GELU_GRAD) {
+        const float4 a = Vec4<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n);
+        v.x *= erf_gelu_grad_f(a.x); v.y *= erf_gelu_grad_f(a.y);
+        v.z *= erf_gelu_grad_f(a.z); v.w *= erf_gelu_grad_f(a.w);
+    }
+    if (ep.residual) {
+        const size_t rr = ep.resid_mod > 0 ? (size_t)(m % ep.resid_mod) : orow;
+        const float4 r = *(const float4*)(ep.residual + rr * ep.ld_res + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    TC* cp = (TC*)ep.c + orow * ep.ldc + n;
+    if (ep.accumulate) {
+        const float4 o = Vec4<TC>::load(cp);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    Vec4<TC>::store(cp, v);
+    if (ep.c2) Vec4<bf16_t>::store((bf16_t*)ep.c2 + orow * ep.ldc + n, v);
+}
+
+#define CT_LD 132   // fp32 staging tile leading dimension (128 + 4 pad)
+
+// Drain the 128x128 fp32 tile staged in LDS with coalesced 16-byte accesses.
+template <typename TC, typename TD>
+__device__ __forceinline__ void tile_epilogue(const float* ct, const EpiParams& ep, int m0, int n0,
+                                              float* slab /* split-K partial or null */) {
+    for (int idx = threadIdx.x; idx < 128 * 32; idx += 256) {
+        const int r = idx >> 5, c4 = idx & 31;
+        const int m = m0 + r, n = n0 + c4 * 4;
+        if (m < ep.m && n < ep.n) {
+            const float4 v = *(const float4*)(ct + r * CT_LD + c4 * 4);
+            if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
+            else epilogue_store4<TC, TD>(ep, m, n, v);
+        }
+    }
+}
+
+// XCD-aware bijective remap of a 1-D block id (guide T1, non-multiple-of-8 safe).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+// =====================================================================================
+//                                   bf16 MFMA kernel
+// =====================================================================================
+struct GemmDims {
+    int m, n, k;        // problem
+    int lda, ldb;
+    int tiles_m, tiles_n;
+    int k_per_split;    // multiple of the K tile
+};
+
+// ---- global -> register tile loads (4 x 16 B per thread per operand) -------------------
+// KC: element (r,k) at p[r*ld + k];  KS: element (r,k) at p[k*ld + r].
+template <bool KS>
+__device__ __forceinline__ void bf16_tile_load(uint4 (&reg)[4], const bf16_t* __restrict__ p, int ld,
+                                               int r0, int rtot, int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!KS) {
+            const int row = q >> 3, ch = q & 7;
+            const int r = r0 + row, k = k0 + ch * 8;
+            if (r < rtot && k < kend) v = *(const uint4*)(p + (size_t)r * ld + k);
+        } else {
+            const int krow = q >> 4, ch = q & 15;
+            const int k = k0 + krow, r = r0 + ch * 8;
+            if (k < kend && r < rtot) v = *(const uint4*)(p + (size_t)k * ld + r);
+        }
+        reg[i] = v;
+    }
+}
+__device__ __forceinline__ int ks_swz(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+
+template <bool KS>
+__device__ __forceinline__ void bf16_tile_store(const uint4 (&reg)[4], char* lds) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        int off;
+        if (!KS) {
+            const int row = q >> 3, ch = q & 7;
+            off = row * 128 + ((ch ^ (row & 7)) << 4);
+        } else {
+            const int krow = q >> 4, ch = q & 15;
+            off = krow * 256 + ((ch ^ ks_swz(krow)) << 4);
+        }
+        *(uint4*)(lds + off) = reg[i];
+    }
+}
+
+// ---- LDS -> MFMA fragment (16 rows x 32 k), rows [rbase, rbase+16), k-substep s -------
+template <bool KS>
+__device__ __forceinline__ bf16x8 bf16_frag(const char* lds, int rbase, int s, int lane) {
+    if (!KS) {
+        const int row = rbase + (lane & 15);
+        const int ch = s * 4 + (lane >> 4);
+        return *(const bf16x8*)(lds + row * 128 + ((ch ^ (row & 7)) << 4));
+    } else {
+        const int gl = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+        const int kk = s * 32 + gl * 8 + q;
+        const int rc = (rbase >> 3) + (p >> 1);
+        const int sw = ks_swz(kk);                       // identical for kk and kk+4
+        const int o0 = kk * 256 + ((rc ^ sw) << 4) + ((p & 1) << 3);
+        typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lds + o0));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lds + o0 + 4 * 256));
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+template <bool A_KS, bool B_KS, typename TC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
+                                                           const bf16_t* __restrict__ B,
+                                                           GemmDims d, EpiParams ep,
+                                                           float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [buf][A 16 KB | B 16 KB] x 2 = 64 KB, reused as the fp32 staging tile (66 KB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int z = blockIdx.x / tiles;
+    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
+    const int tm = t / d.tiles_n, tn = t - tm * d.tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = z * d.k_per_split;
+    const int kend = min(d.k, kbeg + d.k_per_split);
+    const int nk = (kend - kbeg + 63) >> 6;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    bf16_tile_load<A_KS>(ra, A, d.lda, m0, d.m, kbeg, kend);
+    bf16_tile_load<B_KS>(rb, B, d.ldb, n0, d.n, kbeg, kend);
+    bf16_tile_store<A_KS>(ra, smem);
+    bf16_tile_store<B_KS>(rb, smem + 16384);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * 32768;
+        const char* lb = la + 16384;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            bf16_tile_load<A_KS>(ra, A, d.lda, m0, d.m, kbeg + (kt + 1) * 64, kend);
+            bf16_tile_load<B_KS>(rb, B, d.ldb, n0, d.n, kbeg + (kt + 1) * 64, kend);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = bf16_frag<A_KS>(la, wm * 64 + i * 16, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag<B_KS>(lb, wn * 64 + j * 16, s, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* na = smem + ((kt + 1) & 1) * 32768;
+            bf16_tile_store<A_KS>(ra, na);
+            bf16_tile_store<B_KS>(rb, na + 16384);
+        }
+        __syncthreads();
+    }
+
+    // stage accumulators: D layout col = lane&15, row = (lane>>4)*4 + reg
+    float* ct = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ct[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CT_LD + wn * 64 + j * 16 + (lane & 15)] =
+                    acc[i][j][r];
+    __syncthreads();
+    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
+    tile_epilogue<TC, bf16_t>(ct, ep, m0, n0, slab);
+}
+
+// =====================================================================================
+//                                   exact fp32 MFMA kernel
+// =====================================================================================
+#define F32_LD 132  // [16][128+4] k-major operand tiles
+
+struct GemmDimsF {
+    int m, n, k;
+    int lda, ldb;
+    int tiles_m, tiles_n;
+    int k_per_split;
+};
+
+// KC: element (r,k) at p[r*ld+k]; tile = 128 r x 16 k, thread loads 2 float4 along k.
+// KS: element (r,k) at p[k*ld+r]; tile = 16 k x 128 r, thread loads 2 float4 along r.
+template <bool KS>
+__device__ __forceinline__ void f32_tile_load(float4 (&reg)[2], const float* __restrict__ p, int ld,
+                                              int r0, int rtot, int k0, int kend) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!KS) {
+            const int row = q >> 2, kc = q & 3;
+            const int r = r0 + row, k = k0 + kc * 4;
+            if (r < rtot) {
+                const float* src = p + (size_t)r * ld + k;
+                if (k + 3 < kend) v = *(const float4*)src;
+                else {
+                    if (k < kend) v.x = src[0];
+                    if (k + 1 < kend) v.y = src[1];
+                    if (k + 2 < kend) v.z = src[2];
+                }
+            }
+        } else {
+            const int krow = q >> 5, rc = q & 31;
+            const int k = k0 + krow, r = r0 + rc * 4;
+            if (k < kend) {
+                const float* src = p + (size_t)k * ld + r;
+                if (r + 3 < rtot) v = *(const float4*)src;
+                else {
+                    if (r < rtot) v.x = src[0];
+                    if (r + 1 < rtot) v.y = src[1];
+                    if (r + 2 < rtot) v.z = src[2];
+                }
+            }
+        }
+        reg[i] = v;
+    }
+}
+template <bool KS>
+__device__ __forceinline__ void f32_tile_store(const float4 (&reg)[2], float* lds) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i;
+        if (!KS) {
+            const int row = q >> 2, kc = q & 3;
+            lds[(kc * 4 + 0) * F32_LD + row] = reg[i].x;
+            lds[(kc * 4 + 1) * F32_LD + row] = reg[i].y;
+            lds[(kc * 4 + 2) * F32_LD + row] = reg[i].z;
+            lds[(kc * 4 + 3) * F32_LD + row] = reg[i].w;
+        } else {
+            const int krow = q >> 5, rc = q & 31;
+            *(float4*)(lds + krow * F32_LD + rc * 4) = reg[i];
+        }
+    }
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const float* __restrict__ A,
+                                                          const float* __restrict__ B, GemmDimsF d,
+                                                          EpiParams ep, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* fs = (float*)smem;   // [buf][A 16*132 | B 16*132]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int z = blockIdx.x / tiles;
+    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
+    const int tm = t / d.tiles_n, tn = t - tm * d.tiles_n;
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = z * d.k_per_split;
+    const int kend = min(d.k, kbeg + d.k_per_split);
+    const int nk = (kend - kbeg + 15) >> 4;
+    const int TS = 16 * F32_LD;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    f32_tile_load<A_KS>(ra, A, d.lda, m0, d.m, kbeg, kend);
+    f32_tile_load<B_KS>(rb, B, d.ldb, n0, d.n, kbeg, kend);
+    f32_tile_store<A_KS>(ra, fs);
+    f32_tile_store<B_KS>(rb, fs + TS);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* la = fs + (kt & 1) * 2 * TS;
+        const float* lb = la + TS;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            f32_tile_load<A_KS>(ra, A, d.lda, m0, d.m, kbeg + (kt + 1) * 16, kend);
+            f32_tile_load<B_KS>(rb, B, d.ldb, n0, d.n, kbeg + (kt + 1) * 16, kend);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const int krow = kk + (lane >> 5);
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = la[krow * F32_LD + wm * 64 + i * 32 + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = lb[krow * F32_LD + wn * 64 + j * 32 + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float* na = fs + ((kt + 1) & 1) * 2 * TS;
+            f32_tile_store<A_KS>(ra, na);
+            f32_tile_store<B_KS>(rb, na + TS);
+        }
+        __syncthreads();
+    }
+    // D layout 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    float* ct = fs;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ct[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CT_LD + wn * 64 +
+                   j * 32 + (lane & 31)] = acc[i][j][r];
+    __syncthreads();
+    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
+    tile_epilogue<float, float>(ct, ep, m0, n0, slab);
+}
+
+// exact-mode variant with a bf16 C is not needed: in exact mode every tensor is fp32.
+
+// =====================================================================================
+//                                split-K reduction + epilogue
+// =====================================================================================
+template <typename TC, typename TD>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs,
+                                                            int split, EpiParams ep) {
+    const int n4 = ep.n >> 2;
+    const size_t total = (size_t)ep.m * n4;
+    const size_t slab = (size_t)ep.m * ep.n;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+        float4 acc = *(const float4*)(slabs + (size_t)m * ep.n + n);
+        for (int z = 1; z < split; ++z) {
+            const float4 v = *(const float4*)(slabs + z * slab + (size_t)m * ep.n + n);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        epilogue_store4<TC, TD>(ep, m, n, acc);
+    }
+}
+
+// =====================================================================================
+//                                        host
+// =====================================================================================
+extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
+    BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
+    BF_REQUIRE(g->m > 0 && g->n > 0 && g->k > 0, BF_EINVAL, "bf_gemm: m, n, k must be > 0 (%d %d %d)",
+               g->m, g->n, g->k);
+    BF_REQUIRE(g->cdt == BF_F32 || g->cdt == BF_BF16, BF_EINVAL, "bf_gemm: bad cdt %d", g->cdt);
+    BF_REQUIRE(g->c_dtype == BF_F32 || g->c_dtype == BF_BF16, BF_EINVAL, "bf_gemm: bad c_dtype");
+    BF_REQUIRE(!(g->cdt == BF_F32 && g->c_dtype != BF_F32), BF_EINVAL,
+               "bf_gemm: fp32 operands produce fp32 output only");
+    BF_REQUIRE(!(g->accumulate && g->c_dtype != BF_F32), BF_EINVAL,
+               "bf_gemm: accumulate needs an fp32 C");
+    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_ERF_GELU_GRAD, BF_EINVAL, "bf_gemm: bad act");
+    BF_REQUIRE(g->act != BF_ACT_ERF_GELU_GRAD || g->aux, BF_EINVAL, "bf_gemm: GELU_GRAD needs aux");
+    const int vec = g->cdt == BF_BF16 ? 8 : 4;
+    BF_REQUIRE((g->n & 3) == 0 && (g->ldc & 3) == 0 && g->ldc >= g->n, BF_EINVAL,
+               "bf_gemm: n and ldc must be multiples of 4 (n=%d ldc=%d)", g->n, g->ldc);
+    BF_REQUIRE(g->lda % vec == 0 && g->ldb % vec == 0, BF_EALIGN,
+               "bf_gemm: lda/ldb must be multiples of %d elements (lda=%d ldb=%d)", vec, g->lda, g->ldb);
+    if (g->cdt == BF_BF16) {
+        // 16-byte chunks along the contiguous dimension must not straddle the extent
+        BF_REQUIRE(g->trans_a ? (g->m & 7) == 0 : (g->k & 7) == 0, BF_EINVAL,
+                   "bf_gemm(bf16): contiguous extent of A must be a multiple of 8");
+        BF_REQUIRE(g->b_kn ? (g->n & 7) == 0 : (g->k & 7) == 0, BF_EINVAL,
+                   "bf_gemm(bf16): contiguous extent of B must be a multiple of 8");
+    }
+    BF_REQUIRE(g->lda >= (g->trans_a ? g->m : g->k) && g->ldb >= (g->b_kn ? g->n : g->k), BF_EINVAL,
+               "bf_gemm: leading dimension smaller than the row length");
+    BF_REQUIRE(bf_aligned16(g->a) && bf_aligned16(g->b) && bf_aligned16(g->c) &&
+                   (!g->bias || bf_aligned16(g->bias)) && (!g->residual || bf_aligned16(g->residual)) &&
+                   (!g->pre || bf_aligned16(g->pre)) && (!g->aux || bf_aligned16(g->aux)) &&
+                   (!g->c2 || bf_aligned16(g->c2)),
+               BF_EALIGN, "bf_gemm: pointers must be 16-byte aligned");
+    BF_REQUIRE(!g->residual || ((g->ld_res & 3) == 0 && g->ld_res >= g->n), BF_EINVAL,
+               "bf_gemm: bad ld_res %d", g->ld_res);
+    BF_REQUIRE(!g->aux || ((g->ld_aux & 3) == 0 && g->ld_aux >= g->n), BF_EINVAL, "bf_gemm: bad ld_aux");
+    BF_REQUIRE(g->rows_in >= 0 && (g->rows_in == 0 || (g->rows_out >= g->rows_in + g->row_off && g->row_off >= 0)),
+               BF_EINVAL, "bf_gemm: bad row remap (%d -> %d + %d)", g->rows_in, g->rows_out, g->row_off);
+
+    const int ktile = g->cdt == BF_BF16 ? 64 : 16;
+    int split = g->split_k > 1 ? g->split_k : 1;
+    int kps = ((bf_cdiv(g->k, split) + ktile - 1) / ktile) * ktile;
+    split = bf_cdiv(g->k, kps);
+    float* slabs = nullptr;
+    if (split > 1) {
+        const size_t need = (size_t)split * g->m * g->n * sizeof(float);
+        BF_REQUIRE(g->workspace && g->workspace_bytes >= need, BF_EWORKSPACE,
+                   "bf_gemm: split_k=%d needs %zu workspace bytes, got %zu", split, need, g->workspace_bytes);
+        BF_REQUIRE(bf_aligned16(g->workspace), BF_EALIGN, "bf_gemm: unaligned workspace");
+        slabs = (float*)g->workspace;
+    }
+
+    EpiParams ep;
+    ep.c = g->c; ep.c2 = g->c2; ep.pre = g->pre; ep.aux = g->aux; ep.bias = g->bias;
+    ep.residual = g->residual; ep.m = g->m; ep.n = g->n; ep.ldc = g->ldc; ep.ld_aux = g->ld_aux;
+    ep.ld_res = g->ld_res; ep.resid_mod = g->resid_mod; ep.rows_in = g->rows_in;
+    ep.rows_out = g->rows_out; ep.row_off = g->row_off; ep.act = g->act;
+    ep.accumulate = g->accumulate; ep.alpha = g->alpha;
+
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_m = bf_cdiv(g->m, 128), tiles_n = bf_cdiv(g->n, 128);
+    const long nblk = (long)tiles_m * tiles_n * split;
+    BF_REQUIRE(nblk < (1L << 31), BF_EINVAL, "bf_gemm: grid too large");
+    dim3 grid((unsigned)nblk), block(256);
+    const size_t lds = (size_t)128 * CT_LD * sizeof(float);   // 67,584 B >= operand buffers
+
+    if (g->cdt == BF_BF16) {
+        GemmDims d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps};
+        const bf16_t* A = (const bf16_t*)g->a;
+        const bf16_t* B = (const bf16_t*)g->b;
+#define LAUNCH_BF16(AKS, BKS, TC)                                                                  \
+    do {                                                                                          \
+        static bool lds_ok = false;  /* > 64 KB of dynamic LDS must be opted into, once */        \
+        if (!lds_ok) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKS, BKS, TC>,                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            lds_ok = true;                                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_kernel<AKS, BKS, TC>), grid, block, lds, s, A, B, d, ep, slabs); \
+    } while (0)
+        const bool f32out = (g->c_dtype == BF_F32) || slabs;   // slabs path ignores TC
+        if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_BF16(false, false, float); else LAUNCH_BF16(false, false, bf16_t); }
+        else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_BF16(false, true, float); else LAUNCH_BF16(false, true, bf16_t); }
+        else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_BF16(true, true, float); else LAUNCH_BF16(true, true, bf16_t); }
+        else { if (f32out) LAUNCH_BF16(true, false, float); else LAUNCH_BF16(true, false, bf16_t); }
+#undef LAUNCH_BF16
+    } else {
+        GemmDimsF d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps};
+        const float* A = (const float*)g->a;
+        const float* B = (const float*)g->b;
+#define LAUNCH_F32(AKS, BKS)                                                                       \
+    do {                                                                                          \
+        static bool lds_ok = false;                                                               \
+        if (!lds_ok) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<AKS, BKS>,                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+            lds_ok = true;                                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS>), grid, block, lds, s, A, B, d, ep, slabs);  \
+    } while (0)
+        if (!g->trans_a && !g->b_kn) LAUNCH_F32(false, false);
+        else if (!g->trans_a && g->b_kn) LAUNCH_F32(false, true);
+        else if (g->trans_a && g->b_kn) LAUNCH_F32(true, true);
+        else LAUNCH_F32(true, false);
+#undef LAUNCH_F32
+    }
+    BF_CHECK_LAUNCH("bf_gemm");
+
+    if (slabs) {
+        const size_t total = (size_t)g->m * (g->n / 4);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        dim3 rgrid((unsigned)blocks);
+        if (g->cdt == BF_BF16) {
+            if (g->c_dtype == BF_F32)
+                hipLaunchKernelGGL((splitk_reduce_kernel<float, bf16_t>), rgrid, block, 0, s, slabs, split, ep);
+            else
+                hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, bf16_t>), rgrid, block, 0, s, slabs, split, ep);
+        } else {
+            hipLaunchKernelGGL((splitk_reduce_kernel<float, float>), rgrid, block, 0, s, slabs, split, ep);
+        }
+        BF_CHECK_LAUNCH("bf_gemm/splitk_reduce");
+    }
+    return BF_OK;
+}

@@ -1,0 +1,554 @@
+// LayerNorm fwd/bwd, column sums, casts and the token/patch plumbing kernels.
+// All of these are HBM-bound: one wavefront (64 lanes) per row, 16-byte accesses,
+// wave-shuffle reductions, fp32 math.
+#include "common.h"
+
+#define LN_MAXC 8   // float4 chunks per lane kept in registers -> cols <= 2048
+
+// ------------------------------------------------------------------ LayerNorm fwd
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     TY* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int rows, int cols,
+                                                     float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = cols >> 2;
+    const TX* xr = x + (size_t)row * cols;
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            v[i] = Vec4<TX>::load(xr + c * 4);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    TY* yr = y + (size_t)row * cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float4 g = *(const float4*)(gamma + c * 4);
+            const float4 b = *(const float4*)(beta + c * 4);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x;
+            o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z;
+            o.w = (v[i].w - mu) * rs * g.w + b.w;
+            Vec4<TY>::store(yr + c * 4, o);
+        }
+    }
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+}
+
+extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
+                                void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
+                                float eps, bf_stream_t stream) {
+    BF_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && cols <= LN_MAXC * 256, BF_EINVAL,
+               "bf_layernorm_fwd: need cols %% 4 == 0 and cols <= %d (got rows=%d cols=%d)",
+               LN_MAXC * 256, rows, cols);
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(y) && bf_aligned16(gamma) && bf_aligned16(beta),
+               BF_EALIGN, "bf_layernorm_fwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bf_cdiv(rows, 4)), block(256);
+#define LN_LAUNCH(TX, TY)                                                                       \
+    hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, gamma, beta,  \
+                       (TY*)y, mean, rstd, rows, cols, eps)
+    if (x_dtype == BF_F32 && y_dtype == BF_F32) LN_LAUNCH(float, float);
+    else if (x_dtype == BF_F32 && y_dtype == BF_BF16) LN_LAUNCH(float, bf16_t);
+    else if (x_dtype == BF_BF16 && y_dtype == BF_BF16) LN_LAUNCH(bf16_t, bf16_t);
+    else if (x_dtype == BF_BF16 && y_dtype == BF_F32) LN_LAUNCH(bf16_t, float);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_layernorm_fwd: bad dtype codes %d/%d", x_dtype, y_dtype);
+#undef LN_LAUNCH
+    BF_CHECK_LAUNCH("bf_layernorm_fwd");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ LayerNorm bwd
+#define LN_BWD_ROWS_PER_WAVE 8
+extern "C" int bf_layernorm_bwd_parts(int rows) {
+    int p = bf_cdiv(rows, 4 * LN_BWD_ROWS_PER_WAVE);
+    return p < 1 ? 1 : (p > 1024 ? 1024 : p);
+}
+
+template <typename TDY, typename TC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres,
+    float* __restrict__ dx, TC* __restrict__ dx_cdt, float* __restrict__ dgamma_part,
+    float* __restrict__ dbeta_part, int rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4][cols]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nvec = cols >> 2;
+    float4 dg[LN_MAXC], db[LN_MAXC], gm[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        dg[i] = make_float4(0, 0, 0, 0);
+        db[i] = make_float4(0, 0, 0, 0);
+        const int c = lane + i * 64;
+        gm[i] = (c < nvec) ? *(const float4*)(gamma + c * 4) : make_float4(0, 0, 0, 0);
+    }
+    const float inv_cols = 1.0f / (float)cols;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const size_t off = (size_t)row * cols;
+        float4 xh[LN_MAXC], g[LN_MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                const float4 xv = *(const float4*)(x + off + c * 4);
+                const float4 d = Vec4<TDY>::load(dy + off + c * 4);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs,
+                                    (xv.w - mu) * rs);
+                g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+                s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+                s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+                dg[i].x += d.x * xh[i].x; dg[i].y += d.y * xh[i].y;
+                dg[i].z += d.z * xh[i].z; dg[i].w += d.w * xh[i].w;
+                db[i].x += d.x; db[i].y += d.y; db[i].z += d.z; db[i].w += d.w;
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_cols;
+        const float m2 = wave_sum(s2) * inv_cols;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                float4 o;
+                o.x = rs * (g[i].x - m1 - xh[i].x * m2);
+                o.y = rs * (g[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (g[i].z - m1 - xh[i].z * m2);
+                o.w = rs * (g[i].w - m1 - xh[i].w * m2);
+                if (dres) {
+                    const float4 r = *(const float4*)(dres + off + c * 4);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *(float4*)(dx + off + c * 4) = o;
+                if (dx_cdt) Vec4<TC>::store(dx_cdt + off + c * 4, o);
+            }
+        }
+    }
+    // combine the 4 waves of the block, write one partial row per block
+    float* rg = red;
+    float* rb = red + 4 * cols;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            *(float4*)(rg + wave * cols + c * 4) = dg[i];
+            *(float4*)(rb + wave * cols + c * 4) = db[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        dgamma_part[(size_t)blockIdx.x * cols + c] =
+            (rg[c] + rg[cols + c]) + (rg[2 * cols + c] + rg[3 * cols + c]);
+        dbeta_part[(size_t)blockIdx.x * cols + c] =
+            (rb[c] + rb[cols + c]) + (rb[2 * cols + c] + rb[3 * cols + c]);
+    }
+}
+
+extern "C" int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                                const float* mean, const float* rstd, const float* dres, float* dx,
+                                void* dx_cdt, int cdt_dtype, float* dgamma_part, float* dbeta_part,
+                                int rows, int cols, bf_stream_t stream) {
+    BF_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && cols <= LN_MAXC * 256, BF_EINVAL,
+               "bf_layernorm_bwd: need cols %% 4 == 0 and cols <= %d (got rows=%d cols=%d)",
+               LN_MAXC * 256, rows, cols);
+    BF_REQUIRE(bf_aligned16(dy) && bf_aligned16(x) && bf_aligned16(dx) && bf_aligned16(gamma) &&
+                   (!dres || bf_aligned16(dres)) && (!dx_cdt || bf_aligned16(dx_cdt)),
+               BF_EALIGN, "bf_layernorm_bwd: pointers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bf_layernorm_bwd_parts(rows)), block(256);
+    const size_t lds = (size_t)8 * cols * sizeof(float);
+#define LNB_LAUNCH(TDY, TC)                                                                       \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), grid, block, lds, s, (const TDY*)dy, x, gamma,  \
+                       mean, rstd, dres, dx, (TC*)dx_cdt, dgamma_part, dbeta_part, rows, cols)
+    const int cd = dx_cdt ? cdt_dtype : BF_F32;
+    if (dy_dtype == BF_F32 && cd == BF_F32) LNB_LAUNCH(float, float);
+    else if (dy_dtype == BF_F32 && cd == BF_BF16) LNB_LAUNCH(float, bf16_t);
+    else if (dy_dtype == BF_BF16 && cd == BF_BF16) LNB_LAUNCH(bf16_t, bf16_t);
+    else if (dy_dtype == BF_BF16 && cd == BF_F32) LNB_LAUNCH(bf16_t, float);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_layernorm_bwd: bad dtype codes");
+#undef LNB_LAUNCH
+    BF_CHECK_LAUNCH("bf_layernorm_bwd");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ column sums
+// grid (col tiles of 256, row chunks); block 256 = 64 float4 column groups x 4 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x,
+                                                     float* __restrict__ out, int rows, int cols,
+                                                     int ld, int rows_per_block) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = blockIdx.x * 64 + lane;
+    const bool live = c4 * 4 < cols;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(rows, r0 + rows_per_block);
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (live) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const float4 v = Vec4<T>::load(x + (size_t)r * ld + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && live) {
+        const float4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+        float* o = out + c4 * 4;
+        atomicAdd(o + 0, (a.x + b.x) + (c.x + d.x));
+        atomicAdd(o + 1, (a.y + b.y) + (c.y + d.y));
+        atomicAdd(o + 2, (a.z + b.z) + (c.z + d.z));
+        atomicAdd(o + 3, (a.w + b.w) + (c.w + d.w));
+    }
+}
+
+extern "C" int bf_colsum(const void* x, int x_dtype, float* out, int rows, int cols, int ld,
+                         int accumulate, bf_stream_t stream) {
+    BF_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && (ld & 3) == 0 && ld >= cols, BF_EINVAL,
+               "bf_colsum: need cols %% 4 == 0, ld %% 4 == 0 (rows=%d cols=%d ld=%d)", rows, cols, ld);
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(out), BF_EALIGN, "bf_colsum: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s);
+        BF_REQUIRE(e == hipSuccess, BF_ELAUNCH, "bf_colsum: memset failed");
+    }
+    const int col_tiles = bf_cdiv(cols, 256);
+    int row_chunks = bf_cdiv(2048, col_tiles);
+    int rpb = bf_cdiv(rows, row_chunks);
+    if (rpb < 16) rpb = 16;
+    row_chunks = bf_cdiv(rows, rpb);
+    dim3 grid(col_tiles, row_chunks), block(256);
+    if (x_dtype == BF_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, out, rows, cols, ld, rpb);
+    else if (x_dtype == BF_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, out, rows, cols, ld, rpb);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_colsum: bad dtype %d", x_dtype);
+    BF_CHECK_LAUNCH("bf_colsum");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ cast
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst,
+                                                   size_t n4, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+        Vec4<TD>::store(dst + i * 4, Vec4<TS>::load(src + i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3))
+        dst[n4 * 4 + threadIdx.x] = from_f32<TD>(to_f32<TS>(src[n4 * 4 + threadIdx.x]));
+}
+
+extern "C" int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,
+                       bf_stream_t stream) {
+    BF_REQUIRE(count > 0, BF_EINVAL, "bf_cast: count must be > 0");
+    BF_REQUIRE(bf_aligned16(src) && bf_aligned16(dst), BF_EALIGN, "bf_cast: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    dim3 grid((unsigned)blocks), block(256);
+    if (src_dtype == BF_F32 && dst_dtype == BF_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, block, 0, s, (const float*)src, (bf16_t*)dst, n4, count);
+    else if (src_dtype == BF_BF16 && dst_dtype == BF_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)src, (float*)dst, n4, count);
+    else if (src_dtype == BF_F32 && dst_dtype == BF_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, s, (const float*)src, (float*)dst, n4, count);
+    else if (src_dtype == BF_BF16 && dst_dtype == BF_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, n4, count);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_cast: bad dtype codes");
+    BF_CHECK_LAUNCH("bf_cast");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ patchify (im2col)
+// One thread per 4 consecutive kx of one (patch, c, ky): reads 16 B of the image row,
+// writes 4 elements of the column matrix.  Consecutive threads walk kx, ky, c, patch.
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img,
+                                                       T* __restrict__ cols, int batch, int size,
+                                                       int patch) {
+    const int g = size / patch;
+    const int kq = patch >> 2;                          // float4 per kernel row
+    const size_t per_patch = (size_t)3 * patch * kq;
+    const size_t total = (size_t)batch * g * g * per_patch;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pidx = i / per_patch;
+        int r = (int)(i - pidx * per_patch);
+        const int c = r / (patch * kq);
+        r -= c * patch * kq;
+        const int ky = r / kq, kx4 = r - ky * kq;
+        const int b = (int)(pidx / (g * g));
+        const int pp = (int)(pidx - (size_t)b * g * g);
+        const int py = pp / g, px = pp - py * g;
+        const float4 v = *(const float4*)(img + (((size_t)b * 3 + c) * size + (py * patch + ky)) * size +
+                                          px * patch + kx4 * 4);
+        Vec4<T>::store(cols + pidx * ((size_t)3 * patch * patch) + ((size_t)c * patch + ky) * patch + kx4 * 4, v);
+    }
+}
+
+extern "C" int bf_patchify(const float* img, void* cols, int cdt, int batch, int size, int patch,
+                           bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && patch > 0 && (patch & 3) == 0 && size % patch == 0, BF_EINVAL,
+               "bf_patchify: need patch %% 4 == 0 and size %% patch == 0 (size=%d patch=%d)", size, patch);
+    BF_REQUIRE(bf_aligned16(img) && bf_aligned16(cols), BF_EALIGN, "bf_patchify: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)batch * 3 * size * size / 4;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    if (cdt == BF_F32)
+        hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, s, img, (float*)cols, batch, size, patch);
+    else if (cdt == BF_BF16)
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, s, img, (bf16_t*)cols, batch, size, patch);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_patchify: bad dtype %d", cdt);
+    BF_CHECK_LAUNCH("bf_patchify");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ vision assemble + ln_pre
+__global__ __launch_bounds__(256) void vision_assemble_kernel(
+    const float* __restrict__ patches, const float* __restrict__ cls, const float* __restrict__ pos,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ x,
+    int batch, int n_patch, int width, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int L = n_patch + 1;
+    if (row >= batch * L) return;
+    const int b = row / L, t = row - b * L;
+    const float* src = (t == 0) ? cls : patches + ((size_t)b * n_patch + (t - 1)) * width;
+    const float* pr = pos + (size_t)t * width;
+    const int nvec = width >> 2;
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float4 a = *(const float4*)(src + c * 4);
+            const float4 p = *(const float4*)(pr + c * 4);
+            v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mu = wave_sum(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float a = v[i].x - mu, bb = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)width + eps);
+    float* xr = x + (size_t)row * width;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float4 g = *(const float4*)(gamma + c * 4);
+            const float4 be = *(const float4*)(beta + c * 4);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + be.x;
+            o.y = (v[i].y - mu) * rs * g.y + be.y;
+            o.z = (v[i].z - mu) * rs * g.z + be.z;
+            o.w = (v[i].w - mu) * rs * g.w + be.w;
+            *(float4*)(xr + c * 4) = o;
+        }
+    }
+}
+
+extern "C" int bf_vision_assemble(const float* patches, const float* cls, const float* pos,
+                                  const float* gamma, const float* beta, float* x, int batch,
+                                  int n_patch, int width, float eps, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_patch > 0 && (width & 3) == 0 && width <= LN_MAXC * 256, BF_EINVAL,
+               "bf_vision_assemble: bad shape (n_patch=%d width=%d)", n_patch, width);
+    BF_REQUIRE(bf_aligned16(patches) && bf_aligned16(cls) && bf_aligned16(pos) && bf_aligned16(x),
+               BF_EALIGN, "bf_vision_assemble: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bf_cdiv((long)batch * (n_patch + 1), 4)), block(256);
+    hipLaunchKernelGGL(vision_assemble_kernel, grid, block, 0, s, patches, cls, pos, gamma, beta, x,
+                       batch, n_patch, width, eps);
+    BF_CHECK_LAUNCH("bf_vision_assemble");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ token embedding
+__global__ __launch_bounds__(256) void embed_tokens_kernel(
+    const int32_t* __restrict__ tokens, const float* __restrict__ table,
+    const float* __restrict__ pos, float* __restrict__ x, int rows, int ctx, int width, int vocab,
+    int* __restrict__ err_flag) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int id = tokens[row];
+    if (id < 0 || id >= vocab) {
+        if (lane == 0 && err_flag) atomicExch(err_flag, 1);
+        id = 0;
+    }
+    const int t = row % ctx;
+    const float* e = table + (size_t)id * width;
+    const float* p = pos + (size_t)t * width;
+    float* o = x + (size_t)row * width;
+    for (int c = lane; c < (width >> 2); c += 64) {
+        const float4 a = *(const float4*)(e + c * 4);
+        const float4 b = *(const float4*)(p + c * 4);
+        *(float4*)(o + c * 4) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+extern "C" int bf_embed_tokens(const int32_t* tokens, const float* table, const float* pos, float* x,
+                               int batch, int ctx, int width, int vocab, int* err_flag,
+                               bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && ctx > 0 && (width & 3) == 0 && vocab > 0, BF_EINVAL,
+               "bf_embed_tokens: bad shape (ctx=%d width=%d vocab=%d)", ctx, width, vocab);
+    BF_REQUIRE(bf_aligned16(table) && bf_aligned16(pos) && bf_aligned16(x), BF_EALIGN,
+               "bf_embed_tokens: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = batch * ctx;
+    dim3 grid(bf_cdiv(rows, 4)), block(256);
+    hipLaunchKernelGGL(embed_tokens_kernel, grid, block, 0, s, tokens, table, pos, x, rows, ctx, width,
+                       vocab, err_flag);
+    BF_CHECK_LAUNCH("bf_embed_tokens");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ fusion input assembly
+__global__ __launch_bounds__(256) void fusion_assemble_kernel(
+    const float* __restrict__ text_feat, const float* __restrict__ rgb_feat,
+    const float* __restrict__ text_token, const float* __restrict__ text_pos,
+    const float* __restrict__ rgb_pos, const float* __restrict__ type_emb, float* __restrict__ x,
+    int batch, int n_text, int n_rgb, int dim) {
+    const int L = 1 + n_text + n_rgb;
+    const int nvec = dim >> 2;
+    const size_t total = (size_t)batch * L * nvec;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % nvec);
+        const size_t row = i / nvec;
+        const int b = (int)(row / L), t = (int)(row - (size_t)b * L);
+        const float* src;
+        const float* ps;
+        const float* ty;
+        if (t == 0) {
+            src = text_token; ps = text_pos; ty = type_emb;
+        } else if (t <= n_text) {
+            src = text_feat + ((size_t)b * n_text + (t - 1)) * dim;
+            ps = text_pos + (size_t)t * dim; ty = type_emb;
+        } else {
+            const int p = t - 1 - n_text;
+            src = rgb_feat + ((size_t)b * n_rgb + p) * dim;
+            ps = rgb_pos + (size_t)p * dim; ty = type_emb + dim;
+        }
+        const float4 a = *(const float4*)(src + c * 4);
+        const float4 p4 = *(const float4*)(ps + c * 4);
+        const float4 t4 = *(const float4*)(ty + c * 4);
+        // reference order: (feat + pos) + type   (rgb_clip.py:55,64 then fusion.py:52)
+        *(float4*)(x + row * dim + c * 4) = make_float4((a.x + p4.x) + t4.x, (a.y + p4.y) + t4.y,
+                                                        (a.z + p4.z) + t4.z, (a.w + p4.w) + t4.w);
+    }
+}
+
+extern "C" int bf_fusion_assemble(const float* text_feat, const float* rgb_feat,
+                                  const float* text_token, const float* text_pos,
+                                  const float* rgb_pos, const float* type_emb, float* x, int batch,
+                                  int n_text, int n_rgb, int dim, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_text > 0 && n_rgb > 0 && (dim & 3) == 0, BF_EINVAL,
+               "bf_fusion_assemble: bad shape");
+    BF_REQUIRE(bf_aligned16(text_feat) && bf_aligned16(rgb_feat) && bf_aligned16(text_token) &&
+                   bf_aligned16(text_pos) && bf_aligned16(rgb_pos) && bf_aligned16(type_emb) &&
+                   bf_aligned16(x), BF_EALIGN, "bf_fusion_assemble: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)batch * (1 + n_text + n_rgb) * (dim / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fusion_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, s, text_feat,
+                       rgb_feat, text_token, text_pos, rgb_pos, type_emb, x, batch, n_text, n_rgb, dim);
+    BF_CHECK_LAUNCH("bf_fusion_assemble");
+    return BF_OK;
+}
+
+// backward, stage 1: one thread per (token, float4 column): sum dX over the batch, and
+// write the rgb rows out in the compute dtype.
+template <typename TC>
+__global__ __launch_bounds__(256) void fusion_assemble_bwd_kernel(
+    const float* __restrict__ dx, TC* __restrict__ d_rgb_feat, float* __restrict__ d_text_pos,
+    float* __restrict__ d_rgb_pos, int batch, int n_text, int n_rgb, int dim) {
+    const int L = 1 + n_text + n_rgb;
+    const int nvec = dim >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= L * nvec) return;
+    const int t = i / nvec, c = i - t * nvec;
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int b = 0; b < batch; ++b) {
+        const float4 v = *(const float4*)(dx + ((size_t)b * L + t) * dim + c * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        if (t > n_text)
+            Vec4<TC>::store(d_rgb_feat + ((size_t)b * n_rgb + (t - 1 - n_text)) * dim + c * 4, v);
+    }
+    if (t <= n_text) *(float4*)(d_text_pos + (size_t)t * dim + c * 4) = acc;
+    else *(float4*)(d_rgb_pos + (size_t)(t - 1 - n_text) * dim + c * 4) = acc;
+}
+// stage 2: type-embedding gradients (sum the per-token sums over each modality) and text_token.
+__global__ __launch_bounds__(256) void fusion_assemble_bwd2_kernel(
+    const float* __restrict__ d_text_pos, const float* __restrict__ d_rgb_pos,
+    float* __restrict__ d_text_token, float* __restrict__ d_type, int n_text, int n_rgb, int dim) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= dim) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int t = 0; t <= n_text; ++t) s0 += d_text_pos[(size_t)t * dim + c];
+    for (int p = 0; p < n_rgb; ++p) s1 += d_rgb_pos[(size_t)p * dim + c];
+    d_type[c] = s0;
+    d_type[dim + c] = s1;
+    d_text_token[c] = d_text_pos[c];
+}
+
+extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt,
+                                      float* d_text_token, float* d_text_pos, float* d_rgb_pos,
+                                      float* d_type, int batch, int n_text, int n_rgb, int dim,
+                                      bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_text > 0 && n_rgb > 0 && (dim & 3) == 0, BF_EINVAL,
+               "bf_fusion_assemble_bwd: bad shape");
+    BF_REQUIRE(bf_aligned16(dx) && bf_aligned16(d_rgb_feat) && bf_aligned16(d_text_pos) &&
+                   bf_aligned16(d_rgb_pos), BF_EALIGN, "bf_fusion_assemble_bwd: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int L = 1 + n_text + n_rgb;
+    dim3 grid(bf_cdiv((long)L * (dim / 4), 256)), block(256);
+    if (cdt == BF_F32)
+        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<float>, grid, block, 0, s, dx, (float*)d_rgb_feat,
+                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim);
+    else if (cdt == BF_BF16)
+        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<bf16_t>, grid, block, 0, s, dx, (bf16_t*)d_rgb_feat,
+                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_fusion_assemble_bwd: bad dtype %d", cdt);
+    BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/1");
+    hipLaunchKernelGGL(fusion_assemble_bwd2_kernel, dim3(bf_cdiv(dim, 256)), block, 0, s, d_text_pos,
+                       d_rgb_pos, d_text_token, d_type, n_text, n_rgb, dim);
+    BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/2");
+    return BF_OK;
+}

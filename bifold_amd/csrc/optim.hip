@@ -1,0 +1,124 @@
+// Fused Adam / AdamW over the flat fp32 parameter arena, gradient sum-of-squares and the
+// clip coefficient.  HBM-bound: 4 fp32 reads + 3 fp32 writes (+ 1 bf16 write) per element.
+#include "common.h"
+
+#include <math.h>
+
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ shadow, size_t n4, float lr,
+                                                   float beta1, float beta2, float eps, float wd,
+                                                   int decoupled, float step_size, float sqrt_bc2,
+                                                   const float* __restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.0f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 pv = ((const float4*)p)[i];
+        float4 gv = ((const float4*)g)[i];
+        float4 mv = ((const float4*)m)[i];
+        float4 vv = ((const float4*)v)[i];
+        float* pp = (float*)&pv; float* gp = (float*)&gv; float* mp = (float*)&mv; float* vp = (float*)&vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float grad = gp[e] * gs;
+            float par = pp[e];
+            if (wd != 0.f) {
+                if (decoupled) par *= (1.0f - lr * wd);
+                else grad = fmaf(wd, par, grad);
+            }
+            // torch: exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+            const float m1 = mp[e] + (grad - mp[e]) * (1.0f - beta1);
+            const float v1 = vp[e] * beta2 + (1.0f - beta2) * grad * grad;
+            const float denom = sqrtf(v1) / sqrt_bc2 + eps;
+            par -= step_size * (m1 / denom);
+            pp[e] = par; mp[e] = m1; vp[e] = v1;
+        }
+        ((float4*)p)[i] = pv;
+        ((float4*)m)[i] = mv;
+        ((float4*)v)[i] = vv;
+        if (SHADOW) Vec4<bf16_t>::store(shadow + i * 4, pv);
+    }
+}
+
+extern "C" int bf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
+                            size_t count, int step, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int decoupled, const float* grad_scale_dev,
+                            bf_stream_t stream) {
+    BF_REQUIRE(count > 0 && (count & 3) == 0, BF_EINVAL,
+               "bf_adam_step: the arena length must be a multiple of 4 (got %zu)", count);
+    BF_REQUIRE(step >= 1, BF_EINVAL, "bf_adam_step: step is 1-based (got %d)", step);
+    BF_REQUIRE(bf_aligned16(param) && bf_aligned16(grad) && bf_aligned16(exp_avg) && bf_aligned16(exp_avg_sq) &&
+                   (!shadow || bf_aligned16(shadow)), BF_EALIGN, "bf_adam_step: unaligned pointer");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (shadow)
+        hipLaunchKernelGGL(adam_kernel<true>, grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow,
+                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
+    else
+        hipLaunchKernelGGL(adam_kernel<false>, grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)nullptr,
+                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
+    BF_CHECK_LAUNCH("bf_adam_step");
+    return BF_OK;
+}
+
+#define SUMSQ_BLOCKS 1024
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n4, size_t count,
+                                                    float* __restrict__ partial) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = ((const float4*)x)[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const float t = x[n4 * 4 + threadIdx.x];
+        acc += t * t;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ partial, int n,
+                                                           float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int bf_sumsq(const float* x, size_t count, float* partial_ws, float* out, bf_stream_t stream) {
+    BF_REQUIRE(count > 0, BF_EINVAL, "bf_sumsq: count must be > 0");
+    BF_REQUIRE(bf_aligned16(x), BF_EALIGN, "bf_sumsq: unaligned pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n4, count, partial_ws);
+    BF_CHECK_LAUNCH("bf_sumsq/1");
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, partial_ws, (int)blocks, out);
+    BF_CHECK_LAUNCH("bf_sumsq/2");
+    return BF_OK;
+}
+
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ out) {
+    const float norm = sqrtf(sumsq[0]);
+    out[0] = fminf(1.0f, max_norm / (norm + 1e-6f));
+}
+extern "C" int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_stream_t stream) {
+    BF_REQUIRE(sumsq && out && max_norm > 0.f, BF_EINVAL, "bf_clip_coef: bad args");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, out);
+    BF_CHECK_LAUNCH("bf_clip_coef");
+    return BF_OK;
+}

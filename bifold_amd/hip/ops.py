@@ -1,0 +1,357 @@
+"""Tensor-level wrappers over the C ABI: shape/dtype/device checks, output
+allocation through PyTorch's caching allocator, launch on the current HIP stream.
+
+PyTorch is plumbing here (device memory + streams); every kernel launched from
+this file lives in bifold_amd/csrc/*.hip.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from .lib import check, lib
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+_TORCH = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return _TORCH[code]
+
+
+def dtype_code(t) -> int:
+    dt = t if isinstance(t, torch.dtype) else t.dtype
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"bifold_hip supports float32 / bfloat16 tensors, got {dt}") from None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, contiguous: bool = True):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got {t.device}); there is no CPU path")
+    if contiguous and not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """2-D tensor with unit column stride; returns (tensor, rows, cols, ld)."""
+    _dev(t, name, contiguous=False)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"{name} must be 2-D with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+    return t, t.shape[0], t.shape[1], t.stride(0)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype: torch.dtype,
+                  save_stats: bool = False, eps: float = 1e-5, out: Optional[torch.Tensor] = None):
+    _dev(x, "x"); _dev(gamma, "gamma"); _dev(beta, "beta")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = out if out is not None else torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.bf_layernorm_fwd(_ptr(x), dtype_code(x), _ptr(gamma), _ptr(beta), _ptr(y), dtype_code(y),
+                               _ptr(mean), _ptr(rstd), rows, cols, eps, _stream()), "bf_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
+                  rstd: torch.Tensor, dres: Optional[torch.Tensor], cdt: Optional[torch.dtype],
+                  dgamma_out: torch.Tensor, dbeta_out: torch.Tensor):
+    """Returns (dx fp32, dx_cdt or None); writes dgamma/dbeta into the given fp32 vectors."""
+    _dev(dy, "dy"); _dev(x, "x")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dx_c = torch.empty(x.shape, dtype=cdt, device=x.device) if (cdt is not None and cdt != torch.float32) else None
+    nparts = lib.bf_layernorm_bwd_parts(rows)
+    parts = torch.empty(2, nparts, cols, dtype=torch.float32, device=x.device)
+    check(lib.bf_layernorm_bwd(_ptr(dy), dtype_code(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
+                               _ptr(dres), _ptr(dx), _ptr(dx_c), L.BF16 if dx_c is not None else L.F32,
+                               _ptr(parts[0]), _ptr(parts[1]), rows, cols, _stream()), "bf_layernorm_bwd")
+    colsum(parts[0], out=dgamma_out)
+    colsum(parts[1], out=dbeta_out)
+    return dx, dx_c
+
+
+# ----------------------------------------------------------------------------- GEMM
+def pick_split_k(m: int, n: int, k: int) -> int:
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    if tiles >= 256 or k < 1024:
+        return 1
+    return max(1, min(64, 768 // tiles, k // 512))
+
+
+def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool = False,
+         bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, want_pre: bool = False,
+         aux: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         resid_mod: int = 0, out: Optional[torch.Tensor] = None,
+         out_dtype: Optional[torch.dtype] = None, rows_in: int = 0, rows_out: int = 0,
+         row_off: int = 0, accumulate: bool = False, want_bf16_copy: bool = False,
+         alpha: float = 1.0, split_k: Optional[int] = None):
+    """C = epilogue(alpha * op(A) op(B)); see include/bifold_hip.h for the epilogue order.
+    Returns C, or (C, pre) / (C, copy) when asked for."""
+    a, ar, ac, lda = _rows2d(a, "A")
+    b, br, bc, ldb = _rows2d(b, "B")
+    if a.dtype != b.dtype:
+        raise TypeError(f"A and B must share a dtype ({a.dtype} vs {b.dtype})")
+    m, k = (ac, ar) if trans_a else (ar, ac)
+    n, kb = (bc, br) if b_kn else (br, bc)
+    if k != kb:
+        raise RuntimeError(f"GEMM inner dimensions differ: {k} vs {kb}")
+    cdt = dtype_code(a)
+    if out is None:
+        od = out_dtype or a.dtype
+        if rows_in:
+            raise RuntimeError("row remap needs an explicit `out`")
+        out = torch.empty(m, n, dtype=od, device=a.device)
+    out2, orows, ocols, ldc = _rows2d(out, "C")
+    g = L.GemmArgs()
+    g.a, g.b, g.c = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    g.m, g.n, g.k = m, n, k
+    g.lda, g.ldb, g.ldc = lda, ldb, ldc
+    g.cdt, g.c_dtype = cdt, dtype_code(out)
+    g.trans_a, g.b_kn = int(trans_a), int(b_kn)
+    g.alpha = alpha
+    g.bias = _ptr(bias)
+    g.act = act
+    pre = None
+    if want_pre:
+        pre = torch.empty(out.shape, dtype=a.dtype, device=a.device)
+        if pre.stride(0) != ldc:
+            raise RuntimeError("pre-activation output needs the same leading dimension as C")
+        g.pre = pre.data_ptr()
+    if aux is not None:
+        aux, _, _, ld_aux = _rows2d(aux, "aux")
+        g.aux, g.ld_aux = aux.data_ptr(), ld_aux
+    if residual is not None:
+        residual, _, _, ld_res = _rows2d(residual, "residual")
+        if residual.dtype != torch.float32:
+            raise TypeError("residual must be float32")
+        g.residual, g.ld_res = residual.data_ptr(), ld_res
+    g.resid_mod = resid_mod
+    g.rows_in, g.rows_out, g.row_off = rows_in, rows_out, row_off
+    g.accumulate = int(accumulate)
+    copy = None
+    if want_bf16_copy:
+        copy = torch.empty(out.shape, dtype=torch.bfloat16, device=a.device)
+        g.c2 = copy.data_ptr()
+    sk = pick_split_k(m, n, k) if split_k is None else split_k
+    ws = None
+    if sk > 1:
+        ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    g.split_k = sk
+    check(lib.bf_gemm(C.byref(g), _stream()), "bf_gemm")
+    if want_pre:
+        return out, pre
+    if want_bf16_copy:
+        return out, copy
+    return out
+
+
+def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    x, rows, cols, ld = _rows2d(x, "x")
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    check(lib.bf_colsum(_ptr(x), dtype_code(x), _ptr(out), rows, cols, ld, int(accumulate), _stream()),
+          "bf_colsum")
+    return out
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None):
+    _dev(src, "src")
+    dst = out if out is not None else torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib.bf_cast(_ptr(src), dtype_code(src), _ptr(dst), dtype_code(dst), src.numel(), _stream()),
+          "bf_cast")
+    return dst
+
+
+# ----------------------------------------------------------------------------- attention
+def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale: float,
+                  mask_mode: int = L.MASK_NONE, row_mask: Optional[torch.Tensor] = None,
+                  need_lse: bool = False):
+    _dev(qkv, "qkv")
+    if qkv.numel() != batch * seq * 3 * heads * head_dim:
+        raise RuntimeError("qkv has the wrong number of elements")
+    out = torch.empty(batch * seq, heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device) if need_lse else None
+    if row_mask is not None and row_mask.dtype != torch.int32:
+        raise TypeError("row_mask must be int32")
+    check(lib.bf_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(row_mask), batch, seq, heads,
+                               head_dim, scale, mask_mode, dtype_code(qkv), _stream()), "bf_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_mode=L.MASK_NONE,
+                  row_mask=None):
+    _dev(qkv, "qkv"); _dev(out, "out"); _dev(dout, "dout")
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
+    check(lib.bf_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
+                               _ptr(delta), batch, seq, heads, head_dim, scale, mask_mode,
+                               dtype_code(qkv), _stream()), "bf_attention_bwd")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------- token plumbing
+def patchify(img: torch.Tensor, patch: int, cdt: torch.dtype):
+    _dev(img, "rgb")
+    if img.dtype != torch.float32 or img.dim() != 4 or img.shape[1] != 3 or img.shape[2] != img.shape[3]:
+        raise RuntimeError(f"rgb must be float32 [B,3,S,S], got {img.dtype} {tuple(img.shape)}")
+    b, _, s, _ = img.shape
+    g = s // patch
+    cols = torch.empty(b * g * g, 3 * patch * patch, dtype=cdt, device=img.device)
+    check(lib.bf_patchify(_ptr(img), _ptr(cols), dtype_code(cols), b, s, patch, _stream()), "bf_patchify")
+    return cols
+
+
+def vision_assemble(patches, cls, pos, gamma, beta, batch: int, n_patch: int, eps: float = 1e-5):
+    width = patches.shape[-1]
+    x = torch.empty(batch * (n_patch + 1), width, dtype=torch.float32, device=patches.device)
+    check(lib.bf_vision_assemble(_ptr(patches), _ptr(cls), _ptr(pos), _ptr(gamma), _ptr(beta), _ptr(x),
+                                 batch, n_patch, width, eps, _stream()), "bf_vision_assemble")
+    return x
+
+
+def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, err_flag: torch.Tensor):
+    _dev(tokens, "instruction")
+    if tokens.dtype != torch.int32:
+        raise TypeError("token ids must be int32")
+    b, ctx = tokens.shape
+    vocab, width = table.shape
+    x = torch.empty(b * ctx, width, dtype=torch.float32, device=table.device)
+    check(lib.bf_embed_tokens(_ptr(tokens), _ptr(table), _ptr(pos), _ptr(x), b, ctx, width, vocab,
+                              _ptr(err_flag), _stream()), "bf_embed_tokens")
+    return x
+
+
+def fusion_assemble(text_feat, rgb_feat, text_token, text_pos, rgb_pos, type_emb, batch, n_text, n_rgb):
+    dim = text_feat.shape[-1]
+    x = torch.empty(batch * (1 + n_text + n_rgb), dim, dtype=torch.float32, device=text_feat.device)
+    check(lib.bf_fusion_assemble(_ptr(text_feat), _ptr(rgb_feat), _ptr(text_token), _ptr(text_pos),
+                                 _ptr(rgb_pos), _ptr(type_emb), _ptr(x), batch, n_text, n_rgb, dim,
+                                 _stream()), "bf_fusion_assemble")
+    return x
+
+
+def fusion_assemble_bwd(dx, cdt: torch.dtype, d_text_token, d_text_pos, d_rgb_pos, d_type, batch, n_text,
+                        n_rgb):
+    dim = dx.shape[-1]
+    d_rgb = torch.empty(batch * n_rgb, dim, dtype=cdt, device=dx.device)
+    check(lib.bf_fusion_assemble_bwd(_ptr(dx), _ptr(d_rgb), dtype_code(d_rgb), _ptr(d_text_token),
+                                     _ptr(d_text_pos), _ptr(d_rgb_pos), _ptr(d_type), batch, n_text,
+                                     n_rgb, dim, _stream()), "bf_fusion_assemble_bwd")
+    return d_rgb
+
+
+# ----------------------------------------------------------------------------- decoder + BCE
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def decoder_collapse_fwd(ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor], w_eff, b_eff, rows_ws):
+    dim = ws[0].shape[1]
+    check(lib.bf_decoder_collapse_fwd(_ptr_array(ws), _ptr_array(bs), _ptr(w_eff), _ptr(b_eff),
+                                      _ptr(rows_ws), dim, _stream()), "bf_decoder_collapse_fwd")
+
+
+def decoder_collapse_bwd(ws, bs, rows_ws, g_w_eff, g_b_eff, dws, dbs):
+    dim = ws[0].shape[1]
+    check(lib.bf_decoder_collapse_bwd(_ptr_array(ws), _ptr_array(bs), _ptr(rows_ws), _ptr(g_w_eff),
+                                      _ptr(g_b_eff), _ptr_array(dws), _ptr_array(dbs), dim, _stream()),
+          "bf_decoder_collapse_bwd")
+
+
+def decoder_project(tok: torch.Tensor, tok_bstride: int, w_eff, b_eff, batch, n_heads, n_patch, dim):
+    low = torch.empty(n_heads, batch, n_patch, dtype=torch.float32, device=w_eff.device)
+    check(lib.bf_decoder_project(_ptr(tok), tok_bstride, _ptr(w_eff), _ptr(b_eff), _ptr(low), batch, n_heads,
+                                 n_patch, dim, _stream()), "bf_decoder_project")
+    return low
+
+
+def decoder_upsample_sigmoid(low, U, n_maps: int, grid: int):
+    s = grid * 16
+    heat = torch.empty(n_maps, s, s, dtype=torch.float32, device=low.device)
+    check(lib.bf_decoder_upsample_sigmoid(_ptr(low), _ptr(U), _ptr(heat), n_maps, grid, _stream()),
+          "bf_decoder_upsample_sigmoid")
+    return heat
+
+
+def decoder_upsample_sigmoid_bwd(heat, d_heat, U, n_maps: int, grid: int):
+    g_low = torch.empty(n_maps, grid * grid, dtype=torch.float32, device=heat.device)
+    check(lib.bf_decoder_upsample_sigmoid_bwd(_ptr(heat), _ptr(d_heat), _ptr(U), _ptr(g_low), n_maps, grid,
+                                              _stream()), "bf_decoder_upsample_sigmoid_bwd")
+    return g_low
+
+
+def decoder_project_bwd(tok, tok_bstride, w_eff, g_low, d_tok, dtok_bstride, g_w_eff, g_b_eff, batch,
+                        n_heads, n_patch, dim):
+    ws = torch.empty(lib.bf_decoder_project_bwd_ws(batch, n_heads, dim), dtype=torch.float32,
+                     device=w_eff.device)
+    check(lib.bf_decoder_project_bwd(_ptr(tok), tok_bstride, _ptr(w_eff), _ptr(g_low), _ptr(d_tok),
+                                     dtok_bstride, _ptr(g_w_eff), _ptr(g_b_eff), _ptr(ws), batch, n_heads,
+                                     n_patch, dim, _stream()), "bf_decoder_project_bwd")
+
+
+def bce_mean(heat: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """mean BCE of one head; heat/target [B, ...] fp32 contiguous.  Returns a 1-element tensor."""
+    _dev(heat, "heatmap"); _dev(target, "target")
+    if heat.shape != target.shape or heat.dtype != torch.float32 or target.dtype != torch.float32:
+        raise RuntimeError(f"BCE needs matching float32 tensors, got {tuple(heat.shape)} {heat.dtype} vs "
+                           f"{tuple(target.shape)} {target.dtype}")
+    batch = heat.shape[0]
+    pixels = heat.numel() // batch
+    nparts = lib.bf_bce_parts(batch)
+    parts = torch.empty(nparts, dtype=torch.float32, device=heat.device)
+    loss = torch.empty(1, dtype=torch.float32, device=heat.device)
+    check(lib.bf_bce_fwd(_ptr(heat), _ptr(target), _ptr(parts), batch, 1, pixels, pixels, 0, pixels, 0,
+                         _stream()), "bf_bce_fwd")
+    check(lib.bf_bce_finish(_ptr(parts), _ptr(loss), 1, nparts, 1.0 / heat.numel(), _stream()), "bf_bce_finish")
+    return loss
+
+
+def bce_mean_bwd(heat, target, gscale: torch.Tensor):
+    d = torch.empty_like(heat)
+    check(lib.bf_bce_bwd(_ptr(heat), _ptr(target), _ptr(gscale), _ptr(d), heat.numel(), 1.0 / heat.numel(),
+                         _stream()), "bf_bce_bwd")
+    return d
+
+
+# ----------------------------------------------------------------------------- optimiser
+def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, step, lr, beta1, beta2, eps, weight_decay,
+              decoupled, grad_scale=None):
+    check(lib.bf_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(shadow),
+                           param.numel(), step, lr, beta1, beta2, eps, weight_decay, int(decoupled),
+                           _ptr(grad_scale), _stream()), "bf_adam_step")
+
+
+def sumsq(x: torch.Tensor) -> torch.Tensor:
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib.bf_sumsq(_ptr(x), x.numel(), _ptr(ws), _ptr(out), _stream()), "bf_sumsq")
+    return out
+
+
+def clip_coef(sumsq_t: torch.Tensor, max_norm: float) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.float32, device=sumsq_t.device)
+    check(lib.bf_clip_coef(_ptr(sumsq_t), max_norm, _ptr(out), _stream()), "bf_clip_coef")
+    return out

@@ -1,0 +1,282 @@
+/*
+ * bifold_hip.h -- C ABI of libbifold_hip.so: the MI355X (gfx950 / CDNA4) kernels
+ * behind BiFold's VLM training step.
+ *
+ * The reference (Barbany/bifold) has NO native boundary on this path: every FLOP
+ * is a stock ATen kernel reached through nn.Module.forward.  This ABI is the
+ * boundary the build introduces *beneath* the reference's Python plugin surface
+ * (bifold.models / bifold.losses / bifold.optim); each entry point names the
+ * reference call site(s) it replaces (paths relative to the reference's bifold/).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ *    name ends in _host; the caller owns all memory, the library never allocates,
+ *    frees or synchronises, and holds no state besides a thread-local error string;
+ *  - every launch goes to the hipStream_t passed as `stream` (void*; NULL = the
+ *    legacy default stream);
+ *  - tensors are row-major and contiguous unless a leading dimension is given;
+ *    pointers must be 16-byte aligned;
+ *  - dtype codes: BF_F32 = 0 (IEEE fp32), BF_BF16 = 1 (bfloat16).  "cdt" below is
+ *    the compute dtype of a call: operands of matrix products; accumulation,
+ *    LayerNorm statistics, softmax, the residual stream, losses and optimiser
+ *    state are always fp32;
+ *  - return value: 0 on success, a negative BF_E* code otherwise;
+ *    bf_last_error() returns a human-readable description for this thread.
+ */
+#ifndef BIFOLD_HIP_H
+#define BIFOLD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BF_ABI_VERSION 1
+
+enum { BF_F32 = 0, BF_BF16 = 1 };
+
+enum {
+    BF_OK = 0,
+    BF_EINVAL = -1,     /* bad shape / dtype / flag combination        */
+    BF_EALIGN = -2,     /* pointer or leading dimension not aligned    */
+    BF_ELAUNCH = -3,    /* hipGetLastError() != hipSuccess after launch */
+    BF_EWORKSPACE = -4  /* workspace too small                          */
+};
+
+typedef void* bf_stream_t;
+
+int bf_abi_version(void);
+const char* bf_last_error(void);
+int bf_last_hip_error(void);
+
+/* ------------------------------------------------------------------------
+ * LayerNorm (eps inside the sqrt, biased variance; fp32 statistics).
+ * Replaces nn.LayerNorm at models/clip/model.py:178-184 (ln_pre, ln_1, ln_2,
+ * ln_post, ln_final) and models/modules.py:11 (PreNorm.norm).
+ *   x [rows, cols] x_dtype -> y [rows, cols] y_dtype; mean/rstd [rows] fp32 (may
+ *   be NULL when not needed for a backward pass).
+ * ---------------------------------------------------------------------- */
+int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, void* y,
+                     int y_dtype, float* mean, float* rstd, int rows, int cols, float eps,
+                     bf_stream_t stream);
+
+/* Backward of the above fused with the residual branch:
+ *   dx = (dres ? dres : 0) + dLN(dy)          fp32 [rows, cols]
+ *   dx_cdt (optional, cdt_dtype) = cast(dx)   -- operand for the next dX/dW GEMMs
+ *   dgamma_part/dbeta_part: fp32 [n_part, cols] per-workgroup partial sums,
+ *   n_part = bf_layernorm_bwd_parts(rows); reduce them with bf_colsum. */
+int bf_layernorm_bwd_parts(int rows);
+int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
+                     const float* mean, const float* rstd, const float* dres, float* dx,
+                     void* dx_cdt, int cdt_dtype, float* dgamma_part, float* dbeta_part, int rows,
+                     int cols, bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C = epilogue(alpha * op(A) * op(B)).
+ * Replaces every nn.Linear / Conv2d-as-matmul on the path:
+ *   conv1 patch-embed (models/clip/model.py:250-256,297-299), MHA in/out
+ *   projections (:196,214-217), c_fc/c_proj (:198-204), project
+ *   (models/rgb_clip.py:34,54), to_qkv/to_out (models/transformer.py:19-24),
+ *   FeedForward (models/modules.py:21-27), and their autograd backward.
+ *
+ * Layouts (all row-major):
+ *   trans_a = 0: A is [M, K]           trans_a = 1: A is stored [K, M]
+ *   b_kn    = 0: B is [N, K] (weights) b_kn    = 1: B is stored [K, N]
+ *   forward  y = x W^T      : trans_a 0, b_kn 0
+ *   backward dx = dy W      : trans_a 0, b_kn 1
+ *   backward dW = dy^T x    : trans_a 1, b_kn 1   (split-K over tokens, see workspace)
+ * cdt = dtype of A and B.  Epilogue, applied in this order on the fp32 accumulator:
+ *   v = alpha*acc + bias[n]
+ *   act: BF_ACT_NONE | BF_ACT_QUICK_GELU (x*sigmoid(1.702x), clip/model.py:187-189)
+ *        | BF_ACT_ERF_GELU (nn.GELU, modules.py:23); `pre` (cdt, optional) receives v
+ *        before the activation (saved for backward);
+ *        BF_ACT_ERF_GELU_GRAD: v *= gelu'(aux[m,n]) (aux = saved pre-activation, cdt)
+ *   v += residual[r(m), n]  (fp32; row r = m % resid_mod if resid_mod > 0, else the
+ *        output row)
+ *   out row = (m / rows_in) * rows_out + row_off + m % rows_in   (rows_in = 0: identity)
+ *   C[out row, n] (c_dtype) = v   (or += v when accumulate != 0, fp32 C only);
+ *   c2 (optional, BF16) receives a bf16 copy of v at the same position.
+ * ---------------------------------------------------------------------- */
+enum { BF_ACT_NONE = 0, BF_ACT_QUICK_GELU = 1, BF_ACT_ERF_GELU = 2, BF_ACT_ERF_GELU_GRAD = 3 };
+
+typedef struct bf_gemm_args {
+    const void* a;
+    const void* b;
+    void* c;
+    int m, n, k;
+    int lda, ldb, ldc;       /* leading dimensions in elements                     */
+    int cdt;                 /* dtype of a, b (and of pre / aux)                   */
+    int c_dtype;             /* dtype of c                                         */
+    int trans_a, b_kn;
+    float alpha;
+    const float* bias;       /* [n] or NULL                                        */
+    int act;
+    void* pre;               /* optional [m, ldc] cdt                              */
+    const void* aux;         /* BF_ACT_ERF_GELU_GRAD: [m, ld_aux] cdt              */
+    int ld_aux;
+    const float* residual;   /* optional fp32, leading dimension ld_res            */
+    int ld_res;
+    int resid_mod;
+    int rows_in, rows_out, row_off;
+    int accumulate;
+    void* c2;                /* optional bf16 copy, leading dimension ldc          */
+    int split_k;             /* >1: K is split, fp32 partials go through workspace  */
+    void* workspace;         /* split_k * m * n * 4 bytes when split_k > 1          */
+    size_t workspace_bytes;
+} bf_gemm_args;
+
+int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
+
+/* Column sums  out[n] (+)= sum_m x[m, n]  (bias gradients, LayerNorm partials). */
+int bf_colsum(const void* x, int x_dtype, float* out, int rows, int cols, int ld, int accumulate,
+              bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-head attention on a packed QKV buffer.
+ * Replaces F.multi_head_attention_forward under nn.MultiheadAttention
+ * (models/clip/model.py:196,207-214; causal mask :414-420) and
+ * Attention.forward (models/transformer.py:26-41) incl. its query-row mask.
+ *   qkv [B, L, 3, H, D] cdt (the output of the in-projection GEMM, untouched)
+ *   out [B, L, H*D] cdt      lse [B, H, L] fp32 (log-sum-exp of the scaled, masked
+ *   scores; NULL in inference)
+ *   mask_mode: BF_MASK_NONE | BF_MASK_CAUSAL (key j > query i -> -inf)
+ *            | BF_MASK_QUERY_ROW (row_mask[b, i] == 0 -> the whole score row is
+ *              filled with -1e5, i.e. that query attends uniformly; this is what
+ *              the reference does, transformer.py:33-35)
+ *   D in {32, 48, 64}.
+ * ---------------------------------------------------------------------- */
+enum { BF_MASK_NONE = 0, BF_MASK_CAUSAL = 1, BF_MASK_QUERY_ROW = 2 };
+
+int bf_attention_fwd(const void* qkv, void* out, float* lse, const int32_t* row_mask, int batch,
+                     int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
+                     bf_stream_t stream);
+
+/* dqkv [B, L, 3, H, D] cdt from dout [B, L, H*D] cdt; delta_ws fp32 [B, H, L] scratch. */
+int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                     const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq,
+                     int heads, int head_dim, float scale, int mask_mode, int cdt,
+                     bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Token / patch plumbing.
+ * ---------------------------------------------------------------------- */
+/* im2col for the stride=patch conv (models/clip/model.py:297-299):
+ * img [B, 3, S, S] fp32 -> cols [B*g*g, 3*P*P] cdt, column order (c, ky, kx) =
+ * conv1.weight.flatten(1), row order = row-major patches. */
+int bf_patchify(const float* img, void* cols, int cdt, int batch, int size, int patch,
+                bf_stream_t stream);
+
+/* Vision-token assembly + ln_pre (models/clip/model.py:300-309):
+ * x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b*n+p,:] + pos[1+p]; x = LN(x). */
+int bf_vision_assemble(const float* patches, const float* cls, const float* pos,
+                       const float* gamma, const float* beta, float* x, int batch, int n_patch,
+                       int width, float eps, bf_stream_t stream);
+
+/* Token-embedding gather + positional add (models/clip/model.py:448-450):
+ * x[b,t,:] = table[tokens[b,t],:] + pos[t,:]; ids out of [0, vocab) are an error
+ * flag written to err_flag (device int, may be NULL). */
+int bf_embed_tokens(const int32_t* tokens, const float* table, const float* pos, float* x,
+                    int batch, int ctx, int width, int vocab, int* err_flag, bf_stream_t stream);
+
+/* Fusion-input assembly (models/rgb_clip.py:55,59-66 + models/fusion.py:45-56):
+ *   X[b, 0, :]        = text_token + text_pos[0] + type[0]
+ *   X[b, 1+t, :]      = text_feat[b,t,:] + text_pos[1+t] + type[0]      t < n_text
+ *   X[b, 1+n_text+p,:]= rgb_feat[b,p,:] + rgb_pos[p] + type[1]          p < n_rgb
+ * X is fp32 [B, 1+n_text+n_rgb, dim]; text_feat fp32 (frozen ln_final output),
+ * rgb_feat fp32 (project output incl. bias). */
+int bf_fusion_assemble(const float* text_feat, const float* rgb_feat, const float* text_token,
+                       const float* text_pos, const float* rgb_pos, const float* type_emb, float* x,
+                       int batch, int n_text, int n_rgb, int dim, bf_stream_t stream);
+
+/* Its backward: dX fp32 [B, L, dim] -> d_rgb_feat (cdt, [B*n_rgb, dim]: the dY operand of
+ * project's backward GEMMs) and the batch-reduced parameter gradients (fp32, overwritten):
+ * d_text_token [dim], d_text_pos [1+n_text, dim], d_rgb_pos [n_rgb, dim], d_type [2, dim]. */
+int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt, float* d_text_token,
+                           float* d_text_pos, float* d_rgb_pos, float* d_type, int batch,
+                           int n_text, int n_rgb, int dim, bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Heatmap decoder (collapsed) + BCE.
+ * ConvDecoder (models/modules.py:33-74) has no nonlinearity: its five 1x1 convs fold
+ * into one vector w_eff[D] and scalar b_eff, and its four bilinear x2 upsamples into a
+ * fixed separable operator U [16g, g] (rows sum to 1).  logits = U (tok . w_eff + b_eff) U^T.
+ * ---------------------------------------------------------------------- */
+/* w[5] / b[5]: the conv weights [Cout, Cin] / biases, channels D, D/2, D/2, D/4, D/4, 1.
+ * rows_ws: fp32 scratch >= 4*D floats (keeps the partial products r2..r5 for backward). */
+int bf_decoder_collapse_fwd(const float* const* w, const float* const* b, float* w_eff,
+                            float* b_eff, float* rows_ws, int dim, bf_stream_t stream);
+int bf_decoder_collapse_bwd(const float* const* w, const float* const* b, const float* rows_ws,
+                            const float* g_w_eff, const float* g_b_eff, float* const* dw,
+                            float* const* db, int dim, bf_stream_t stream);
+
+/* low[h, b, p] = tok[b, 1+p, :] . w_eff[h, :] + b_eff[h]     (models/pickplace.py:71 drops
+ * token 0 and lays tokens out as a row-major g x g grid).  tok is fp32 with rows of `dim`
+ * and a batch stride of tok_bstride elements (so the last-modality slice of the fusion
+ * output is used in place); low is head-major fp32 [n_heads, B, n_patch]. */
+int bf_decoder_project(const float* tok, long tok_bstride, const float* w_eff, const float* b_eff,
+                       float* low, int batch, int n_heads, int n_patch, int dim, bf_stream_t stream);
+/* heat[i, :, :] = sigmoid(U low[i] U^T) for i < n_maps (= n_heads * B, head-major)
+ * (models/pickplace.py:108-123), fp32 [n_maps, S, S], S = 16 g;  U fp32 [S, g]. */
+int bf_decoder_upsample_sigmoid(const float* low, const float* U, float* heat, int n_maps, int grid,
+                                bf_stream_t stream);
+/* Backward of sigmoid o upsample: g_low[i] = U^T (d_heat[i] * p (1-p)) U, fp32 [n_maps, g*g]. */
+int bf_decoder_upsample_sigmoid_bwd(const float* heat, const float* d_heat, const float* U,
+                                    float* g_low, int n_maps, int grid, bf_stream_t stream);
+
+/* nn.BCELoss(mean) per head (losses/__init__.py:61,100-103) incl. the -100 log clamp.
+ * heat/target fp32 [B, n_heads, pixels] addressed with the given strides (elements);
+ * loss_part fp32 [n_heads, n_part] partial sums (n_part = bf_bce_parts(batch));
+ * loss[h] = sum * inv_count is finished by bf_bce_finish. */
+int bf_bce_parts(int batch);
+int bf_bce_fwd(const float* heat, const float* target, float* loss_part, int batch, int n_heads,
+               int pixels, long heat_bstride, long heat_hstride, long tgt_bstride,
+               long tgt_hstride, bf_stream_t stream);
+int bf_bce_finish(const float* loss_part, float* loss, int n_heads, int n_part, float inv_count,
+                  bf_stream_t stream);
+/* Backward of BCE(mean) w.r.t. the probabilities, exactly as torch computes it:
+ *   d_heat = gscale[0] * inv_count * (p - t) / max(p (1-p), 1e-12)     (count elements) */
+int bf_bce_bwd(const float* heat, const float* target, const float* gscale, float* d_heat,
+               size_t count, float inv_count, bf_stream_t stream);
+
+/* Backward of bf_decoder_project:
+ *   d_tok[b, 1+p, :] = sum_h g_low[h,b,p] w_eff[h,:], d_tok[b,0,:] = 0   (fp32, overwritten;
+ *   batch stride dtok_bstride)
+ *   g_w_eff[h,:] = sum_{b,p} g_low[h,b,p] tok[b,1+p,:], g_b_eff[h] = sum g_low[h,:,:]
+ *   part_ws: fp32 scratch >= bf_decoder_project_bwd_ws(batch, n_heads, dim) floats. */
+size_t bf_decoder_project_bwd_ws(int batch, int n_heads, int dim);
+int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_eff, const float* g_low,
+                           float* d_tok, long dtok_bstride, float* g_w_eff, float* g_b_eff,
+                           float* part_ws, int batch, int n_heads, int n_patch, int dim,
+                           bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Optimiser (optim/__init__.py:4-14 -> torch.optim.Adam / AdamW) over a flat fp32
+ * arena: all trainable parameters, gradients and both moments live in four
+ * contiguous fp32 buffers of `count` elements, so one launch updates the model.
+ *   step is 1-based; decoupled != 0 selects AdamW's decay.
+ *   shadow (optional, bf16 [count]) receives the bf16 copy of the new parameters
+ *   (the cdt operands of next step's GEMMs).
+ *   grad_scale_dev (optional device fp32 scalar) multiplies the gradient first
+ *   (gradient clipping, __main__.py:148-149; DDP averaging).
+ * ---------------------------------------------------------------------- */
+int bf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
+                 size_t count, int step, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int decoupled, const float* grad_scale_dev,
+                 bf_stream_t stream);
+
+/* sum of squares of x (fp32 [count]) -> out[0] (fp32; partial_ws >= 1024 floats). */
+int bf_sumsq(const float* x, size_t count, float* partial_ws, float* out, bf_stream_t stream);
+/* clip coefficient: out[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))
+ * (torch.nn.utils.clip_grad_norm_, __main__.py:148-149). */
+int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_stream_t stream);
+
+/* Elementwise cast between fp32 and bf16 (count elements). */
+int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,
+            bf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIFOLD_HIP_H */

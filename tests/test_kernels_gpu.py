@@ -1,0 +1,411 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point against a plain PyTorch
+fp32/fp64 CPU formula of the same op (and the oracle where it has one).
+
+Tolerances: the exact (fp32) mode is held to 1e-4 relative or tighter, well inside the
+north-star's 1e-3; the bf16 mode is compared against the same formula evaluated on the
+bf16-ROUNDED operands, so what is left is accumulation order and the final bf16 rounding
+(2^-8 relative), stated per test.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.fixture(scope="module")
+def ops(gpu):
+    from bifold_amd.hip import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def L(gpu):
+    from bifold_amd.hip import lib as _lib
+    return _lib
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,cols", [(7, 512), (197 * 3, 768), (5, 96), (33, 2048)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd(ops, gpu, rows, cols, out_dtype):
+    g = torch.Generator().manual_seed(rows * cols)
+    x = torch.randn(rows, cols, generator=g) * 3 + 0.7
+    w = 1 + 0.2 * torch.randn(cols, generator=g)
+    b = 0.2 * torch.randn(cols, generator=g)
+    ref = F.layer_norm(x.double(), (cols,), w.double(), b.double(), 1e-5)
+    y, mean, rstd = ops.layernorm_fwd(x.to(gpu), w.to(gpu), b.to(gpu), out_dtype, save_stats=True)
+    tol = 2e-6 if out_dtype == torch.float32 else 2 ** -8
+    assert rel_err(y.float(), ref) < tol
+    assert rel_err(mean, x.double().mean(1)) < 1e-5
+    assert rel_err(rstd, 1 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(9, 512), (275 * 2, 768), (40, 96)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_layernorm_bwd(ops, gpu, rows, cols, cdt):
+    g = torch.Generator().manual_seed(1 + rows)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.3).requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(cols, generator=g)).requires_grad_(True)
+    b = (0.2 * torch.randn(cols, generator=g)).requires_grad_(True)
+    dy = torch.randn(rows, cols, generator=g)
+    dres = torch.randn(rows, cols, generator=g)
+    dy_used = bf16_round(dy) if cdt == torch.bfloat16 else dy
+    y = F.layer_norm(x, (cols,), w, b, 1e-5)
+    y.backward(dy_used)
+    ref_dx = x.grad + dres
+    xg = x.detach().to(gpu)
+    _, mean, rstd = ops.layernorm_fwd(xg, w.detach().to(gpu), b.detach().to(gpu), torch.float32, True)
+    dgam = torch.empty(cols, device=gpu)
+    dbet = torch.empty(cols, device=gpu)
+    dx, dxc = ops.layernorm_bwd(dy.to(gpu).to(cdt), xg, w.detach().to(gpu), mean, rstd, dres.to(gpu), cdt,
+                                dgam, dbet)
+    assert rel_err(dx, ref_dx) < 1e-5
+    assert rel_err(dgam, w.grad) < 1e-5
+    assert rel_err(dbet, b.grad) < 1e-5
+    if cdt == torch.bfloat16:
+        assert dxc is not None and rel_err(dxc.float(), ref_dx) < 2 ** -8
+    else:
+        assert dxc is None
+
+
+# ------------------------------------------------------------------ GEMM
+def ref_gemm(a, b, trans_a, b_kn):
+    a = a.double()
+    b = b.double()
+    A = a.t() if trans_a else a
+    B = b if b_kn else b.t()
+    return A @ B
+
+
+GEMM_SHAPES = [  # m, n, k
+    (197 * 2, 768, 768), (100, 128, 64), (275, 1536, 512), (77 * 3, 512, 2048), (130, 256, 192)]
+
+
+@pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt):
+    trans_a = layout[0] == "t"
+    b_kn = layout[1] == "n"
+    if trans_a and m % 8:          # A stored [K, M]: the leading dimension must stay 16-byte aligned
+        m = (m + 7) // 8 * 8
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn((k, m) if trans_a else (m, k), generator=g)
+    b = torch.randn((k, n) if b_kn else (n, k), generator=g)
+    if cdt == torch.bfloat16:
+        a, b = bf16_round(a), bf16_round(b)
+    ref = ref_gemm(a, b, trans_a, b_kn)
+    out = ops.gemm(a.to(gpu).to(cdt), b.to(gpu).to(cdt), trans_a=trans_a, b_kn=b_kn,
+                   out_dtype=torch.float32, split_k=1)
+    assert out.shape == (m, n)
+    assert rel_err(out, ref) < 2e-6 * math.sqrt(k) + 1e-6
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("split", [1, 3, 8])
+def test_gemm_splitk_tn(ops, gpu, cdt, split):
+    """dW = dY^T X with the token dimension (not a multiple of the K tile) split."""
+    g = torch.Generator().manual_seed(5)
+    tokens, n_out, k_in = 275 * 3 + 1, 256, 136
+    dy = torch.randn(tokens, n_out, generator=g)
+    x = torch.randn(tokens, k_in, generator=g)
+    if cdt == torch.bfloat16:
+        dy, x = bf16_round(dy), bf16_round(x)
+    ref = dy.double().t() @ x.double()
+    out = ops.gemm(dy.to(gpu).to(cdt), x.to(gpu).to(cdt), trans_a=True, b_kn=True, out_dtype=torch.float32,
+                   split_k=split)
+    assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["none", "quick", "erf"])
+def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act):
+    g = torch.Generator().manual_seed(11)
+    m, n, k = 200, 384, 128
+    a, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) * k ** -0.5
+    bias = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    if cdt == torch.bfloat16:
+        a, w = bf16_round(a), bf16_round(w)
+    pre = a.double() @ w.double().t() + bias.double()
+    if act == "quick":
+        v = pre * torch.sigmoid(1.702 * pre)
+    elif act == "erf":
+        v = F.gelu(pre)
+    else:
+        v = pre
+    ref = v + res.double()
+    code = {"none": L.ACT_NONE, "quick": L.ACT_QUICK_GELU, "erf": L.ACT_ERF_GELU}[act]
+    got = ops.gemm(a.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=bias.to(gpu), act=code,
+                   want_pre=(act != "none"), residual=res.to(gpu), out_dtype=torch.float32)
+    if act != "none":
+        got, got_pre = got
+        assert rel_err(got_pre.float(), pre) < (2e-6 if cdt == torch.float32 else 2 ** -8)
+    assert rel_err(got, ref) < 5e-6
+    # bf16 output + in-place residual (C aliases the residual)
+    if cdt == torch.bfloat16:
+        o16 = ops.gemm(a.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=bias.to(gpu), act=code,
+                       out_dtype=torch.bfloat16)
+        assert rel_err(o16.float(), v) < 2 ** -8
+    xres = res.to(gpu).clone()
+    ops.gemm(a.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=bias.to(gpu), residual=xres, out=xres)
+    assert rel_err(xres, pre + res.double()) < 5e-6
+
+
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt):
+    g = torch.Generator().manual_seed(13)
+    m, n, k = 3 * 17, 256, 64
+    dy, w = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)     # dX = dY W, W stored [K,N]
+    pre = torch.randn(m, n, generator=g)
+    if cdt == torch.bfloat16:
+        dy, w, pre = bf16_round(dy), bf16_round(w), bf16_round(pre)
+    p = pre.double().requires_grad_(True)
+    F.gelu(p).backward(dy.double() @ w.double())
+    got = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
+                   aux=pre.to(gpu).to(cdt), out_dtype=torch.float32)
+    assert rel_err(got, p.grad) < 1e-5
+    # row remap: 3 batches of 17 rows scattered into [3, 20, n] at row offset 2, + broadcast table
+    table = torch.randn(17, n, generator=g)
+    out = torch.full((3 * 20, n), -7.0, device=gpu)
+    ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, residual=table.to(gpu), resid_mod=17,
+             out=out, rows_in=17, rows_out=20, row_off=2)
+    ref = (dy.double() @ w.double()).reshape(3, 17, n) + table.double()
+    o = out.reshape(3, 20, n).cpu()
+    assert rel_err(o[:, 2:19], ref) < 1e-5
+    assert (o[:, :2] == -7).all() and (o[:, 19:] == -7).all()
+
+
+def test_colsum_and_cast(ops, gpu):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(1234, 768, generator=g)
+    assert rel_err(ops.colsum(x.to(gpu)), x.double().sum(0)) < 1e-5
+    assert rel_err(ops.colsum(x.to(gpu).bfloat16()), bf16_round(x).double().sum(0)) < 1e-5
+    acc = torch.ones(768, device=gpu)
+    ops.colsum(x.to(gpu), out=acc, accumulate=True)
+    assert rel_err(acc, x.double().sum(0) + 1) < 1e-5
+    y = torch.randn(1001, generator=g)
+    assert torch.equal(ops.cast(y.to(gpu), torch.bfloat16).cpu(), y.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------ attention
+def ref_attention(qkv, B, Lq, H, D, scale, mode, row_mask):
+    q, k, v = qkv.double().reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * scale
+    if mode == 1:
+        s = s.masked_fill(torch.ones(Lq, Lq, dtype=torch.bool).triu(1), float("-inf"))
+    if mode == 2:
+        s = s.masked_fill(row_mask[:, None, :, None] == 0, -100000.0)
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * Lq, H * D), torch.logsumexp(s, -1)
+
+
+ATTN_CASES = [  # B, L, H, D, mode
+    (2, 77, 2, 64, 1), (2, 197, 3, 64, 0), (2, 275, 4, 32, 0), (3, 275, 2, 32, 2), (2, 130, 2, 48, 2),
+    (1, 600, 2, 48, 0), (1, 31, 1, 32, 1), (2, 64, 2, 64, 0)]
+
+
+@pytest.mark.parametrize("B,Lq,H,D,mode", ATTN_CASES)
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_attention_fwd(ops, gpu, B, Lq, H, D, mode, cdt):
+    g = torch.Generator().manual_seed(B * Lq + D)
+    qkv = torch.randn(B * Lq, 3 * H * D, generator=g)
+    if cdt == torch.bfloat16:
+        qkv = bf16_round(qkv)
+    row_mask = None
+    if mode == 2:
+        row_mask = (torch.rand(B, Lq, generator=g) > 0.3).int()
+        row_mask[:, 0] = 0
+    ref_o, ref_lse = ref_attention(qkv, B, Lq, H, D, D ** -0.5, mode, row_mask)
+    out, lse = ops.attention_fwd(qkv.to(gpu).to(cdt), B, Lq, H, D, D ** -0.5, mode,
+                                 None if row_mask is None else row_mask.to(gpu), need_lse=True)
+    # bf16: P is rounded to bf16 before P V and the output is bf16
+    assert rel_err(out.float(), ref_o) < (1e-5 if cdt == torch.float32 else 1.5e-2)
+    assert rel_err(lse, ref_lse) < 1e-5
+
+
+@pytest.mark.parametrize("B,Lq,H,D,mode", [(2, 275, 2, 32, 0), (2, 100, 2, 32, 2), (1, 77, 2, 64, 1),
+                                            (2, 90, 2, 48, 2)])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_attention_bwd(ops, gpu, B, Lq, H, D, mode, cdt):
+    g = torch.Generator().manual_seed(Lq + D)
+    qkv = torch.randn(B * Lq, 3 * H * D, generator=g)
+    dout = torch.randn(B * Lq, H * D, generator=g)
+    if cdt == torch.bfloat16:
+        qkv, dout = bf16_round(qkv), bf16_round(dout)
+    row_mask = None
+    if mode == 2:
+        row_mask = (torch.rand(B, Lq, generator=g) > 0.3).int()
+    leaf = qkv.double().requires_grad_(True)
+    ref_o, _ = ref_attention(leaf, B, Lq, H, D, D ** -0.5, mode, row_mask)
+    ref_o.backward(dout.double())
+    qg = qkv.to(gpu).to(cdt)
+    rm = None if row_mask is None else row_mask.to(gpu)
+    out, lse = ops.attention_fwd(qg, B, Lq, H, D, D ** -0.5, mode, rm, need_lse=True)
+    dqkv = ops.attention_bwd(qg, out, dout.to(gpu).to(cdt), lse, B, Lq, H, D, D ** -0.5, mode, rm)
+    assert rel_err(dqkv.float(), leaf.grad) < (2e-5 if cdt == torch.float32 else 2e-2)
+
+
+# ------------------------------------------------------------------ token plumbing
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_patchify_matches_conv(ops, gpu, cdt):
+    g = torch.Generator().manual_seed(23)
+    img = torch.randn(2, 3, 64, 64, generator=g)
+    w = torch.randn(40, 3, 16, 16, generator=g)
+    cols = ops.patchify(img.to(gpu), 16, cdt)
+    ref = F.conv2d(img, w, stride=16).flatten(2).transpose(1, 2).reshape(-1, 40)
+    got = cols.float().cpu() @ w.flatten(1).t()
+    assert rel_err(got, ref) < (1e-5 if cdt == torch.float32 else 1e-2)
+    assert torch.equal(cols.float().cpu(), (bf16_round(cols.float().cpu()) if cdt == torch.bfloat16
+                                            else cols.cpu()))
+
+
+def test_vision_assemble_embed_fusion(ops, gpu):
+    g = torch.Generator().manual_seed(29)
+    B, n, W = 3, 16, 128
+    patches, cls, pos = torch.randn(B * n, W, generator=g), torch.randn(W, generator=g), torch.randn(n + 1, W, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(W, generator=g), 0.1 * torch.randn(W, generator=g)
+    x = torch.cat([cls.expand(B, 1, W), patches.reshape(B, n, W)], 1) + pos
+    ref = F.layer_norm(x, (W,), gam, bet, 1e-5)
+    got = ops.vision_assemble(patches.to(gpu), cls.to(gpu), pos.to(gpu), gam.to(gpu), bet.to(gpu), B, n)
+    assert rel_err(got.reshape(B, n + 1, W), ref) < 2e-6
+    # embedding
+    table, tpos = torch.randn(50, 64, generator=g), torch.randn(7, 64, generator=g)
+    tok = torch.randint(0, 50, (B, 7), generator=g).int()
+    flag = torch.zeros(1, dtype=torch.int32, device=gpu)
+    e = ops.embed_tokens(tok.to(gpu), table.to(gpu), tpos.to(gpu), flag)
+    assert torch.equal(e.reshape(B, 7, 64).cpu(), table[tok.long()] + tpos)
+    assert flag.item() == 0
+    bad = tok.clone(); bad[0, 0] = 50
+    ops.embed_tokens(bad.to(gpu), table.to(gpu), tpos.to(gpu), flag)
+    assert flag.item() == 1
+    # fusion assemble + backward
+    nt, nr, D = 5, 9, 64
+    tf, rf = torch.randn(B * nt, D, generator=g), torch.randn(B * nr, D, generator=g)
+    tt, tp = torch.randn(D, generator=g), torch.randn(nt + 1, D, generator=g)
+    rp, ty = torch.randn(nr, D, generator=g), torch.randn(2, D, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (tf, rf, tt, tp, rp, ty)]
+    tf_, rf_, tt_, tp_, rp_, ty_ = leaves
+    xt = torch.cat([tt_.expand(B, 1, D), tf_.reshape(B, nt, D)], 1) + tp_ + ty_[0]
+    xr = rf_.reshape(B, nr, D) + rp_ + ty_[1]
+    xref = torch.cat([xt, xr], 1)
+    got = ops.fusion_assemble(*(t.to(gpu) for t in (tf, rf, tt, tp, rp, ty)), B, nt, nr)
+    assert rel_err(got.reshape(B, 1 + nt + nr, D), xref) < 1e-6
+    dx = torch.randn(B, 1 + nt + nr, D, generator=g)
+    xref.backward(dx)
+    d_tt, d_tp = torch.empty(D, device=gpu), torch.empty(nt + 1, D, device=gpu)
+    d_rp, d_ty = torch.empty(nr, D, device=gpu), torch.empty(2, D, device=gpu)
+    d_rgb = ops.fusion_assemble_bwd(dx.to(gpu), torch.float32, d_tt, d_tp, d_rp, d_ty, B, nt, nr)
+    assert rel_err(d_rgb, rf_.grad) < 1e-6
+    assert rel_err(d_tt, tt_.grad) < 1e-5 and rel_err(d_tp, tp_.grad) < 1e-5
+    assert rel_err(d_rp, rp_.grad) < 1e-5 and rel_err(d_ty, ty_.grad) < 1e-5
+
+
+# ------------------------------------------------------------------ decoder + BCE
+@pytest.mark.parametrize("dim,grid,heads", [(512, 14, 2), (96, 3, 4), (768, 24, 1)])
+def test_decoder_collapsed_matches_as_written(ops, gpu, dim, grid, heads):
+    from oracle import bifold_oracle as O
+    from bifold_amd.models.decoder_math import upsample_operator
+    g = torch.Generator().manual_seed(dim + grid)
+    B = 2
+    state = {k: v for k, v in O.make_tail_state(g, dim=dim, depth=0, is_bimanual=(heads == 4)).items()
+             if "decoder" in k}
+    names = O.decoder_heads(heads == 4)[:heads]
+    tok = torch.randn(B, 7 + grid * grid + 1, dim, generator=g)       # slice [7:] is the image modality
+    img = tok[:, 7:]
+    feat = img[:, 1:].reshape(B, grid, grid, dim).permute(0, 3, 1, 2)
+    chans = [dim, dim // 2, dim // 2, dim // 4, dim // 4, 1]
+    U = upsample_operator(grid).to(gpu)
+    assert rel_err(U, O.upsample_operator(grid)) < 1e-7
+    w_eff = torch.empty(heads, dim, device=gpu)
+    b_eff = torch.empty(heads, device=gpu)
+    rows_ws = torch.empty(heads, 4 * dim, device=gpu)
+    params = []
+    leaves = {}
+    for h, nme in enumerate(names):
+        ws = [state[f"pick_place.{nme}_decoder.decoder_net.{i}.weight"].reshape(chans[j + 1], chans[j])
+              for j, i in enumerate((0, 2, 4, 6, 8))]
+        bs = [state[f"pick_place.{nme}_decoder.decoder_net.{i}.bias"] for i in (0, 2, 4, 6, 8)]
+        params.append(([w.to(gpu).contiguous() for w in ws], [b.to(gpu) for b in bs]))
+        ops.decoder_collapse_fwd(params[-1][0], params[-1][1], w_eff[h], b_eff[h:h + 1], rows_ws[h])
+    tok_g = tok.to(gpu)
+    L_all = tok.shape[1]
+    img_ptr_view = tok_g[:, 7:]
+    low = ops.decoder_project(img_ptr_view, L_all * dim, w_eff, b_eff, B, heads, grid * grid, dim)
+    heat = ops.decoder_upsample_sigmoid(low, U, heads * B, grid).reshape(heads, B, grid * 16, grid * 16)
+    # reference: the decoder as written, with autograd for the backward check
+    leaf_tok = tok.clone().requires_grad_(True)
+    st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+    feat = leaf_tok[:, 8:].reshape(B, grid, grid, dim).permute(0, 3, 1, 2)
+    refs = [torch.sigmoid(O.conv_decoder_logits(st, f"pick_place.{n}_decoder.", feat).squeeze(1)) for n in names]
+    for h in range(heads):
+        assert rel_err(heat[h], refs[h]) < 2e-5
+    d_heat = torch.randn(heads, B, grid * 16, grid * 16, generator=g) * 1e-3
+    torch.autograd.backward(refs, [d_heat[h] for h in range(heads)])
+    g_low = ops.decoder_upsample_sigmoid_bwd(heat, d_heat.to(gpu), U, heads * B, grid)
+    d_tok = torch.full((B, L_all, dim), 5.0, device=gpu)
+    g_w, g_b = torch.empty(heads, dim, device=gpu), torch.empty(heads, device=gpu)
+    ops.decoder_project_bwd(img_ptr_view, L_all * dim, w_eff, g_low, d_tok[:, 7:], L_all * dim, g_w, g_b, B,
+                            heads, grid * grid, dim)
+    assert rel_err(d_tok[:, 7:], leaf_tok.grad[:, 7:]) < 5e-5
+    assert (d_tok[:, :7] == 5.0).all()
+    for h, nme in enumerate(names):
+        dws = [torch.empty_like(w) for w in params[h][0]]
+        dbs = [torch.empty_like(b) for b in params[h][1]]
+        ops.decoder_collapse_bwd(params[h][0], params[h][1], rows_ws[h], g_w[h], g_b[h:h + 1], dws, dbs)
+        for j, i in enumerate((0, 2, 4, 6, 8)):
+            rw = st[f"pick_place.{nme}_decoder.decoder_net.{i}.weight"].grad.flatten(1)
+            rb = st[f"pick_place.{nme}_decoder.decoder_net.{i}.bias"].grad
+            assert rel_err(dws[j], rw) < 1e-4, (nme, i)
+            assert rel_err(dbs[j], rb) < 1e-4, (nme, i)
+
+
+def test_bce_forward_backward(ops, gpu):
+    g = torch.Generator().manual_seed(31)
+    p = torch.rand(5, 64, 64, generator=g)
+    t = torch.rand(5, 64, 64, generator=g)
+    p[0, 0, :4] = torch.tensor([0.0, 1.0, 1e-30, 1.0 - 1e-7])       # clamp edges
+    t[0, 0, :4] = torch.tensor([1.0, 0.0, 1.0, 0.0])
+    leaf = p.clone().requires_grad_(True)
+    ref = torch.nn.BCELoss()(leaf, t)
+    (ref * 0.7).backward()
+    loss = ops.bce_mean(p.to(gpu), t.to(gpu))
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    d = ops.bce_mean_bwd(p.to(gpu), t.to(gpu), torch.tensor([0.7], device=gpu))
+    assert rel_err(d, leaf.grad) < 1e-6
+
+
+# ------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("decoupled,wd", [(False, 0.0), (True, 0.01), (False, 0.01)])
+def test_adam_matches_torch(ops, gpu, decoupled, wd):
+    g = torch.Generator().manual_seed(37)
+    n = 4096 + 4
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref_p], lr=1e-3, weight_decay=wd)
+    p, m, v = p0.to(gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=gpu)
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=g)
+        ref_p.grad = gr.clone()
+        opt.step()
+        ops.adam_step(p, gr.to(gpu), m, v, shadow, step, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled)
+    assert rel_err(p, ref_p.detach()) < 1e-6
+    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+    ss = ops.sumsq(p)
+    assert abs(ss.item() - (p.double() ** 2).sum().item()) < 1e-4 * ss.item()
+    c = ops.clip_coef(ss, 1.0)
+    assert abs(c.item() - min(1.0, 1.0 / (math.sqrt(ss.item()) + 1e-6))) < 1e-6
