@@ -1,0 +1,204 @@
+"""Frozen CLIP image/text towers on libbifold_hip.
+
+Parameter names follow OpenAI CLIP's state dict (the reference vendors it under
+bifold/models/clip/model.py; key list in SURVEY.md §8b), so a CLIP checkpoint loads with
+`load_state_dict`.  Only what BiFold uses is computed: per-token embeddings of both towers
+(`forward_with_embeddings` model.py:296-317, `encode_text_with_embeddings` :447-461) --
+no pooling, no output projections, no logits.  Both towers are frozen in BiFold
+(models/rgb_clip.py:31), so this file is forward-only and keeps no activations.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from ..hip import lib as L
+from ..hip import ops
+from .arena import ParamArena
+from .params import add_param, layernorm_init
+
+# Hyper-parameters that `build_model` (clip/model.py:509-556) infers from the published
+# checkpoints of each name in clip/__init__.py:_MODELS (ViT variants only: the ResNet
+# towers are reachable only through the out-of-scope text_unet model).
+CLIP_CONFIGS: Dict[str, Dict[str, int]] = {
+    "ViT-B/32": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768,
+                     vision_patch_size=32, context_length=77, vocab_size=49408, transformer_width=512,
+                     transformer_heads=8, transformer_layers=12),
+    "ViT-B/16": dict(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768,
+                     vision_patch_size=16, context_length=77, vocab_size=49408, transformer_width=512,
+                     transformer_heads=8, transformer_layers=12),
+    "ViT-L/14": dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024,
+                     vision_patch_size=14, context_length=77, vocab_size=49408, transformer_width=768,
+                     transformer_heads=12, transformer_layers=12),
+    "ViT-L/14@336px": dict(embed_dim=768, image_resolution=336, vision_layers=24, vision_width=1024,
+                           vision_patch_size=14, context_length=77, vocab_size=49408,
+                           transformer_width=768, transformer_heads=12, transformer_layers=12),
+}
+_MODELS = CLIP_CONFIGS  # the name the reference asserts against (rgb_clip.py:29)
+
+
+class CLIPEncoder(nn.Module):
+    def __init__(self, *, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size,
+                 context_length, vocab_size, transformer_width, transformer_heads, transformer_layers):
+        super().__init__()
+        self.cfg = dict(embed_dim=embed_dim, image_resolution=image_resolution, vision_layers=vision_layers,
+                        vision_width=vision_width, vision_patch_size=vision_patch_size,
+                        context_length=context_length, vocab_size=vocab_size,
+                        transformer_width=transformer_width, transformer_heads=transformer_heads,
+                        transformer_layers=transformer_layers)
+        vw, tw, p = vision_width, transformer_width, vision_patch_size
+        g = image_resolution // p
+        self.grid = g
+        self.vision_heads = vw // 64                      # clip/model.py:351
+        self.text_heads = transformer_heads
+        self.vision_layers, self.text_layers = vision_layers, transformer_layers
+        self.vision_width, self.text_width = vw, tw
+        self.patch = p
+        self.context_length = context_length
+
+        def rn(*shape, std):
+            return torch.randn(*shape) * std
+
+        # same initial scales as CLIP.__init__/initialize_parameters (clip/model.py:250-262,380-412)
+        fan = 3 * p * p
+        add_param(self, "visual.conv1.weight", torch.empty(vw, 3, p, p).uniform_(-fan ** -0.5, fan ** -0.5))
+        add_param(self, "visual.class_embedding", rn(vw, std=vw ** -0.5))
+        add_param(self, "visual.positional_embedding", rn(g * g + 1, vw, std=vw ** -0.5))
+        add_param(self, "visual.proj", rn(vw, embed_dim, std=vw ** -0.5))
+        for ln in ("ln_pre", "ln_post"):
+            for k, v in layernorm_init(vw).items():
+                add_param(self, f"visual.{ln}.{k}", v)
+        self._blocks("visual.transformer.resblocks", vw, vision_layers)
+        self._blocks("transformer.resblocks", tw, transformer_layers)
+        add_param(self, "token_embedding.weight", rn(vocab_size, tw, std=0.02))
+        add_param(self, "positional_embedding", rn(context_length, tw, std=0.01))
+        for k, v in layernorm_init(tw).items():
+            add_param(self, f"ln_final.{k}", v)
+        add_param(self, "text_projection", rn(tw, embed_dim, std=tw ** -0.5))
+        add_param(self, "logit_scale", torch.tensor(math.log(1 / 0.07)))
+        self.transformer.width = tw                          # read by RGBOnly (rgb_clip.py:32)
+        self.visual.output_width = vw
+        self._arena: Optional[ParamArena] = None
+        self._err_flag: Optional[torch.Tensor] = None
+
+    def _blocks(self, prefix: str, width: int, layers: int):
+        proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+        fc_std = (2 * width) ** -0.5
+        bound = width ** -0.5
+        for i in range(layers):
+            b = f"{prefix}.{i}."
+            add_param(self, b + "attn.in_proj_weight", torch.randn(3 * width, width) * width ** -0.5)
+            add_param(self, b + "attn.in_proj_bias", torch.zeros(3 * width))
+            add_param(self, b + "attn.out_proj.weight", torch.randn(width, width) * proj_std)
+            add_param(self, b + "attn.out_proj.bias", torch.zeros(width))
+            for ln in ("ln_1", "ln_2"):
+                for k, v in layernorm_init(width).items():
+                    add_param(self, f"{b}{ln}.{k}", v)
+            add_param(self, b + "mlp.c_fc.weight", torch.randn(4 * width, width) * fc_std)
+            add_param(self, b + "mlp.c_fc.bias", torch.empty(4 * width).uniform_(-bound, bound))
+            add_param(self, b + "mlp.c_proj.weight", torch.randn(width, 4 * width) * proj_std)
+            add_param(self, b + "mlp.c_proj.bias", torch.empty(width).uniform_(-0.5 * bound, 0.5 * bound))
+
+    # ------------------------------------------------------------------ runtime
+    def _runtime(self, cdt: torch.dtype) -> ParamArena:
+        a = self._arena
+        if a is None or not a.still_bound() or (cdt != torch.float32 and a.shadow is None):
+            a = ParamArena(self.named_parameters(), with_grad=False, with_shadow=(cdt != torch.float32))
+            self._arena = a
+        a.sync_shadow()
+        return a
+
+    def _w(self, name: str, cdt: torch.dtype) -> torch.Tensor:
+        return self._arena.operand(self.get_parameter(name), cdt)
+
+    def _f(self, name: str) -> torch.Tensor:
+        return self.get_parameter(name).data
+
+    def _tower(self, x: torch.Tensor, prefix: str, layers: int, heads: int, batch: int, seq: int,
+               cdt: torch.dtype, causal: bool) -> torch.Tensor:
+        """ResidualAttentionBlock x layers (clip/model.py:192-219) on the fp32 residual stream
+        x [B*L, W]; every GEMM is fused with its bias / QuickGELU / residual epilogue."""
+        width = x.shape[1]
+        d = width // heads
+        mode = L.MASK_CAUSAL if causal else L.MASK_NONE
+        for i in range(layers):
+            b = f"{prefix}.{i}."
+            h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_1.weight"), self._f(b + "ln_1.bias"), cdt)
+            qkv = ops.gemm(h, self._w(b + "attn.in_proj_weight", cdt), bias=self._f(b + "attn.in_proj_bias"))
+            o, _ = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mode)
+            ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"),
+                     residual=x, out=x)
+            h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
+            a = ops.gemm(h, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
+                         act=L.ACT_QUICK_GELU)
+            ops.gemm(a, self._w(b + "mlp.c_proj.weight", cdt), bias=self._f(b + "mlp.c_proj.bias"),
+                     residual=x, out=x)
+        return x
+
+    @torch.no_grad()
+    def encode_image_with_embeddings(self, img: torch.Tensor, cdt: torch.dtype, out_dtype=None):
+        """[B,3,S,S] fp32 -> ln_post(tokens) [B*(g*g+1), W] (clip/model.py:296-317)."""
+        self._runtime(cdt)
+        batch, _, size, _ = img.shape
+        if size != self.grid * self.patch:
+            raise ValueError(f"image size {size} != {self.grid * self.patch} expected by the vision tower")
+        n = self.grid * self.grid
+        vw = self.vision_width
+        cols = ops.patchify(img.contiguous(), self.patch, cdt)
+        wconv = self._w("visual.conv1.weight", cdt).view(vw, -1)
+        patches = ops.gemm(cols, wconv, out_dtype=torch.float32)
+        x = ops.vision_assemble(patches, self._f("visual.class_embedding"),
+                                self._f("visual.positional_embedding"), self._f("visual.ln_pre.weight"),
+                                self._f("visual.ln_pre.bias"), batch, n)
+        x = self._tower(x, "visual.transformer.resblocks", self.vision_layers, self.vision_heads, batch,
+                        n + 1, cdt, causal=False)
+        y, _, _ = ops.layernorm_fwd(x, self._f("visual.ln_post.weight"), self._f("visual.ln_post.bias"),
+                                    out_dtype or cdt)
+        return y
+
+    @torch.no_grad()
+    def encode_text_with_embeddings(self, tokens: torch.Tensor, cdt: torch.dtype):
+        """[B,ctx] int -> ln_final(tokens) fp32 [B*ctx, W] (clip/model.py:447-461)."""
+        self._runtime(cdt)
+        if tokens.dtype != torch.int32:
+            tokens = tokens.to(torch.int32)
+        tokens = tokens.contiguous()
+        batch, ctx = tokens.shape
+        if ctx != self.context_length:
+            raise ValueError(f"instruction length {ctx} != CLIP context length {self.context_length}")
+        if self._err_flag is None or self._err_flag.device != tokens.device:
+            self._err_flag = torch.zeros(1, dtype=torch.int32, device=tokens.device)
+        x = ops.embed_tokens(tokens, self._f("token_embedding.weight"), self._f("positional_embedding"),
+                             self._err_flag)
+        x = self._tower(x, "transformer.resblocks", self.text_layers, self.text_heads, batch, ctx, cdt,
+                        causal=True)
+        y, _, _ = ops.layernorm_fwd(x, self._f("ln_final.weight"), self._f("ln_final.bias"), torch.float32)
+        return y
+
+    def check_token_ids(self) -> None:
+        """Raise if any forward since the last call saw a token id outside the vocabulary
+        (device flag; reading it synchronises, so it is not called on the hot path)."""
+        if self._err_flag is not None and int(self._err_flag.item()) != 0:
+            self._err_flag.zero_()
+            raise IndexError("instruction contains a token id outside the CLIP vocabulary")
+
+
+def load(name: str, device="cpu", checkpoint: Optional[str] = None, **_):
+    """Stand-in for clip.load (clip/__init__.py:117-176), which downloads weights: there is
+    no network here, so the tower is built from its hyper-parameters and filled from
+    `checkpoint` (a state dict saved with torch.save) when one is given."""
+    if name not in CLIP_CONFIGS:
+        raise RuntimeError(f"Model {name} not found; available models = {list(CLIP_CONFIGS)}")
+    model = CLIPEncoder(**CLIP_CONFIGS[name])
+    if checkpoint:
+        sd = torch.load(checkpoint, map_location="cpu")
+        sd = {k: v.float() for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+        model.load_state_dict(sd, strict=False)
+    else:
+        warnings.warn(f"CLIP {name}: no checkpoint given, using random initialisation "
+                      f"(set model.clip_checkpoint=<state_dict.pt> to load weights)")
+    return model.eval(), None

@@ -1,0 +1,276 @@
+"""Fusion transformer + pick/place heatmap heads on libbifold_hip, with a hand-written
+backward pass.
+
+Parameter containers keep the reference's state-dict keys:
+  pick_place.fusion.token_type_embeddings.weight                       (models/fusion.py:15)
+  pick_place.fusion.transformer_encoder.layers.{i}.0.norm.{weight,bias}   PreNorm(Attention)
+  ...layers.{i}.0.fn.to_qkv.weight / .0.fn.to_out.0.{weight,bias}     (models/transformer.py:19-24)
+  ...layers.{i}.1.norm.* / .1.fn.net.0.* / .1.fn.net.3.*              (models/modules.py:21-27)
+  pick_place.{pick,place | left_pick,...}_decoder.decoder_net.{0,2,4,6,8}.{weight,bias}
+The compute is one autograd.Function for the whole trainable tail of RGBOnly:
+project -> token assembly -> depth x (LN, QKV GEMM, attention, out-proj(+res), LN, FC1(+GELU),
+FC2(+res)) -> collapsed decoder -> sigmoid; its backward replays the chain with fused
+epilogues and writes parameter gradients straight into the flat gradient arena.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from ..hip import lib as L
+from ..hip import ops
+from . import Components
+from .arena import ParamArena
+from .decoder_math import upsample_operator
+from .params import add_param, layernorm_init, linear_init
+
+DEC_IDX = (0, 2, 4, 6, 8)
+
+
+def head_names(is_bimanual: bool) -> List[str]:
+    """Decoder order of PickPlaceConvDecoder (models/pickplace.py:34-47)."""
+    return ["left_pick", "right_pick", "left_place", "right_place"] if is_bimanual else ["pick", "place"]
+
+
+class ConcatTransformer(nn.Module):
+    """Parameter container of the concat-fusion transformer (models/fusion.py:8-33)."""
+
+    def __init__(self, dim, heads, depth, dropout, mlp_ratio, num_modalities=2, num_registers=0, **kwargs):
+        super().__init__()
+        if dropout != 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (all shipped configs use 0)")
+        if num_registers:
+            raise NotImplementedError("register tokens are not used by any shipped config")
+        if dim % heads:
+            raise ValueError("dim must be divisible by heads")
+        self.dim, self.heads, self.depth = dim, heads, depth
+        self.dim_head = dim // heads
+        self.mlp_dim = dim * mlp_ratio
+        self.num_modalities = num_modalities
+        add_param(self, "token_type_embeddings.weight", torch.randn(num_modalities, dim) * 0.02)
+        for i in range(depth):
+            b = f"transformer_encoder.layers.{i}."
+            for n in ("0.norm", "1.norm"):
+                for k, v in layernorm_init(dim).items():
+                    add_param(self, f"{b}{n}.{k}", v)
+            add_param(self, b + "0.fn.to_qkv.weight", linear_init(3 * dim, dim, bias=False)["weight"])
+            for k, v in linear_init(dim, dim).items():
+                add_param(self, f"{b}0.fn.to_out.0.{k}", v)
+            for k, v in linear_init(self.mlp_dim, dim).items():
+                add_param(self, f"{b}1.fn.net.0.{k}", v)
+            for k, v in linear_init(dim, self.mlp_dim).items():
+                add_param(self, f"{b}1.fn.net.3.{k}", v)
+
+    def layer_params(self, i: int) -> Dict[str, nn.Parameter]:
+        lay = self.transformer_encoder.layers._modules[str(i)]
+        a, f = lay._modules["0"], lay._modules["1"]
+        return dict(g1=a.norm.weight, b1=a.norm.bias, wqkv=a.fn.to_qkv.weight,
+                    wo=a.fn.to_out._modules["0"].weight, bo=a.fn.to_out._modules["0"].bias,
+                    g2=f.norm.weight, b2=f.norm.bias, w1=f.fn.net._modules["0"].weight,
+                    bb1=f.fn.net._modules["0"].bias, w2=f.fn.net._modules["3"].weight,
+                    bb2=f.fn.net._modules["3"].bias)
+
+    def forward(self, *inputs, **kwargs):
+        raise NotImplementedError("ConcatTransformer runs inside PickPlaceConvDecoder's fused tail")
+
+
+class PickPlaceConvDecoder(nn.Module):
+    def __init__(self, dim, is_bimanual, fusion_model, num_patches, patch_size, compute_mask=False,
+                 detach_mask=False, **kwargs):
+        super().__init__()
+        if compute_mask:
+            raise NotImplementedError("compute_mask=True (mask head) is off in every shipped config "
+                                      "and not built on the HIP path")
+        self.is_bimanual = is_bimanual
+        self.dim = dim
+        self.num_patches = num_patches
+        self.grid = int(math.isqrt(num_patches))
+        if self.grid * self.grid != num_patches:
+            raise ValueError("num_patches must be a perfect square")
+        self.fusion = Components.get_by_name(fusion_model, dim=dim, **kwargs)
+        self.heads_out = head_names(is_bimanual)
+        chans = [dim, dim // 2, dim // 2, dim // 4, dim // 4, 1]
+        for name in self.heads_out:
+            for j, i in enumerate(DEC_IDX):
+                init = linear_init(chans[j + 1], chans[j])
+                add_param(self, f"{name}_decoder.decoder_net.{i}.weight", init["weight"].view(chans[j + 1], chans[j], 1, 1))
+                add_param(self, f"{name}_decoder.decoder_net.{i}.bias", init["bias"])
+        self._U: Optional[torch.Tensor] = None
+
+    def decoder_params(self, name: str):
+        net = self._modules[f"{name}_decoder"].decoder_net
+        ws = [net._modules[str(i)].weight for i in DEC_IDX]
+        bs = [net._modules[str(i)].bias for i in DEC_IDX]
+        return ws, bs
+
+    def upsample_matrix(self, device) -> torch.Tensor:
+        if self._U is None or self._U.device != device:
+            self._U = upsample_operator(self.grid).to(device)
+        return self._U
+
+    def forward(self, *inputs, **kwargs):
+        raise NotImplementedError("use RGBOnly.forward: the fusion/decoder tail is fused with its inputs")
+
+
+# ======================================================================================
+#                                 fused tail: forward
+# ======================================================================================
+class _Ctx:
+    """What the backward needs; plain attributes instead of save_for_backward because the
+    buffers are never exposed to autograd (they are produced and consumed by HIP kernels)."""
+    pass
+
+
+def _w2d(t: torch.Tensor) -> torch.Tensor:
+    return t.view(t.shape[0], -1)
+
+
+def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, save: bool):
+    d = x.shape[1] // heads
+    h1, m1, r1 = ops.layernorm_fwd(x, P["g1"].data, P["b1"].data, cdt, save_stats=save)
+    qkv = ops.gemm(h1, A.operand(P["wqkv"], cdt))
+    o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mask_mode, row_mask, need_lse=save)
+    x2 = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, residual=x, out_dtype=torch.float32)
+    h2, m2, r2 = ops.layernorm_fwd(x2, P["g2"].data, P["b2"].data, cdt, save_stats=save)
+    if save:
+        a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data, act=L.ACT_ERF_GELU, want_pre=True)
+    else:
+        a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data, act=L.ACT_ERF_GELU), None
+    x3 = ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data, residual=x2, out_dtype=torch.float32)
+    saved = None
+    if save:
+        saved = dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, x2=x2, m2=m2, r2=r2, h2=h2,
+                     a_pre=a_pre, a=a)
+    return x3, saved
+
+
+def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask):
+    """dx3 fp32 [M, D] (+ its cdt copy or None in fp32 mode) -> (dx, dx_c) for the layer input."""
+    d = dx3.shape[1] // heads
+    g = A.grad_view
+    op3 = dx3_c if dx3_c is not None else dx3
+    # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
+    da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD, aux=S["a_pre"])
+    ops.gemm(op3, S["a"], trans_a=True, b_kn=True, out=g(P["w2"]))
+    ops.colsum(dx3, out=g(P["bb2"]))
+    dh2 = ops.gemm(da_pre, A.operand(P["w1"], cdt), b_kn=True)
+    ops.gemm(da_pre, S["h2"], trans_a=True, b_kn=True, out=g(P["w1"]))
+    ops.colsum(da_pre, out=g(P["bb1"]))
+    dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]))
+    op2 = dx2_c if dx2_c is not None else dx2
+    # attention:  x2 = x + attn(h1 Wqkv^T) Wo^T + bo
+    do = ops.gemm(op2, A.operand(P["wo"], cdt), b_kn=True)
+    ops.gemm(op2, S["o"], trans_a=True, b_kn=True, out=g(P["wo"]))
+    ops.colsum(dx2, out=g(P["bo"]))
+    dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask)
+    dh1 = ops.gemm(dqkv, A.operand(P["wqkv"], cdt), b_kn=True)
+    ops.gemm(dqkv, S["h1"], trans_a=True, b_kn=True, out=g(P["wqkv"]))
+    return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
+
+
+class RGBTailFn(torch.autograd.Function):
+    """project + token assembly + fusion transformer + decoders for RGBOnly
+    (models/rgb_clip.py:52-73 -> fusion.py:35-64 -> pickplace.py:59-124)."""
+
+    @staticmethod
+    def forward(ctx, model, text_feat, vis_feat, *params):
+        # `params` only tie the graph to the trainable parameters; values are read from the arena.
+        pp: PickPlaceConvDecoder = model.pick_place
+        fus: ConcatTransformer = pp.fusion
+        A: ParamArena = model.trainable_arena()
+        cdt = model.compute_dtype
+        save = any(ctx.needs_input_grad)      # False under no_grad (inference / get_action)
+        dim, nh = pp.dim, len(pp.heads_out)
+        n_rgb = pp.num_patches + 1
+        batch = vis_feat.shape[0] // n_rgb
+        n_text = text_feat.shape[0] // batch
+        seq = 1 + n_text + n_rgb
+        dev = vis_feat.device
+
+        rgb_feat = ops.gemm(vis_feat, A.operand(model.project.weight, cdt), bias=model.project.bias.data,
+                            out_dtype=torch.float32)
+        x = ops.fusion_assemble(text_feat, rgb_feat, model.text_token.data.view(-1),
+                                model.text_pos_embedding.data.view(-1, dim),
+                                model.rgb_pos_embedding.data.view(-1, dim),
+                                fus.token_type_embeddings.weight.data, batch, n_text, n_rgb)
+        del rgb_feat
+        layers = []
+        for i in range(fus.depth):
+            x, s = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, L.MASK_NONE, None, save)
+            layers.append(s)
+        # decoder: collapse the five 1x1 convs per head, project the image tokens, upsample, sigmoid
+        w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+        b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
+        rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
+        for h, name in enumerate(pp.heads_out):
+            ws, bs = pp.decoder_params(name)
+            ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
+                                     rows_ws[h])
+        xv = x.view(batch, seq, dim)
+        img_tok = xv[:, 1 + n_text:]                       # last modality's tokens, used in place
+        low = ops.decoder_project(img_tok, seq * dim, w_eff, b_eff, batch, nh, pp.num_patches, dim)
+        U = pp.upsample_matrix(dev)
+        heat = ops.decoder_upsample_sigmoid(low, U, nh * batch, pp.grid)
+        size = pp.grid * 16
+        heat = heat.view(nh, batch, size, size)
+        if save:
+            c = _Ctx()
+            c.model, c.layers, c.vis_feat, c.x_out = model, layers, vis_feat, x
+            c.w_eff, c.rows_ws, c.heat = w_eff, rows_ws, heat
+            c.batch, c.n_text, c.n_rgb, c.seq = batch, n_text, n_rgb, seq
+            ctx.c = c
+        return tuple(heat[h] for h in range(nh))
+
+    @staticmethod
+    def backward(ctx, *d_heats):
+        c: _Ctx = ctx.c
+        model = c.model
+        pp: PickPlaceConvDecoder = model.pick_place
+        fus: ConcatTransformer = pp.fusion
+        A: ParamArena = model.trainable_arena()
+        cdt = model.compute_dtype
+        g = A.grad_view
+        dim, nh = pp.dim, len(pp.heads_out)
+        batch, n_text, n_rgb, seq = c.batch, c.n_text, c.n_rgb, c.seq
+        dev = c.x_out.device
+        U = pp.upsample_matrix(dev)
+        gg = pp.grid * pp.grid
+        # sigmoid o upsample backward, per head (a head the loss ignores contributes zeros)
+        g_low = torch.empty(nh, batch, gg, dtype=torch.float32, device=dev)
+        for h in range(nh):
+            if d_heats[h] is None:
+                g_low[h].zero_()
+            else:
+                dh = d_heats[h].contiguous()
+                gl = ops.decoder_upsample_sigmoid_bwd(c.heat[h], dh, U, batch, pp.grid)
+                g_low[h].copy_(gl.view(batch, gg))
+        dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=dev)
+        g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+        g_b = torch.empty(nh, dtype=torch.float32, device=dev)
+        xv = c.x_out.view(batch, seq, dim)
+        dxv = dx.view(batch, seq, dim)
+        ops.decoder_project_bwd(xv[:, 1 + n_text:], seq * dim, c.w_eff, g_low, dxv[:, 1 + n_text:], seq * dim,
+                                g_w, g_b, batch, nh, pp.num_patches, dim)
+        for h, name in enumerate(pp.heads_out):
+            ws, bs = pp.decoder_params(name)
+            ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], c.rows_ws[h], g_w[h],
+                                     g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
+        dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
+        for i in reversed(range(fus.depth)):
+            dx, dx_c = fusion_layer_bwd(dx, dx_c, c.layers[i], fus.layer_params(i), A, cdt, batch, seq,
+                                        fus.heads, L.MASK_NONE, None)
+            c.layers[i] = None                      # free this layer's activations early
+            model._grad_ready(i)
+        d_rgb = ops.fusion_assemble_bwd(dx, cdt, g(model.text_token).view(-1),
+                                        g(model.text_pos_embedding).view(-1, dim),
+                                        g(model.rgb_pos_embedding).view(-1, dim),
+                                        g(fus.token_type_embeddings.weight), batch, n_text, n_rgb)
+        ops.gemm(d_rgb, c.vis_feat, trans_a=True, b_kn=True, out=g(model.project.weight))
+        ops.colsum(d_rgb, out=g(model.project.bias))
+        model._grad_ready(-1)
+        ctx.c = None
+        # gradients were written into the arena (and attached as .grad) by the kernels
+        return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))

@@ -1,0 +1,177 @@
+"""Optimiser / scheduler plugin surface: mirrors `bifold.optim`
+(reference bifold/optim/__init__.py:4-92).
+
+`Optimizers.get_by_name(cfg, params)` returns a FusedAdam: torch.optim.Adam / AdamW math as
+ONE HIP launch over the flat parameter arena (bf_adam_step), exposing the attributes the
+Trainer touches (`zero_grad`, `step`, `param_groups`, `state_dict`, `load_state_dict`;
+bifold/__main__.py:115,139,150,158,294,319).  `Schedulers.get_by_name` returns None or a
+LinearWarmup that reproduces the reference's LR sequence including its first-step quirk.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from ..hip import ops
+from ..models.arena import ParamArena, arena_of
+
+
+def _cfg_get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _pop_name(cfg):
+    name = cfg["name"] if isinstance(cfg, dict) else cfg.name
+    try:
+        del cfg["name"]
+    except TypeError:
+        del cfg.name
+    return name
+
+
+class FusedAdam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, decoupled=False, **unused):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        if any(not p.is_cuda for p in self.params):
+            raise RuntimeError("FusedAdam updates parameters in HBM: move the model to the GPU first")
+        arena = arena_of(self.params)
+        if arena is None:
+            arena = ParamArena([(f"p{i}", p) for i, p in enumerate(self.params)], with_grad=True,
+                               with_shadow=True)
+        self.arena = arena
+        self.decoupled = bool(decoupled)
+        self.param_groups = [dict(params=self.params, lr=float(lr), betas=tuple(float(b) for b in betas),
+                                  eps=float(eps), weight_decay=float(weight_decay), amsgrad=False,
+                                  maximize=False, foreach=None, capturable=False, differentiable=False,
+                                  fused=True)]
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        self.step_count = 0
+        self.grad_scale: Optional[torch.Tensor] = None       # device scalar: clip coef and/or 1/world
+
+    # -- Trainer-facing API ---------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        """Gradients are OVERWRITTEN by every backward pass of the fused tail (they are not
+        accumulated across backward calls), so there is nothing to clear."""
+        self.grad_scale = None
+
+    def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
+        """torch.nn.utils.clip_grad_norm_ (bifold/__main__.py:148-149) without a host sync: the
+        coefficient stays on the device and is applied inside the Adam kernel."""
+        ss = ops.sumsq(self.arena.grad)
+        self.grad_scale = ops.clip_coef(ss, float(max_norm))
+        return ss
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not supported")
+        g = self.param_groups[0]
+        self.step_count += 1
+        ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.arena.shadow,
+                      self.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                      self.decoupled, self.grad_scale)
+        self.arena.mark_synced()
+
+    # -- checkpoint format of torch.optim.Adam --------------------------------------------
+    def state_dict(self) -> Dict:
+        state = {}
+        if self.step_count > 0:
+            for i, p in enumerate(self.params):
+                o, cnt = self.arena.offsets[self.arena.name_of(p)]
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[o:o + cnt].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + cnt].view(p.shape).clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        group = sd["param_groups"][0]
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in group:
+                self.param_groups[0][k] = tuple(group[k]) if k == "betas" else group[k]
+        steps = set()
+        for i, st in sd.get("state", {}).items():
+            p = self.params[int(i)]
+            o, cnt = self.arena.offsets[self.arena.name_of(p)]
+            self.exp_avg[o:o + cnt].view(p.shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[o:o + cnt].view(p.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; FusedAdam keeps one step counter")
+        self.step_count = steps.pop() if steps else 0
+
+
+class Optimizers:
+    @staticmethod
+    def get_by_name(cfg, params):
+        name = _cfg_get(cfg, "name")
+        if name not in ("adam", "adamw"):
+            raise ValueError(f"Optimizer {name} not recognized")
+        _pop_name(cfg)
+        return FusedAdam(params, decoupled=(name == "adamw"), **cfg)
+
+
+class LinearWarmup:
+    """LR = start + (base - start) * last_step / warmup_steps while last_step <= warmup_steps,
+    then cosine annealing over max_iters - warmup_steps steps (optim/__init__.py:28-92).
+    Quirk kept on purpose: `last_step` starts at -1 and `step()` already runs in __init__, so
+    the first optimiser step uses a NEGATIVE learning rate when warmup_start_lr = 0."""
+
+    def __init__(self, cfg, optimizer, max_iters):
+        self.warmup_steps = int(_cfg_get(cfg, "warmup_portion") * max_iters)
+        self.optimizer = optimizer
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_step = -1
+        start = _cfg_get(cfg, "warmup_start_lr")
+        if isinstance(start, (list, tuple)):
+            assert len(start) == len(self.base_lrs), (
+                f"The length of warmup_start_lr {len(start)} and optimizer.param_group "
+                f"{len(self.base_lrs)} do not correspond")
+            self.warmup_start_lrs = list(start)
+        else:
+            self.warmup_start_lrs = [start] * len(self.base_lrs)
+        self.use_cosine_decay = bool(_cfg_get(cfg, "use_cosine_decay"))
+        self.t_max = max_iters - self.warmup_steps
+        self.cosine_step = 0
+        self.step()
+
+    def get_last_lr(self):
+        return self._last_lr
+
+    def state_dict(self):
+        return {k: v for k, v in self.__dict__.items() if k != "optimizer"}
+
+    def load_state_dict(self, state_dict):
+        self.__dict__.update(state_dict)
+
+    def step(self, epoch=None):
+        if self.last_step <= self.warmup_steps:
+            for g, start, base in zip(self.optimizer.param_groups, self.warmup_start_lrs, self.base_lrs):
+                g["lr"] = start + (base - start) * (self.last_step / self.warmup_steps)
+            self.last_step += 1
+        elif self.use_cosine_decay:
+            # closed form of torch's CosineAnnealingLR (eta_min = 0) started from base_lr
+            self.cosine_step += 1
+            for g, base in zip(self.optimizer.param_groups, self.base_lrs):
+                g["lr"] = base * (1.0 + math.cos(math.pi * self.cosine_step / self.t_max)) / 2.0
+        self._last_lr = [g["lr"] for g in self.optimizer.param_groups]
+
+
+class Schedulers:
+    @staticmethod
+    def get_by_name(cfg, *args, **kwargs):
+        name = _cfg_get(cfg, "name")
+        if name is None:
+            return None
+        if name == "linear_warmup":
+            return LinearWarmup(cfg, *args, **kwargs)
+        raise ValueError(f"Scheduler {name} not recognized")
