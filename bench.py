@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Throughput of BiFold's VLM training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full optimisation step on one synthetic batch per GPU: frozen CLIP ViT-B/16
+image tower + CLIP text tower forward, project + 8-layer fusion transformer + 2 heatmap
+decoders forward AND backward, BCE loss, (gradient all-reduce,) Adam.  Workload =
+BASELINE.json configs[1]: 224x224 RGB + 77-token (32 real) instructions, batch 256 per GPU,
+bf16 MFMA operands with fp32 accumulation.  Inputs are resident in HBM before the timed
+region (PCIe-inclusive rate: see DESIGN.md).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (the bf16 NT GEMM)
+from HIP events recorded on its own stream during the timed steps; `step_roofline` prices
+the whole step with SURVEY.md §8d's 91.49 GFLOP/sample.  `cpu_baseline` (N = 1, rank 0) is
+the CPU oracle timed on this host on a bounded sample of the same workload (B = 4).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GF_PER_SAMPLE = 91.49          # 57.89 fwd + 33.60 bwd (frozen encoders)
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(batch: int, device, seed: int, size: int = 224, ctx: int = 77, vocab: int = 49408):
+    """SURVEY.md §8d inputs, generated directly in HBM."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rgb = torch.randn(batch, 3, size, size, generator=g, device=device)
+    instr = torch.zeros(batch, ctx, dtype=torch.int32, device=device)
+    instr[:, 0] = vocab - 2
+    instr[:, 1:31] = torch.randint(1, vocab - 2, (batch, 30), generator=g, device=device).int()
+    instr[:, 31] = vocab - 1
+    sample = {"rgb": rgb, "instruction": instr}
+    ys = torch.arange(size, device=device, dtype=torch.float32).view(1, size, 1)
+    xs = torch.arange(size, device=device, dtype=torch.float32).view(1, 1, size)
+    for name in ("pick", "place"):
+        c = torch.randint(0, size, (batch, 2), generator=g, device=device).float()
+        sample[f"{name}_heatmap"] = torch.exp(-((xs - c[:, 0].view(-1, 1, 1)) ** 2 +
+                                                (ys - c[:, 1].view(-1, 1, 1)) ** 2) / 50.0).contiguous()
+    return sample
+
+
+def cpu_baseline(steps: int = 2, batch: int = 4):
+    """The CPU oracle (a port of the reference path, pinned against it by tests/golden) on the
+    same workload at B = 4 (BASELINE.json configs[0]), fwd + loss + bwd + Adam, all host cores."""
+    from oracle import bifold_oracle as O
+    gen = torch.Generator().manual_seed(3407)
+    state = {**O.make_clip_state(gen), **O.make_tail_state(gen)}
+    sample = O.synthetic_sample(batch, torch.Generator().manual_seed(3418))
+    keys = [k for k in state if O.is_trainable_key(k)]
+    m = {k: torch.zeros_like(state[k]) for k in keys}
+    v = {k: torch.zeros_like(state[k]) for k in keys}
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        for k in keys:
+            state[k] = state[k].detach().requires_grad_(True)
+        out = O.rgb_clip_forward(state, sample, heads=16)
+        loss, _ = O.bce_gaussmap(out, sample, False)
+        grads = torch.autograd.grad(loss, [state[k] for k in keys])
+        with torch.no_grad():
+            for k, gr in zip(keys, grads):
+                state[k], m[k], v[k] = O.adam_update(state[k].detach(), gr, m[k], v[k], it + 1, 1e-4)
+        times.append(time.perf_counter() - t0)
+    timed = sorted(times[1:])
+    med = timed[len(timed) // 2]
+    return {"value": round(batch / med, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"config A at B={batch} fp32 (BASELINE configs[0]), 1 warm-up + {steps} timed full "
+                      f"steps, median {med:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    from bifold_amd import dist as bdist
+    rank, local_rank, world = bdist.init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from bifold_amd.hip import ops
+    from bifold_amd.losses import Losses
+    from bifold_amd.models import Models
+    from bifold_amd.optim import Optimizers
+
+    torch.manual_seed(3407)                       # identical replicas on every rank
+    cfg = dict(name="rgb_clip", image_size=224, is_bimanual=False, requires_graph=False,
+               text_encoder="ViT-B/16", patch_size=16, depth=8, heads=16, mlp_ratio=4, dropout=0.0,
+               text_dropout=0.0, rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
+               fusion_model="concat_transformer", dtype=args.dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")           # random-init CLIP (no network for weights)
+        model = Models.get_by_name(cfg, device=dev).to(dev)
+    model.train()
+    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))
+    opt = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
+                                 params=[p for p in model.parameters() if p.requires_grad])
+    sample = synthetic_batch(args.batch, dev, seed=3407 + rank)
+
+    sync = None
+    if world > 1:
+        arena = model.trainable_arena()
+        buckets = bdist.layer_buckets(arena.names, arena.offsets, model.pick_place.fusion.depth, arena.count)
+        sync = bdist.GradSync(arena.grad, buckets, model.pick_place.fusion.depth)
+        model.register_grad_ready_hook(sync.on_ready)
+
+    def step():
+        out = model(sample)
+        loss, _ = loss_fn(out, sample)
+        opt.zero_grad()
+        loss.backward()
+        if sync is not None:
+            sync.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer()
+        ops.PROFILER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER = None
+    final_loss = float(loss.item())
+    if not (final_loss == final_loss and abs(final_loss) < 1e6):
+        raise SystemExit(f"training diverged in the bench: loss = {final_loss}")
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        global_batch = args.batch * world
+        ms = 1e3 * elapsed / args.steps
+        value = global_batch * args.steps / elapsed
+        step_tflops = value * GF_PER_SAMPLE / 1e3
+        line = {
+            "metric": "train samples/sec (224x224 RGB + 32-tok instr)",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
+                                   "fusion 8x512 (16 heads) + 2 conv decoders, BCE, Adam; frozen encoders; "
+                                   "random-init weights", "per_gpu_batch": args.batch,
+                       "global_batch": global_batch, "parallelism": f"dp{world}", "final_loss": final_loss},
+            "step_roofline": {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
+                              "flops_per_sample": GF_PER_SAMPLE * 1e9},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = "gemm_bf16_nt" if args.dtype == "bf16" else "gemm_f32_nt"
+            d = summ.get(dom)
+            if d:
+                peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+                line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),
+                                    "peak": peak, "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
+                                    "traffic": None, "launches": d["launches"], "avg_us": round(d["avg_us"], 2),
+                                    "share_of_step": round(d["ms"] / (1e3 * elapsed), 4)}
+            line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
+                                   "tflops": round(v["tflops"], 1),
+                                   "share_of_step": round(v["ms"] / (1e3 * elapsed), 4)}
+                               for k, v in sorted(summ.items())}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

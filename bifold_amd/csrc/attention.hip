@@ -378,6 +378,242 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
 }
 
 // =====================================================================================
+//                               bf16 MFMA backward
+// =====================================================================================
+// One workgroup per (batch, head); wave w owns the 32 keys [32w, 32w+32) and keeps dK^T and
+// dV^T of those keys in accumulators for the whole kernel, so dK/dV need no sum across waves.
+// Per step t it visits query block qb = (w + t) mod nw (staggered, so no two waves add into
+// the same dQ rows in a step; one barrier per step):
+//   S  = Q_qb K_w^T  and  dP = dO_qb V_w^T  with the KEY on the MFMA lane; their accumulators
+//   start at -lse/scale and -delta (row constants), so p = exp2(c S) and dS = p dP need no
+//   further reductions, and P / dS (packed to bf16) ARE the B operands of
+//   dV^T += dO^T P and dK^T += Q^T dS (sums over the accumulator's ROW index, guide §3).
+//   Only dS crosses LDS, once, transposed, for dQ += dS K_w (sum over the lane index).
+// Q, dO, K tiles of the whole sequence live in LDS as bf16 rows of D*2+16 bytes; the
+// transposed operands (Q^T, dO^T, K as B) are read with ds_read_b64_tr_b16.
+template <int D>
+struct BwdCfg {
+    static constexpr int DP = (D + 31) / 32 * 32;
+    static constexpr int KS = D / 16;
+    static constexpr int DB = DP / 32;
+    static constexpr int ROW = D * 2 + 16;
+    static constexpr int MAXW = (D == 32) ? 16 : 8;
+    static size_t lds_bytes(int nw) {
+        const size_t lp = (size_t)nw * 32;
+        return 3 * (lp * ROW + 64) + lp * DP * 4 + (size_t)nw * 32 * 64 + 3 * lp * 4;
+    }
+};
+
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    int L, int H, float scale, int mask_mode) {
+    using Cf = BwdCfg<D>;
+    constexpr int DP = Cf::DP, KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nw = blockDim.x >> 6;
+    const int Lp = nw * 32;
+    char* q_lds = smem;
+    char* do_lds = q_lds + (size_t)Lp * ROW + 64;
+    char* k_lds = do_lds + (size_t)Lp * ROW + 64;
+    float* dq_lds = (float*)(k_lds + (size_t)Lp * ROW + 64);
+    char* ds_img = (char*)(dq_lds + (size_t)Lp * DP);
+    float* lse_s = (float*)(ds_img + (size_t)nw * 32 * 64);
+    float* del_s = lse_s + Lp;
+    int* msk_s = (int*)(del_s + Lp);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int nthreads = blockDim.x;
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+
+    // ---- prologue: stage Q, dO, K (zero rows beyond L), lse, delta, row mask; clear dQ ------
+    for (int idx = threadIdx.x; idx < Lp * (D / 8); idx += nthreads) {
+        const int i = idx / (D / 8), c = idx - i * (D / 8);
+        uint4 qv = make_uint4(0, 0, 0, 0), dv = qv, kv = qv;
+        if (i < L) {
+            qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
+            kv = *(const uint4*)(qkv + qkv_off(b, i, 1, h, L, H, D) + c * 8);
+            dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
+        }
+        *(uint4*)(q_lds + i * ROW + c * 16) = qv;
+        *(uint4*)(do_lds + i * ROW + c * 16) = dv;
+        *(uint4*)(k_lds + i * ROW + c * 16) = kv;
+    }
+    for (int i = threadIdx.x; i < Lp; i += nthreads) {
+        float dl = 0.f, ls = 1e30f;
+        int mk = 0;
+        if (i < L) {
+            const size_t oo = ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+            for (int c = 0; c < D / 8; ++c) {
+                const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
+                const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
+            }
+            ls = lse[((size_t)b * H + h) * L + i];
+            mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
+        }
+        lse_s[i] = ls; del_s[i] = dl; msk_s[i] = mk;
+    }
+    for (int idx = threadIdx.x; idx < Lp * DP; idx += nthreads) dq_lds[idx] = 0.f;
+
+    // this wave's K and V fragments (B operands: B[k = d][col = key]), straight from HBM
+    const int key = w * 32 + r;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (key < L) {
+            kf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
+            vf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[ks][e] = (bf16_t)0.f; vf[ks][e] = (bf16_t)0.f; }
+        }
+    }
+    f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[db][e] = 0.f; dvacc[db][e] = 0.f; }
+    const float inv_len = 1.0f / (float)L;
+    char* my_img = ds_img + w * (32 * 64);
+    __syncthreads();
+
+    for (int t = 0; t < nw; ++t) {
+        int qb = w + t;
+        if (qb >= nw) qb -= nw;
+        const int qrow0 = qb * 32;
+        // causal: a query block entirely before this key block contributes nothing
+        const bool skip = (mask_mode == BF_MASK_CAUSAL) && (qrow0 + 31 < w * 32);
+        if (!skip) {
+            // ---- S and dP with row constants as the initial accumulators ------------------
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *(const float4*)(lse_s + qrow0 + 8 * g + 4 * hh);
+                const float4 d4 = *(const float4*)(del_s + qrow0 + 8 * g + 4 * hh);
+                sacc[4 * g + 0] = -l4.x * inv_scale; sacc[4 * g + 1] = -l4.y * inv_scale;
+                sacc[4 * g + 2] = -l4.z * inv_scale; sacc[4 * g + 3] = -l4.w * inv_scale;
+                pacc[4 * g + 0] = -d4.x; pacc[4 * g + 1] = -d4.y; pacc[4 * g + 2] = -d4.z; pacc[4 * g + 3] = -d4.w;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qa = *(const bf16x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+                const bf16x8 da = *(const bf16x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+            }
+            // ---- P and dS (lane = key column, register = query row) -----------------------
+            const bool key_ok = key < L;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                float p = exp2f(sl2 * sacc[e]);
+                float ds = p * pacc[e] * scale;
+                if (mask_mode == BF_MASK_QUERY_ROW && msk_s[qi]) { p = inv_len; ds = 0.f; }
+                if (!key_ok || (mask_mode == BF_MASK_CAUSAL && key > qi)) { p = 0.f; ds = 0.f; }
+                sacc[e] = p;
+                pacc[e] = ds;
+            }
+            bf16x8 pb[2], dsb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+            // dS image for dQ: [key column][query row], 64-byte rows
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)pacc[4 * g + e];
+                *(bf16x4*)(my_img + r * 64 + (8 * g + 4 * hh) * 2) = v4;
+            }
+            // ---- dV^T += dO^T P ;  dK^T += Q^T dS   (A operands by transposed LDS reads) ----
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row0 = qrow0 + 16 * s + 4 * hh + q4;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                    const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                    const bf16x8 qt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsb[s], dkacc[db], 0, 0, 0);
+                }
+            }
+            // ---- dQ_qb += dS K_w : A = dS^T image (transposed read), B = K rows (transposed read)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                f32x16 dq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int krow = 16 * s + 8 * hh + q4;          // key within the block (natural k order)
+                    const int cq = (16 * (g16 & 1) + 4 * p4) * 2;   // query column in the image
+                    const bf16x8 a = tr_pair(my_img + krow * 64 + cq, my_img + (krow + 4) * 64 + cq);
+                    const int cd = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                    const char* kr = k_lds + (w * 32 + krow) * ROW + cd;
+                    const bf16x8 kb2 = tr_pair(kr, kr + 4 * ROW);
+                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb2, dq, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int qi = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    dq_lds[qi * DP + db * 32 + r] += dq[e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: dK, dV from the accumulators (lane = key, 4 consecutive d per store) -------
+    if (key < L) {
+        bf16_t* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+        bf16_t* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 k4, v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { k4[e] = (bf16_t)dkacc[db][4 * g + e]; v4[e] = (bf16_t)dvacc[db][4 * g + e]; }
+                    *(bf16x4*)(dkp + d0) = k4;
+                    *(bf16x4*)(dvp + d0) = v4;
+                }
+            }
+    }
+    for (int idx = threadIdx.x; idx < L * (D / 8); idx += nthreads) {
+        const int i = idx / (D / 8), c = idx - i * (D / 8);
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)dq_lds[i * DP + c * 8 + e];
+        *(bf16x8*)(dqkv + qkv_off(b, i, 0, h, L, H, D) + c * 8) = o8;
+    }
+}
+
+// =====================================================================================
 //                                        host
 // =====================================================================================
 static int attn_check(const char* who, const void* qkv, int batch, int seq, int heads, int head_dim,
@@ -455,7 +691,32 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     BF_REQUIRE(bf_aligned16(out) && bf_aligned16(dout) && bf_aligned16(dqkv), BF_EALIGN,
                "bf_attention_bwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
-    if (cdt == BF_BF16)
+    const int nw = bf_cdiv(seq, 32);
+    const int maxw = head_dim == 32 ? 16 : 8;
+    const size_t bwd_lds = head_dim == 32 ? BwdCfg<32>::lds_bytes(nw)
+                         : head_dim == 48 ? BwdCfg<48>::lds_bytes(nw) : BwdCfg<64>::lds_bytes(nw);
+    // the one-workgroup-per-(batch, head) kernel needs the whole sequence in the 160 KB LDS;
+    // longer sequences take the (slow, VALU) tiled kernels below
+    if (cdt == BF_BF16 && nw <= maxw && bwd_lds <= 160 * 1024) {
+        dim3 grid(batch * heads), block(nw * 64);
+#define BWD_MFMA(DD)                                                                                \
+    do {                                                                                            \
+        const size_t lds = BwdCfg<DD>::lds_bytes(nw);                                               \
+        static size_t lds_set = 0;                                                                  \
+        if (lds > lds_set) {                                                                        \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD>,                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            lds_set = lds;                                                                          \
+        }                                                                                           \
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel<DD>, grid, block, lds, s, (const bf16_t*)qkv,       \
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv, seq, \
+                           heads, scale, mask_mode);                                                \
+    } while (0)
+        if (head_dim == 32) BWD_MFMA(32);
+        else if (head_dim == 48) BWD_MFMA(48);
+        else BWD_MFMA(64);
+#undef BWD_MFMA
+    } else if (cdt == BF_BF16)
         attn_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
                                 head_dim, scale, mask_mode, s);
     else

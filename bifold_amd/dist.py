@@ -1,0 +1,125 @@
+"""Data-parallel gradient synchronisation for the BiFold training step (new work: the
+reference is single-process).
+
+One process per GPU; parameters and optimiser state are replicated, every rank draws a
+disjoint minibatch, and the only exchange is ONE sum of the trainable gradients per step.
+Because all gradients live in a flat arena (models/arena.py), a bucket is just a slice:
+no flatten / unflatten copies.  Buckets follow the backward order of the fused tail --
+decoders, then fusion layers depth-1 ... 0, then the input-side parameters -- and each is
+all-reduced (RCCL over xGMI; `nccl` backend == RCCL on ROCm) on a side HIP stream as soon
+as the backward pass reports it complete, while the remaining layers are still computing.
+The optimiser waits on the last bucket only.
+
+Each rank's loss is a mean over its local batch, so the AVERAGE of the per-rank gradients
+equals the single-process gradient of the concatenated batch.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(device_backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world).  Reads the torchrun environment; a bare `python bench.py`
+    is world 1 and needs no process group."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = device_backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def layer_buckets(names: List[str], offsets, depth: int, count: int) -> List[Tuple[int, int]]:
+    """Arena slices in the order the fused backward completes them.
+    Index 0: everything after the last fusion layer (the decoders); 1..depth: fusion layers
+    depth-1 ... 0; depth+1: everything before layer 0 (tokens, positional embeddings,
+    project, type embeddings).  `offsets[name] = (start, numel)`; slices cover the
+    256-byte-aligned padding too, so together they tile [0, count)."""
+    marker = "transformer_encoder.layers."
+    starts = {}
+    for n in names:
+        if marker in n:
+            i = int(n.split(marker)[1].split(".")[0])
+            starts[i] = min(starts.get(i, 1 << 62), offsets[n][0])
+    if sorted(starts) != list(range(depth)):
+        raise ValueError("parameter names do not contain the expected fusion layers")
+    # start of the first parameter after the last layer
+    after = min((offsets[n][0] for n in names if marker not in n and offsets[n][0] > starts[depth - 1]),
+                default=count)
+    buckets = [(after, count)]
+    for i in reversed(range(depth)):
+        end = starts[i + 1] if i + 1 < depth else after
+        buckets.append((starts[i], end))
+    buckets.append((0, starts[0]))
+    return buckets
+
+
+class GradSync:
+    """Overlapped all-reduce of a flat gradient arena.
+
+    usage:  sync = GradSync(arena.grad, buckets);  model.register_grad_ready_hook(sync.on_ready)
+            ... loss.backward() ...;  sync.finish()  (before optimizer.step())
+    `on_ready(i)`: i = depth-1 ... 0 as fusion layer i completes, then -1 at the end.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], depth: int,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.grad = flat_grad
+        self.buckets = buckets
+        self.depth = depth
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.on_gpu = flat_grad.is_cuda
+        self.side = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
+        self.pending: List = []
+        self._sent = 0
+        self.avg_native = self.on_gpu        # RCCL implements ReduceOp.AVG; gloo does not
+
+    def _launch(self, idx: int) -> None:
+        a, b = self.buckets[idx]
+        if b <= a or self.world == 1:
+            return
+        view = self.grad[a:b]
+        if self.on_gpu:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            self.pending.append(work)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(self.world)
+
+    def on_ready(self, layer: int) -> None:
+        if layer >= 0:
+            # first call (layer depth-1... actually the decoders finished before any layer):
+            if self._sent == 0:
+                self._launch(0)
+                self._sent = 1
+            self._launch(1 + (self.depth - 1 - layer))
+            self._sent = max(self._sent, 2 + (self.depth - 1 - layer))
+        else:
+            if self._sent == 0:          # depth == 0
+                self._launch(0)
+            self._launch(len(self.buckets) - 1)
+
+    def finish(self) -> None:
+        """Make the compute stream wait for every outstanding bucket."""
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+        self._sent = 0

@@ -10,6 +10,10 @@ import ctypes as C
 import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
+# PyTorch-ROCm ships its own libamdhip64; it must be in the process BEFORE libbifold_hip.so so
+# that both resolve to ONE HIP runtime (device pointers and streams cross this boundary).
+import torch  # noqa: F401
+
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD = 0, 1, 2, 3
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2

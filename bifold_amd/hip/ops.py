@@ -18,6 +18,45 @@ _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
 _TORCH = {L.F32: torch.float32, L.BF16: torch.bfloat16}
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the matrix kernels, on the stream they are launched on
+    (bench.py turns it on for the timed region to price the dominant kernel against the MFMA
+    roofline).  records: (label, algorithmic FLOPs, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        out = {}
+        for label, flops, e0, e1 in self.records:
+            ms = e0.elapsed_time(e1)
+            d = out.setdefault(label, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += ms
+            d["flops"] += flops
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["ms"] / d["launches"]
+            d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        return out
+
+
+PROFILER: Optional[KernelTimer] = None
+
+
+class _Span:
+    __slots__ = ("label", "flops", "e0")
+
+    def __init__(self, label, flops):
+        self.label, self.flops = label, flops
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def close(self):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILER.records.append((self.label, self.flops, self.e0, e1))
+
+
 def torch_dtype(code: int) -> torch.dtype:
     return _TORCH[code]
 
@@ -157,7 +196,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.split_k = sk
+    span = None
+    if PROFILER is not None:
+        span = _Span(f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}",
+                     2.0 * m * n * k)
     check(lib.bf_gemm(C.byref(g), _stream()), "bf_gemm")
+    if span is not None:
+        span.close()
     if want_pre:
         return out, pre
     if want_bf16_copy:
@@ -193,8 +238,15 @@ def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim:
     lse = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device) if need_lse else None
     if row_mask is not None and row_mask.dtype != torch.int32:
         raise TypeError("row_mask must be int32")
+    span = None
+    if PROFILER is not None:
+        causal = 0.5 if mask_mode == L.MASK_CAUSAL else 1.0
+        span = _Span(f"attn_fwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
+                     4.0 * batch * heads * seq * seq * head_dim * causal)
     check(lib.bf_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(row_mask), batch, seq, heads,
                                head_dim, scale, mask_mode, dtype_code(qkv), _stream()), "bf_attention_fwd")
+    if span is not None:
+        span.close()
     return out, lse
 
 
@@ -203,9 +255,15 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_
     _dev(qkv, "qkv"); _dev(out, "out"); _dev(dout, "dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
+    span = None
+    if PROFILER is not None:
+        span = _Span(f"attn_bwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
+                     10.0 * batch * heads * seq * seq * head_dim)
     check(lib.bf_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
                                _ptr(delta), batch, seq, heads, head_dim, scale, mask_mode,
                                dtype_code(qkv), _stream()), "bf_attention_bwd")
+    if span is not None:
+        span.close()
     return dqkv
 
 
@@ -296,8 +354,8 @@ def decoder_upsample_sigmoid(low, U, n_maps: int, grid: int):
     return heat
 
 
-def decoder_upsample_sigmoid_bwd(heat, d_heat, U, n_maps: int, grid: int):
-    g_low = torch.empty(n_maps, grid * grid, dtype=torch.float32, device=heat.device)
+def decoder_upsample_sigmoid_bwd(heat, d_heat, U, n_maps: int, grid: int, out: Optional[torch.Tensor] = None):
+    g_low = out if out is not None else torch.empty(n_maps, grid * grid, dtype=torch.float32, device=heat.device)
     check(lib.bf_decoder_upsample_sigmoid_bwd(_ptr(heat), _ptr(d_heat), _ptr(U), _ptr(g_low), n_maps, grid,
                                               _stream()), "bf_decoder_upsample_sigmoid_bwd")
     return g_low

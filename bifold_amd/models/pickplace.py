@@ -245,8 +245,7 @@ class RGBTailFn(torch.autograd.Function):
                 g_low[h].zero_()
             else:
                 dh = d_heats[h].contiguous()
-                gl = ops.decoder_upsample_sigmoid_bwd(c.heat[h], dh, U, batch, pp.grid)
-                g_low[h].copy_(gl.view(batch, gg))
+                ops.decoder_upsample_sigmoid_bwd(c.heat[h], dh, U, batch, pp.grid, out=g_low[h])
         dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=dev)
         g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
         g_b = torch.empty(nh, dtype=torch.float32, device=dev)
