@@ -19,6 +19,8 @@
 // panel run on one XCD back to back.
 #include "common.h"
 
+#include <stdlib.h>
+
 struct EpiParams {
     void* c;
     void* c2;
@@ -87,6 +89,21 @@ __device__ __forceinline__ void tile_epilogue(const float* ct, const EpiParams& 
     }
 }
 
+// Tile order inside an XCD's contiguous range: GROUP_M row tiles form a group; inside a
+// group the ROW tile index runs fastest, then the column tile.  The ~64 blocks co-resident
+// on an XCD then cover a GROUP_M x (64/GROUP_M) patch of output tiles, so their A row panels
+// and B column panels together fit the XCD's 4 MB L2 (with the column index fastest they
+// span every column tile, i.e. the whole weight matrix, which thrashes L2 for N >= 2048).
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int group_m, int& tm, int& tn) {
+    const int per_group = group_m * tiles_n;
+    const int grp = t / per_group;
+    const int first_m = grp * group_m;
+    const int gsz = min(group_m, tiles_m - first_m);
+    const int loc = t - grp * per_group;
+    tm = first_m + loc % gsz;
+    tn = loc / gsz;
+}
+
 // XCD-aware bijective remap of a 1-D block id (guide T1, non-multiple-of-8 safe).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
@@ -101,6 +118,7 @@ struct GemmDims {
     int lda, ldb;
     int tiles_m, tiles_n;
     int k_per_split;    // multiple of the K tile
+    int group_m;
 };
 
 // ---- global -> register tile loads (4 x 16 B per thread per operand) -------------------
@@ -240,6 +258,118 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     __syncthreads();
     float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
     tile_epilogue<TC, bf16_t>(ct, ep, m0, n0, slab);
+}
+
+// =====================================================================================
+//                        bf16 MFMA kernel, LDS-DMA staged (main path)
+// =====================================================================================
+// Same tile geometry and LDS images as gemm_bf16_kernel, but operand tiles go HBM -> LDS
+// with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no ds_write: the ds_write_b128
+// staging pass alone kept the LDS port busier than the MFMAs).  An LDS-DMA wave-instruction
+// writes 1 KB LINEARLY (M0 base + lane*16), so the XOR swizzle is applied to the per-lane
+// SOURCE address: lane l of a piece fetches the chunk that belongs in slot l of the swizzled
+// image.  Buffer descriptors carry the exact byte extent of A and B, so rows past the end of
+// a matrix read as zeros (M/N tails, and the token tail of dW = dY^T X).
+// Epilogue: the MFMA operand roles are swapped (D'[n][m] = sum_k B[n][k] A[m][k]) so each
+// lane owns 4 CONSECUTIVE output columns of one row: bias / activation / residual / store
+// are 16-byte accesses straight from the accumulators, with no LDS staging and no barrier.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+template <bool KS>
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int r0,
+                                         int k0, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pc = wave * 4 + i;                       // 1 KB piece of the 16 KB tile
+        unsigned voff;
+        if (!KS) {
+            const int row = pc * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ (row & 7);
+            voff = (unsigned)(((size_t)(r0 + row) * ld + k0 + ch * 8) * 2);
+        } else {
+            const int krow = pc * 4 + (lane >> 4);
+            const int ch = (lane & 15) ^ ks_swz(krow);
+            voff = (unsigned)(((size_t)(k0 + krow) * ld + r0 + ch * 8) * 2);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(lds_tile + pc * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+template <bool A_KS, bool B_KS, typename TC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A,
+                                                               const bf16_t* __restrict__ B,
+                                                               GemmDims d, EpiParams ep,
+                                                               float* __restrict__ slabs,
+                                                               unsigned a_bytes, unsigned b_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (A 16 KB | B 16 KB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int z = blockIdx.x / tiles;
+    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
+    int tm, tn;
+    tile_coords(t, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = z * d.k_per_split;
+    const int kend = min(d.k, kbeg + d.k_per_split);
+    const int nk = (kend - kbeg + 63) >> 6;
+
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+
+    f32x4 acc[4][4];          // acc[j][i]: rows n (j tile), cols m (i tile)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    dma_tile<A_KS>(ra, smem, d.lda, m0, kbeg, wave, lane);
+    dma_tile<B_KS>(rb, smem + 16384, d.ldb, n0, kbeg, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * 32768;
+        const char* lb = la + 16384;
+        if (kt + 1 < nk) {
+            char* na = smem + ((kt + 1) & 1) * 32768;
+            dma_tile<A_KS>(ra, na, d.lda, m0, kbeg + (kt + 1) * 64, wave, lane);
+            dma_tile<B_KS>(rb, na + 16384, d.ldb, n0, kbeg + (kt + 1) * 64, wave, lane);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = bf16_frag<A_KS>(la, wm * 64 + i * 16, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag<B_KS>(lb, wn * 64 + j * 16, s, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // D' layout: col = lane&15 -> m, row = (lane>>4)*4 + reg -> n : 4 consecutive n per lane
+    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (m < ep.m && n < ep.n) {
+                const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+                if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
+                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
+            }
+        }
+    }
 }
 
 // =====================================================================================
@@ -476,7 +606,9 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
     const size_t lds = (size_t)128 * CT_LD * sizeof(float);   // 67,584 B >= operand buffers
 
     if (g->cdt == BF_BF16) {
-        GemmDims d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps};
+        static int group_m_env = -1;
+        if (group_m_env < 0) { const char* e = getenv("BIFOLD_GEMM_GROUP_M"); group_m_env = e ? atoi(e) : 16; if (group_m_env < 1) group_m_env = 1; }
+        GemmDims d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps, group_m_env};
         const bf16_t* A = (const bf16_t*)g->a;
         const bf16_t* B = (const bf16_t*)g->b;
 #define LAUNCH_BF16(AKS, BKS, TC)                                                                  \
@@ -490,6 +622,31 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         hipLaunchKernelGGL((gemm_bf16_kernel<AKS, BKS, TC>), grid, block, lds, s, A, B, d, ep, slabs); \
     } while (0)
         const bool f32out = (g->c_dtype == BF_F32) || slabs;   // slabs path ignores TC
+        // LDS-DMA kernel: K-contiguous operands need whole 64-wide K slabs (no in-row tail),
+        // and the byte extents must fit the 32-bit buffer descriptor.
+        const size_t a_ext = ((size_t)((g->trans_a ? g->k : g->m) - 1) * g->lda + (g->trans_a ? g->m : g->k)) * 2;
+        const size_t b_ext = ((size_t)((g->b_kn ? g->k : g->n) - 1) * g->ldb + (g->b_kn ? g->n : g->k)) * 2;
+        const bool dma_ok = ((g->trans_a && g->b_kn) || (g->k % 64) == 0) && a_ext < (1ull << 32) &&
+                            b_ext < (1ull << 32) && !getenv("BIFOLD_GEMM_NO_DMA");
+        if (dma_ok) {
+            const size_t lds2 = 65536;
+            const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
+#define LAUNCH_DMA(AKS, BKS, TC)                                                                    \
+    do {                                                                                          \
+        static bool lds_ok = false;                                                               \
+        if (!lds_ok) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AKS, BKS, TC>,            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);     \
+            lds_ok = true;                                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<AKS, BKS, TC>), grid, block, lds2, s, A, B, d, ep, slabs, ab, bb); \
+    } while (0)
+            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_DMA(false, false, float); else LAUNCH_DMA(false, false, bf16_t); }
+            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_DMA(false, true, float); else LAUNCH_DMA(false, true, bf16_t); }
+            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_DMA(true, true, float); else LAUNCH_DMA(true, true, bf16_t); }
+            else { if (f32out) LAUNCH_DMA(true, false, float); else LAUNCH_DMA(true, false, bf16_t); }
+#undef LAUNCH_DMA
+        } else
         if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_BF16(false, false, float); else LAUNCH_BF16(false, false, bf16_t); }
         else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_BF16(false, true, float); else LAUNCH_BF16(false, true, bf16_t); }
         else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_BF16(true, true, float); else LAUNCH_BF16(true, true, bf16_t); }

@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Per-shape GEMM microbenchmark on the shapes of the BiFold training step (B = 256).
+Interleaved rounds in one process (guide §5.4 rule 24), random bf16 operands (rule 25)."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bifold_amd.hip import ops  # noqa: E402
+
+SHAPES = [  # name, layout, m, n, k
+    ("vis qkv", "nt", 50432, 2304, 768), ("vis out", "nt", 50432, 768, 768),
+    ("vis fc1", "nt", 50432, 3072, 768), ("vis fc2", "nt", 50432, 768, 3072),
+    ("txt qkv", "nt", 19712, 1536, 512), ("txt fc1", "nt", 19712, 2048, 512),
+    ("fus qkv", "nt", 70400, 1536, 512), ("fus out", "nt", 70400, 512, 512),
+    ("fus fc1", "nt", 70400, 2048, 512), ("fus fc2", "nt", 70400, 512, 2048),
+    ("fus dA", "nn", 70400, 2048, 512), ("fus dH", "nn", 70400, 512, 2048), ("fus dqkv", "nn", 70400, 512, 1536),
+    ("fus dW2", "tn", 512, 2048, 70400), ("fus dW1", "tn", 2048, 512, 70400), ("fus dWqkv", "tn", 1536, 512, 70400),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    cases = []
+    for name, lay, m, n, k in SHAPES:
+        if args.only and args.only not in name:
+            continue
+        ta, bkn = lay[0] == "t", lay[1] == "n"
+        a = torch.randn((k, m) if ta else (m, k), device=dev, generator=g).bfloat16()
+        b = torch.randn((k, n) if bkn else (n, k), device=dev, generator=g).bfloat16()
+        out = torch.empty(m, n, device=dev, dtype=torch.float32 if ta else torch.bfloat16)
+        cases.append((name, lay, m, n, k, a, b, out, ta, bkn))
+    res = {c[0]: [] for c in cases}
+    for r in range(args.rounds + 1):
+        for name, lay, m, n, k, a, b, out, ta, bkn in cases:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            if r > 0:
+                res[name].append(e0.elapsed_time(e1) / 3)
+    tot_ms, tot_fl = 0.0, 0.0
+    for name, lay, m, n, k, *_ in cases:
+        ts = sorted(res[name])
+        med = ts[len(ts) // 2]
+        fl = 2.0 * m * n * k
+        tot_ms += med
+        tot_fl += fl
+        print(f"{name:10s} {lay} {m:6d}x{n:5d}x{k:6d}  {med * 1e3:8.1f} us  {fl / med / 1e9:7.1f} TF/s (min {fl / ts[0] / 1e9:7.1f})")
+    print(f"TOTAL {tot_ms:.3f} ms  {tot_fl / tot_ms / 1e9:.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()
