@@ -1,0 +1,175 @@
+"""Host-side logic that needs no GPU: plugin factories and their error behaviour, the
+state-dict schema, the LR schedule, config composition, the C ABI's exported symbols and its
+argument validation (which returns before any kernel launch)."""
+import ctypes as C
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY_CLIP = dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+                 context_length=77, vocab_size=512, transformer_width=64, transformer_heads=1,
+                 transformer_layers=2)
+
+
+def tiny_cfg(**over):
+    from bifold_amd.models.clip_encoder import CLIP_CONFIGS
+    CLIP_CONFIGS["tiny-test"] = TINY_CLIP
+    cfg = dict(name="rgb_clip", image_size=64, is_bimanual=False, requires_graph=False, text_encoder="tiny-test",
+               patch_size=16, depth=2, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
+               pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype="fp32")
+    cfg.update(over)
+    return cfg
+
+
+def test_header_symbols_are_exported_and_bound():
+    from bifold_amd.hip import lib as L
+    hdr = open(os.path.join(ROOT, "include", "bifold_hip.h")).read()
+    declared = set(re.findall(r"\b(bf_[a-z0-9_]+)\s*\(", hdr)) - {"bf_gemm_args"}
+    assert declared, "no declarations found"
+    assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
+    for name in declared:
+        assert hasattr(L.lib, name)
+    assert L.lib.bf_abi_version() == 1
+
+
+def test_c_abi_rejects_bad_arguments_before_launching():
+    from bifold_amd.hip import lib as L
+    g = L.GemmArgs()
+    assert L.lib.bf_gemm(C.byref(g), None) == -1                       # m = n = k = 0
+    assert b"m, n, k" in L.lib.bf_last_error()
+    assert L.lib.bf_layernorm_fwd(None, 0, None, None, None, 0, None, None, 4, 30, 1e-5, None) == -1
+    assert L.lib.bf_attention_fwd(None, None, None, None, 1, 8, 1, 40, 1.0, 0, 1, None) == -1   # head_dim 40
+    assert b"head_dim" in L.lib.bf_last_error()
+    assert L.lib.bf_adam_step(None, None, None, None, None, 6, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1
+    assert L.lib.bf_bce_parts(256) == 1024 and L.lib.bf_layernorm_bwd_parts(70400) > 0
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import subprocess, sys
+    code = "import os; os.environ['BIFOLD_HIP_LIB']='/nonexistent/lib.so'; import bifold_amd.hip.lib"
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_factories_and_error_behaviour():
+    from bifold_amd.losses import Losses
+    from bifold_amd.models import Components, Models
+    from bifold_amd.optim import Optimizers, Schedulers
+    with pytest.raises(ValueError, match="not recognized"):
+        Models.get_by_name(dict(name="nope"))
+    with pytest.raises(ValueError, match="not recognized"):
+        Components.get_by_name("nope")
+    with pytest.raises(ValueError, match="not recognized"):
+        Losses.get_by_name(cfg=dict(name="nope"))
+    with pytest.raises(ValueError, match="not recognized"):
+        Optimizers.get_by_name(dict(name="sgd"), [])
+    with pytest.raises(ValueError, match="not recognized"):
+        Schedulers.get_by_name(dict(name="step"))
+    assert Schedulers.get_by_name(dict(name=None)) is None
+    with pytest.raises(NotImplementedError):
+        Models.get_by_name(dict(name="siglip_sequential"))
+    cfg = tiny_cfg()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = Models.get_by_name(cfg, device=torch.device("cpu"))
+    assert "name" not in cfg                                   # like the reference: `del cfg.name`
+    assert m.threshold == 0.01 and m.image_size == 64
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert frozen and all("clip_encoder" in n for n in frozen)
+    assert all("clip_encoder" not in n for n, p in m.named_parameters() if p.requires_grad)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m({"rgb": torch.zeros(1, 3, 64, 64), "instruction": torch.zeros(1, 77, dtype=torch.int32)})
+    with pytest.raises(AssertionError):
+        Models.get_by_name(tiny_cfg(image_size=70), device=torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        Models.get_by_name(tiny_cfg(dropout=0.1), device=torch.device("cpu"))
+    loss = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=True, mask_pick_heatmap=False))
+    assert loss.heads() == ["left_pick", "left_place", "right_pick", "right_place"]
+
+
+@pytest.mark.parametrize("fixture,bim", [("tiny_unimanual.npz", False), ("tiny_bimanual.npz", True)])
+def test_state_dict_schema_matches_reference(golden_dir, fixture, bim):
+    from bifold_amd.models import Models
+    z = np.load(os.path.join(golden_dir, fixture))
+    ref = {k[6:]: tuple(z[k].shape) for k in z.files if k.startswith("state/")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = Models.get_by_name(tiny_cfg(is_bimanual=bim), device=torch.device("cpu"))
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
+    m.load_state_dict({k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("state/")}, strict=True)
+
+
+def test_linear_warmup_reproduces_reference_trace(golden_dir):
+    from bifold_amd.optim import Schedulers
+
+    class FakeOpt:
+        param_groups = [{"lr": 1e-4}]
+    opt = FakeOpt()
+    sch = Schedulers.get_by_name(dict(name="linear_warmup", warmup_portion=0.1, warmup_start_lr=0,
+                                      use_cosine_decay=True), optimizer=opt, max_iters=100)
+    trace = []
+    for _ in range(30):
+        trace.append(opt.param_groups[0]["lr"])
+        sch.step()
+    ref = np.load(os.path.join(golden_dir, "per_op.npz"))["warmup/lrs"]
+    assert np.allclose(trace, ref, rtol=1e-9, atol=1e-15)
+    assert trace[0] < 0 and trace[1] == 0.0                    # quirk: -1e-5, 0, 1e-5, ...
+    sd = sch.state_dict()
+    assert "optimizer" not in sd and sd["last_step"] == sch.last_step
+
+
+def test_upsample_operator_matches_interpolate():
+    import torch.nn.functional as F
+    from bifold_amd.models.decoder_math import upsample_operator
+    for g in (3, 14, 24):
+        U = upsample_operator(g).double()
+        x = torch.randn(2, 1, g, g, dtype=torch.float64)
+        ref = x
+        for _ in range(4):
+            ref = F.interpolate(ref, scale_factor=2, mode="bilinear", align_corners=False)
+        got = torch.einsum("yi,bcij,xj->bcyx", U, x, U)
+        assert torch.allclose(got, ref, atol=1e-6)
+        assert torch.allclose(U.sum(1), torch.ones(16 * g, dtype=torch.float64), atol=1e-6)
+
+
+def test_config_composition_and_overrides():
+    from bifold_amd.config import compose
+    conf = os.path.join(ROOT, "bifold_amd", "conf")
+    cfg = compose(conf, [])
+    assert cfg.model.name == "rgb_clip" and cfg.model.is_bimanual is False
+    assert cfg.optim.lr == 1e-4 and isinstance(cfg.optim.lr, float)
+    assert cfg.loss.is_bimanual is False and cfg.scheduler.name is None
+    assert cfg.processor.model_image_size == 224 and cfg.processor.text_encoder == "ViT-B/16"
+    cfg = compose(conf, ["optim=adamw", "scheduler=linear_warmup", "batch_size=8", "model.depth=4",
+                         "dataset@train_dataset=single", "train_dataset.n_samples=1000"])
+    assert cfg.optim.name == "adamw" and cfg.optim.weight_decay == 0.01
+    assert cfg.scheduler.warmup_portion == 0.1 and cfg.batch_size == 8 and cfg.model.depth == 4
+    assert cfg.train_dataset.dataset_path.endswith("single_data/All_1000.pkl")
+    node = cfg.optim
+    del node.name
+    assert "name" not in node and dict(**node)["lr"] == 1e-4
+    with pytest.raises(FileNotFoundError):
+        compose(conf, ["model=does_not_exist"])
+
+
+def test_layer_buckets_tile_the_arena():
+    from bifold_amd.dist import layer_buckets
+    names, offsets, off = [], {}, 0
+    def add(n, cnt):
+        nonlocal off
+        names.append(n); offsets[n] = (off, cnt); off += (cnt + 63) // 64 * 64
+    add("text_token", 64); add("project.weight", 1000)
+    for i in range(3):
+        add(f"pick_place.fusion.transformer_encoder.layers.{i}.0.norm.weight", 64)
+        add(f"pick_place.fusion.transformer_encoder.layers.{i}.1.fn.net.3.bias", 70)
+    add("pick_place.pick_decoder.decoder_net.0.weight", 500)
+    b = layer_buckets(names, offsets, 3, off)
+    assert len(b) == 5 and b[0][1] == off and b[-1][0] == 0
+    covered = sorted(b)
+    assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(4)) and covered[-1][1] == off
+    assert b[1] == (offsets[names[6]][0], b[0][0])             # layer 2 comes right after the decoders

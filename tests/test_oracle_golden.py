@@ -1,0 +1,118 @@
+"""The CPU oracle against the frozen outputs of the reference itself (tests/golden/*.npz were
+produced by oracle/gen_golden.py importing /root/reference).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bifold_oracle as O
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name))
+    groups = {}
+    for k in z.files:
+        head, _, rest = k.partition("/")
+        groups.setdefault(head, {})[rest] = torch.from_numpy(z[k])
+    return groups
+
+
+def close(a, b, rtol=2e-5, atol=2e-6):
+    a, b = a.double(), b.double()
+    return (a - b).abs().max().item() <= atol + rtol * b.abs().max().item()
+
+
+@pytest.mark.parametrize("fixture", ["tiny_unimanual.npz", "tiny_bimanual.npz"])
+def test_end_to_end_step_matches_reference(golden_dir, fixture):
+    fx = load(golden_dir, fixture)
+    bim = bool(int(fx["meta"]["is_bimanual"]))
+    heads = int(fx["meta"]["heads"])
+    state, sample = dict(fx["state"]), fx["sample"]
+    with torch.no_grad():
+        assert close(O.clip_vision_tokens(state, sample["rgb"]), fx["mid"]["clip_vision"])
+        assert close(O.clip_text_tokens(state, sample["instruction"]), fx["mid"]["clip_text"])
+    keys = [k for k in state if O.is_trainable_key(k)]
+    assert set(keys) == set(fx["grad"])
+    m = {k: torch.zeros_like(state[k]) for k in keys}
+    v = {k: torch.zeros_like(state[k]) for k in keys}
+    losses = []
+    for it in range(3):
+        for k in keys:
+            state[k] = state[k].detach().requires_grad_(True)
+        out = O.rgb_clip_forward(state, sample, heads, bim)
+        loss, parts = O.bce_gaussmap(out, sample, bim)
+        grads = torch.autograd.grad(loss, [state[k] for k in keys])
+        if it == 0:
+            assert out["attn_weights"] is None
+            for k, ref in fx["out"].items():
+                assert close(out[k].detach(), ref), k
+            assert close(loss.detach(), fx["loss"][""], rtol=1e-6)
+            for k, ref in fx["loss_part"].items():
+                assert close(parts[k].detach(), ref, rtol=1e-6), k
+            for k, g in zip(keys, grads):
+                assert close(g, fx["grad"][k], rtol=1e-4, atol=1e-7), k
+        losses.append(float(loss))
+        with torch.no_grad():
+            for k, g in zip(keys, grads):
+                state[k], m[k], v[k] = O.adam_update(state[k].detach(), g, m[k], v[k], it + 1, 1e-4)
+    assert np.allclose(losses, fx["losses3"][""].numpy(), rtol=1e-5)
+    for k, ref in fx["param3"].items():
+        assert close(state[k].detach(), ref, rtol=1e-5, atol=1e-6), k
+
+
+def test_masked_three_input_fusion_matches_reference(golden_dir):
+    fx = load(golden_dir, "fusion_masked_bimanual.npz")
+    i = fx["in"]
+    with torch.no_grad():
+        out = O.pick_place_convdecoder(fx["state"], [i["x_text"], i["x_ctx"], i["x_img"]],
+                                       int(fx["meta"]["heads"]), True, modalities=[0, 1, 1],
+                                       attention_masks=i["mask"])
+    assert set(fx["out"]) == {f"{a}_{k}_heatmap" for a in ("left", "right") for k in ("pick", "place")}
+    for k, ref in fx["out"].items():
+        assert close(out[k], ref), k
+
+
+def test_per_op_vectors(golden_dir):
+    fx = load(golden_dir, "per_op.npz")
+    for w in (512, 768):
+        g = fx[f"ln{w}"]
+        assert close(O.layer_norm(g["x"], g["w"], g["b"]), g["y"])
+    a = fx["act"]
+    assert close(O.quick_gelu(a["x"]), a["quick_gelu"])
+    assert close(O.erf_gelu(a["x"]), a["erf_gelu"])
+    cb = fx["clipblock"]
+    st = {k[len("state/"):]: v for k, v in cb.items() if k.startswith("state/")}
+    with torch.no_grad():
+        assert close(O.clip_resblock(st, "b.", cb["x"], 2, causal=True), cb["y"])
+    d = fx["decoder"]
+    st = {k[len("state/"):]: v for k, v in d.items() if k.startswith("state/")}
+    with torch.no_grad():
+        assert close(O.conv_decoder_logits(st, "d.", d["feat"]), d["logits"])
+    w_eff, b_eff = O.collapse_decoder(st, "d.")
+    U = O.upsample_operator(14)
+    assert close(U, d["upsample_operator_14"], rtol=1e-12, atol=0)
+    assert torch.allclose(U.sum(1), torch.ones(224, dtype=torch.float64), atol=1e-12)
+    low = torch.einsum("d,bdij->bij", w_eff, d["feat"].double()) + b_eff
+    coll = torch.einsum("yi,bij,xj->byx", U, low, U)
+    assert close(coll, d["logits"].squeeze(1), rtol=1e-5, atol=1e-6)        # the decoder IS affine
+    b = fx["bce"]
+    assert close(O.bce_mean(b["p"], b["t"]), b["loss"], rtol=1e-6)
+    assert np.allclose(O.linear_warmup_lrs(1e-4, 100, 30), fx["warmup"]["lrs"].numpy(), rtol=1e-9, atol=1e-15)
+    assert fx["warmup"]["lrs"][0] < 0                                        # the reference's first-step quirk
+    ad = fx["adam"]
+    q, m, v = ad["p0"].clone(), torch.zeros(64), torch.zeros(64)
+    for i in range(4):
+        q, m, v = O.adam_update(q, ad["grads"][i], m, v, i + 1, 1e-3)
+    assert close(q, ad["p4"], rtol=1e-6, atol=1e-7)
+
+
+def test_full_size_weights_are_reproducible_from_the_seed(golden_dir):
+    """config_a_summary.npz was produced from weights built by these constructors; the GPU test
+    rebuilds them from the seed, so the construction must be deterministic."""
+    fx = load(golden_dir, "config_a_summary.npz")
+    seed = int(fx["meta"]["seed"])
+    s1 = O.make_tail_state(torch.Generator().manual_seed(seed))
+    s2 = O.make_tail_state(torch.Generator().manual_seed(seed))
+    assert all(torch.equal(s1[k], s2[k]) for k in s1)
+    assert sum(v.numel() for v in s1.values()) == 26_236_162      # config A's trainable parameters (26.2 M)
