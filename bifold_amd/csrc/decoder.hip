@@ -12,13 +12,33 @@ struct Ptr5 { const float* p[5]; };
 struct MPtr5 { float* p[5]; };
 
 // out[c] = sum_k r[k] * W[k*cols + c]   (r in LDS), all threads of the block
+// (the k range is split over blockDim.x / cols thread groups and summed through LDS `part`, so
+// that all 1024 threads stream W with coalesced, independent loads: these kernels are single
+// workgroups on tiny matrices and purely latency-bound)
 __device__ __forceinline__ void vecmat(const float* r, const float* __restrict__ W, int rows, int cols,
-                                       float* out_lds, float* out_glb) {
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+                                       float* out_lds, float* out_glb, float* part) {
+    const int groups = max(1, (int)blockDim.x / cols);
+    const int gidx = threadIdx.x / cols, c = threadIdx.x - gidx * cols;
+    if (gidx < groups) {
+        const int per = (rows + groups - 1) / groups;
+        const int k0 = gidx * per, k1 = min(rows, k0 + per);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = k0;
+        for (; k + 3 < k1; k += 4) {
+            a0 = fmaf(r[k], W[(size_t)k * cols + c], a0);
+            a1 = fmaf(r[k + 1], W[(size_t)(k + 1) * cols + c], a1);
+            a2 = fmaf(r[k + 2], W[(size_t)(k + 2) * cols + c], a2);
+            a3 = fmaf(r[k + 3], W[(size_t)(k + 3) * cols + c], a3);
+        }
+        for (; k < k1; ++k) a0 = fmaf(r[k], W[(size_t)k * cols + c], a0);
+        part[gidx * cols + c] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    for (int cc = threadIdx.x; cc < cols; cc += blockDim.x) {
         float acc = 0.f;
-        for (int k = 0; k < rows; ++k) acc = fmaf(r[k], W[(size_t)k * cols + c], acc);
-        if (out_lds) out_lds[c] = acc;
-        if (out_glb) out_glb[c] = acc;
+        for (int gi = 0; gi < groups; ++gi) acc += part[gi * cols + cc];
+        if (out_lds) out_lds[cc] = acc;
+        if (out_glb) out_glb[cc] = acc;
     }
 }
 __device__ __forceinline__ float block_dot(const float* a, const float* __restrict__ b, int n, float* red) {
@@ -33,7 +53,7 @@ __device__ __forceinline__ float block_dot(const float* a, const float* __restri
     return t;
 }
 
-__global__ __launch_bounds__(256) void collapse_fwd_kernel(Ptr5 w, Ptr5 b, float* __restrict__ w_eff,
+__global__ __launch_bounds__(1024) void collapse_fwd_kernel(Ptr5 w, Ptr5 b, float* __restrict__ w_eff,
                                                            float* __restrict__ b_eff,
                                                            float* __restrict__ rows_ws, int D) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -42,16 +62,17 @@ __global__ __launch_bounds__(256) void collapse_fwd_kernel(Ptr5 w, Ptr5 b, float
     float* r3 = r2 + C1;        // [C1]
     float* r4 = r3 + C1;        // [C3]
     float* r5 = r4 + C3;        // [C3]
-    float* red = r5 + C3;       // [4]
-    for (int i = threadIdx.x; i < C3; i += 256) { r5[i] = w.p[4][i]; rows_ws[2 * C1 + C3 + i] = w.p[4][i]; }
+    float* red = r5 + C3;       // [16]
+    float* part = red + 16;     // [1024]
+    for (int i = threadIdx.x; i < C3; i += blockDim.x) { r5[i] = w.p[4][i]; rows_ws[2 * C1 + C3 + i] = w.p[4][i]; }
     __syncthreads();
-    vecmat(r5, w.p[3], C3, C3, r4, rows_ws + 2 * C1);
+    vecmat(r5, w.p[3], C3, C3, r4, rows_ws + 2 * C1, part);
     __syncthreads();
-    vecmat(r4, w.p[2], C3, C1, r3, rows_ws + C1);
+    vecmat(r4, w.p[2], C3, C1, r3, rows_ws + C1, part);
     __syncthreads();
-    vecmat(r3, w.p[1], C1, C1, r2, rows_ws);
+    vecmat(r3, w.p[1], C1, C1, r2, rows_ws, part);
     __syncthreads();
-    vecmat(r2, w.p[0], C1, D, nullptr, w_eff);
+    vecmat(r2, w.p[0], C1, D, nullptr, w_eff, part);
     const float t4 = block_dot(r5, b.p[3], C3, red);
     const float t3 = block_dot(r4, b.p[2], C3, red);
     const float t2 = block_dot(r3, b.p[1], C1, red);
@@ -64,8 +85,9 @@ extern "C" int bf_decoder_collapse_fwd(const float* const* w, const float* const
     BF_REQUIRE(w && b && dim > 0 && (dim & 3) == 0, BF_EINVAL, "bf_decoder_collapse_fwd: bad dim %d", dim);
     Ptr5 pw, pb;
     for (int i = 0; i < 5; ++i) { pw.p[i] = w[i]; pb.p[i] = b[i]; }
-    const size_t lds = (size_t)(dim + dim / 2 + 8) * sizeof(float);
-    hipLaunchKernelGGL(collapse_fwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, pw, pb, w_eff,
+    BF_REQUIRE(dim <= 1024, BF_EINVAL, "bf_decoder_collapse_fwd: dim must be <= 1024");
+    const size_t lds = (size_t)(dim + dim / 2 + 16 + 1024) * sizeof(float);
+    hipLaunchKernelGGL(collapse_fwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, pw, pb, w_eff,
                        b_eff, rows_ws, dim);
     BF_CHECK_LAUNCH("bf_decoder_collapse_fwd");
     return BF_OK;
@@ -75,8 +97,8 @@ extern "C" int bf_decoder_collapse_fwd(const float* const* w, const float* const
 __device__ __forceinline__ void back_step(const float* __restrict__ W, const float* __restrict__ bias,
                                           const float* r_glb, const float* g_lds, float gb, int rows,
                                           int cols, float* dW, float* dbias, float* dr_lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k = wave; k < rows; k += 4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int k = wave; k < rows; k += nwaves) {
         float s = 0.f;
         for (int c = lane; c < cols; c += 64) s = fmaf(W[(size_t)k * cols + c], g_lds[c], s);
         s = wave_sum(s);
@@ -85,13 +107,13 @@ __device__ __forceinline__ void back_step(const float* __restrict__ W, const flo
             dbias[k] = gb * r_glb[k];
         }
     }
-    for (int i = threadIdx.x; i < rows * cols; i += 256) {
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
         const int k = i / cols, c = i - k * cols;
         dW[i] = r_glb[k] * g_lds[c];
     }
 }
 
-__global__ __launch_bounds__(256) void collapse_bwd_kernel(Ptr5 w, Ptr5 b, const float* __restrict__ rows_ws,
+__global__ __launch_bounds__(1024) void collapse_bwd_kernel(Ptr5 w, Ptr5 b, const float* __restrict__ rows_ws,
                                                            const float* __restrict__ g_w_eff,
                                                            const float* __restrict__ g_b_eff, MPtr5 dw,
                                                            MPtr5 db, int D) {
@@ -100,7 +122,7 @@ __global__ __launch_bounds__(256) void collapse_bwd_kernel(Ptr5 w, Ptr5 b, const
     float* ga = sm;          // [D]
     float* gbuf = ga + D;    // [D]
     const float gb = g_b_eff[0];
-    for (int i = threadIdx.x; i < D; i += 256) ga[i] = g_w_eff[i];
+    for (int i = threadIdx.x; i < D; i += blockDim.x) ga[i] = g_w_eff[i];
     __syncthreads();
     const float* r2 = rows_ws;
     const float* r3 = rows_ws + C1;
@@ -114,7 +136,7 @@ __global__ __launch_bounds__(256) void collapse_bwd_kernel(Ptr5 w, Ptr5 b, const
     __syncthreads();
     back_step(w.p[3], b.p[3], r5, gbuf, gb, C3, C3, dw.p[3], db.p[3], ga);    // -> dr5 in ga
     __syncthreads();
-    for (int i = threadIdx.x; i < C3; i += 256) dw.p[4][i] = ga[i];
+    for (int i = threadIdx.x; i < C3; i += blockDim.x) dw.p[4][i] = ga[i];
     if (threadIdx.x == 0) db.p[4][0] = gb;
 }
 
@@ -126,7 +148,7 @@ extern "C" int bf_decoder_collapse_bwd(const float* const* w, const float* const
     MPtr5 pdw, pdb;
     for (int i = 0; i < 5; ++i) { pw.p[i] = w[i]; pb.p[i] = b[i]; pdw.p[i] = dw[i]; pdb.p[i] = db[i]; }
     const size_t lds = (size_t)2 * dim * sizeof(float);
-    hipLaunchKernelGGL(collapse_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, pw, pb, rows_ws,
+    hipLaunchKernelGGL(collapse_bwd_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, pw, pb, rows_ws,
                        g_w_eff, g_b_eff, pdw, pdb, dim);
     BF_CHECK_LAUNCH("bf_decoder_collapse_bwd");
     return BF_OK;
@@ -336,65 +358,64 @@ extern "C" int bf_bce_bwd(const float* heat, const float* target, const float* g
 
 // ------------------------------------------------------------------ sigmoid o upsample backward
 // per map: dlogit = d_heat * p (1 - p);  g_low = U^T dlogit U      (adjoint of the separable upsample)
+#define UB_ROWS 16
 __global__ __launch_bounds__(256) void upsample_sigmoid_bwd_kernel(const float* __restrict__ heat,
                                                                    const float* __restrict__ d_heat,
                                                                    const float* __restrict__ U,
                                                                    float* __restrict__ g_low, int g) {
+    // per map: dl = d_heat * p(1-p);  R = dl U  (S x g);  g_low = U^T R  (g x g).
+    // Rows are processed in chunks of 16 staged in LDS; thread (y, j) owns R[y][j] of the chunk
+    // and thread (i, j) owns g_low[i][j], so there are no cross-lane reductions at all.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int S = g * 16;
-    float* Us = sm;                 // [S][g]
-    float* Rw = Us + S * g;         // [4 waves][DEC_MAXG]
-    float* Gw = Rw + 4 * DEC_MAXG;  // [4 waves][g*g]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Us = sm;                       // [S][g]
+    float* dl = Us + S * g;               // [UB_ROWS][S]
+    float* Rc = dl + UB_ROWS * S;         // [UB_ROWS][g]
     const size_t bh = blockIdx.x;
     for (int i = threadIdx.x; i < S * g; i += 256) Us[i] = U[i];
-    __syncthreads();
     const float* hp = heat + bh * (size_t)S * S;
     const float* dp = d_heat + bh * (size_t)S * S;
     const int gg = g * g;
-    constexpr int NE = (DEC_MAXG * DEC_MAXG + 63) / 64;
-    float gacc[NE];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) gacc[e] = 0.f;
-    for (int y = wave; y < S; y += 4) {
-        float rj[DEC_MAXG];
-#pragma unroll
-        for (int j = 0; j < DEC_MAXG; ++j) rj[j] = 0.f;
-        for (int x = lane; x < S; x += 64) {
-            const float p = hp[(size_t)y * S + x];
-            const float dl = dp[(size_t)y * S + x] * (p * (1.0f - p));
-#pragma unroll
-            for (int j = 0; j < DEC_MAXG; ++j)
-                if (j < g) rj[j] = fmaf(dl, Us[x * g + j], rj[j]);
+    float gacc[3] = {0.f, 0.f, 0.f};      // g*g <= 576 entries over 256 threads
+    const int S4 = S >> 2;
+    for (int y0 = 0; y0 < S; y0 += UB_ROWS) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < UB_ROWS * S4; idx += 256) {
+            const int y = idx / S4, x4 = (idx - y * S4) * 4;
+            const float4 p = *(const float4*)(hp + (size_t)(y0 + y) * S + x4);
+            const float4 d = *(const float4*)(dp + (size_t)(y0 + y) * S + x4);
+            float4 o;
+            o.x = d.x * (p.x * (1.0f - p.x)); o.y = d.y * (p.y * (1.0f - p.y));
+            o.z = d.z * (p.z * (1.0f - p.z)); o.w = d.w * (p.w * (1.0f - p.w));
+            *(float4*)(dl + y * S + x4) = o;
         }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < UB_ROWS * g; idx += 256) {
+            const int y = idx / g, j = idx - y * g;
+            // U[x][j] is non-zero only for x within one coarse cell of j (bilinear support)
+            const int x_lo = max(0, (j - 1) * 16), x_hi = min(S, (j + 2) * 16);
+            float a = 0.f;
+            for (int x = x_lo; x < x_hi; ++x) a = fmaf(dl[y * S + x], Us[x * g + j], a);
+            Rc[idx] = a;
+        }
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < DEC_MAXG; ++j)
-            if (j < g) {
-                const float s = wave_sum(rj[j]);
-                if (lane == 0) Rw[wave * DEC_MAXG + j] = s;
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int ij = lane + e * 64;
+        for (int e = 0; e < 3; ++e) {
+            const int ij = threadIdx.x + e * 256;
             if (ij < gg) {
                 const int i = ij / g, j = ij - i * g;
-                gacc[e] = fmaf(Us[y * g + i], Rw[wave * DEC_MAXG + j], gacc[e]);
+                float a = gacc[e];
+#pragma unroll
+                for (int y = 0; y < UB_ROWS; ++y) a = fmaf(Us[(y0 + y) * g + i], Rc[y * g + j], a);
+                gacc[e] = a;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int ij = lane + e * 64;
-        if (ij < gg) Gw[wave * gg + ij] = gacc[e];
+    for (int e = 0; e < 3; ++e) {
+        const int ij = threadIdx.x + e * 256;
+        if (ij < gg) g_low[bh * gg + ij] = gacc[e];
     }
-    __syncthreads();
-    for (int ij = threadIdx.x; ij < gg; ij += 256)
-        g_low[bh * gg + ij] = (Gw[ij] + Gw[gg + ij]) + (Gw[2 * gg + ij] + Gw[3 * gg + ij]);
 }
 
 extern "C" int bf_decoder_upsample_sigmoid_bwd(const float* heat, const float* d_heat, const float* U,
@@ -402,7 +423,7 @@ extern "C" int bf_decoder_upsample_sigmoid_bwd(const float* heat, const float* d
     BF_REQUIRE(n_maps > 0 && grid > 0 && grid <= DEC_MAXG, BF_EINVAL,
                "bf_decoder_upsample_sigmoid_bwd: grid must be in 1..%d", DEC_MAXG);
     const int S = grid * 16;
-    const size_t lds = (size_t)(S * grid + 4 * DEC_MAXG + 4 * grid * grid) * sizeof(float);
+    const size_t lds = (size_t)(S * grid + UB_ROWS * S + UB_ROWS * grid) * sizeof(float);
     hipLaunchKernelGGL(upsample_sigmoid_bwd_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream, heat,
                        d_heat, U, g_low, grid);
     BF_CHECK_LAUNCH("bf_decoder_upsample_sigmoid_bwd");

@@ -95,16 +95,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres,
     float* __restrict__ dx, TC* __restrict__ dx_cdt, float* __restrict__ dgamma_part,
-    float* __restrict__ dbeta_part, int rows, int cols) {
+    float* __restrict__ dbeta_part, float* __restrict__ dres_sum_part, float* __restrict__ dx_sum_part,
+    int rows, int cols) {
     extern __shared__ __attribute__((aligned(16))) float red[];   // [2][4][cols]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nvec = cols >> 2;
-    float4 dg[LN_MAXC], db[LN_MAXC], gm[LN_MAXC];
+    float4 dg[LN_MAXC], db[LN_MAXC], gm[LN_MAXC], sr[LN_MAXC], sx[LN_MAXC];
+    const bool want_sums = dres_sum_part != nullptr;     // bias gradients of the two residual GEMMs
 #pragma unroll
     for (int i = 0; i < LN_MAXC; ++i) {
         dg[i] = make_float4(0, 0, 0, 0);
         db[i] = make_float4(0, 0, 0, 0);
+        sr[i] = make_float4(0, 0, 0, 0);
+        sx[i] = make_float4(0, 0, 0, 0);
         const int c = lane + i * 64;
         gm[i] = (c < nvec) ? *(const float4*)(gamma + c * 4) : make_float4(0, 0, 0, 0);
     }
@@ -144,7 +148,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
                 if (dres) {
                     const float4 r = *(const float4*)(dres + off + c * 4);
                     o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                    if (want_sums) { sr[i].x += r.x; sr[i].y += r.y; sr[i].z += r.z; sr[i].w += r.w; }
                 }
+                if (want_sums) { sx[i].x += o.x; sx[i].y += o.y; sx[i].z += o.z; sx[i].w += o.w; }
                 *(float4*)(dx + off + c * 4) = o;
                 if (dx_cdt) Vec4<TC>::store(dx_cdt + off + c * 4, o);
             }
@@ -168,15 +174,36 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         dbeta_part[(size_t)blockIdx.x * cols + c] =
             (rb[c] + rb[cols + c]) + (rb[2 * cols + c] + rb[3 * cols + c]);
     }
+    if (want_sums) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                *(float4*)(rg + wave * cols + c * 4) = sr[i];
+                *(float4*)(rb + wave * cols + c * 4) = sx[i];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            dres_sum_part[(size_t)blockIdx.x * cols + c] =
+                (rg[c] + rg[cols + c]) + (rg[2 * cols + c] + rg[3 * cols + c]);
+            dx_sum_part[(size_t)blockIdx.x * cols + c] =
+                (rb[c] + rb[cols + c]) + (rb[2 * cols + c] + rb[3 * cols + c]);
+        }
+    }
 }
 
 extern "C" int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                                 const float* mean, const float* rstd, const float* dres, float* dx,
                                 void* dx_cdt, int cdt_dtype, float* dgamma_part, float* dbeta_part,
-                                int rows, int cols, bf_stream_t stream) {
+                                float* dres_sum_part, float* dx_sum_part, int rows, int cols,
+                                bf_stream_t stream) {
     BF_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && cols <= LN_MAXC * 256, BF_EINVAL,
                "bf_layernorm_bwd: need cols %% 4 == 0 and cols <= %d (got rows=%d cols=%d)",
                LN_MAXC * 256, rows, cols);
+    BF_REQUIRE((dres_sum_part == nullptr) == (dx_sum_part == nullptr) && (!dres_sum_part || dres), BF_EINVAL,
+               "bf_layernorm_bwd: dres_sum_part and dx_sum_part come together and need dres");
     BF_REQUIRE(bf_aligned16(dy) && bf_aligned16(x) && bf_aligned16(dx) && bf_aligned16(gamma) &&
                    (!dres || bf_aligned16(dres)) && (!dx_cdt || bf_aligned16(dx_cdt)),
                BF_EALIGN, "bf_layernorm_bwd: pointers must be 16-byte aligned");
@@ -185,7 +212,8 @@ extern "C" int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     const size_t lds = (size_t)8 * cols * sizeof(float);
 #define LNB_LAUNCH(TDY, TC)                                                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), grid, block, lds, s, (const TDY*)dy, x, gamma,  \
-                       mean, rstd, dres, dx, (TC*)dx_cdt, dgamma_part, dbeta_part, rows, cols)
+                       mean, rstd, dres, dx, (TC*)dx_cdt, dgamma_part, dbeta_part, dres_sum_part,   \
+                       dx_sum_part, rows, cols)
     const int cd = dx_cdt ? cdt_dtype : BF_F32;
     if (dy_dtype == BF_F32 && cd == BF_F32) LNB_LAUNCH(float, float);
     else if (dy_dtype == BF_F32 && cd == BF_BF16) LNB_LAUNCH(float, bf16_t);

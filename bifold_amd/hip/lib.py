@@ -55,8 +55,8 @@ PROTOTYPES = {
                                  c_void_p, c_int, c_int, c_float, c_void_p]),
     "bf_layernorm_bwd_parts": (c_int, [c_int]),
     "bf_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
-                                 c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_void_p]),
     "bf_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "bf_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

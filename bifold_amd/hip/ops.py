@@ -111,20 +111,27 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
 
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
                   rstd: torch.Tensor, dres: Optional[torch.Tensor], cdt: Optional[torch.dtype],
-                  dgamma_out: torch.Tensor, dbeta_out: torch.Tensor):
-    """Returns (dx fp32, dx_cdt or None); writes dgamma/dbeta into the given fp32 vectors."""
+                  dgamma_out: torch.Tensor, dbeta_out: torch.Tensor,
+                  dres_sum_out: Optional[torch.Tensor] = None, dx_sum_out: Optional[torch.Tensor] = None):
+    """Returns (dx fp32, dx_cdt or None); writes dgamma/dbeta (and, when asked, the column sums
+    of dres and of dx) into the given fp32 vectors."""
     _dev(dy, "dy"); _dev(x, "x")
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     dx_c = torch.empty(x.shape, dtype=cdt, device=x.device) if (cdt is not None and cdt != torch.float32) else None
     nparts = lib.bf_layernorm_bwd_parts(rows)
-    parts = torch.empty(2, nparts, cols, dtype=torch.float32, device=x.device)
+    want = dres_sum_out is not None
+    parts = torch.empty(4 if want else 2, nparts, cols, dtype=torch.float32, device=x.device)
     check(lib.bf_layernorm_bwd(_ptr(dy), dtype_code(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
                                _ptr(dres), _ptr(dx), _ptr(dx_c), L.BF16 if dx_c is not None else L.F32,
-                               _ptr(parts[0]), _ptr(parts[1]), rows, cols, _stream()), "bf_layernorm_bwd")
+                               _ptr(parts[0]), _ptr(parts[1]), _ptr(parts[2]) if want else None,
+                               _ptr(parts[3]) if want else None, rows, cols, _stream()), "bf_layernorm_bwd")
     colsum(parts[0], out=dgamma_out)
     colsum(parts[1], out=dbeta_out)
+    if want:
+        colsum(parts[2], out=dres_sum_out)
+        colsum(parts[3], out=dx_sum_out)
     return dx, dx_c
 
 

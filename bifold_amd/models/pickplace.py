@@ -155,16 +155,17 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
     da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD, aux=S["a_pre"])
     ops.gemm(op3, S["a"], trans_a=True, b_kn=True, out=g(P["w2"]))
-    ops.colsum(dx3, out=g(P["bb2"]))
     dh2 = ops.gemm(da_pre, A.operand(P["w1"], cdt), b_kn=True)
     ops.gemm(da_pre, S["h2"], trans_a=True, b_kn=True, out=g(P["w1"]))
     ops.colsum(da_pre, out=g(P["bb1"]))
-    dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]))
+    # the LayerNorm backward streams dx3 (in) and dx2 (out): it also emits their column sums,
+    # i.e. the bias gradients of net.3 and to_out
+    dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]),
+                                   dres_sum_out=g(P["bb2"]), dx_sum_out=g(P["bo"]))
     op2 = dx2_c if dx2_c is not None else dx2
     # attention:  x2 = x + attn(h1 Wqkv^T) Wo^T + bo
     do = ops.gemm(op2, A.operand(P["wo"], cdt), b_kn=True)
     ops.gemm(op2, S["o"], trans_a=True, b_kn=True, out=g(P["wo"]))
-    ops.colsum(dx2, out=g(P["bo"]))
     dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask)
     dh1 = ops.gemm(dqkv, A.operand(P["wqkv"], cdt), b_kn=True)
     ops.gemm(dqkv, S["h1"], trans_a=True, b_kn=True, out=g(P["wqkv"]))

@@ -66,12 +66,16 @@ int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
  *   dx = (dres ? dres : 0) + dLN(dy)          fp32 [rows, cols]
  *   dx_cdt (optional, cdt_dtype) = cast(dx)   -- operand for the next dX/dW GEMMs
  *   dgamma_part/dbeta_part: fp32 [n_part, cols] per-workgroup partial sums,
- *   n_part = bf_layernorm_bwd_parts(rows); reduce them with bf_colsum. */
+ *   n_part = bf_layernorm_bwd_parts(rows); reduce them with bf_colsum.
+ *   dres_sum_part / dx_sum_part (optional, both or neither): partial column sums of dres and
+ *   of dx -- the bias gradients of the two residual-branch Linears around this LayerNorm
+ *   (FeedForward.net.3 and Attention.to_out), which this kernel streams anyway. */
 int bf_layernorm_bwd_parts(int rows);
 int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                      const float* mean, const float* rstd, const float* dres, float* dx,
-                     void* dx_cdt, int cdt_dtype, float* dgamma_part, float* dbeta_part, int rows,
-                     int cols, bf_stream_t stream);
+                     void* dx_cdt, int cdt_dtype, float* dgamma_part, float* dbeta_part,
+                     float* dres_sum_part, float* dx_sum_part, int rows, int cols,
+                     bf_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * GEMM with fused epilogue:  C = epilogue(alpha * op(A) * op(B)).

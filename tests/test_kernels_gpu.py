@@ -70,9 +70,14 @@ def test_layernorm_bwd(ops, gpu, rows, cols, cdt):
     _, mean, rstd = ops.layernorm_fwd(xg, w.detach().to(gpu), b.detach().to(gpu), torch.float32, True)
     dgam = torch.empty(cols, device=gpu)
     dbet = torch.empty(cols, device=gpu)
+    s_res, s_dx = torch.empty(cols, device=gpu), torch.empty(cols, device=gpu)
     dx, dxc = ops.layernorm_bwd(dy.to(gpu).to(cdt), xg, w.detach().to(gpu), mean, rstd, dres.to(gpu), cdt,
-                                dgam, dbet)
+                                dgam, dbet, dres_sum_out=s_res, dx_sum_out=s_dx)
     assert rel_err(dx, ref_dx) < 1e-5
+    assert rel_err(s_res, dres.double().sum(0)) < 1e-5 and rel_err(s_dx, ref_dx.double().sum(0)) < 1e-5
+    dx_b, _ = ops.layernorm_bwd(dy.to(gpu).to(cdt), xg, w.detach().to(gpu), mean, rstd, dres.to(gpu), cdt,
+                                dgam, dbet)                       # the variant without the sums
+    assert torch.equal(dx_b, dx)
     assert rel_err(dgam, w.grad) < 1e-5
     assert rel_err(dbet, b.grad) < 1e-5
     if cdt == torch.bfloat16:
@@ -91,7 +96,8 @@ def ref_gemm(a, b, trans_a, b_kn):
 
 
 GEMM_SHAPES = [  # m, n, k
-    (197 * 2, 768, 768), (100, 128, 64), (275, 1536, 512), (77 * 3, 512, 2048), (130, 256, 192)]
+    (197 * 2, 768, 768), (100, 128, 64), (275, 1536, 512), (77 * 3, 512, 2048), (130, 256, 192),
+    (1000, 640, 128), (777, 384, 320)]
 
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
