@@ -226,11 +226,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
 //      V^T tile [DP][KT keys'] bf16, row stride KT*2+16 bytes; DP = D rounded up to 32;
 //      within every 16-key group the key index has bits 2 and 3 swapped, which is the k
 //      order of an accumulator tile reused as an MFMA operand (guide §3).
-template <int D>
+template <int D, int MASK>
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-    const int32_t* __restrict__ row_mask, int L, int H, float scale, int mask_mode,
-    int waves_per_block) {
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int waves_per_block) {
+    constexpr int mask_mode = MASK;
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;                // k-steps of Q K^T
     constexpr int DB = DP / 32;               // 32-row blocks of O^T
@@ -307,29 +307,41 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
             }
         }
-        // ---- masks + online softmax (log2 domain) --------------------------------------
+        // ---- masks + online softmax (log2 domain; raw scores stay in sacc) --------------
+        // Per score: one max, one FMA (scale and -max folded), one v_exp, one add.  The key-tail
+        // and causal tests run only on tiles that can contain a masked key.
+        const bool edge = (j0 + KT > L) || (mask_mode == BF_MASK_CAUSAL && j0 + KT - 1 > q0);
+        if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[kb][e] = -100000.0f / scale;   // all scores equal
+        }
+        if (edge) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[kb][e] = -INFINITY;
+                }
+        }
         float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                float s = row_masked ? -100000.0f * 1.44269504088896340736f : sacc[kb][e] * sl2;
-                if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) s = -INFINITY;
-                sacc[kb][e] = s;
-                tmax = fmaxf(tmax, s);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;       // sl2 > 0: max commutes with the scale
         const float m_new = fmaxf(m, tmax);
         // m_new is finite for every live query: tile 0 always holds an unmasked key
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m - m_use);
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = exp2f(sacc[kb][e] - m_use);
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], sl2, -m_use));
                 sacc[kb][e] = p;
                 psum += p;
             }
@@ -414,11 +426,12 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
     return r;
 }
 
-template <int D>
+template <int D, int MASK>
 __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
-    int L, int H, float scale, int mask_mode) {
+    int L, int H, float scale) {
+    constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
     constexpr int DP = Cf::DP, KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -520,17 +533,22 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
             }
             // ---- P and dS (lane = key column, register = query row) -----------------------
-            const bool key_ok = key < L;
+            // keys beyond L have zero K/V rows but a non-zero exp(-lse): kill the whole lane once
+            const float lane_on = key < L ? 1.0f : 0.0f;
+            const float lane_scale = lane_on * scale;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int qi = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                float p = exp2f(sl2 * sacc[e]);
+                float p = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * lane_on;
                 float ds = p * pacc[e] * scale;
-                if (mask_mode == BF_MASK_QUERY_ROW && msk_s[qi]) { p = inv_len; ds = 0.f; }
-                if (!key_ok || (mask_mode == BF_MASK_CAUSAL && key > qi)) { p = 0.f; ds = 0.f; }
+                if (mask_mode != BF_MASK_NONE) {
+                    const int qi = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (mask_mode == BF_MASK_QUERY_ROW && msk_s[qi]) { p = inv_len * lane_on; ds = 0.f; }
+                    if (mask_mode == BF_MASK_CAUSAL && key > qi) { p = 0.f; ds = 0.f; }
+                }
                 sacc[e] = p;
                 pacc[e] = ds;
             }
+            (void)lane_scale;
             bf16x8 pb[2], dsb[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -641,13 +659,20 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         const int chunks = bf_cdiv(nq32, 8);
         const int wpb = bf_cdiv(nq32, chunks);
         dim3 grid(batch * heads, chunks), block(wpb * 64);
+#define FWD_MFMA2(DD, MM)                                                                         \
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<DD, MM>), grid, block, 0, s, (const bf16_t*)qkv,     \
+                       (bf16_t*)out, lse, row_mask, seq, heads, scale, wpb)
 #define FWD_MFMA(DD)                                                                              \
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel<DD>, grid, block, 0, s, (const bf16_t*)qkv, (bf16_t*)out, \
-                       lse, row_mask, seq, heads, scale, mask_mode, wpb)
+    do {                                                                                          \
+        if (mask_mode == BF_MASK_NONE) FWD_MFMA2(DD, BF_MASK_NONE);                               \
+        else if (mask_mode == BF_MASK_CAUSAL) FWD_MFMA2(DD, BF_MASK_CAUSAL);                      \
+        else FWD_MFMA2(DD, BF_MASK_QUERY_ROW);                                                    \
+    } while (0)
         if (head_dim == 32) FWD_MFMA(32);
         else if (head_dim == 48) FWD_MFMA(48);
         else FWD_MFMA(64);
 #undef FWD_MFMA
+#undef FWD_MFMA2
     } else {
         dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
 #define FWD_SIMPLE(DD)                                                                            \
@@ -699,23 +724,30 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     // longer sequences take the (slow, VALU) tiled kernels below
     if (cdt == BF_BF16 && nw <= maxw && bwd_lds <= 160 * 1024) {
         dim3 grid(batch * heads), block(nw * 64);
-#define BWD_MFMA(DD)                                                                                \
+#define BWD_MFMA2(DD, MM)                                                                           \
     do {                                                                                            \
         const size_t lds = BwdCfg<DD>::lds_bytes(nw);                                               \
         static size_t lds_set = 0;                                                                  \
         if (lds > lds_set) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD>,                        \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM>,                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             lds_set = lds;                                                                          \
         }                                                                                           \
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel<DD>, grid, block, lds, s, (const bf16_t*)qkv,       \
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<DD, MM>), grid, block, lds, s, (const bf16_t*)qkv, \
                            (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv, seq, \
-                           heads, scale, mask_mode);                                                \
+                           heads, scale);                                                           \
+    } while (0)
+#define BWD_MFMA(DD)                                                                                \
+    do {                                                                                            \
+        if (mask_mode == BF_MASK_NONE) BWD_MFMA2(DD, BF_MASK_NONE);                                 \
+        else if (mask_mode == BF_MASK_CAUSAL) BWD_MFMA2(DD, BF_MASK_CAUSAL);                        \
+        else BWD_MFMA2(DD, BF_MASK_QUERY_ROW);                                                      \
     } while (0)
         if (head_dim == 32) BWD_MFMA(32);
         else if (head_dim == 48) BWD_MFMA(48);
         else BWD_MFMA(64);
 #undef BWD_MFMA
+#undef BWD_MFMA2
     } else if (cdt == BF_BF16)
         attn_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
                                 head_dim, scale, mask_mode, s);
