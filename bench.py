@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--per-shape", action="store_true", help="diagnostic: time every GEMM shape separately")
     args = ap.parse_args()
 
     from bifold_amd import dist as bdist
@@ -150,7 +151,7 @@ def main():
     fence()
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.KernelTimer()
+        timer = ops.KernelTimer(per_shape=args.per_shape)
         ops.PROFILER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -189,6 +190,10 @@ def main():
         if timer is not None:
             summ = timer.summary()
             dom = "gemm_bf16_nt" if args.dtype == "bf16" else "gemm_f32_nt"
+            if args.per_shape:
+                for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                    print(f"{v['ms'] / args.steps:8.3f} ms/step {v['launches'] / args.steps:5.1f}x {v['avg_us']:8.1f} us "
+                          f"{v['tflops']:7.1f} TF/s  {k}", file=sys.stderr)
             d = summ.get(dom)
             if d:
                 peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3

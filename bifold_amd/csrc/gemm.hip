@@ -720,6 +720,81 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_w128_kernel(const bf16_t* __
 }
 
 // =====================================================================================
+//     bf16 MFMA kernel, 128x128x32 tile, 2 stages (32 KB LDS) -> up to 4 blocks per CU
+// =====================================================================================
+// In-step timings show the main loops at 620-690 TF/s and the time going to epilogue-heavy
+// GEMMs (fp32 residual read + write, dual outputs, GELU' aux reads): their HBM traffic is a
+// serial phase per tile.  More co-resident workgroups overlap one tile's epilogue with other
+// tiles' MFMAs; halving BK halves the LDS footprint and doubles the blocks per CU.
+template <bool A_KS, bool B_KS, typename TC>
+__global__ __launch_bounds__(256, 4) void gemm_bf16_k32_kernel(const bf16_t* __restrict__ A,
+                                                               const bf16_t* __restrict__ B, GemmDims d,
+                                                               EpiParams ep, float* __restrict__ slabs,
+                                                               unsigned a_bytes, unsigned b_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 8 KB | B 8 KB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int z = blockIdx.x / tiles;
+    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
+    int tm, tn;
+    tile_coords(t, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int kbeg = z * d.k_per_split;
+    const int kend = min(d.k, kbeg + d.k_per_split);
+    const int nk = (kend - kbeg + 31) >> 5;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto stage_tile = [&](int kt) {
+        char* st = smem + (kt & 1) * 16384;
+        dma_pieces32<A_KS>(ra, st, d.lda, m0, kbeg + kt * 32, wave * 2, 2, lane);
+        dma_pieces32<B_KS>(rb, st + 8192, d.ldb, n0, kbeg + kt * 32, wave * 2, 2, lane);
+    };
+    stage_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* la = smem + (kt & 1) * 16384;
+        const char* lb = la + 8192;
+        if (kt + 1 < nk) stage_tile(kt + 1);
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS>(la, wm * 64 + i * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (m < ep.m && n < ep.n) {
+                const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+                if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
+                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
+            }
+        }
+    }
+}
+
+// =====================================================================================
 //                                   exact fp32 MFMA kernel
 // =====================================================================================
 #define F32_LD 132  // [16][128+4] k-major operand tiles
@@ -975,9 +1050,26 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         const size_t b_ext = ((size_t)((g->b_kn ? g->k : g->n) - 1) * g->ldb + (g->b_kn ? g->n : g->k)) * 2;
         const bool dma_ok = ((g->trans_a && g->b_kn) || (g->k % 64) == 0) && a_ext < (1ull << 32) &&
                             b_ext < (1ull << 32) && !getenv("BIFOLD_GEMM_NO_DMA");
-        static int pipe_env = -1;
-        if (pipe_env < 0) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : 0; }
-        if (dma_ok && pipe_env == 3 && g->m >= 512) {
+        static int pipe_env = -2;
+        if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+        // Kernel choice (measured in-step at B = 256): the BK = 32 kernel runs 4
+        // workgroups per CU, which overlaps the epilogue traffic of one tile with the MFMAs of the
+        // others and wins on every NN / TN shape and on short-K NT; long-K, large NT GEMMs
+        // (K >= 2048 with >= 2e7 outputs) keep the BK = 64 kernel (half the barriers per FLOP).
+        // BIFOLD_GEMM_PIPE forces a variant: 0 = BK64, 4 = BK32, 1/2/3 = experimental tiles.
+        const bool long_nt = !g->trans_a && !g->b_kn && g->k >= 2048 && (double)g->m * g->n >= 2.0e7;
+        const int variant = pipe_env >= 0 ? pipe_env : (long_nt ? 0 : 4);
+        if (dma_ok && variant == 4) {
+            const size_t lds4 = 32768;
+            const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
+#define LAUNCH_K32(AKS, BKS, TC) \
+    hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC>), grid, block, lds4, s, A, B, d, ep, slabs, ab, bb)
+            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_K32(false, false, float); else LAUNCH_K32(false, false, bf16_t); }
+            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(false, true, float); else LAUNCH_K32(false, true, bf16_t); }
+            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(true, true, float); else LAUNCH_K32(true, true, bf16_t); }
+            else { if (f32out) LAUNCH_K32(true, false, float); else LAUNCH_K32(true, false, bf16_t); }
+#undef LAUNCH_K32
+        } else if (dma_ok && variant == 3 && g->m >= 512) {
             const int ptm = bf_cdiv(g->m, W_BM), ptn = bf_cdiv(g->n, W_BN);
             GemmDims dp{g->m, g->n, g->k, g->lda, g->ldb, ptm, ptn, kps, group_m_env > 8 ? group_m_env / 2 : group_m_env};
             dim3 pgrid((unsigned)((long)ptm * ptn * split)), pblock(256);
@@ -998,7 +1090,7 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
             else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_W128(true, true, float); else LAUNCH_W128(true, true, bf16_t); }
             else { if (f32out) LAUNCH_W128(true, false, float); else LAUNCH_W128(true, false, bf16_t); }
 #undef LAUNCH_W128
-        } else if (dma_ok && pipe_env == 2 && g->m >= 1024 && g->n >= 256) {
+        } else if (dma_ok && variant == 2 && g->m >= 1024 && g->n >= 256) {
             const int ptm = bf_cdiv(g->m, G_BM), ptn = bf_cdiv(g->n, G_BN);
             GemmDims dp{g->m, g->n, g->k, g->lda, g->ldb, ptm, ptn, kps, group_m_env > 8 ? group_m_env / 2 : group_m_env};
             dim3 pgrid((unsigned)((long)ptm * ptn * split)), pblock(512);
@@ -1019,7 +1111,7 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
             else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_BIG(true, true, float); else LAUNCH_BIG(true, true, bf16_t); }
             else { if (f32out) LAUNCH_BIG(true, false, float); else LAUNCH_BIG(true, false, bf16_t); }
 #undef LAUNCH_BIG
-        } else if (dma_ok && pipe_env == 1 && g->m >= 1024) {
+        } else if (dma_ok && variant == 1 && g->m >= 1024) {
             // 256x128 tiles, 3-stage ring: its own grid
             const int ptm = bf_cdiv(g->m, P_BM), ptn = bf_cdiv(g->n, P_BN);
             GemmDims dp{g->m, g->n, g->k, g->lda, g->ldb, ptm, ptn, kps, group_m_env > 8 ? group_m_env / 2 : group_m_env};

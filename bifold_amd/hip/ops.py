@@ -23,8 +23,9 @@ class KernelTimer:
     (bench.py turns it on for the timed region to price the dominant kernel against the MFMA
     roofline).  records: (label, algorithmic FLOPs, start event, end event)."""
 
-    def __init__(self):
+    def __init__(self, per_shape: bool = False):
         self.records = []
+        self.per_shape = per_shape
 
     def summary(self):
         out = {}
@@ -205,8 +206,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
     g.split_k = sk
     span = None
     if PROFILER is not None:
-        span = _Span(f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}",
-                     2.0 * m * n * k)
+        label = f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}"
+        if PROFILER.per_shape:
+            extras = "".join(t for t, on in (("+bias", bias is not None), (f"+act{act}", act != 0),
+                                              ("+pre", want_pre), ("+res", residual is not None),
+                                              ("+f32out", out.dtype == torch.float32)) if on)
+            label += f" {m}x{n}x{k}{extras}"
+        span = _Span(label, 2.0 * m * n * k)
     check(lib.bf_gemm(C.byref(g), _stream()), "bf_gemm")
     if span is not None:
         span.close()
