@@ -726,12 +726,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_w128_kernel(const bf16_t* __
 // GEMMs (fp32 residual read + write, dual outputs, GELU' aux reads): their HBM traffic is a
 // serial phase per tile.  More co-resident workgroups overlap one tile's epilogue with other
 // tiles' MFMAs; halving BK halves the LDS footprint and doubles the blocks per CU.
-template <bool A_KS, bool B_KS, typename TC>
-__global__ __launch_bounds__(256, 4) void gemm_bf16_k32_kernel(const bf16_t* __restrict__ A,
-                                                               const bf16_t* __restrict__ B, GemmDims d,
-                                                               EpiParams ep, float* __restrict__ slabs,
-                                                               unsigned a_bytes, unsigned b_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 8 KB | B 8 KB)
+// WT = 16-row MFMA tiles per wave along M: 4 -> 128x128 block (4 blocks/CU), 2 -> 64x128 block
+// (24 KB LDS, 6 blocks/CU).  The small tile is for narrow-N GEMMs whose 128x128 tiling fills the
+// chip's workgroup slots only ~70 % in its last round (e.g. 70400x512: 2200 tiles on 1024 slots).
+template <bool A_KS, bool B_KS, typename TC, int WT>
+__global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmDims d, EpiParams ep,
+    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes) {
+    constexpr int BM = WT * 32;                    // 2 waves along M
+    constexpr int A_BYTES = BM * 64;               // one BK=32 stage of A
+    constexpr int STAGE = A_BYTES + 8192;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A | B 8 KB)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -740,48 +745,48 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_k32_kernel(const bf16_t* __r
     const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
     int tm, tn;
     tile_coords(t, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
-    const int m0 = tm * 128, n0 = tn * 128;
+    const int m0 = tm * BM, n0 = tn * 128;
     const int kbeg = z * d.k_per_split;
     const int kend = min(d.k, kbeg + d.k_per_split);
     const int nk = (kend - kbeg + 31) >> 5;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][WT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < WT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto stage_tile = [&](int kt) {
-        char* st = smem + (kt & 1) * 16384;
-        dma_pieces32<A_KS>(ra, st, d.lda, m0, kbeg + kt * 32, wave * 2, 2, lane);
-        dma_pieces32<B_KS>(rb, st + 8192, d.ldb, n0, kbeg + kt * 32, wave * 2, 2, lane);
+        char* st = smem + (kt & 1) * STAGE;
+        dma_pieces32<A_KS>(ra, st, d.lda, m0, kbeg + kt * 32, wave * (WT / 2), WT / 2, lane);
+        dma_pieces32<B_KS>(rb, st + A_BYTES, d.ldb, n0, kbeg + kt * 32, wave * 2, 2, lane);
     };
     stage_tile(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const char* la = smem + (kt & 1) * 16384;
-        const char* lb = la + 8192;
+        const char* la = smem + (kt & 1) * STAGE;
+        const char* lb = la + A_BYTES;
         if (kt + 1 < nk) stage_tile(kt + 1);
-        bf16x8 af[4], bfr[4];
+        bf16x8 af[WT], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS>(la, wm * 64 + i * 16, lane);
+        for (int i = 0; i < WT; ++i) af[i] = bf16_frag32<A_KS>(la, wm * (WT * 16) + i * 16, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < WT; ++i)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < WT; ++i) {
+        const int m = m0 + wm * (WT * 16) + i * 16 + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
@@ -1060,10 +1065,27 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         const bool long_nt = !g->trans_a && !g->b_kn && g->k >= 2048 && (double)g->m * g->n >= 2.0e7;
         const int variant = pipe_env >= 0 ? pipe_env : (long_nt ? 0 : 4);
         if (dma_ok && variant == 4) {
-            const size_t lds4 = 32768;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-#define LAUNCH_K32(AKS, BKS, TC) \
-    hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC>), grid, block, lds4, s, A, B, d, ep, slabs, ab, bb)
+            // 64-row tiles when they fill the chip's workgroup slots better (256 CUs x 4 vs x 6)
+            const long t128 = (long)tiles_m * tiles_n * split;
+            const long t64 = (long)bf_cdiv(g->m, 64) * tiles_n * split;
+            const double e128 = (double)t128 / ((double)((t128 + 1023) / 1024) * 1024.0);
+            const double e64 = (double)t64 / ((double)((t64 + 1535) / 1536) * 1536.0);
+            static int bm_env = -2;
+            if (bm_env == -2) { const char* e = getenv("BIFOLD_GEMM_BM"); bm_env = e ? atoi(e) : -1; }
+            // measured: the 64-row tile does not pay even where it fills the slots better (more
+            // L2 -> LDS bytes per FLOP), so it is opt-in (BIFOLD_GEMM_BM=64), K-contiguous A only
+            (void)e128; (void)e64;
+            const bool small = bm_env == 64 && !g->trans_a;
+#define LAUNCH_K32(AKS, BKS, TC)                                                                    \
+    do {                                                                                          \
+        if (small) {                                                                              \
+            GemmDims d64 = d; d64.tiles_m = bf_cdiv(g->m, 64);                                    \
+            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 2>), dim3((unsigned)t64), block, 24576, s, A, B, d64, ep, slabs, ab, bb); \
+        } else {                                                                                  \
+            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 4>), grid, block, 32768, s, A, B, d, ep, slabs, ab, bb); \
+        }                                                                                         \
+    } while (0)
             if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_K32(false, false, float); else LAUNCH_K32(false, false, bf16_t); }
             else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(false, true, float); else LAUNCH_K32(false, true, bf16_t); }
             else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(true, true, float); else LAUNCH_K32(true, true, bf16_t); }

@@ -90,7 +90,9 @@ extern "C" int bf_layernorm_bwd_parts(int rows) {
     return p < 1 ? 1 : (p > 1024 ? 1024 : p);
 }
 
-template <typename TDY, typename TC>
+// NC = float4 chunks per lane (cols <= NC*256): sized per call so that the five per-lane
+// accumulator arrays do not cost occupancy at the common widths (512 -> 2, 768 -> 3).
+template <typename TDY, typename TC, int NC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const TDY* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ dres,
@@ -101,10 +103,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nvec = cols >> 2;
-    float4 dg[LN_MAXC], db[LN_MAXC], gm[LN_MAXC], sr[LN_MAXC], sx[LN_MAXC];
+    float4 dg[NC], db[NC], gm[NC], sr[NC], sx[NC];
     const bool want_sums = dres_sum_part != nullptr;     // bias gradients of the two residual GEMMs
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         dg[i] = make_float4(0, 0, 0, 0);
         db[i] = make_float4(0, 0, 0, 0);
         sr[i] = make_float4(0, 0, 0, 0);
@@ -116,10 +118,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         const size_t off = (size_t)row * cols;
-        float4 xh[LN_MAXC], g[LN_MAXC];
+        float4 xh[NC], g[NC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + i * 64;
             if (c < nvec) {
                 const float4 xv = *(const float4*)(x + off + c * 4);
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         const float m1 = wave_sum(s1) * inv_cols;
         const float m2 = wave_sum(s2) * inv_cols;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + i * 64;
             if (c < nvec) {
                 float4 o;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     float* rg = red;
     float* rb = red + 4 * cols;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int c = lane + i * 64;
         if (c < nvec) {
             *(float4*)(rg + wave * cols + c * 4) = dg[i];
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     if (want_sums) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < LN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i) {
             const int c = lane + i * 64;
             if (c < nvec) {
                 *(float4*)(rg + wave * cols + c * 4) = sr[i];
@@ -210,10 +212,17 @@ extern "C" int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bf_layernorm_bwd_parts(rows)), block(256);
     const size_t lds = (size_t)8 * cols * sizeof(float);
-#define LNB_LAUNCH(TDY, TC)                                                                       \
-    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC>), grid, block, lds, s, (const TDY*)dy, x, gamma,  \
+#define LNB_LAUNCH_NC(TDY, TC, NCV)                                                               \
+    hipLaunchKernelGGL((ln_bwd_kernel<TDY, TC, NCV>), grid, block, lds, s, (const TDY*)dy, x, gamma, \
                        mean, rstd, dres, dx, (TC*)dx_cdt, dgamma_part, dbeta_part, dres_sum_part,   \
                        dx_sum_part, rows, cols)
+#define LNB_LAUNCH(TDY, TC)                                                                       \
+    do {                                                                                          \
+        if (cols <= 512) LNB_LAUNCH_NC(TDY, TC, 2);                                               \
+        else if (cols <= 768) LNB_LAUNCH_NC(TDY, TC, 3);                                          \
+        else if (cols <= 1024) LNB_LAUNCH_NC(TDY, TC, 4);                                         \
+        else LNB_LAUNCH_NC(TDY, TC, 8);                                                           \
+    } while (0)
     const int cd = dx_cdt ? cdt_dtype : BF_F32;
     if (dy_dtype == BF_F32 && cd == BF_F32) LNB_LAUNCH(float, float);
     else if (dy_dtype == BF_F32 && cd == BF_BF16) LNB_LAUNCH(float, bf16_t);
@@ -221,6 +230,7 @@ extern "C" int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     else if (dy_dtype == BF_BF16 && cd == BF_F32) LNB_LAUNCH(bf16_t, float);
     else BF_REQUIRE(false, BF_EINVAL, "bf_layernorm_bwd: bad dtype codes");
 #undef LNB_LAUNCH
+#undef LNB_LAUNCH_NC
     BF_CHECK_LAUNCH("bf_layernorm_bwd");
     return BF_OK;
 }

@@ -138,9 +138,12 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
 
 # ----------------------------------------------------------------------------- GEMM
 def pick_split_k(m: int, n: int, k: int) -> int:
+    """Split the contraction when the output alone cannot fill the chip (the dW = dY^T X GEMMs:
+    16-64 output tiles, 70 k tokens deep)."""
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     if tiles >= 256 or k < 1024:
         return 1
+    # measured at B = 256: ~768 blocks beat a "full" 1024 (fewer fp32 partial slabs to write + reduce)
     return max(1, min(64, 768 // tiles, k // 512))
 
 
