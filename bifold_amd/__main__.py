@@ -46,6 +46,8 @@ class SyntheticLoader:
         self.steps = max(1, int(cfg.train_dataset.length) // (self.batch * world))
         self.device, self.rank, self.seed, self.epoch = device, rank, int(cfg.seed), 0
         self.sigma = float(cfg.processor.sigma)
+        self.siglip = str(cfg.model.name).startswith("siglip")
+        self.context = int(cfg.model.get("context_length", 0) or 0) if cfg.model.name == "siglip_sequential" else 0
 
     def __len__(self):
         return self.steps
@@ -59,12 +61,20 @@ class SyntheticLoader:
         names = ([f"{a}_{k}" for a in ("left", "right") for k in ("pick", "place")]
                  if self.is_bimanual else ["pick", "place"])
         for _ in range(self.steps):
-            instr = torch.zeros(b, 77, dtype=torch.int32, device=dev)
-            instr[:, 0] = 49406
-            instr[:, 1:31] = torch.randint(1, 49406, (b, 30), generator=g, device=dev).int()
-            instr[:, 31] = 49407
+            if self.siglip:        # 32 sentencepiece ids + 32 pad (id 1), int64 like the HF processor
+                instr = torch.ones(b, 64, dtype=torch.int64, device=dev)
+                instr[:, :32] = torch.randint(0, 32000, (b, 32), generator=g, device=dev)
+            else:                  # CLIP BPE ids: <start> 30 tokens <end>, zero padded to 77
+                instr = torch.zeros(b, 77, dtype=torch.int32, device=dev)
+                instr[:, 0] = 49406
+                instr[:, 1:31] = torch.randint(1, 49406, (b, 30), generator=g, device=dev).int()
+                instr[:, 31] = 49407
             sample = {"rgb": torch.randn(b, 3, s, s, generator=g, device=dev), "instruction": instr,
                       "mask": torch.ones(b, 1, s, s, device=dev)}
+            if self.context:
+                sample["rgb_context"] = torch.randn(b, self.context, 3, s, s, generator=g, device=dev)
+                k = torch.randint(0, self.context + 1, (b, 1), generator=g, device=dev)
+                sample["context_attention_mask"] = (torch.arange(self.context, device=dev)[None, :] < k).long()
             for n in names:
                 c = torch.randint(0, s, (b, 2), generator=g, device=dev).float()
                 sample[f"{n}_heatmap"] = torch.exp(
@@ -155,7 +165,9 @@ class Trainer:
             dt = time.time() - t0
             print(f"epoch {epoch}: mean loss {mean:.6f}  {n * self.cfg.batch_size * self.world / dt:.1f} samples/s "
                   f"lr {self.optimizer.param_groups[0]['lr']:.3e}")
-        self.model.clip_encoder.check_token_ids()
+        tower = getattr(self.model, "clip_encoder", None) or getattr(self.model, "siglip_model", None)
+        if tower is not None:
+            tower.check_token_ids()
 
     def train(self):
         for epoch in range(self.start_epoch, self.cfg.epochs):

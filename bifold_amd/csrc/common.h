@@ -120,14 +120,25 @@ __device__ __forceinline__ float quick_gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
 
+__device__ __forceinline__ float tanh_gelu_f(float x) {          // gelu_pytorch_tanh (HF SigLIP MLP)
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float tanh_gelu_fast(float x) {       // tanh(u) = 1 - 2 / (1 + e^{2u})
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+    return 0.5f * x * (1.0f + t);
+}
+
 template <typename TD> struct ActMath;      // TD = compute dtype of the call
 template <> struct ActMath<float> {
     static __device__ __forceinline__ float quick(float x) { return quick_gelu_f(x); }
     static __device__ __forceinline__ float erf(float x) { return erf_gelu_f(x); }
     static __device__ __forceinline__ float erf_grad(float x) { return erf_gelu_grad_f(x); }
+    static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_f(x); }
 };
 template <> struct ActMath<bf16_t> {
     static __device__ __forceinline__ float quick(float x) { return quick_gelu_fast(x); }
     static __device__ __forceinline__ float erf(float x) { return erf_gelu_fast(x); }
     static __device__ __forceinline__ float erf_grad(float x) { return erf_gelu_grad_fast(x); }
+    static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_fast(x); }
 };

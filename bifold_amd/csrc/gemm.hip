@@ -46,11 +46,13 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
     }
     size_t orow = (size_t)m;
     if (ep.rows_in > 0) orow = (size_t)(m / ep.rows_in) * ep.rows_out + ep.row_off + (m % ep.rows_in);
-    if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU) {
+    if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU || ep.act == BF_ACT_TANH_GELU) {
         if (ep.pre) Vec4<TD>::store((TD*)ep.pre + orow * ep.ldc + n, v);
         using AM = ActMath<TD>;
         if (ep.act == BF_ACT_QUICK_GELU) {
             v.x = AM::quick(v.x); v.y = AM::quick(v.y); v.z = AM::quick(v.z); v.w = AM::quick(v.w);
+        } else if (ep.act == BF_ACT_TANH_GELU) {
+            v.x = AM::tanh_gelu(v.x); v.y = AM::tanh_gelu(v.y); v.z = AM::tanh_gelu(v.z); v.w = AM::tanh_gelu(v.w);
         } else {
             v.x = AM::erf(v.x); v.y = AM::erf(v.y); v.z = AM::erf(v.z); v.w = AM::erf(v.w);
         }
@@ -978,7 +980,7 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
                "bf_gemm: fp32 operands produce fp32 output only");
     BF_REQUIRE(!(g->accumulate && g->c_dtype != BF_F32), BF_EINVAL,
                "bf_gemm: accumulate needs an fp32 C");
-    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_ERF_GELU_GRAD, BF_EINVAL, "bf_gemm: bad act");
+    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_TANH_GELU, BF_EINVAL, "bf_gemm: bad act");
     BF_REQUIRE(g->act != BF_ACT_ERF_GELU_GRAD || g->aux, BF_EINVAL, "bf_gemm: GELU_GRAD needs aux");
     const int vec = g->cdt == BF_BF16 ? 8 : 4;
     BF_REQUIRE((g->n & 3) == 0 && (g->ldc & 3) == 0 && g->ldc >= g->n, BF_EINVAL,

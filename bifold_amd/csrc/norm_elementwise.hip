@@ -590,3 +590,83 @@ extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt
     BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/2");
     return BF_OK;
 }
+
+// ------------------------------------------------------------------ generic fusion-input segment
+__global__ __launch_bounds__(256) void segment_assemble_kernel(
+    const float* __restrict__ src, long src_bstride, const float* __restrict__ lead,
+    const float* __restrict__ pos, const float* __restrict__ type_vec, float* __restrict__ x, int batch,
+    int n, int seq_total, int row_off, int dim) {
+    const int nvec = dim >> 2;
+    const size_t total = (size_t)batch * (n + 1) * nvec;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % nvec);
+        const size_t row = i / nvec;
+        const int b = (int)(row / (n + 1)), t = (int)(row - (size_t)b * (n + 1));
+        const float* s = (t == 0) ? lead : src + (size_t)b * src_bstride + (size_t)(t - 1) * dim;
+        float4 v = *(const float4*)(s + c * 4);
+        if (pos) {
+            const float4 p = *(const float4*)(pos + (size_t)t * dim + c * 4);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const float4 ty = *(const float4*)(type_vec + c * 4);
+        v.x += ty.x; v.y += ty.y; v.z += ty.z; v.w += ty.w;
+        *(float4*)(x + ((size_t)b * seq_total + row_off + t) * dim + c * 4) = v;
+    }
+}
+
+extern "C" int bf_segment_assemble(const float* src, long src_bstride, const float* lead, const float* pos,
+                                   const float* type_vec, float* x, int batch, int n, int seq_total,
+                                   int row_off, int dim, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n > 0 && (dim & 3) == 0 && row_off >= 0 && row_off + n + 1 <= seq_total, BF_EINVAL,
+               "bf_segment_assemble: bad shape (n=%d row_off=%d seq_total=%d dim=%d)", n, row_off, seq_total, dim);
+    BF_REQUIRE(bf_aligned16(src) && bf_aligned16(lead) && bf_aligned16(type_vec) && bf_aligned16(x) &&
+                   (!pos || bf_aligned16(pos)) && (src_bstride & 3) == 0, BF_EALIGN,
+               "bf_segment_assemble: unaligned pointer or stride");
+    const size_t total = (size_t)batch * (n + 1) * (dim / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(segment_assemble_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                       src_bstride, lead, pos, type_vec, x, batch, n, seq_total, row_off, dim);
+    BF_CHECK_LAUNCH("bf_segment_assemble");
+    return BF_OK;
+}
+
+__global__ __launch_bounds__(256) void segment_bwd1_kernel(const float* __restrict__ dx, float* __restrict__ tmp,
+                                                           float* __restrict__ d_pos, int batch, int n,
+                                                           int seq_total, int row_off, int dim) {
+    const int nvec = dim >> 2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (n + 1) * nvec) return;
+    const int t = i / nvec, c = i - t * nvec;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < batch; ++b) {
+        const float4 v = *(const float4*)(dx + ((size_t)b * seq_total + row_off + t) * dim + c * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *(float4*)(tmp + (size_t)t * dim + c * 4) = acc;
+    if (d_pos) *(float4*)(d_pos + (size_t)t * dim + c * 4) = acc;
+}
+__global__ __launch_bounds__(256) void segment_bwd2_kernel(const float* __restrict__ tmp, float* __restrict__ d_lead,
+                                                           float* __restrict__ d_type, int n, int dim) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= dim) return;
+    float s = 0.f;
+    for (int t = 0; t <= n; ++t) s += tmp[(size_t)t * dim + c];
+    d_type[c] += s;
+    d_lead[c] += tmp[c];
+}
+
+extern "C" int bf_segment_assemble_bwd(const float* dx, float* d_lead, float* d_pos, float* d_type, float* tmp_ws,
+                                       int batch, int n, int seq_total, int row_off, int dim, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n > 0 && (dim & 3) == 0 && row_off >= 0 && row_off + n + 1 <= seq_total, BF_EINVAL,
+               "bf_segment_assemble_bwd: bad shape");
+    BF_REQUIRE(bf_aligned16(dx) && bf_aligned16(tmp_ws) && (!d_pos || bf_aligned16(d_pos)) && d_lead && d_type,
+               BF_EALIGN, "bf_segment_assemble_bwd: unaligned or missing pointer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(segment_bwd1_kernel, dim3(bf_cdiv((long)(n + 1) * (dim / 4), 256)), dim3(256), 0, s, dx,
+                       tmp_ws, d_pos, batch, n, seq_total, row_off, dim);
+    BF_CHECK_LAUNCH("bf_segment_assemble_bwd/1");
+    hipLaunchKernelGGL(segment_bwd2_kernel, dim3(bf_cdiv(dim, 256)), dim3(256), 0, s, tmp_ws, d_lead, d_type, n, dim);
+    BF_CHECK_LAUNCH("bf_segment_assemble_bwd/2");
+    return BF_OK;
+}

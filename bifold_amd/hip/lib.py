@@ -15,7 +15,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 import torch  # noqa: F401
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD = 0, 1, 2, 3
+ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU = 0, 1, 2, 3, 4
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 ABI_VERSION = 1
 
@@ -71,6 +71,10 @@ PROTOTYPES = {
     "bf_fusion_assemble": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
     "bf_fusion_assemble_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "bf_segment_assemble": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p]),
+    "bf_segment_assemble_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_int, c_void_p]),
     "bf_decoder_collapse_fwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p,
                                         c_void_p, c_int, c_void_p]),
     "bf_decoder_collapse_bwd": (c_int, [POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p,

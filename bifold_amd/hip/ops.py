@@ -334,6 +334,20 @@ def fusion_assemble_bwd(dx, cdt: torch.dtype, d_text_token, d_text_pos, d_rgb_po
     return d_rgb
 
 
+def segment_assemble(src: torch.Tensor, src_bstride: int, lead, pos, type_vec, x, batch: int, n: int,
+                     seq_total: int, row_off: int):
+    dim = x.shape[-1]
+    check(lib.bf_segment_assemble(_ptr(src), src_bstride, _ptr(lead), _ptr(pos), _ptr(type_vec), _ptr(x), batch,
+                                  n, seq_total, row_off, dim, _stream()), "bf_segment_assemble")
+
+
+def segment_assemble_bwd(dx, d_lead, d_pos, d_type, batch: int, n: int, seq_total: int, row_off: int):
+    dim = dx.shape[-1]
+    tmp = torch.empty(n + 1, dim, dtype=torch.float32, device=dx.device)
+    check(lib.bf_segment_assemble_bwd(_ptr(dx), _ptr(d_lead), _ptr(d_pos), _ptr(d_type), _ptr(tmp), batch, n,
+                                      seq_total, row_off, dim, _stream()), "bf_segment_assemble_bwd")
+
+
 # ----------------------------------------------------------------------------- decoder + BCE
 def _ptr_array(tensors: Sequence[torch.Tensor]):
     arr = (C.c_void_p * len(tensors))()

@@ -37,6 +37,8 @@ def _lazy(module: str, attr: str) -> Callable:
 
 _MODELS: Dict[str, Callable] = {
     "rgb_clip": _lazy(".rgb_clip", "RGBOnly"),
+    "siglip": _lazy(".siglip", "SigLip"),
+    "siglip_sequential": _lazy(".siglip", "SiglipSequential"),
 }
 _COMPONENTS: Dict[str, Callable] = {
     "pick_place_convdecoder": _lazy(".pickplace", "PickPlaceConvDecoder"),
@@ -44,7 +46,7 @@ _COMPONENTS: Dict[str, Callable] = {
 }
 # Names the reference knows (models/__init__.py:15-24,33-42) that this hot-path build does
 # not cover yet; they fail loudly instead of silently running something else.
-_NOT_BUILT = {"siglip", "siglip_sequential", "text_unet", "pick_place_transdecoder", "crossattention"}
+_NOT_BUILT = {"text_unet", "pick_place_transdecoder", "crossattention"}
 
 
 def _pop_name(cfg):

@@ -172,6 +172,76 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
 
 
+def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch: int, seq: int,
+                       mask_mode: int, row_mask, save: bool):
+    """x fp32 [B*seq, dim] (the assembled fusion input) -> heat [n_heads, B, S, S] and what the
+    backward needs.  The LAST n_patches+1 tokens of every sequence are the image modality whose
+    tokens feed the decoders (models/fusion.py:62-63, models/pickplace.py:71)."""
+    fus: ConcatTransformer = pp.fusion
+    dim, nh = pp.dim, len(pp.heads_out)
+    dev = x.device
+    layers = []
+    for i in range(fus.depth):
+        x, s = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, mask_mode, row_mask, save)
+        layers.append(s)
+    w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+    b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
+    rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
+    for h, name in enumerate(pp.heads_out):
+        ws, bs = pp.decoder_params(name)
+        ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
+                                 rows_ws[h])
+    first = seq - (pp.num_patches + 1)
+    img_tok = x.view(batch, seq, dim)[:, first:]           # used in place through its batch stride
+    low = ops.decoder_project(img_tok, seq * dim, w_eff, b_eff, batch, nh, pp.num_patches, dim)
+    heat = ops.decoder_upsample_sigmoid(low, pp.upsample_matrix(dev), nh * batch, pp.grid)
+    size = pp.grid * 16
+    heat = heat.view(nh, batch, size, size)
+    saved = None
+    if save:
+        saved = dict(layers=layers, x_out=x, w_eff=w_eff, rows_ws=rows_ws, heat=heat, batch=batch, seq=seq,
+                     mask_mode=mask_mode, row_mask=row_mask)
+    return heat, saved
+
+
+def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heats, on_layer_done=None):
+    """Backward of fusion_decoder_fwd: writes every fusion / decoder parameter gradient into the
+    arena and returns d(fusion input) fp32 [B*seq, dim]."""
+    fus: ConcatTransformer = pp.fusion
+    g = A.grad_view
+    dim, nh = pp.dim, len(pp.heads_out)
+    batch, seq = S["batch"], S["seq"]
+    dev = S["x_out"].device
+    U = pp.upsample_matrix(dev)
+    gg = pp.grid * pp.grid
+    g_low = torch.empty(nh, batch, gg, dtype=torch.float32, device=dev)
+    for h in range(nh):
+        if d_heats[h] is None:                             # a head the loss ignores
+            g_low[h].zero_()
+        else:
+            ops.decoder_upsample_sigmoid_bwd(S["heat"][h], d_heats[h].contiguous(), U, batch, pp.grid, out=g_low[h])
+    dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=dev)
+    g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+    g_b = torch.empty(nh, dtype=torch.float32, device=dev)
+    first = seq - (pp.num_patches + 1)
+    xv = S["x_out"].view(batch, seq, dim)
+    dxv = dx.view(batch, seq, dim)
+    ops.decoder_project_bwd(xv[:, first:], seq * dim, S["w_eff"], g_low, dxv[:, first:], seq * dim, g_w, g_b,
+                            batch, nh, pp.num_patches, dim)
+    for h, name in enumerate(pp.heads_out):
+        ws, bs = pp.decoder_params(name)
+        ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], S["rows_ws"][h], g_w[h],
+                                 g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
+    dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
+    for i in reversed(range(fus.depth)):
+        dx, dx_c = fusion_layer_bwd(dx, dx_c, S["layers"][i], fus.layer_params(i), A, cdt, batch, seq, fus.heads,
+                                    S["mask_mode"], S["row_mask"])
+        S["layers"][i] = None                              # free this layer's activations early
+        if on_layer_done is not None:
+            on_layer_done(i)
+    return dx
+
+
 class RGBTailFn(torch.autograd.Function):
     """project + token assembly + fusion transformer + decoders for RGBOnly
     (models/rgb_clip.py:52-73 -> fusion.py:35-64 -> pickplace.py:59-124)."""
@@ -189,8 +259,6 @@ class RGBTailFn(torch.autograd.Function):
         batch = vis_feat.shape[0] // n_rgb
         n_text = text_feat.shape[0] // batch
         seq = 1 + n_text + n_rgb
-        dev = vis_feat.device
-
         rgb_feat = ops.gemm(vis_feat, A.operand(model.project.weight, cdt), bias=model.project.bias.data,
                             out_dtype=torch.float32)
         x = ops.fusion_assemble(text_feat, rgb_feat, model.text_token.data.view(-1),
@@ -198,30 +266,11 @@ class RGBTailFn(torch.autograd.Function):
                                 model.rgb_pos_embedding.data.view(-1, dim),
                                 fus.token_type_embeddings.weight.data, batch, n_text, n_rgb)
         del rgb_feat
-        layers = []
-        for i in range(fus.depth):
-            x, s = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, L.MASK_NONE, None, save)
-            layers.append(s)
-        # decoder: collapse the five 1x1 convs per head, project the image tokens, upsample, sigmoid
-        w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
-        b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
-        rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
-        for h, name in enumerate(pp.heads_out):
-            ws, bs = pp.decoder_params(name)
-            ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
-                                     rows_ws[h])
-        xv = x.view(batch, seq, dim)
-        img_tok = xv[:, 1 + n_text:]                       # last modality's tokens, used in place
-        low = ops.decoder_project(img_tok, seq * dim, w_eff, b_eff, batch, nh, pp.num_patches, dim)
-        U = pp.upsample_matrix(dev)
-        heat = ops.decoder_upsample_sigmoid(low, U, nh * batch, pp.grid)
-        size = pp.grid * 16
-        heat = heat.view(nh, batch, size, size)
+        heat, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, L.MASK_NONE, None, save)
         if save:
             c = _Ctx()
-            c.model, c.layers, c.vis_feat, c.x_out = model, layers, vis_feat, x
-            c.w_eff, c.rows_ws, c.heat = w_eff, rows_ws, heat
-            c.batch, c.n_text, c.n_rgb, c.seq = batch, n_text, n_rgb, seq
+            c.model, c.saved, c.vis_feat = model, saved, vis_feat
+            c.batch, c.n_text, c.n_rgb = batch, n_text, n_rgb
             ctx.c = c
         return tuple(heat[h] for h in range(nh))
 
@@ -230,47 +279,84 @@ class RGBTailFn(torch.autograd.Function):
         c: _Ctx = ctx.c
         model = c.model
         pp: PickPlaceConvDecoder = model.pick_place
-        fus: ConcatTransformer = pp.fusion
         A: ParamArena = model.trainable_arena()
         cdt = model.compute_dtype
         g = A.grad_view
-        dim, nh = pp.dim, len(pp.heads_out)
-        batch, n_text, n_rgb, seq = c.batch, c.n_text, c.n_rgb, c.seq
-        dev = c.x_out.device
-        U = pp.upsample_matrix(dev)
-        gg = pp.grid * pp.grid
-        # sigmoid o upsample backward, per head (a head the loss ignores contributes zeros)
-        g_low = torch.empty(nh, batch, gg, dtype=torch.float32, device=dev)
-        for h in range(nh):
-            if d_heats[h] is None:
-                g_low[h].zero_()
-            else:
-                dh = d_heats[h].contiguous()
-                ops.decoder_upsample_sigmoid_bwd(c.heat[h], dh, U, batch, pp.grid, out=g_low[h])
-        dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=dev)
-        g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
-        g_b = torch.empty(nh, dtype=torch.float32, device=dev)
-        xv = c.x_out.view(batch, seq, dim)
-        dxv = dx.view(batch, seq, dim)
-        ops.decoder_project_bwd(xv[:, 1 + n_text:], seq * dim, c.w_eff, g_low, dxv[:, 1 + n_text:], seq * dim,
-                                g_w, g_b, batch, nh, pp.num_patches, dim)
-        for h, name in enumerate(pp.heads_out):
-            ws, bs = pp.decoder_params(name)
-            ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], c.rows_ws[h], g_w[h],
-                                     g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
-        dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
-        for i in reversed(range(fus.depth)):
-            dx, dx_c = fusion_layer_bwd(dx, dx_c, c.layers[i], fus.layer_params(i), A, cdt, batch, seq,
-                                        fus.heads, L.MASK_NONE, None)
-            c.layers[i] = None                      # free this layer's activations early
-            model._grad_ready(i)
+        dim = pp.dim
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, model._grad_ready)
         d_rgb = ops.fusion_assemble_bwd(dx, cdt, g(model.text_token).view(-1),
                                         g(model.text_pos_embedding).view(-1, dim),
                                         g(model.rgb_pos_embedding).view(-1, dim),
-                                        g(fus.token_type_embeddings.weight), batch, n_text, n_rgb)
+                                        g(pp.fusion.token_type_embeddings.weight), c.batch, c.n_text, c.n_rgb)
         ops.gemm(d_rgb, c.vis_feat, trans_a=True, b_kn=True, out=g(model.project.weight))
         ops.colsum(d_rgb, out=g(model.project.bias))
         model._grad_ready(-1)
         ctx.c = None
         # gradients were written into the arena (and attached as .grad) by the kernels
+        return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))
+
+
+class SegmentTailFn(torch.autograd.Function):
+    """Fusion + decoders for models whose fusion input is a list of [lead token | frozen tower
+    tokens] segments (SigLip / SiglipSequential, models/siglip.py:56-70,85-137).
+
+    `segments`: list of dicts  {src: fp32 [B, n, dim] view (frozen tower output), bstride, n,
+    lead: Parameter (image/text token), pos: (Parameter, first_row) or None, modality: int}."""
+
+    @staticmethod
+    def forward(ctx, model, segments, row_mask, *params):
+        pp: PickPlaceConvDecoder = model.pick_place
+        fus: ConcatTransformer = pp.fusion
+        A: ParamArena = model.trainable_arena()
+        cdt = model.compute_dtype
+        save = any(ctx.needs_input_grad)
+        dim, nh = pp.dim, len(pp.heads_out)
+        batch = segments[0]["batch"]
+        seq = sum(1 + sg["n"] for sg in segments)
+        dev = segments[0]["src"].device
+        x = torch.empty(batch * seq, dim, dtype=torch.float32, device=dev)
+        type_w = fus.token_type_embeddings.weight.data
+        off = 0
+        for sg in segments:
+            pos = None
+            if sg["pos"] is not None:
+                prm, row0 = sg["pos"]
+                pos = prm.data.view(-1, dim)[row0:row0 + 1 + sg["n"]]
+            ops.segment_assemble(sg["src"], sg["bstride"], sg["lead"].data.view(-1), pos, type_w[sg["modality"]],
+                                 x, batch, sg["n"], seq, off)
+            sg["row_off"] = off
+            off += 1 + sg["n"]
+        mode = L.MASK_QUERY_ROW if row_mask is not None else L.MASK_NONE
+        heat, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, mode, row_mask, save)
+        if save:
+            c = _Ctx()
+            c.model, c.saved, c.batch, c.seq = model, saved, batch, seq
+            c.segments = [{k: v for k, v in sg.items() if k != "src"} for sg in segments]
+            ctx.c = c
+        return tuple(heat[h] for h in range(nh))
+
+    @staticmethod
+    def backward(ctx, *d_heats):
+        c: _Ctx = ctx.c
+        model = c.model
+        pp: PickPlaceConvDecoder = model.pick_place
+        A: ParamArena = model.trainable_arena()
+        cdt = model.compute_dtype
+        g = A.grad_view
+        dim = pp.dim
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, model._grad_ready)
+        d_type = g(pp.fusion.token_type_embeddings.weight)
+        d_type.zero_()
+        leads = {id(sg["lead"]): sg["lead"] for sg in c.segments}
+        for prm in leads.values():
+            g(prm).zero_()
+        for sg in c.segments:
+            d_pos = None
+            if sg["pos"] is not None:
+                prm, row0 = sg["pos"]
+                d_pos = g(prm).view(-1, dim)[row0:row0 + 1 + sg["n"]]
+            ops.segment_assemble_bwd(dx, g(sg["lead"]).view(-1), d_pos, d_type[sg["modality"]], c.batch, sg["n"],
+                                     c.seq, sg["row_off"])
+        model._grad_ready(-1)
+        ctx.c = None
         return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))

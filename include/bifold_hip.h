@@ -103,7 +103,8 @@ int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
  *   C[out row, n] (c_dtype) = v   (or += v when accumulate != 0, fp32 C only);
  *   c2 (optional, BF16) receives a bf16 copy of v at the same position.
  * ---------------------------------------------------------------------- */
-enum { BF_ACT_NONE = 0, BF_ACT_QUICK_GELU = 1, BF_ACT_ERF_GELU = 2, BF_ACT_ERF_GELU_GRAD = 3 };
+enum { BF_ACT_NONE = 0, BF_ACT_QUICK_GELU = 1, BF_ACT_ERF_GELU = 2, BF_ACT_ERF_GELU_GRAD = 3,
+       BF_ACT_TANH_GELU = 4 /* gelu_pytorch_tanh: the MLP of transformers' SiglipModel */ };
 
 typedef struct bf_gemm_args {
     const void* a;
@@ -200,6 +201,23 @@ int bf_fusion_assemble(const float* text_feat, const float* rgb_feat, const floa
 int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt, float* d_text_token,
                            float* d_text_pos, float* d_rgb_pos, float* d_type, int batch,
                            int n_text, int n_rgb, int dim, bf_stream_t stream);
+
+/* Generic fusion-input segment (models/siglip.py:56-70,85-137 + models/fusion.py:45-56): one
+ * modality segment of 1+n tokens written into the concatenated fusion input X [B, seq_total, dim]:
+ *   X[b, row_off, :]       = lead[:]            (+ pos[0, :])   + type_vec[:]
+ *   X[b, row_off+1+t, :]   = src[b, t, :]       (+ pos[1+t, :]) + type_vec[:]       t < n
+ * src fp32 with batch stride src_bstride elements (a context frame of a [B, T, n, dim] tensor is
+ * a segment with src offset t*n*dim and stride T*n*dim); lead = the learned image/text token;
+ * pos may be NULL (SigLip) or the frame's rows of context_pos_embedding (SiglipSequential). */
+int bf_segment_assemble(const float* src, long src_bstride, const float* lead, const float* pos,
+                        const float* type_vec, float* x, int batch, int n, int seq_total, int row_off,
+                        int dim, bf_stream_t stream);
+/* Its backward w.r.t. the parameters (src comes from a frozen tower):
+ *   tmp[t, :] = sum_b dx[b, row_off+t, :]    t < 1+n       (tmp_ws fp32 [(1+n), dim])
+ *   d_pos[t, :]  = tmp[t, :]   (if d_pos != NULL; overwritten)
+ *   d_lead[:]   += tmp[0, :] ;  d_type[:] += sum_t tmp[t, :]      (accumulated: callers zero first) */
+int bf_segment_assemble_bwd(const float* dx, float* d_lead, float* d_pos, float* d_type, float* tmp_ws,
+                            int batch, int n, int seq_total, int row_off, int dim, bf_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Heatmap decoder (collapsed) + BCE.

@@ -131,6 +131,61 @@ def clip_text_tokens(state: State, tokens: torch.Tensor, pfx: str = "clip_encode
 
 
 # --------------------------------------------------------------------------
+# SigLIP towers (third-party arithmetic: `transformers` SiglipModel, unpinned in the
+# reference's pyproject.toml:31; restated from its published definition and pinned by
+# running transformers 5.15 itself in oracle/gen_golden.py)
+# --------------------------------------------------------------------------
+def gelu_tanh(x: torch.Tensor):
+    """`gelu_pytorch_tanh`: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))."""
+    return 0.5 * x * (1.0 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x * x * x)))
+
+
+def siglip_layer(state: State, pfx: str, x: torch.Tensor, heads: int, eps: float = 1e-6):
+    """SiglipEncoderLayer: pre-LN, q/k/v/out projections WITH bias, scale d^-0.5, no mask,
+    MLP fc1 -> tanh-GELU -> fc2."""
+    h = layer_norm(x, state[pfx + "layer_norm1.weight"], state[pfx + "layer_norm1.bias"], eps)
+    q, k, v = (split_heads(F.linear(h, state[f"{pfx}self_attn.{n}_proj.weight"],
+                                    state[f"{pfx}self_attn.{n}_proj.bias"]), heads) for n in "qkv")
+    o = attention_core(q, k, v, scale=(x.shape[-1] // heads) ** -0.5)
+    x = x + F.linear(merge_heads(o), state[pfx + "self_attn.out_proj.weight"],
+                     state[pfx + "self_attn.out_proj.bias"])
+    h = layer_norm(x, state[pfx + "layer_norm2.weight"], state[pfx + "layer_norm2.bias"], eps)
+    h = gelu_tanh(F.linear(h, state[pfx + "mlp.fc1.weight"], state[pfx + "mlp.fc1.bias"]))
+    return x + F.linear(h, state[pfx + "mlp.fc2.weight"], state[pfx + "mlp.fc2.bias"])
+
+
+def _siglip_encoder(state: State, pfx: str, x: torch.Tensor, heads: int):
+    i = 0
+    while f"{pfx}encoder.layers.{i}.layer_norm1.weight" in state:
+        x = siglip_layer(state, f"{pfx}encoder.layers.{i}.", x, heads)
+        i += 1
+    return x
+
+
+def siglip_vision_tokens(state: State, img: torch.Tensor, heads: int,
+                         pfx: str = "siglip_model.vision_model."):
+    """vision_model(pixel_values).last_hidden_state: patch conv (with bias) + learned position
+    embedding (no class token) -> encoder -> post_layernorm.  [B,3,S,S] -> [B,(S/p)^2,W].
+    (The attention-pooling head is computed by HF and discarded by the reference,
+    models/siglip.py:59-60.)"""
+    w = state[pfx + "embeddings.patch_embedding.weight"]
+    x = F.conv2d(img, w, state[pfx + "embeddings.patch_embedding.bias"], stride=w.shape[-1])
+    x = x.flatten(2).transpose(1, 2) + state[pfx + "embeddings.position_embedding.weight"]
+    x = _siglip_encoder(state, pfx, x, heads)
+    return layer_norm(x, state[pfx + "post_layernorm.weight"], state[pfx + "post_layernorm.bias"], 1e-6)
+
+
+def siglip_text_tokens(state: State, ids: torch.Tensor, heads: int,
+                       pfx: str = "siglip_model.text_model."):
+    """text_model(input_ids).last_hidden_state: token + position embeddings -> encoder (no
+    attention mask) -> final_layer_norm.  [B,L] int -> [B,L,W]."""
+    x = state[pfx + "embeddings.token_embedding.weight"][ids.long()]
+    x = x + state[pfx + "embeddings.position_embedding.weight"][: ids.shape[1]]
+    x = _siglip_encoder(state, pfx, x, heads)
+    return layer_norm(x, state[pfx + "final_layer_norm.weight"], state[pfx + "final_layer_norm.bias"], 1e-6)
+
+
+# --------------------------------------------------------------------------
 # trainable tail: fusion transformer + heatmap decoders
 # --------------------------------------------------------------------------
 def fusion_layer(state: State, pfx: str, x: torch.Tensor, heads: int,
@@ -246,6 +301,39 @@ def rgb_clip_forward(state: State, sample: Mapping[str, torch.Tensor], heads: in
     v = clip_vision_tokens(state, sample["rgb"])
     x_rgb = F.linear(v, state["project.weight"], state["project.bias"]) + state["rgb_pos_embedding"]
     return pick_place_convdecoder(state, [x_text, x_rgb], heads, is_bimanual)
+
+
+def _prepend(token: torch.Tensor, feats: torch.Tensor):
+    return torch.cat([token.expand(feats.shape[0], 1, -1), feats], dim=1)
+
+
+def siglip_forward(state: State, sample: Mapping[str, torch.Tensor], tower_heads: int, fusion_heads: int,
+                   is_bimanual: bool):
+    """SigLip.forward (models/siglip.py:56-70): prepend the learned image / text tokens to the
+    towers' last hidden states and hand both to the pick/place head."""
+    img = _prepend(state["image_token"], siglip_vision_tokens(state, sample["rgb"], tower_heads))
+    txt = _prepend(state["text_token"], siglip_text_tokens(state, sample["instruction"], tower_heads))
+    return pick_place_convdecoder(state, [txt, img], fusion_heads, is_bimanual)
+
+
+def siglip_sequential_forward(state: State, sample: Mapping[str, torch.Tensor], tower_heads: int,
+                              fusion_heads: int, is_bimanual: bool):
+    """SiglipSequential.forward (models/siglip.py:85-137): the vision tower also encodes the T
+    context frames; each gets the image token prepended, frames are concatenated and
+    `context_pos_embedding` added; the fusion mask is [ones | ctx_mask repeated n+1 | ones] and
+    masks QUERY rows; modalities = [0, 1, 1]."""
+    img = _prepend(state["image_token"], siglip_vision_tokens(state, sample["rgb"], tower_heads))
+    txt = _prepend(state["text_token"], siglip_text_tokens(state, sample["instruction"], tower_heads))
+    ctx = sample["rgb_context"]
+    b, t = ctx.shape[:2]
+    n = img.shape[1]
+    cf = siglip_vision_tokens(state, ctx.flatten(0, 1), tower_heads)              # [(b t), n-1, W]
+    cf = _prepend(state["image_token"], cf).reshape(b, t * n, -1) + state["context_pos_embedding"]
+    mask = torch.cat([torch.ones(b, txt.shape[1]),
+                      sample["context_attention_mask"].float().repeat_interleave(n, dim=1),
+                      torch.ones(b, n)], dim=1)
+    return pick_place_convdecoder(state, [txt, cf, img], fusion_heads, is_bimanual,
+                                  modalities=[0, 1, 1], attention_masks=mask)
 
 
 def bce_mean(p: torch.Tensor, t: torch.Tensor):

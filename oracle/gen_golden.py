@@ -46,7 +46,19 @@ for _n in ("CenterCrop", "Compose", "Normalize", "Resize", "ToTensor", "Interpol
     if not hasattr(_tv, _n):
         setattr(_tv, _n, type(_n, (), {"BICUBIC": 3}))
 
+# `peft` (LoRA) is absent here and imported at the top of models/siglip.py; only the
+# lora=False path is exercised, which never touches these names.
+if "peft" not in sys.modules:
+    try:
+        import peft  # noqa: F401
+    except Exception:
+        for _name in ("peft", "peft.tuners", "peft.tuners.lora"):
+            sys.modules[_name] = types.ModuleType(_name)
+        sys.modules["peft.tuners.lora"].LoraConfig = type("LoraConfig", (), {})
+        sys.modules["peft.tuners.lora"].LoraModel = type("LoraModel", (), {})
+
 import bifold.models.rgb_clip as ref_rgb_clip  # noqa: E402
+import bifold.models.siglip as ref_siglip  # noqa: E402
 from bifold.losses import Losses as RefLosses  # noqa: E402
 from bifold.models import Components as RefComponents  # noqa: E402
 from bifold.models.clip.model import CLIP as RefCLIP  # noqa: E402
@@ -350,6 +362,97 @@ def per_op_fixture(seed: int):
     print("  wrote per_op.npz")
 
 
+TINY_SIGLIP = dict(text_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                    num_attention_heads=2, vocab_size=100, max_position_embeddings=64),
+                   vision_config=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                                      num_attention_heads=2, image_size=32, patch_size=16))
+
+
+def siglip_fixture(sequential: bool, fname: str, seed: int):
+    """SigLip / SiglipSequential (models/siglip.py) with lora=False around a random-init
+    transformers.SiglipModel: the towers are third-party code, run here as the reference runs it."""
+    from transformers import SiglipConfig, SiglipModel
+    print(f"== tiny siglip, sequential={sequential}")
+    torch.manual_seed(seed)
+
+    class FakeAuto:
+        @staticmethod
+        def from_pretrained(name):
+            m = SiglipModel(SiglipConfig(**TINY_SIGLIP)).float().eval()
+            g = torch.Generator().manual_seed(seed + 5)
+            with torch.no_grad():                      # exercise LayerNorm scale/shift and biases
+                for k, p in m.named_parameters():
+                    if "layer_norm" in k or "layernorm" in k or k.endswith("bias"):
+                        p.add_(0.1 * torch.randn(p.shape, generator=g))
+            return m
+
+    ref_siglip.AutoModel = FakeAuto
+    is_bimanual = sequential                      # the reference pairs sequential with bimanual data
+    kw = dict(device=torch.device("cpu"), image_size=32, is_bimanual=is_bimanual, requires_graph=False,
+              patch_size=16, dim=64, lora=False, r=8, lora_alpha=32, lora_dropout=0.01, automodel_name="tiny",
+              target_modules=["q_proj", "v_proj"], pick_place_model="pick_place_convdecoder",
+              fusion_model="concat_transformer", depth=2, heads=2, mlp_ratio=4, dropout=0.0, emb_dropout=0.0,
+              threshold=0.5, text_encoder=None)
+    T = 2
+    model = (ref_siglip.SiglipSequential(context_length=T, **kw) if sequential else ref_siglip.SigLip(**kw))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if ".norm." in k:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B = 3
+    gen = torch.Generator().manual_seed(seed + 7)
+    sample = {"rgb": torch.randn(B, 3, 32, 32, generator=gen),
+              "instruction": torch.randint(0, 100, (B, 8), generator=gen)}
+    if sequential:
+        sample["rgb_context"] = torch.randn(B, T, 3, 32, 32, generator=gen)
+        sample["context_attention_mask"] = torch.tensor([[1, 0], [1, 1], [0, 0]], dtype=torch.int64)
+    for n in O.decoder_heads(is_bimanual):
+        c = torch.randint(0, 32, (B, 2), generator=gen)
+        sample[f"{n}_heatmap"] = O.gaussian_heatmaps(c, 32, sigma=3.0)
+    with torch.no_grad():
+        out = model.siglip_model(input_ids=sample["instruction"], pixel_values=sample["rgb"])
+        vis = out.vision_model_output.last_hidden_state.clone()
+        txt = out.text_model_output.last_hidden_state.clone()
+        check("siglip vision tokens", O.siglip_vision_tokens(state0, sample["rgb"], 2), vis)
+        check("siglip text tokens", O.siglip_text_tokens(state0, sample["instruction"], 2), txt)
+    assert all(not p.requires_grad for k, p in model.named_parameters() if "siglip_model" in k)
+    rec = run_reference_training(model, sample, is_bimanual, steps=3)
+    fwd = O.siglip_sequential_forward if sequential else O.siglip_forward
+    state = {k: v.clone() for k, v in state0.items()}
+    keys = [k for k in state if "siglip_model" not in k]
+    for k in keys:
+        state[k].requires_grad_(True)
+    oo = fwd(state, sample, 2, 2, is_bimanual)
+    loss, _ = O.bce_gaussmap(oo, sample, is_bimanual)
+    grads = dict(zip(keys, torch.autograd.grad(loss, [state[k] for k in keys])))
+    for k, t in rec["out"].items():
+        check(f"out[{k}]", oo[k].detach(), t)
+    check("loss", loss.detach(), rec["loss"], rtol=1e-6)
+    assert set(rec["grads"]) == set(keys), set(rec["grads"]) ^ set(keys)
+    for k, gr in rec["grads"].items():
+        check(f"grad[{k}]", grads[k], gr, rtol=1e-4, atol=1e-7)
+    blob = {}
+    for k, t in np_state(state0).items():
+        blob["state/" + k] = t
+    for k, t in sample.items():
+        blob["sample/" + k] = t.numpy()
+    blob["mid/siglip_vision"], blob["mid/siglip_text"] = vis.numpy(), txt.numpy()
+    for k, t in rec["out"].items():
+        blob["out/" + k] = t.numpy()
+    blob["loss"] = rec["loss"].numpy()
+    blob["losses3"] = np.array(rec["losses"], dtype=np.float64)
+    for k, t in rec["grads"].items():
+        blob["grad/" + k] = t.numpy()
+    for k, t in rec["params_after"].items():
+        blob["param3/" + k] = t.numpy()
+    blob["meta/is_bimanual"] = np.array(int(is_bimanual))
+    blob["meta/context_length"] = np.array(T if sequential else 0)
+    np.savez_compressed(os.path.join(GOLD, fname), **blob)
+    print(f"  wrote {fname}")
+
+
 def stats(t: torch.Tensor):
     t = t.detach().double().flatten()
     return np.concatenate([[t.mean().item(), t.std().item(), t.abs().max().item()],
@@ -391,9 +494,14 @@ def full_size_summary(seed: int, batch: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only-siglip", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    siglip_fixture(False, "tiny_siglip.npz", seed=3411)
+    siglip_fixture(True, "tiny_siglip_sequential.npz", seed=3412)
+    if args.only_siglip:
+        return
     tiny_end_to_end(False, "tiny_unimanual.npz", seed=3407)
     tiny_end_to_end(True, "tiny_bimanual.npz", seed=3408)
     masked_fusion_fixture(seed=3409)

@@ -72,7 +72,7 @@ def test_factories_and_error_behaviour():
         Schedulers.get_by_name(dict(name="step"))
     assert Schedulers.get_by_name(dict(name=None)) is None
     with pytest.raises(NotImplementedError):
-        Models.get_by_name(dict(name="siglip_sequential"))
+        Models.get_by_name(dict(name="text_unet"))
     cfg = tiny_cfg()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -173,3 +173,36 @@ def test_layer_buckets_tile_the_arena():
     covered = sorted(b)
     assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(4)) and covered[-1][1] == off
     assert b[1] == (offsets[names[6]][0], b[0][0])             # layer 2 comes right after the decoders
+
+
+@pytest.mark.parametrize("name,fixture,extra", [("siglip", "tiny_siglip.npz", {}),
+                                                ("siglip_sequential", "tiny_siglip_sequential.npz", {"context_length": 2})])
+def test_siglip_state_dict_schema_matches_reference(golden_dir, name, fixture, extra):
+    from bifold_amd.models import Models
+    from bifold_amd.models.siglip_encoder import SIGLIP_CONFIGS
+    SIGLIP_CONFIGS["tiny"] = dict(
+        vision=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16),
+        text=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=100,
+                  max_position_embeddings=64))
+    z = np.load(os.path.join(golden_dir, fixture))
+    ref = {k[6:]: tuple(z[k].shape) for k in z.files if k.startswith("state/")}
+    cfg = dict(name=name, image_size=32, is_bimanual=bool(int(z["meta/is_bimanual"])), requires_graph=False, patch_size=16,
+               automodel_name="tiny", dim=64, emb_dropout=0.0, lora=False, r=8, lora_alpha=32, lora_dropout=0.01,
+               target_modules=["q_proj", "v_proj"], threshold=0.5, text_encoder=None,
+               pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", depth=2, heads=2,
+               mlp_ratio=4, dropout=0.0, dtype="fp32", **extra)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = Models.get_by_name(dict(cfg), device=torch.device("cpu"))
+        with pytest.raises(NotImplementedError, match="peft"):
+            Models.get_by_name(dict(cfg, lora=True), device=torch.device("cpu"))
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
+    assert all("siglip_model" in n for n, p in m.named_parameters() if not p.requires_grad)
+
+
+def test_siglip_config_resolves():
+    from bifold_amd.config import compose
+    cfg = compose(os.path.join(ROOT, "bifold_amd", "conf"),
+                  ["model=siglip_sequential", "dataset@train_dataset=synthetic_bimanual_sequential"])
+    assert cfg.model.automodel_name == "google/siglip-base-patch16-384"
+    assert cfg.model.context_length == 3 and cfg.model.is_bimanual is True and cfg.loss.is_bimanual is True

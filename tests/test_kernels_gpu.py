@@ -137,7 +137,7 @@ def test_gemm_splitk_tn(ops, gpu, cdt, split):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("act", ["none", "quick", "erf"])
+@pytest.mark.parametrize("act", ["none", "quick", "erf", "tanh"])
 def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act):
     g = torch.Generator().manual_seed(11)
     m, n, k = 200, 384, 128
@@ -151,10 +151,12 @@ def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act):
         v = pre * torch.sigmoid(1.702 * pre)
     elif act == "erf":
         v = F.gelu(pre)
+    elif act == "tanh":
+        v = F.gelu(pre, approximate="tanh")
     else:
         v = pre
     ref = v + res.double()
-    code = {"none": L.ACT_NONE, "quick": L.ACT_QUICK_GELU, "erf": L.ACT_ERF_GELU}[act]
+    code = {"none": L.ACT_NONE, "quick": L.ACT_QUICK_GELU, "erf": L.ACT_ERF_GELU, "tanh": L.ACT_TANH_GELU}[act]
     got = ops.gemm(a.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=bias.to(gpu), act=code,
                    want_pre=(act != "none"), residual=res.to(gpu), out_dtype=torch.float32)
     if act != "none":
@@ -319,6 +321,45 @@ def test_vision_assemble_embed_fusion(ops, gpu):
     assert rel_err(d_rgb, rf_.grad) < 1e-6
     assert rel_err(d_tt, tt_.grad) < 1e-5 and rel_err(d_tp, tp_.grad) < 1e-5
     assert rel_err(d_rp, rp_.grad) < 1e-5 and rel_err(d_ty, ty_.grad) < 1e-5
+
+
+def test_segment_assemble_and_backward(ops, gpu):
+    g = torch.Generator().manual_seed(41)
+    B, T, n, D = 3, 2, 5, 64
+    txt = torch.randn(B, 4, D, generator=g)
+    ctx = torch.randn(B, T, n, D, generator=g)
+    img = torch.randn(B, n, D, generator=g)
+    leaves = [t.requires_grad_(True) for t in (torch.randn(D, generator=g), torch.randn(D, generator=g),
+                                                torch.randn(T * (n + 1), D, generator=g), torch.randn(2, D, generator=g))]
+    tt, it, cpos, ty = leaves
+    xt = torch.cat([tt.expand(B, 1, D), txt], 1) + ty[0]
+    xc = torch.cat([it.expand(B, T, 1, D), ctx], 2).reshape(B, T * (n + 1), D) + cpos + ty[1]
+    xi = torch.cat([it.expand(B, 1, D), img], 1) + ty[1]
+    ref = torch.cat([xt, xc, xi], 1)
+    seq = ref.shape[1]
+    x = torch.empty(B * seq, D, device=gpu)
+    ctx_g = ctx.to(gpu)
+    ttg, itg, cposg, tyg = (t.detach().to(gpu) for t in leaves)
+    ops.segment_assemble(txt.to(gpu), 4 * D, ttg, None, tyg[0], x, B, 4, seq, 0)
+    off = 5
+    for f in range(T):
+        ops.segment_assemble(ctx_g[:, f], T * n * D, itg, cposg[f * (n + 1):(f + 1) * (n + 1)], tyg[1], x, B, n, seq, off)
+        off += n + 1
+    ops.segment_assemble(img.to(gpu), n * D, itg, None, tyg[1], x, B, n, seq, off)
+    assert rel_err(x.view(B, seq, D), ref) < 1e-6
+    dx = torch.randn(B, seq, D, generator=g)
+    ref.backward(dx)
+    d_tt, d_it = torch.zeros(D, device=gpu), torch.zeros(D, device=gpu)
+    d_cpos, d_ty = torch.empty(T * (n + 1), D, device=gpu), torch.zeros(2, D, device=gpu)
+    dxg = dx.to(gpu).reshape(B * seq, D)
+    ops.segment_assemble_bwd(dxg, d_tt, None, d_ty[0], B, 4, seq, 0)
+    off = 5
+    for f in range(T):
+        ops.segment_assemble_bwd(dxg, d_it, d_cpos[f * (n + 1):(f + 1) * (n + 1)], d_ty[1], B, n, seq, off)
+        off += n + 1
+    ops.segment_assemble_bwd(dxg, d_it, None, d_ty[1], B, n, seq, off)
+    assert rel_err(d_tt, tt.grad) < 1e-5 and rel_err(d_it, it.grad) < 1e-5
+    assert rel_err(d_cpos, cpos.grad) < 1e-5 and rel_err(d_ty, ty.grad) < 1e-5
 
 
 # ------------------------------------------------------------------ decoder + BCE

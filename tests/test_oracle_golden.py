@@ -116,3 +116,28 @@ def test_full_size_weights_are_reproducible_from_the_seed(golden_dir):
     s2 = O.make_tail_state(torch.Generator().manual_seed(seed))
     assert all(torch.equal(s1[k], s2[k]) for k in s1)
     assert sum(v.numel() for v in s1.values()) == 26_236_162      # config A's trainable parameters (26.2 M)
+
+
+@pytest.mark.parametrize("fixture,sequential", [("tiny_siglip.npz", False), ("tiny_siglip_sequential.npz", True)])
+def test_siglip_models_match_reference(golden_dir, fixture, sequential):
+    """SigLip / SiglipSequential (lora=False): towers are transformers' SiglipModel as the reference
+    ran it; fixtures hold tower outputs, heatmaps, loss and all trainable gradients."""
+    fx = load(golden_dir, fixture)
+    bim = bool(int(fx["meta"]["is_bimanual"]))
+    state, sample = dict(fx["state"]), fx["sample"]
+    with torch.no_grad():
+        assert close(O.siglip_vision_tokens(state, sample["rgb"], 2), fx["mid"]["siglip_vision"])
+        assert close(O.siglip_text_tokens(state, sample["instruction"], 2), fx["mid"]["siglip_text"])
+    keys = [k for k in state if "siglip_model" not in k]
+    assert set(keys) == set(fx["grad"])
+    for k in keys:
+        state[k] = state[k].clone().requires_grad_(True)
+    fwd = O.siglip_sequential_forward if sequential else O.siglip_forward
+    out = fwd(state, sample, 2, 2, bim)
+    loss, _ = O.bce_gaussmap(out, sample, bim)
+    grads = torch.autograd.grad(loss, [state[k] for k in keys])
+    for k, ref in fx["out"].items():
+        assert close(out[k].detach(), ref), k
+    assert close(loss.detach(), fx["loss"][""], rtol=1e-6)
+    for k, g in zip(keys, grads):
+        assert close(g, fx["grad"][k], rtol=1e-4, atol=1e-7), k
