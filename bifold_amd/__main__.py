@@ -39,15 +39,15 @@ class SyntheticLoader:
     (rgb ~ N(0,1), CLIP-style token ids, one sigma=5 Gaussian per target map), generated on
     the device with a per-rank, per-epoch seed."""
 
-    def __init__(self, cfg, device, rank: int, world: int):
+    def __init__(self, cfg, device, rank: int, world: int, model_name: str):
         self.batch = int(cfg.batch_size)
         self.size = int(cfg.train_dataset.image_size)
         self.is_bimanual = bool(cfg.train_dataset.is_bimanual)
         self.steps = max(1, int(cfg.train_dataset.length) // (self.batch * world))
         self.device, self.rank, self.seed, self.epoch = device, rank, int(cfg.seed), 0
         self.sigma = float(cfg.processor.sigma)
-        self.siglip = str(cfg.model.name).startswith("siglip")
-        self.context = int(cfg.model.get("context_length", 0) or 0) if cfg.model.name == "siglip_sequential" else 0
+        self.siglip = model_name.startswith("siglip")
+        self.context = int(cfg.model.get("context_length", 0) or 0) if model_name == "siglip_sequential" else 0
 
     def __len__(self):
         return self.steps
@@ -93,6 +93,7 @@ class Trainer:
         torch.cuda.set_device(self.local_rank)
         self.device = torch.device("cuda", self.local_rank)
         self.seed_randomness()
+        self.model_name = str(cfg.model.name)          # the factory deletes cfg.model.name, like the reference
         self.model = Models.get_by_name(cfg.model, device=self.device).to(self.device)
         self.train_dataloader = self._make_loader()
         self.sync = None
@@ -102,7 +103,7 @@ class Trainer:
     def _make_loader(self):
         name = self.cfg.train_dataset.name
         if name == "synthetic":
-            return SyntheticLoader(self.cfg, self.device, self.rank, self.world)
+            return SyntheticLoader(self.cfg, self.device, self.rank, self.world, self.model_name)
         try:
             from bifold.data import Datasets            # the reference's CPU pipeline, if installed
         except ImportError as e:
