@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="diagnostic: time every GEMM shape separately")
+    ap.add_argument("--all-kernels", action="store_true", help="time every matrix kernel, not just the dominant one")
     args = ap.parse_args()
 
     from bifold_amd import dist as bdist
@@ -151,7 +152,11 @@ def main():
     fence()
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.KernelTimer(per_shape=args.per_shape)
+        dom_label = "gemm_bf16_nt" if args.dtype == "bf16" else "gemm_f32_nt"
+        # default: HIP events around the dominant kernel only (event pairs around EVERY matrix
+        # kernel cost ~3 % of the step); --per-shape / --all-kernels time everything
+        timer = ops.KernelTimer(per_shape=args.per_shape,
+                                only_prefix=None if (args.per_shape or args.all_kernels) else dom_label)
         ops.PROFILER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -377,231 +377,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const bf16_t* __r
 }
 
 // =====================================================================================
-//            bf16 MFMA kernel, 256x128 tile, 3-stage LDS-DMA ring (large-M path)
+//                      BK = 32 LDS images (used by gemm_bf16_k32_kernel)
 // =====================================================================================
-// PMC on the 128x128 kernel: 0 bank conflicts, but SQ_WAIT_ANY = 41 % of wave cycles and the
-// MFMA pipe ~36 % busy -- one K-step of prefetch distance does not cover L2 / HBM latency.
-// Here 8 waves (4 along M x 2 along N, 64x64 each) share a 256x128x64 stage (A 32 KB + B 16 KB)
-// and THREE stages form a ring (144 KB, one workgroup per CU, two waves per SIMD): the DMA of
-// tile t+2 is issued while tile t is computed, a counted `s_waitcnt vmcnt(6)` (this wave's six
-// pieces of tile t+1 may stay in flight) retires tile t, and a raw `s_barrier` -- not
-// __syncthreads(), whose fence would drain the DMA queue -- publishes it.  A staged buffer is
-// read only AFTER the wait + barrier that retire it, and refilled only after the barrier that
-// follows its last read.
-#define P_BM 256
-#define P_BN 128
-#define P_STAGE (48 * 1024)
-
-template <bool KS>
-__device__ __forceinline__ void dma_pieces(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int r0,
-                                           int k0, int first_piece, int n_pieces, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < n_pieces) {
-            const int pc = first_piece + i;                // 1 KB piece; 16 pieces per 128-row sub-tile
-            unsigned voff;
-            if (!KS) {
-                const int row = pc * 8 + (lane >> 3);
-                const int ch = (lane & 7) ^ (row & 7);
-                voff = (unsigned)(((size_t)(r0 + row) * ld + k0 + ch * 8) * 2);
-            } else {
-                const int sub = pc >> 4;
-                const int krow = (pc & 15) * 4 + (lane >> 4);
-                const int ch = (lane & 15) ^ ks_swz(krow);
-                voff = (unsigned)(((size_t)(k0 + krow) * ld + r0 + sub * 128 + ch * 8) * 2);
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_ptr)(lds_tile + pc * 1024), 16, voff, 0, 0, 0);
-        }
-    }
-}
-
-// fragment from a tile made of 128-row sub-tiles (KC rows are independent, KS sub-tiles are 16 KB)
-template <bool KS>
-__device__ __forceinline__ bf16x8 bf16_frag_big(const char* lds, int rbase, int s, int lane) {
-    if (!KS) return bf16_frag<false>(lds, rbase, s, lane);
-    return bf16_frag<true>(lds + (rbase >> 7) * 16384, rbase & 127, s, lane);
-}
-
-template <bool A_KS, bool B_KS, typename TC>
-__global__ __launch_bounds__(512) void gemm_bf16_pipe_kernel(const bf16_t* __restrict__ A,
-                                                             const bf16_t* __restrict__ B, GemmDims d,
-                                                             EpiParams ep, float* __restrict__ slabs,
-                                                             unsigned a_bytes, unsigned b_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x (A 32 KB | B 16 KB)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tiles = d.tiles_m * d.tiles_n;
-    const int z = blockIdx.x / tiles;
-    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
-    int tm, tn;
-    tile_coords(t, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
-    const int m0 = tm * P_BM, n0 = tn * P_BN;
-    const int kbeg = z * d.k_per_split;
-    const int kend = min(d.k, kbeg + d.k_per_split);
-    const int nk = (kend - kbeg + 63) >> 6;
-
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // each wave moves 4 A pieces + 2 B pieces per tile (6 DMA instructions)
-    auto stage_tile = [&](int kt) {
-        char* st = smem + (kt % 3) * P_STAGE;
-        dma_pieces<A_KS>(ra, st, d.lda, m0, kbeg + kt * 64, wave * 4, 4, lane);
-        dma_pieces<B_KS>(rb, st + 32768, d.ldb, n0, kbeg + kt * 64, wave * 2, 2, lane);
-    };
-    stage_tile(0);
-    if (nk > 1) stage_tile(1);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage_tile(kt + 2);
-        const char* la = smem + (kt % 3) * P_STAGE;
-        const char* lb = la + 32768;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = bf16_frag_big<A_KS>(la, wm * 64 + i * 16, s, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag_big<B_KS>(lb, wn * 64 + j * 16, s, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
-        }
-    }
-
-    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (m < ep.m && n < ep.n) {
-                const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
-                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
-            }
-        }
-    }
-}
-
-// =====================================================================================
-//        bf16 MFMA kernel, 256x256 tile, 128x64 per wave (LDS-read-lean main path)
-// =====================================================================================
-// Why: with 64x64 wave tiles every K-step costs 16 ds_read_b128 per 32 MFMAs per wave; the
-// LDS port is shared by the CU's four SIMDs, so reads + DMA writes keep it ~100 % busy at
-// ~40 % MFMA utilisation (PMC: no conflicts, waves parked).  A 128x64 wave tile needs 24
-// reads per 64 MFMAs -- half the LDS traffic per FLOP -- and a 256x256 block also halves the
-// L2 -> LDS bytes per FLOP.  8 waves = 2 (M) x 4 (N); two 64 KB stages (A 2x16 KB sub-tiles,
-// B 2x16 KB); one workgroup per CU.
-#define G_BM 256
-#define G_BN 256
-#define G_STAGE (64 * 1024)
-
-template <bool A_KS, bool B_KS, typename TC>
-__global__ __launch_bounds__(512) void gemm_bf16_big_kernel(const bf16_t* __restrict__ A,
-                                                            const bf16_t* __restrict__ B, GemmDims d,
-                                                            EpiParams ep, float* __restrict__ slabs,
-                                                            unsigned a_bytes, unsigned b_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (A 32 KB | B 32 KB)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-
-    const int tiles = d.tiles_m * d.tiles_n;
-    const int z = blockIdx.x / tiles;
-    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
-    int tm, tn;
-    tile_coords(t, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
-    const int m0 = tm * G_BM, n0 = tn * G_BN;
-    const int kbeg = z * d.k_per_split;
-    const int kend = min(d.k, kbeg + d.k_per_split);
-    const int nk = (kend - kbeg + 63) >> 6;
-
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
-
-    f32x4 acc[4][8];          // acc[j][i]: rows n (4 tiles of 16), cols m (8 tiles of 16)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto stage_tile = [&](int kt) {
-        char* st = smem + (kt & 1) * G_STAGE;
-        dma_pieces<A_KS>(ra, st, d.lda, m0, kbeg + kt * 64, wave * 4, 4, lane);
-        dma_pieces<B_KS>(rb, st + 32768, d.ldb, n0, kbeg + kt * 64, wave * 4, 4, lane);
-    };
-    stage_tile(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* la = smem + (kt & 1) * G_STAGE;
-        const char* lb = la + 32768;
-        if (kt + 1 < nk) stage_tile(kt + 1);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[8], bfr[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag_big<B_KS>(lb, wn * 64 + j * 16, s, lane);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = bf16_frag_big<A_KS>(la, wm * 128 + i * 16, s, lane);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (m < ep.m && n < ep.n) {
-                const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
-                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
-            }
-        }
-    }
-}
-
-// =====================================================================================
-//   bf16 MFMA kernel, 256x128x32 tile, 4 waves x (128x64), 3-stage ring, 2 blocks per CU
-// =====================================================================================
-// Combines what the experiments above showed is needed at the same time:
-//   * 128x64 wave tiles (12 ds_read_b128 per 32 MFMAs instead of 16): LDS-read-lean;
-//   * TWO workgroups per CU, so one block's tile prologue / epilogue hides under the other's
-//     main loop (the 1-block-per-CU variants lose 20-40 % on the K = 512 / 768 shapes);
-//   * a 3-deep LDS-DMA ring with counted vmcnt + raw s_barrier (two tiles in flight).
-// BK = 32 keeps a stage at 24 KB (A 256x32 + B 128x32 bf16), 72 KB per block.
 // K-contiguous tiles are 64-byte rows; chunk c of row r sits in slot c ^ f(r), f = (-(r>>2))&3,
 // which is conflict-free for ds_read_b128's 16-lane groups; K-strided tiles keep the 256-byte
-// k-row image of the other kernels (32 k-rows per 128-wide sub-tile).
-#define W_BM 256
-#define W_BN 128
-#define W_STAGE (24 * 1024)
-#define W_ASZ (16 * 1024)
+// k-row image of the BK = 64 kernels (32 k-rows per 128-wide sub-tile).
 
 __device__ __forceinline__ int kc32_swz(int row) { return (-(row >> 2)) & 3; }
 
@@ -646,78 +426,6 @@ __device__ __forceinline__ bf16x8 bf16_frag32(const char* lds, int rbase, int la
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
         return r;
-    }
-}
-
-template <bool A_KS, bool B_KS, typename TC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_w128_kernel(const bf16_t* __restrict__ A,
-                                                                const bf16_t* __restrict__ B, GemmDims d,
-                                                                EpiParams ep, float* __restrict__ slabs,
-                                                                unsigned a_bytes, unsigned b_bytes) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 x (A 16 KB | B 8 KB)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tiles = d.tiles_m * d.tiles_n;
-    const int z = blockIdx.x / tiles;
-    const int t = xcd_remap(blockIdx.x - z * tiles, tiles);
-    int tm, tn;
-    tile_coords(t, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
-    const int m0 = tm * W_BM, n0 = tn * W_BN;
-    const int kbeg = z * d.k_per_split;
-    const int kend = min(d.k, kbeg + d.k_per_split);
-    const int nk = (kend - kbeg + 31) >> 5;
-
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    auto stage_tile = [&](int kt) {                       // 6 DMA instructions per wave
-        char* st = smem + (kt % 3) * W_STAGE;
-        dma_pieces32<A_KS>(ra, st, d.lda, m0, kbeg + kt * 32, wave * 4, 4, lane);
-        dma_pieces32<B_KS>(rb, st + W_ASZ, d.ldb, n0, kbeg + kt * 32, wave * 2, 2, lane);
-    };
-    stage_tile(0);
-    if (nk > 1) stage_tile(1);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) stage_tile(kt + 2);
-        const char* la = smem + (kt % 3) * W_STAGE;
-        const char* lb = la + W_ASZ;
-        bf16x8 af[8], bfr[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) af[i] = bf16_frag32<A_KS>(la, wm * 128 + i * 16, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
-    }
-
-    float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wm * 128 + i * 16 + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-            if (m < ep.m && n < ep.n) {
-                const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
-                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
-            }
-        }
     }
 }
 
@@ -1063,7 +771,9 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         // workgroups per CU, which overlaps the epilogue traffic of one tile with the MFMAs of the
         // others and wins on every NN / TN shape and on short-K NT; long-K, large NT GEMMs
         // (K >= 2048 with >= 2e7 outputs) keep the BK = 64 kernel (half the barriers per FLOP).
-        // BIFOLD_GEMM_PIPE forces a variant: 0 = BK64, 4 = BK32, 1/2/3 = experimental tiles.
+        // BIFOLD_GEMM_PIPE forces a variant: 0 = BK64, 4 = BK32.  (Measured and dropped, see
+        // 256x128 and 256x256 blocks, 128x64 wave tiles, 3/4-deep rings with counted
+        // vmcnt -- every one lost to "as many resident workgroups as possible".)
         const bool long_nt = !g->trans_a && !g->b_kn && g->k >= 2048 && (double)g->m * g->n >= 2.0e7;
         const int variant = pipe_env >= 0 ? pipe_env : (long_nt ? 0 : 4);
         if (dma_ok && variant == 4) {
@@ -1093,70 +803,6 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
             else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(true, true, float); else LAUNCH_K32(true, true, bf16_t); }
             else { if (f32out) LAUNCH_K32(true, false, float); else LAUNCH_K32(true, false, bf16_t); }
 #undef LAUNCH_K32
-        } else if (dma_ok && variant == 3 && g->m >= 512) {
-            const int ptm = bf_cdiv(g->m, W_BM), ptn = bf_cdiv(g->n, W_BN);
-            GemmDims dp{g->m, g->n, g->k, g->lda, g->ldb, ptm, ptn, kps, group_m_env > 8 ? group_m_env / 2 : group_m_env};
-            dim3 pgrid((unsigned)((long)ptm * ptn * split)), pblock(256);
-            const size_t lds3 = 3 * W_STAGE;
-            const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-#define LAUNCH_W128(AKS, BKS, TC)                                                                   \
-    do {                                                                                          \
-        static bool lds_ok = false;                                                               \
-        if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_w128_kernel<AKS, BKS, TC>,           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);     \
-            lds_ok = true;                                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_w128_kernel<AKS, BKS, TC>), pgrid, pblock, lds3, s, A, B, dp, ep, slabs, ab, bb); \
-    } while (0)
-            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_W128(false, false, float); else LAUNCH_W128(false, false, bf16_t); }
-            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_W128(false, true, float); else LAUNCH_W128(false, true, bf16_t); }
-            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_W128(true, true, float); else LAUNCH_W128(true, true, bf16_t); }
-            else { if (f32out) LAUNCH_W128(true, false, float); else LAUNCH_W128(true, false, bf16_t); }
-#undef LAUNCH_W128
-        } else if (dma_ok && variant == 2 && g->m >= 1024 && g->n >= 256) {
-            const int ptm = bf_cdiv(g->m, G_BM), ptn = bf_cdiv(g->n, G_BN);
-            GemmDims dp{g->m, g->n, g->k, g->lda, g->ldb, ptm, ptn, kps, group_m_env > 8 ? group_m_env / 2 : group_m_env};
-            dim3 pgrid((unsigned)((long)ptm * ptn * split)), pblock(512);
-            const size_t lds3 = 2 * G_STAGE;
-            const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-#define LAUNCH_BIG(AKS, BKS, TC)                                                                    \
-    do {                                                                                          \
-        static bool lds_ok = false;                                                               \
-        if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<AKS, BKS, TC>,            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);     \
-            lds_ok = true;                                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_big_kernel<AKS, BKS, TC>), pgrid, pblock, lds3, s, A, B, dp, ep, slabs, ab, bb); \
-    } while (0)
-            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_BIG(false, false, float); else LAUNCH_BIG(false, false, bf16_t); }
-            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_BIG(false, true, float); else LAUNCH_BIG(false, true, bf16_t); }
-            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_BIG(true, true, float); else LAUNCH_BIG(true, true, bf16_t); }
-            else { if (f32out) LAUNCH_BIG(true, false, float); else LAUNCH_BIG(true, false, bf16_t); }
-#undef LAUNCH_BIG
-        } else if (dma_ok && variant == 1 && g->m >= 1024) {
-            // 256x128 tiles, 3-stage ring: its own grid
-            const int ptm = bf_cdiv(g->m, P_BM), ptn = bf_cdiv(g->n, P_BN);
-            GemmDims dp{g->m, g->n, g->k, g->lda, g->ldb, ptm, ptn, kps, group_m_env > 8 ? group_m_env / 2 : group_m_env};
-            dim3 pgrid((unsigned)((long)ptm * ptn * split)), pblock(512);
-            const size_t lds3 = 3 * P_STAGE;
-            const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-#define LAUNCH_PIPE(AKS, BKS, TC)                                                                   \
-    do {                                                                                          \
-        static bool lds_ok = false;                                                               \
-        if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<AKS, BKS, TC>,           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);     \
-            lds_ok = true;                                                                        \
-        }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AKS, BKS, TC>), pgrid, pblock, lds3, s, A, B, dp, ep, slabs, ab, bb); \
-    } while (0)
-            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_PIPE(false, false, float); else LAUNCH_PIPE(false, false, bf16_t); }
-            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_PIPE(false, true, float); else LAUNCH_PIPE(false, true, bf16_t); }
-            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_PIPE(true, true, float); else LAUNCH_PIPE(true, true, bf16_t); }
-            else { if (f32out) LAUNCH_PIPE(true, false, float); else LAUNCH_PIPE(true, false, bf16_t); }
-#undef LAUNCH_PIPE
         } else if (dma_ok) {
             const size_t lds2 = 65536;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;

@@ -23,9 +23,13 @@ class KernelTimer:
     (bench.py turns it on for the timed region to price the dominant kernel against the MFMA
     roofline).  records: (label, algorithmic FLOPs, start event, end event)."""
 
-    def __init__(self, per_shape: bool = False):
+    def __init__(self, per_shape: bool = False, only_prefix: Optional[str] = None):
         self.records = []
         self.per_shape = per_shape
+        self.only_prefix = only_prefix        # e.g. "gemm_bf16_nt": time just the dominant kernel
+
+    def wants(self, label: str) -> bool:
+        return self.only_prefix is None or label.startswith(self.only_prefix)
 
     def summary(self):
         out = {}
@@ -208,8 +212,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.split_k = sk
     span = None
-    if PROFILER is not None:
-        label = f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}"
+    label = f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}"
+    if PROFILER is not None and PROFILER.wants(label):
         if PROFILER.per_shape:
             extras = "".join(t for t, on in (("+bias", bias is not None), (f"+act{act}", act != 0),
                                               ("+pre", want_pre), ("+res", residual is not None),
@@ -255,7 +259,7 @@ def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim:
     if row_mask is not None and row_mask.dtype != torch.int32:
         raise TypeError("row_mask must be int32")
     span = None
-    if PROFILER is not None:
+    if PROFILER is not None and PROFILER.wants("attn_fwd"):
         causal = 0.5 if mask_mode == L.MASK_CAUSAL else 1.0
         span = _Span(f"attn_fwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
                      4.0 * batch * heads * seq * seq * head_dim * causal)
@@ -272,7 +276,7 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
     span = None
-    if PROFILER is not None:
+    if PROFILER is not None and PROFILER.wants("attn_bwd"):
         span = _Span(f"attn_bwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
                      10.0 * batch * heads * seq * seq * head_dim)
     check(lib.bf_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
