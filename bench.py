@@ -125,11 +125,8 @@ def main():
     sample = synthetic_batch(args.batch, dev, seed=3407 + rank)
 
     sync = None
-    if world > 1:
-        arena = model.trainable_arena()
-        buckets = bdist.layer_buckets(arena.names, arena.offsets, model.pick_place.fusion.depth, arena.count)
-        sync = bdist.GradSync(arena.grad, buckets, model.pick_place.fusion.depth)
-        model.register_grad_ready_hook(sync.on_ready)
+    if world > 1 or os.environ.get("BIFOLD_FORCE_PG") == "1":
+        sync = bdist.gradient_sync_for(model)
 
     def step():
         out = model(sample)
@@ -214,7 +211,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
 
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -126,11 +126,7 @@ class Trainer:
         self.scheduler = Schedulers.get_by_name(cfg=self.cfg.scheduler, optimizer=self.optimizer,
                                                 max_iters=len(self.train_dataloader) * self.cfg.epochs)
         if self.world > 1:
-            arena = self.model.trainable_arena()
-            depth = self.model.pick_place.fusion.depth
-            buckets = bdist.layer_buckets(arena.names, arena.offsets, depth, arena.count)
-            self.sync = bdist.GradSync(arena.grad, buckets, depth)
-            self.model.register_grad_ready_hook(self.sync.on_ready)
+            self.sync = bdist.gradient_sync_for(self.model)
         self.load_model()
 
     def move_sample_to_device(self, sample):

@@ -28,7 +28,8 @@ def init_process_group_from_env(device_backend: Optional[str] = None) -> Tuple[i
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("BIFOLD_FORCE_PG") == "1"      # rehearse the RCCL path on one GPU
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -67,6 +68,20 @@ def layer_buckets(names: List[str], offsets, depth: int, count: int) -> List[Tup
     return buckets
 
 
+def gradient_sync_for(model, group: Optional[dist.ProcessGroup] = None) -> "GradSync":
+    """GradSync over `model`'s gradient arena, bucketed per fusion layer.  The layout is taken
+    from the model's own parameter names (matched to arena slots by identity), so it does not
+    matter whether the model or the optimiser created the arena first."""
+    arena = model.trainable_arena()
+    named = model.trainable_params()
+    names = [n for n, _ in named]
+    offsets = {n: arena.offsets[arena.name_of(p)] for n, p in named}
+    depth = model.pick_place.fusion.depth
+    sync = GradSync(arena.grad, layer_buckets(names, offsets, depth, arena.count), depth, group)
+    model.register_grad_ready_hook(sync.on_ready)
+    return sync
+
+
 class GradSync:
     """Overlapped all-reduce of a flat gradient arena.
 
@@ -90,7 +105,7 @@ class GradSync:
 
     def _launch(self, idx: int) -> None:
         a, b = self.buckets[idx]
-        if b <= a or self.world == 1:
+        if b <= a or (self.world == 1 and os.environ.get("BIFOLD_FORCE_PG") != "1"):
             return
         view = self.grad[a:b]
         if self.on_gpu:
