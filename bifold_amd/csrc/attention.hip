@@ -426,17 +426,22 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
     return r;
 }
 
+// Generalisation to sequences that do not fit one workgroup: blockIdx.y selects a chunk of
+// 32*nw keys (wave w owns 32 of them); the queries are streamed through LDS in tiles of 32*nw
+// rows.  dK/dV stay in registers across all query tiles.  Each tile's dQ is accumulated in LDS
+// and flushed when the tile is done: straight to dqkv when there is a single key chunk,
+// otherwise by fp32 atomics into dq_ws [B, L, H*D] (cast to bf16 by attn_dq_cast_kernel).
 template <int D, int MASK>
 __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
-    int L, int H, float scale) {
+    float* __restrict__ dq_ws, int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
     constexpr int DP = Cf::DP, KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nw = blockDim.x >> 6;
-    const int Lp = nw * 32;
+    const int Lp = nw * 32;                       // keys per chunk = queries per tile
     char* q_lds = smem;
     char* do_lds = q_lds + (size_t)Lp * ROW + 64;
     char* k_lds = do_lds + (size_t)Lp * ROW + 64;
@@ -450,44 +455,21 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int key0 = blockIdx.y * Lp;             // first key of this workgroup's chunk
+    const int n_chunks = gridDim.y;
+    const int n_qtiles = (L + Lp - 1) / Lp;
     const int nthreads = blockDim.x;
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
 
-    // ---- prologue: stage Q, dO, K (zero rows beyond L), lse, delta, row mask; clear dQ ------
+    // ---- this chunk's K rows (B operand of dQ) and the wave's K / V fragments ---------------
     for (int idx = threadIdx.x; idx < Lp * (D / 8); idx += nthreads) {
         const int i = idx / (D / 8), c = idx - i * (D / 8);
-        uint4 qv = make_uint4(0, 0, 0, 0), dv = qv, kv = qv;
-        if (i < L) {
-            qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
-            kv = *(const uint4*)(qkv + qkv_off(b, i, 1, h, L, H, D) + c * 8);
-            dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
-        }
-        *(uint4*)(q_lds + i * ROW + c * 16) = qv;
-        *(uint4*)(do_lds + i * ROW + c * 16) = dv;
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (key0 + i < L) kv = *(const uint4*)(qkv + qkv_off(b, key0 + i, 1, h, L, H, D) + c * 8);
         *(uint4*)(k_lds + i * ROW + c * 16) = kv;
     }
-    for (int i = threadIdx.x; i < Lp; i += nthreads) {
-        float dl = 0.f, ls = 1e30f;
-        int mk = 0;
-        if (i < L) {
-            const size_t oo = ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D;
-#pragma unroll
-            for (int c = 0; c < D / 8; ++c) {
-                const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
-                const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
-            }
-            ls = lse[((size_t)b * H + h) * L + i];
-            mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
-        }
-        lse_s[i] = ls; del_s[i] = dl; msk_s[i] = mk;
-    }
-    for (int idx = threadIdx.x; idx < Lp * DP; idx += nthreads) dq_lds[idx] = 0.f;
-
-    // this wave's K and V fragments (B operands: B[k = d][col = key]), straight from HBM
-    const int key = w * 32 + r;
+    const int key = key0 + w * 32 + r;
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -505,103 +487,155 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dkacc[db][e] = 0.f; dvacc[db][e] = 0.f; }
     const float inv_len = 1.0f / (float)L;
+    // keys beyond L have zero K/V rows but a non-zero exp(-lse): kill the whole lane once
+    const float lane_on = key < L ? 1.0f : 0.0f;
     char* my_img = ds_img + w * (32 * 64);
-    __syncthreads();
 
-    for (int t = 0; t < nw; ++t) {
-        int qb = w + t;
-        if (qb >= nw) qb -= nw;
-        const int qrow0 = qb * 32;
-        // causal: a query block entirely before this key block contributes nothing
-        const bool skip = (mask_mode == BF_MASK_CAUSAL) && (qrow0 + 31 < w * 32);
-        if (!skip) {
-            // ---- S and dP with row constants as the initial accumulators ------------------
-            f32x16 sacc, pacc;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 l4 = *(const float4*)(lse_s + qrow0 + 8 * g + 4 * hh);
-                const float4 d4 = *(const float4*)(del_s + qrow0 + 8 * g + 4 * hh);
-                sacc[4 * g + 0] = -l4.x * inv_scale; sacc[4 * g + 1] = -l4.y * inv_scale;
-                sacc[4 * g + 2] = -l4.z * inv_scale; sacc[4 * g + 3] = -l4.w * inv_scale;
-                pacc[4 * g + 0] = -d4.x; pacc[4 * g + 1] = -d4.y; pacc[4 * g + 2] = -d4.z; pacc[4 * g + 3] = -d4.w;
+    for (int qt = 0; qt < n_qtiles; ++qt) {
+        const int qbase = qt * Lp;                // first query of this tile
+        // causal: tiles entirely before this key chunk contribute nothing
+        if (mask_mode == BF_MASK_CAUSAL && qbase + Lp - 1 < key0) continue;
+        __syncthreads();                          // previous tile fully consumed / flushed
+        // ---- stage the tile: Q, dO rows (zero beyond L), lse, delta, row mask; clear dQ ------
+        for (int idx = threadIdx.x; idx < Lp * (D / 8); idx += nthreads) {
+            const int i = idx / (D / 8), c = idx - i * (D / 8);
+            uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
+            if (qbase + i < L) {
+                qv = *(const uint4*)(qkv + qkv_off(b, qbase + i, 0, h, L, H, D) + c * 8);
+                dv = *(const uint4*)(dout + ((size_t)b * L + qbase + i) * (size_t)H * D + (size_t)h * D + c * 8);
             }
+            *(uint4*)(q_lds + i * ROW + c * 16) = qv;
+            *(uint4*)(do_lds + i * ROW + c * 16) = dv;
+        }
+        for (int i = threadIdx.x; i < Lp; i += nthreads) {
+            float dl = 0.f, ls = 1e30f;
+            int mk = 0;
+            const int qi = qbase + i;
+            if (qi < L) {
+                const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qa = *(const bf16x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-                const bf16x8 da = *(const bf16x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
-            }
-            // ---- P and dS (lane = key column, register = query row) -----------------------
-            // keys beyond L have zero K/V rows but a non-zero exp(-lse): kill the whole lane once
-            const float lane_on = key < L ? 1.0f : 0.0f;
-            const float lane_scale = lane_on * scale;
+                for (int c = 0; c < D / 8; ++c) {
+                    const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
+                    const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float p = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * lane_on;
-                float ds = p * pacc[e] * scale;
-                if (mask_mode != BF_MASK_NONE) {
-                    const int qi = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (mask_mode == BF_MASK_QUERY_ROW && msk_s[qi]) { p = inv_len * lane_on; ds = 0.f; }
-                    if (mask_mode == BF_MASK_CAUSAL && key > qi) { p = 0.f; ds = 0.f; }
+                    for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
                 }
-                sacc[e] = p;
-                pacc[e] = ds;
+                ls = lse[((size_t)b * H + h) * L + qi];
+                mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + qi] == 0) : 0;
             }
-            (void)lane_scale;
-            bf16x8 pb[2], dsb[2];
+            lse_s[i] = ls; del_s[i] = dl; msk_s[i] = mk;
+        }
+        for (int idx = threadIdx.x; idx < Lp * DP; idx += nthreads) dq_lds[idx] = 0.f;
+        __syncthreads();
+
+        for (int t = 0; t < nw; ++t) {
+            int qb = w + t;
+            if (qb >= nw) qb -= nw;
+            const int qrow0 = qb * 32;            // row inside the tile
+            // causal: a query block entirely before this wave's key block contributes nothing
+            const bool skip = ((mask_mode == BF_MASK_CAUSAL) && (qbase + qrow0 + 31 < key0 + w * 32)) ||
+                              (qbase + qrow0 >= L);
+            if (!skip) {
+                // ---- S and dP with row constants as the initial accumulators ------------------
+                f32x16 sacc, pacc;
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
-            // dS image for dQ: [key column][query row], 64-byte rows
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)pacc[4 * g + e];
-                *(bf16x4*)(my_img + r * 64 + (8 * g + 4 * hh) * 2) = v4;
-            }
-            // ---- dV^T += dO^T P ;  dK^T += Q^T dS   (A operands by transposed LDS reads) ----
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int row0 = qrow0 + 16 * s + 4 * hh + q4;
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                    const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
-                    const bf16x8 qt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsb[s], dkacc[db], 0, 0, 0);
+                for (int g = 0; g < 4; ++g) {
+                    const float4 l4 = *(const float4*)(lse_s + qrow0 + 8 * g + 4 * hh);
+                    const float4 d4 = *(const float4*)(del_s + qrow0 + 8 * g + 4 * hh);
+                    sacc[4 * g + 0] = -l4.x * inv_scale; sacc[4 * g + 1] = -l4.y * inv_scale;
+                    sacc[4 * g + 2] = -l4.z * inv_scale; sacc[4 * g + 3] = -l4.w * inv_scale;
+                    pacc[4 * g + 0] = -d4.x; pacc[4 * g + 1] = -d4.y; pacc[4 * g + 2] = -d4.z; pacc[4 * g + 3] = -d4.w;
                 }
-            }
-            // ---- dQ_qb += dS K_w : A = dS^T image (transposed read), B = K rows (transposed read)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                f32x16 dq;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int krow = 16 * s + 8 * hh + q4;          // key within the block (natural k order)
-                    const int cq = (16 * (g16 & 1) + 4 * p4) * 2;   // query column in the image
-                    const bf16x8 a = tr_pair(my_img + krow * 64 + cq, my_img + (krow + 4) * 64 + cq);
-                    const int cd = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                    const char* kr = k_lds + (w * 32 + krow) * ROW + cd;
-                    const bf16x8 kb2 = tr_pair(kr, kr + 4 * ROW);
-                    dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb2, dq, 0, 0, 0);
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qa = *(const bf16x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+                    const bf16x8 da = *(const bf16x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
                 }
+                // ---- P and dS (lane = key column, register = query row) -----------------------
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int qi = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    dq_lds[qi * DP + db * 32 + r] += dq[e];
+                    float p = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * lane_on;
+                    float ds = p * pacc[e] * scale;
+                    if (mask_mode != BF_MASK_NONE) {
+                        const int ql = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (mask_mode == BF_MASK_QUERY_ROW && msk_s[ql]) { p = inv_len * lane_on; ds = 0.f; }
+                        if (mask_mode == BF_MASK_CAUSAL && key > qbase + ql) { p = 0.f; ds = 0.f; }
+                    }
+                    sacc[e] = p;
+                    pacc[e] = ds;
+                }
+                bf16x8 pb[2], dsb[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+                // dS image for dQ: [key column][query row], 64-byte rows
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)pacc[4 * g + e];
+                    *(bf16x4*)(my_img + r * 64 + (8 * g + 4 * hh) * 2) = v4;
+                }
+                // ---- dV^T += dO^T P ;  dK^T += Q^T dS   (A operands by transposed LDS reads) ----
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int row0 = qrow0 + 16 * s + 4 * hh + q4;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                        const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                        const bf16x8 qtt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
+                        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtt, dsb[s], dkacc[db], 0, 0, 0);
+                    }
+                }
+                // ---- dQ_qb += dS K_w : A = dS^T image (transposed read), B = K rows (transposed read)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    f32x16 dq;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int krow = 16 * s + 8 * hh + q4;          // key within the block (natural k order)
+                        const int cq = (16 * (g16 & 1) + 4 * p4) * 2;   // query column in the image
+                        const bf16x8 a = tr_pair(my_img + krow * 64 + cq, my_img + (krow + 4) * 64 + cq);
+                        const int cd = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                        const char* kr = k_lds + (w * 32 + krow) * ROW + cd;
+                        const bf16x8 kb2 = tr_pair(kr, kr + 4 * ROW);
+                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb2, dq, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ql = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        dq_lds[ql * DP + db * 32 + r] += dq[e];
+                    }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
+        // ---- flush this tile's dQ ------------------------------------------------------------
+        const int rows = min(Lp, L - qbase);
+        if (n_chunks == 1) {
+            for (int idx = threadIdx.x; idx < rows * (D / 8); idx += nthreads) {
+                const int i = idx / (D / 8), c = idx - i * (D / 8);
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)dq_lds[i * DP + c * 8 + e];
+                *(bf16x8*)(dqkv + qkv_off(b, qbase + i, 0, h, L, H, D) + c * 8) = o8;
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < rows * D; idx += nthreads) {
+                const int i = idx / D, c = idx - i * D;
+                atomicAdd(dq_ws + ((size_t)b * L + qbase + i) * (size_t)H * D + (size_t)h * D + c, dq_lds[i * DP + c]);
+            }
+        }
     }
 
     // ---- epilogue: dK, dV from the accumulators (lane = key, 4 consecutive d per store) -------
@@ -622,12 +656,17 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
                 }
             }
     }
-    for (int idx = threadIdx.x; idx < L * (D / 8); idx += nthreads) {
-        const int i = idx / (D / 8), c = idx - i * (D / 8);
-        bf16x8 o8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)dq_lds[i * DP + c * 8 + e];
-        *(bf16x8*)(dqkv + qkv_off(b, i, 0, h, L, H, D) + c * 8) = o8;
+}
+
+// dq_ws fp32 [B, L, H*D] -> the Q slot of dqkv [B, L, 3, H, D] (bf16)
+__global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, bf16_t* __restrict__ dqkv,
+                                                           size_t rows, int hd) {
+    const int c4n = hd >> 2;
+    const size_t total = rows * c4n;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / c4n;
+        const int c = (int)(i - row * c4n) * 4;
+        Vec4<bf16_t>::store(dqkv + row * 3 * hd + c, *(const float4*)(dq_ws + row * hd + c));
     }
 }
 
@@ -706,9 +745,29 @@ static int attn_bwd_launch(const void* qkv, const void* out, const void* dout, c
     return 0;
 }
 
+static size_t bwd_lds_of(int head_dim, int nw) {
+    return head_dim == 32 ? BwdCfg<32>::lds_bytes(nw) : head_dim == 48 ? BwdCfg<48>::lds_bytes(nw)
+                                                                      : BwdCfg<64>::lds_bytes(nw);
+}
+// waves (32-key blocks) per workgroup of the MFMA backward for this sequence; 0 = not applicable
+static int bwd_pick_nw(int seq, int head_dim, bool have_ws) {
+    const int nw_all = bf_cdiv(seq, 32);
+    const int maxw = head_dim == 32 ? 16 : 8;
+    if (nw_all <= maxw && bwd_lds_of(head_dim, nw_all) <= 160 * 1024) return nw_all;
+    if (!have_ws) return 0;
+    int nw = maxw;
+    while (nw > 1 && bwd_lds_of(head_dim, nw) > 160 * 1024) --nw;
+    return nw;
+}
+extern "C" int bf_attention_bwd_needs_dq_ws(int seq, int head_dim) {
+    if (!(head_dim == 32 || head_dim == 48 || head_dim == 64) || seq <= 0) return 0;
+    const int nw = bwd_pick_nw(seq, head_dim, true);
+    return bf_cdiv(seq, nw * 32) > 1 ? 1 : 0;
+}
+
 extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                                const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq,
-                                int heads, int head_dim, float scale, int mask_mode, int cdt,
+                                const int32_t* row_mask, void* dqkv, float* delta_ws, float* dq_ws, int batch,
+                                int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                                 bf_stream_t stream) {
     int rc = attn_check("bf_attention_bwd", qkv, batch, seq, heads, head_dim, mask_mode, row_mask, cdt);
     if (rc) return rc;
@@ -716,17 +775,23 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     BF_REQUIRE(bf_aligned16(out) && bf_aligned16(dout) && bf_aligned16(dqkv), BF_EALIGN,
                "bf_attention_bwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int nw = bf_cdiv(seq, 32);
-    const int maxw = head_dim == 32 ? 16 : 8;
-    const size_t bwd_lds = head_dim == 32 ? BwdCfg<32>::lds_bytes(nw)
-                         : head_dim == 48 ? BwdCfg<48>::lds_bytes(nw) : BwdCfg<64>::lds_bytes(nw);
-    // the one-workgroup-per-(batch, head) kernel needs the whole sequence in the 160 KB LDS;
-    // longer sequences take the (slow, VALU) tiled kernels below
-    if (cdt == BF_BF16 && nw <= maxw && bwd_lds <= 160 * 1024) {
-        dim3 grid(batch * heads), block(nw * 64);
+    // MFMA kernel geometry: one chunk of 32*nw keys per workgroup.  Short sequences run as ONE chunk
+    // (whole sequence in LDS, dQ stored directly); longer ones use the largest nw whose LDS image
+    // fits 160 KB and accumulate dQ across key chunks through dq_ws.
+    const int nw = bwd_pick_nw(seq, head_dim, dq_ws != nullptr);
+    auto lds_of = [&](int n) { return bwd_lds_of(head_dim, n); };
+    if (cdt == BF_BF16 && nw > 0) {
+        const int chunks = bf_cdiv(seq, nw * 32);
+        BF_REQUIRE(chunks == 1 || (dq_ws && bf_aligned16(dq_ws)), BF_EINVAL,
+                   "bf_attention_bwd: dq_ws is required for sequences longer than one key chunk");
+        if (chunks > 1) {
+            hipError_t e = hipMemsetAsync(dq_ws, 0, (size_t)batch * seq * heads * head_dim * sizeof(float), s);
+            BF_REQUIRE(e == hipSuccess, BF_ELAUNCH, "bf_attention_bwd: memset failed");
+        }
+        dim3 grid(batch * heads, chunks), block(nw * 64);
+        const size_t lds = lds_of(nw);
 #define BWD_MFMA2(DD, MM)                                                                           \
     do {                                                                                            \
-        const size_t lds = BwdCfg<DD>::lds_bytes(nw);                                               \
         static size_t lds_set = 0;                                                                  \
         if (lds > lds_set) {                                                                        \
             (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM>,                    \
@@ -734,8 +799,8 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             lds_set = lds;                                                                          \
         }                                                                                           \
         hipLaunchKernelGGL((attn_bwd_mfma_kernel<DD, MM>), grid, block, lds, s, (const bf16_t*)qkv, \
-                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv, seq, \
-                           heads, scale);                                                           \
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,  \
+                           dq_ws, seq, heads, scale);                                               \
     } while (0)
 #define BWD_MFMA(DD)                                                                                \
     do {                                                                                            \
@@ -748,6 +813,14 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         else BWD_MFMA(64);
 #undef BWD_MFMA
 #undef BWD_MFMA2
+        if (chunks > 1) {
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            const size_t rows = (size_t)batch * seq;
+            size_t blocks = (rows * (heads * head_dim / 4) + 255) / 256;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(attn_dq_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dq_ws, (bf16_t*)dqkv,
+                               rows, heads * head_dim);
+        }
     } else if (cdt == BF_BF16)
         attn_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
                                 head_dim, scale, mask_mode, s);

@@ -61,8 +61,9 @@ PROTOTYPES = {
     "bf_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_int, c_void_p]),
+    "bf_attention_bwd_needs_dq_ws": (c_int, [c_int, c_int]),
     "bf_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "bf_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_vision_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_float, c_void_p]),

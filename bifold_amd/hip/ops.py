@@ -275,12 +275,15 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_
     _dev(qkv, "qkv"); _dev(out, "out"); _dev(dout, "dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
+    # long sequences (bf16): dQ is accumulated across key chunks in an fp32 scratch
+    dq_ws = (torch.empty(batch * seq, heads * head_dim, dtype=torch.float32, device=qkv.device)
+             if (qkv.dtype == torch.bfloat16 and lib.bf_attention_bwd_needs_dq_ws(seq, head_dim)) else None)
     span = None
     if PROFILER is not None and PROFILER.wants("attn_bwd"):
         span = _Span(f"attn_bwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
                      10.0 * batch * heads * seq * seq * head_dim)
     check(lib.bf_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
-                               _ptr(delta), batch, seq, heads, head_dim, scale, mask_mode,
+                               _ptr(delta), _ptr(dq_ws), batch, seq, heads, head_dim, scale, mask_mode,
                                dtype_code(qkv), _stream()), "bf_attention_bwd")
     if span is not None:
         span.close()

@@ -158,10 +158,14 @@ int bf_attention_fwd(const void* qkv, void* out, float* lse, const int32_t* row_
                      int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                      bf_stream_t stream);
 
-/* dqkv [B, L, 3, H, D] cdt from dout [B, L, H*D] cdt; delta_ws fp32 [B, H, L] scratch. */
+/* dqkv [B, L, 3, H, D] cdt from dout [B, L, H*D] cdt; delta_ws fp32 [B, H, L] scratch;
+ * dq_ws fp32 [B, L, H*D] scratch, needed (bf16 mode) only when the sequence does not fit one
+ * key chunk of the MFMA kernel (L > 512 at D=32, > 192 at D=48, > 128 at D=64): dQ is then
+ * accumulated across key chunks with fp32 atomics.  NULL falls back to the VALU kernels. */
+int bf_attention_bwd_needs_dq_ws(int seq, int head_dim);   /* 1 if dq_ws is needed in bf16 mode */
 int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                     const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq,
-                     int heads, int head_dim, float scale, int mask_mode, int cdt,
+                     const int32_t* row_mask, void* dqkv, float* delta_ws, float* dq_ws, int batch,
+                     int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                      bf_stream_t stream);
 
 /* ------------------------------------------------------------------------

@@ -47,6 +47,7 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert b"head_dim" in L.lib.bf_last_error()
     assert L.lib.bf_adam_step(None, None, None, None, None, 6, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1
     assert L.lib.bf_bce_parts(256) == 1024 and L.lib.bf_layernorm_bwd_parts(70400) > 0
+    assert L.lib.bf_attention_bwd_needs_dq_ws(275, 32) == 0 and L.lib.bf_attention_bwd_needs_dq_ws(2950, 48) == 1
 
 
 def test_missing_library_fails_loudly(tmp_path):
