@@ -30,14 +30,15 @@ from .config import ConfigNode, compose
 from .losses import Losses
 from .models import Models
 from .optim import Optimizers, Schedulers
+from .targets import heatmap_targets
 
 CONF_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "conf")
 
 
 class SyntheticLoader:
     """Stands in for the DataLoader: `length // batch_size` batches per epoch of
-    (rgb ~ N(0,1), CLIP-style token ids, one sigma=5 Gaussian per target map), generated on
-    the device with a per-rank, per-epoch seed."""
+    (rgb ~ N(0,1), CLIP-style token ids, one annotated pixel per head turned into its target
+    map by bf_gaussian_targets), generated on the device with a per-rank, per-epoch seed."""
 
     def __init__(self, cfg, device, rank: int, world: int, model_name: str):
         self.batch = int(cfg.batch_size)
@@ -46,6 +47,7 @@ class SyntheticLoader:
         self.steps = max(1, int(cfg.train_dataset.length) // (self.batch * world))
         self.device, self.rank, self.seed, self.epoch = device, rank, int(cfg.seed), 0
         self.sigma = float(cfg.processor.sigma)
+        self.strategy = str(cfg.processor.get("strategy", "gmm"))
         self.siglip = model_name.startswith("siglip")
         self.context = int(cfg.model.get("context_length", 0) or 0) if model_name == "siglip_sequential" else 0
 
@@ -56,8 +58,6 @@ class SyntheticLoader:
         g = torch.Generator(device=self.device).manual_seed(self.seed + 1000 * self.epoch + self.rank)
         self.epoch += 1
         s, b, dev = self.size, self.batch, self.device
-        ys = torch.arange(s, device=dev, dtype=torch.float32).view(1, s, 1)
-        xs = torch.arange(s, device=dev, dtype=torch.float32).view(1, 1, s)
         names = ([f"{a}_{k}" for a in ("left", "right") for k in ("pick", "place")]
                  if self.is_bimanual else ["pick", "place"])
         for _ in range(self.steps):
@@ -75,11 +75,8 @@ class SyntheticLoader:
                 sample["rgb_context"] = torch.randn(b, self.context, 3, s, s, generator=g, device=dev)
                 k = torch.randint(0, self.context + 1, (b, 1), generator=g, device=dev)
                 sample["context_attention_mask"] = (torch.arange(self.context, device=dev)[None, :] < k).long()
-            for n in names:
-                c = torch.randint(0, s, (b, 2), generator=g, device=dev).float()
-                sample[f"{n}_heatmap"] = torch.exp(
-                    -((xs - c[:, 0].view(-1, 1, 1)) ** 2 + (ys - c[:, 1].view(-1, 1, 1)) ** 2)
-                    / (2 * self.sigma ** 2)).contiguous()
+            pixels = {n: torch.randint(0, s, (b, 2), generator=g, device=dev).float() for n in names}
+            sample.update(heatmap_targets(pixels, s, self.sigma, self.strategy))
             yield sample
 
 

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 # PyTorch-ROCm ships its own libamdhip64; it must be in the process BEFORE libbifold_hip.so so
 # that both resolve to ONE HIP runtime (device pointers and streams cross this boundary).
@@ -17,6 +17,7 @@ import torch  # noqa: F401
 F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU = 0, 1, 2, 3, 4
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
+TARGETS_FIRST, TARGETS_GMM, MAX_TARGET_POINTS = 0, 1, 16
 ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -99,6 +100,9 @@ PROTOTYPES = {
     "bf_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bf_clip_coef": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "bf_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
+    "bf_heatmap_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bf_gaussian_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int,
+                                    c_void_p]),
 }
 
 

@@ -450,3 +450,46 @@ def clip_coef(sumsq_t: torch.Tensor, max_norm: float) -> torch.Tensor:
     out = torch.empty(1, dtype=torch.float32, device=sumsq_t.device)
     check(lib.bf_clip_coef(_ptr(sumsq_t), max_norm, _ptr(out), _stream()), "bf_clip_coef")
     return out
+
+
+# ----------------------------------------------------------------------------- either side of the step
+def heatmap_pick(heat: torch.Tensor, mask: Optional[torch.Tensor] = None):
+    """heat fp32 [n, S, S]; mask [n, S, S] / [n, 1, S, S] (non-zero = allowed) or None ->
+    (xy int32 [n, 2] as (x, y), confidence fp32 [n]), all on the device."""
+    if heat.dim() != 3 or heat.shape[1] != heat.shape[2] or heat.dtype != torch.float32:
+        raise RuntimeError("heat must be fp32 [n, size, size]")
+    heat = heat.contiguous()
+    _dev(heat, "heat")
+    n, size = heat.shape[0], heat.shape[1]
+    if mask is not None:
+        if mask.numel() != heat.numel():
+            raise RuntimeError("mask must have one value per heatmap pixel")
+        mask = mask.reshape(n, size, size).to(torch.float32).contiguous()
+        _dev(mask, "mask")
+    xy = torch.empty(n, 2, dtype=torch.int32, device=heat.device)
+    conf = torch.empty(n, dtype=torch.float32, device=heat.device)
+    check(lib.bf_heatmap_pick(_ptr(heat), _ptr(mask), _ptr(xy), _ptr(conf), n, size, _stream()),
+          "bf_heatmap_pick")
+    return xy, conf
+
+
+def gaussian_targets(points: torch.Tensor, counts: Optional[torch.Tensor], size: int, sigma: float,
+                     strategy: str = "gmm") -> torch.Tensor:
+    """points fp32 [n, P, 2] (x, y) pixels, counts int32 [n] (None = all P valid) -> fp32 [n, S, S]."""
+    if points.dim() != 3 or points.shape[2] != 2 or points.dtype != torch.float32:
+        raise RuntimeError("points must be fp32 [n_maps, max_points, 2]")
+    codes = {"first": L.TARGETS_FIRST, "gmm": L.TARGETS_GMM}
+    if strategy not in codes:
+        raise ValueError(f"Strategy {strategy} not recognized" if strategy != "fit"
+                         else "Strategy fit (scipy multivariate_normal) is not built on the HIP path")
+    if counts is not None and (counts.dtype != torch.int32 or counts.numel() != points.shape[0]):
+        raise RuntimeError("counts must be int32 [n_maps]")
+    points = points.contiguous()
+    _dev(points, "points")
+    n, p = points.shape[0], points.shape[1]
+    if not 1 <= p <= L.MAX_TARGET_POINTS:
+        raise RuntimeError(f"at most {L.MAX_TARGET_POINTS} points per map (got {p})")
+    heat = torch.empty(n, size, size, dtype=torch.float32, device=points.device)
+    check(lib.bf_gaussian_targets(_ptr(points), _ptr(counts), _ptr(heat), n, p, size, float(sigma),
+                                  codes[strategy], _stream()), "bf_gaussian_targets")
+    return heat

@@ -87,27 +87,40 @@ class Components:
 DUMMY_PICK = -np.ones(2)
 
 
-def nearest_to_mask(u: int, v: int, mask: np.ndarray) -> np.ndarray:
-    """Closest (row, col) of a non-zero mask pixel to (u, v) (models/utils.py:80-83)."""
-    idx = np.argwhere(mask)
-    return idx[((idx - [u, v]) ** 2).sum(1).argmin()]
+def _picks_to_host(picks):
+    """[(xy int32 [B,2], conf fp32 [B]) ...] on the device -> int64 / fp32 numpy arrays with ONE
+    device->host copy each (the reference copies every heatmap, 200 KB per sample, instead)."""
+    xy = torch.stack([p[0] for p in picks]).cpu().numpy().astype(np.int64)
+    conf = torch.stack([p[1] for p in picks]).cpu().numpy()
+    if (xy == -2).any():          # bf_heatmap_pick's marker for an empty mask
+        raise ValueError("attempt to get argmin of an empty sequence (a sample's mask has no pixel set)")
+    return xy, conf
+
+
+def _device_pick(heatmap: torch.Tensor, mask=None):
+    from ..hip import ops
+    if not heatmap.is_cuda:
+        raise RuntimeError("sample_from_heatmap runs on the MI355X (bf_heatmap_pick); the numpy restatement "
+                           "of the reference lives in oracle/ for tests")
+    return ops.heatmap_pick(heatmap.detach().float(), mask)
 
 
 def sample_from_heatmap(heatmap: torch.Tensor, mask=None, return_confidence: bool = False):
-    """Per-sample argmax -> (x, y); optionally snapped to the mask (models/utils.py:60-77)."""
-    hm = heatmap.detach().float().cpu().numpy()
-    pixels, confidences = [], []
-    for i in range(hm.shape[0]):
-        r, c = np.unravel_index(hm[i].argmax(), hm[i].shape)
-        if mask is not None:
-            m = mask[i].squeeze().cpu().numpy()
-            r, c = nearest_to_mask(r, c, m)
-            assert m[r, c]
-        pixels.append([c, r])
-        confidences.append(hm[i][r, c])
+    """Per-sample argmax -> (x, y) pixel, optionally snapped to the nearest mask pixel
+    (models/utils.py:60-83), computed on the device by bf_heatmap_pick; only the [B, 2]
+    pixels and [B] confidences cross to the host."""
+    xy, conf = _picks_to_host([_device_pick(heatmap, mask)])
     if return_confidence:
-        return np.array(pixels), np.array(confidences)
-    return np.array(pixels)
+        return xy[0], conf[0]
+    return xy[0]
+
+
+def select_arms(confidences: np.ndarray, threshold: float) -> np.ndarray:
+    """(2, B) pick confidences -> (2, B) keep flags (models/__init__.py:118-131): an arm acts if it
+    is confident, or if it is the more confident of the two -- at least one arm always acts."""
+    b = confidences.shape[-1]
+    return np.logical_or(confidences >= threshold,
+                         confidences.argmax(axis=0) == np.tile(np.arange(2), (b, 1)).T)
 
 
 class BaseModel(nn.Module):
@@ -145,27 +158,19 @@ class BaseModel(nn.Module):
         with torch.no_grad():
             output = self.forward(sample)
         if self.is_bimanual:
-            picks, confs = [], []
-            for arm in ("left", "right"):
-                p, c = sample_from_heatmap(output[f"{arm}_pick_heatmap"], sample["mask"], True)
-                picks.append(p)
-                confs.append(c)
-            pick = np.stack(picks).astype(np.float64)           # (2, B, 2)
-            conf = np.stack(confs)                              # (2, B)
-            b = conf.shape[-1]
-            # keep an arm if it is confident, or if it is the more confident of the two
-            keep = np.logical_or(conf >= self.threshold,
-                                 conf.argmax(axis=0) == np.tile(np.arange(2), (b, 1)).T)
+            mask = sample["mask"]
+            names = ("left_pick", "right_pick", "left_place", "right_place")
+            xy, conf = _picks_to_host([_device_pick(output[f"{n}_heatmap"], mask if "pick" in n else None)
+                                       for n in names])
+            keep = select_arms(conf[:2], self.threshold)            # (2, B)
+            pick, place = xy[:2], xy[2:]
             pick[~keep] = DUMMY_PICK
-            places = []
-            for i, arm in enumerate(("left", "right")):
-                pl = sample_from_heatmap(output[f"{arm}_place_heatmap"]).astype(np.float64)
-                pl[~keep[i]] = DUMMY_PICK
-                places.append(pl)
-            action = Action(left_pick=pick[0], right_pick=pick[1], left_place=places[0],
-                            right_place=places[1])
+            place[~keep] = DUMMY_PICK
+            action = Action(left_pick=pick[0], right_pick=pick[1], left_place=place[0],
+                            right_place=place[1])
         else:
             mask = sample.get("mask") if self.constrain_pick_mask else None
-            action = Action(pick=sample_from_heatmap(output["pick_heatmap"], mask),
-                            place=sample_from_heatmap(output["place_heatmap"]))
+            xy, _ = _picks_to_host([_device_pick(output["pick_heatmap"], mask),
+                                    _device_pick(output["place_heatmap"])])
+            action = Action(pick=xy[0], place=xy[1])
         return (action, output) if return_raw_output else action

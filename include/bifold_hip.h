@@ -302,6 +302,31 @@ int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_stream_t str
 int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,
             bf_stream_t stream);
 
+/* ----------------------------------------------------------------------
+ * Either side of the step: inference post-processing and target synthesis.
+ *
+ * bf_heatmap_pick: per map, the arg-max pixel of `heat` (fp32 [n_maps, size, size], first
+ *   maximum in row-major order like numpy.argmax), optionally snapped to the nearest
+ *   non-zero pixel of `mask` (fp32 [n_maps, size, size] or NULL; squared Euclidean distance,
+ *   first minimum in row-major order like np.argwhere(...).argmin()).  Replaces
+ *   sample_from_heatmap + nearest_to_mask (bifold/models/utils.py:60-83).
+ *   xy int32 [n_maps, 2] = (x = column, y = row); conf fp32 [n_maps] = heat at that pixel.
+ *   A map whose mask is empty gets xy = (-2, -2) (the reference raises there).
+ * bf_gaussian_targets: the training target maps of Processor._make_gaussmap
+ *   (bifold/data/processor.py:405-439).  points fp32 [n_maps, max_points, 2] as (x, y)
+ *   pixels, counts int32 [n_maps] valid points per map (NULL = all max_points); count 0
+ *   gives the all-zero map (:409-410), count 1 or strategy FIRST the peak-1 Gaussian at
+ *   the rounded first point (:413-417), strategy GMM the max-normalised sum (:418-426).
+ *   fp64 arithmetic like the reference's numpy, stored as fp32.  The `fit` strategy
+ *   (scipy multivariate_normal) is not built.
+ * ---------------------------------------------------------------------- */
+#define BF_MAX_TARGET_POINTS 16
+enum { BF_TARGETS_FIRST = 0, BF_TARGETS_GMM = 1 };
+int bf_heatmap_pick(const float* heat, const float* mask, int32_t* xy, float* conf, int n_maps,
+                    int size, bf_stream_t stream);
+int bf_gaussian_targets(const float* points, const int32_t* counts, float* heat, int n_maps,
+                        int max_points, int size, double sigma, int strategy, bf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ from __future__ import annotations
 import math
 from typing import Dict, Mapping, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -537,3 +538,74 @@ def synthetic_sample(batch: int, gen: torch.Generator, *, size=224, context=77, 
         c = torch.randint(0, size, (batch, 2), generator=gen)
         sample[f"{n}_heatmap"] = gaussian_heatmaps(c, size)
     return sample
+
+
+# ---------------------------------------------------------------------------------------
+# Either side of the step: heatmap -> action, pixel -> target heatmap.
+# numpy like the reference; pinned by tests/golden/postproc.npz (oracle/gen_golden.py).
+# ---------------------------------------------------------------------------------------
+def nearest_to_mask(u, v, mask):
+    """(row, col) of the non-zero mask pixel closest to (u, v): first minimum of the squared
+    distance over np.argwhere's row-major order (bifold/models/utils.py:80-83)."""
+    idx = np.argwhere(mask)
+    return idx[((idx - [u, v]) ** 2).sum(1).argmin()]
+
+
+def sample_from_heatmap(heatmap, mask=None):
+    """heatmap [B,S,S], mask [B,1,S,S] or None -> (pixels int64 [B,2] as (x, y), confidences
+    fp32 [B]) (bifold/models/utils.py:60-77)."""
+    hm = np.asarray(heatmap, dtype=np.float32)
+    pixels, confidences = [], []
+    for i in range(hm.shape[0]):
+        r, c = np.unravel_index(hm[i].argmax(), hm[i].shape)
+        if mask is not None:
+            r, c = nearest_to_mask(r, c, np.asarray(mask[i]).squeeze())
+        pixels.append([c, r])
+        confidences.append(hm[i][r, c])
+    return np.array(pixels, dtype=np.int64), np.array(confidences, dtype=np.float32)
+
+
+def select_action(output, mask, is_bimanual, threshold=0.01, constrain_pick_mask=True):
+    """Heatmaps -> {name: int64 [B,2]} pixel action (bifold/models/__init__.py:79-173, image
+    branch).  Bimanual: an arm is kept if its pick confidence reaches the threshold or it is the
+    more confident arm; a dropped arm's pick and place are (-1, -1)."""
+    if not is_bimanual:
+        pick, _ = sample_from_heatmap(output["pick_heatmap"], mask if constrain_pick_mask else None)
+        place, _ = sample_from_heatmap(output["place_heatmap"])
+        return {"pick": pick, "place": place}
+    lp, lc = sample_from_heatmap(output["left_pick_heatmap"], mask)
+    rp, rc = sample_from_heatmap(output["right_pick_heatmap"], mask)
+    pick = np.stack((lp, rp))
+    conf = np.stack((lc, rc))
+    b = conf.shape[-1]
+    keep = np.logical_or(conf >= threshold, conf.argmax(axis=0) == np.tile(np.arange(2), (b, 1)).T)
+    pick[~keep] = -1
+    lplace, _ = sample_from_heatmap(output["left_place_heatmap"])
+    rplace, _ = sample_from_heatmap(output["right_place_heatmap"])
+    lplace[~keep[0]] = -1
+    rplace[~keep[1]] = -1
+    return {"left_pick": pick[0], "right_pick": pick[1], "left_place": lplace, "right_place": rplace}
+
+
+def make_gaussmap(points, size: int, sigma: float = 5.0, strategy: str = "gmm"):
+    """Target heatmap of one head (bifold/data/processor.py:405-439).  points: None (all-zero
+    map) or fp32 [P,2] (x, y) pixels; one point, or strategy `first`: peak-1 Gaussian at the
+    rounded (half-to-even) first point; `gmm`: sum of normalised Gaussians / its maximum.
+    fp64 arithmetic, fp32 result."""
+    grid = np.arange(size)
+    x, y = np.meshgrid(grid, grid)
+    if points is None:
+        return np.zeros((size, size), dtype=np.float32)
+    points = np.asarray(points, dtype=np.float32)
+    if len(points) == 1 or strategy == "first":
+        cx, cy = round(points[0, 0]), round(points[0, 1])
+        g = np.exp(-((x - cx) ** 2 + (y - cy) ** 2) / (2 * sigma * sigma))
+    elif strategy == "gmm":
+        g = np.zeros((size, size), dtype=np.float64)
+        for cx, cy in np.round(points):
+            d = (x - np.float64(cx)) ** 2 + (y - np.float64(cy)) ** 2
+            g += np.exp(-d / (2 * sigma ** 2)) / ((2 * np.pi) * sigma ** 2)
+        g /= g.max()
+    else:
+        raise ValueError(f"Strategy {strategy} is not restated (only first / gmm)")
+    return g.astype(np.float32)

@@ -10,7 +10,8 @@ test-suite only ever see the resulting fixtures.  Usage:
 What is stubbed, and why it is not on the arithmetic: `timm`
 (import-time symbol for the out-of-scope TransformerDecoder), `torchvision.
 transforms` and `ftfy` (CLIP image preprocessing factory / tokenizer text
-cleaning).  Pretrained weights cannot be downloaded, so `load` is replaced by a
+cleaning), `open3d` and `torchvision.transforms.v2` (module-level imports of the data
+package; Processor._make_gaussmap touches neither).  Pretrained weights cannot be downloaded, so `load` is replaced by a
 random-init CLIP of the requested hyper-parameters: parity is a property of the
 arithmetic, not of the weights, and the fixtures carry the weights explicitly.
 """
@@ -57,10 +58,24 @@ if "peft" not in sys.modules:
         sys.modules["peft.tuners.lora"].LoraConfig = type("LoraConfig", (), {})
         sys.modules["peft.tuners.lora"].LoraModel = type("LoraModel", (), {})
 
+# bifold.data.processor (for Processor._make_gaussmap only) imports open3d and torchvision's v2
+# transforms at module level; neither is installed and neither is touched by _make_gaussmap.
+for _name in ("open3d", "torchvision.transforms.v2"):
+    if _name not in sys.modules:
+        try:
+            __import__(_name)
+        except Exception:
+            sys.modules[_name] = types.ModuleType(_name)
+if not hasattr(_tv, "v2"):
+    _tv.v2 = sys.modules["torchvision.transforms.v2"]
+
 import bifold.models.rgb_clip as ref_rgb_clip  # noqa: E402
 import bifold.models.siglip as ref_siglip  # noqa: E402
 from bifold.losses import Losses as RefLosses  # noqa: E402
+from bifold.data.processor import Processor as RefProcessor  # noqa: E402
+from bifold.models import BaseModel as RefBaseModel  # noqa: E402
 from bifold.models import Components as RefComponents  # noqa: E402
+from bifold.models.utils import sample_from_heatmap as ref_sample_from_heatmap  # noqa: E402
 from bifold.models.clip.model import CLIP as RefCLIP  # noqa: E402
 from bifold.models.modules import ConvDecoder as RefConvDecoder  # noqa: E402
 from bifold.optim import Optimizers as RefOptimizers  # noqa: E402
@@ -453,6 +468,89 @@ def siglip_fixture(sequential: bool, fname: str, seed: int):
     print(f"  wrote {fname}")
 
 
+def postproc_fixture(seed: int):
+    """Heatmap -> action and pixel -> target-map vectors from the reference's own functions
+    (models/utils.py:60-83, models/__init__.py:79-173, data/processor.py:405-439)."""
+    print("postproc fixture")
+    rng = np.random.default_rng(seed)
+    size, batch = 24, 6
+    out = {}
+
+    def heat(n):
+        h = rng.random((n, size, size), dtype=np.float32)
+        h[0, 3, 5] = h[0, 17, 2] = 2.0            # tied maxima: the first in row-major order wins
+        h[1] = 0.25                                # constant map -> pixel (0, 0)
+        return h
+
+    mask = np.zeros((batch, 1, size, size), dtype=np.float32)
+    for i in range(batch):
+        r0, c0 = rng.integers(0, size - 8, 2)
+        mask[i, 0, r0:r0 + rng.integers(2, 8), c0:c0 + rng.integers(2, 8)] = 1.0
+    mask[2, 0] = 0.0
+    mask[2, 0, 4, 4] = mask[2, 0, 4, 20] = mask[2, 0, 20, 4] = 1.0   # equidistant candidates
+    mask[3] = 1.0
+
+    class Fixed(RefBaseModel):
+        def __init__(self, outputs, **kw):
+            super().__init__(image_size=size, device="cpu", **kw)
+            self.outputs = outputs
+
+        def forward(self, x):
+            return self.outputs
+
+    # unimanual, pick constrained to the mask
+    uni = {"pick_heatmap": heat(batch), "place_heatmap": heat(batch)}
+    uni["pick_heatmap"][2] = 0.0
+    uni["pick_heatmap"][2, 12, 12] = 1.0          # (12,12): 3 mask pixels at distance^2 128 -> first
+    sample = {"mask": torch.from_numpy(mask)}
+    ref_act = Fixed({k: torch.from_numpy(v) for k, v in uni.items()}, is_bimanual=False).get_action(sample)
+    mine = O.select_action(uni, mask, False)
+    assert np.array_equal(ref_act.pick, mine["pick"]) and np.array_equal(ref_act.place, mine["place"])
+    for k, v in uni.items():
+        out[f"uni.{k}"] = v
+    out["uni.expect.pick"], out["uni.expect.place"] = ref_act.pick, ref_act.place
+    px, cf = ref_sample_from_heatmap(torch.from_numpy(uni["pick_heatmap"]), torch.from_numpy(mask),
+                                     return_confidence=True)
+    opx, ocf = O.sample_from_heatmap(uni["pick_heatmap"], mask)
+    assert np.array_equal(px, opx) and np.array_equal(cf, ocf)
+    out["uni.expect.pick_conf"] = cf
+
+    # bimanual: confidences straddle the 0.01 threshold in every combination
+    bi = {f"{a}_{k}_heatmap": heat(batch) * 0.5 for a in ("left", "right") for k in ("pick", "place")}
+    scale = {"left": [1.0, 1.0, 0.001, 0.001, 0.004, 1.0], "right": [1.0, 0.001, 1.0, 0.002, 0.004, 1.0]}
+    for a in ("left", "right"):
+        bi[f"{a}_pick_heatmap"] *= np.asarray(scale[a], dtype=np.float32)[:, None, None]
+    ref_act = Fixed({k: torch.from_numpy(v) for k, v in bi.items()}, is_bimanual=True).get_action(sample)
+    mine = O.select_action(bi, mask, True)
+    for k in ("left_pick", "right_pick", "left_place", "right_place"):
+        assert np.array_equal(getattr(ref_act, k), mine[k]), k
+        out[f"bi.expect.{k}"] = getattr(ref_act, k)
+    for k, v in bi.items():
+        out[f"bi.{k}"] = v
+    out["mask"] = mask
+    print("  [ok] get_action uni/bimanual: oracle == reference (exact)")
+
+    # target maps
+    gsize = 40
+    cases = {"single": np.array([[10.5, 20.5]], np.float32),          # half-to-even rounding
+             "single_b": np.array([[11.5, 3.49]], np.float32),
+             "multi": np.array([[5.2, 6.7], [30.1, 30.9], [18.5, 2.5]], np.float32),
+             "dup": np.array([[8.0, 8.0], [8.4, 7.6]], np.float32),
+             "edge": np.array([[0.0, 39.0], [39.0, 0.0], [45.0, -3.0], [20.0, 20.0]], np.float32)}
+    for strategy in ("first", "gmm"):
+        proc = types.SimpleNamespace(image_size=gsize, cfg=types.SimpleNamespace(strategy=strategy, sigma=5))
+        for name, pts in cases.items():
+            ref = RefProcessor._make_gaussmap(proc, torch.from_numpy(pts)).numpy()
+            mine = O.make_gaussmap(pts, gsize, 5, strategy)
+            assert np.array_equal(ref, mine), (strategy, name, np.abs(ref - mine).max())
+            out[f"gauss.{strategy}.{name}.points"] = pts
+            out[f"gauss.{strategy}.{name}.expect"] = ref
+    ref = RefProcessor._make_gaussmap(proc).numpy()
+    assert np.array_equal(ref, O.make_gaussmap(None, gsize)) and not ref.any()
+    print("  [ok] _make_gaussmap first/gmm/None: oracle == reference (exact)")
+    np.savez_compressed(os.path.join(GOLD, "postproc.npz"), **out)
+
+
 def stats(t: torch.Tensor):
     t = t.detach().double().flatten()
     return np.concatenate([[t.mean().item(), t.std().item(), t.abs().max().item()],
@@ -495,9 +593,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-siglip", action="store_true")
+    ap.add_argument("--only-postproc", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    postproc_fixture(seed=3413)
+    if args.only_postproc:
+        return
     siglip_fixture(False, "tiny_siglip.npz", seed=3411)
     siglip_fixture(True, "tiny_siglip_sequential.npz", seed=3412)
     if args.only_siglip:

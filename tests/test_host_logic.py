@@ -207,3 +207,18 @@ def test_siglip_config_resolves():
                   ["model=siglip_sequential", "dataset@train_dataset=synthetic_bimanual_sequential"])
     assert cfg.model.automodel_name == "google/siglip-base-patch16-384"
     assert cfg.model.context_length == 3 and cfg.model.is_bimanual is True and cfg.loss.is_bimanual is True
+
+
+def test_select_arms_matches_reference_action(golden_dir):
+    """The arm-selection rule of get_action (models/__init__.py:118-131) on the golden
+    confidences: which arms the reference kept is visible as non-dummy picks."""
+    from bifold_amd.models import select_arms
+    from oracle import bifold_oracle as O
+    z = np.load(os.path.join(golden_dir, "postproc.npz"))
+    mask = z["mask"]
+    conf = np.stack([O.sample_from_heatmap(z[f"bi.{a}_pick_heatmap"], mask)[1] for a in ("left", "right")])
+    keep = select_arms(conf, 0.01)
+    ref_keep = np.stack([~(z[f"bi.expect.{a}_pick"] == -1).all(axis=1) for a in ("left", "right")])
+    assert np.array_equal(keep, ref_keep)
+    assert keep.any(axis=0).all()           # at least one arm always acts
+    assert (~keep).any()

@@ -459,3 +459,81 @@ def test_adam_matches_torch(ops, gpu, decoupled, wd):
     assert abs(ss.item() - (p.double() ** 2).sum().item()) < 1e-4 * ss.item()
     c = ops.clip_coef(ss, 1.0)
     assert abs(c.item() - min(1.0, 1.0 / (math.sqrt(ss.item()) + 1e-6))) < 1e-6
+
+
+# ------------------------------------------------------------------ either side of the step
+def _postproc():
+    import os
+
+    import numpy as np
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "postproc.npz"))
+
+
+def test_heatmap_pick_matches_reference_fixture(ops):
+    """bf_heatmap_pick against the reference's sample_from_heatmap outputs: exact (index work)."""
+    import numpy as np
+    z = _postproc()
+    mask = torch.from_numpy(z["mask"]).cuda()
+    xy, conf = ops.heatmap_pick(torch.from_numpy(z["uni.pick_heatmap"]).cuda(), mask)
+    assert np.array_equal(xy.cpu().numpy(), z["uni.expect.pick"])
+    assert np.array_equal(conf.cpu().numpy(), z["uni.expect.pick_conf"])
+    xy, _ = ops.heatmap_pick(torch.from_numpy(z["uni.place_heatmap"]).cuda())
+    assert np.array_equal(xy.cpu().numpy(), z["uni.expect.place"])
+
+
+@pytest.mark.parametrize("size,batch", [(224, 5), (64, 3), (7, 2)])
+def test_heatmap_pick_matches_oracle(ops, size, batch):
+    import numpy as np
+    from oracle import bifold_oracle as O
+    g = torch.Generator().manual_seed(size)
+    heat = torch.rand(batch, size, size, generator=g)
+    heat[0] = (heat[0] * 4).floor() / 4                 # heavy ties
+    heat[1, size // 2, size // 3] = float("nan")        # numpy.argmax picks the first NaN
+    mask = (torch.rand(batch, 1, size, size, generator=g) > 0.97).float()
+    mask[:, 0, size - 1, size - 1] = 1.0
+    for m in (None, mask):
+        xy, conf = ops.heatmap_pick(heat.cuda(), None if m is None else m.cuda())
+        exy, econf = O.sample_from_heatmap(heat.numpy(), None if m is None else m.numpy())
+        assert np.array_equal(xy.cpu().numpy(), exy)
+        assert np.array_equal(conf.cpu().numpy(), econf, equal_nan=True)
+    # an empty mask is an error in the reference; the kernel flags it instead of faulting
+    xy, _ = ops.heatmap_pick(heat.cuda(), torch.zeros_like(mask).cuda())
+    assert (xy.cpu() == -2).all()
+
+
+def test_gaussian_targets_match_reference_fixture(ops):
+    """bf_gaussian_targets against Processor._make_gaussmap outputs.  fp64 exp on the device may
+    differ from numpy's in the last fp64 ulp, which can flip the final fp32 rounding: tolerance
+    1 fp32 ulp (1.2e-7 relative), stated here."""
+    import numpy as np
+    z = _postproc()
+    for strategy in ("first", "gmm"):
+        names = [k.split(".")[2] for k in z.files if k.startswith(f"gauss.{strategy}.") and k.endswith(".points")]
+        pmax = max(z[f"gauss.{strategy}.{n}.points"].shape[0] for n in names)
+        pts = torch.zeros(len(names) + 1, pmax, 2)
+        cnt = torch.zeros(len(names) + 1, dtype=torch.int32)
+        for i, n in enumerate(names):
+            p = torch.from_numpy(z[f"gauss.{strategy}.{n}.points"])
+            pts[i, :p.shape[0]] = p
+            cnt[i] = p.shape[0]
+        maps = ops.gaussian_targets(pts.cuda(), cnt.cuda(), 40, 5, strategy).cpu().numpy()
+        for i, n in enumerate(names):
+            exp = z[f"gauss.{strategy}.{n}.expect"]
+            assert np.allclose(maps[i], exp, rtol=2.4e-7, atol=1e-37), (strategy, n, np.abs(maps[i] - exp).max())
+        assert not maps[-1].any()                        # count 0: the absent-arm map
+
+
+def test_gaussian_targets_full_size_properties(ops):
+    """224x224, B*heads maps in one launch: peak exactly 1 at the rounded pixel, symmetric."""
+    from oracle import bifold_oracle as O
+    g = torch.Generator().manual_seed(5)
+    pts = torch.rand(64, 3, 2, generator=g) * 223
+    cnt = torch.randint(1, 4, (64,), generator=g, dtype=torch.int32)
+    for strategy in ("first", "gmm"):
+        maps = ops.gaussian_targets(pts.cuda(), cnt.cuda(), 224, 5.0, strategy).cpu()
+        assert maps.max().item() == 1.0 and maps.min().item() >= 0.0
+        for i in (0, 17, 63):
+            exp = torch.from_numpy(O.make_gaussmap(pts[i, :cnt[i]].numpy(), 224, 5.0, strategy))
+            assert torch.allclose(maps[i], exp, rtol=2.4e-7, atol=1e-37)
+    with pytest.raises(ValueError):
+        ops.gaussian_targets(pts.cuda(), cnt.cuda(), 224, 5.0, "fit")

@@ -141,3 +141,32 @@ def test_siglip_models_match_reference(golden_dir, fixture, sequential):
     assert close(loss.detach(), fx["loss"][""], rtol=1e-6)
     for k, g in zip(keys, grads):
         assert close(g, fx["grad"][k], rtol=1e-4, atol=1e-7), k
+
+
+def test_postprocessing_and_targets_match_reference(golden_dir):
+    """Heatmap -> action and pixel -> target map restatements against the reference's own outputs
+    (models/utils.py:60-83, models/__init__.py:79-173, data/processor.py:405-439): exact."""
+    z = np.load(os.path.join(golden_dir, "postproc.npz"))
+    mask = z["mask"]
+    uni = {k[4:]: z[k] for k in z.files if k.startswith("uni.") and "expect" not in k}
+    got = O.select_action(uni, mask, False)
+    assert np.array_equal(got["pick"], z["uni.expect.pick"])
+    assert np.array_equal(got["place"], z["uni.expect.place"])
+    _, conf = O.sample_from_heatmap(uni["pick_heatmap"], mask)
+    assert np.array_equal(conf, z["uni.expect.pick_conf"])
+    bi = {k[3:]: z[k] for k in z.files if k.startswith("bi.") and "expect" not in k}
+    got = O.select_action(bi, mask, True)
+    dropped = 0
+    for k in ("left_pick", "right_pick", "left_place", "right_place"):
+        assert np.array_equal(got[k], z[f"bi.expect.{k}"]), k
+        dropped += int((z[f"bi.expect.{k}"] == -1).all(axis=1).sum())
+    assert dropped > 0                      # the fixture exercises the dropped-arm branch
+    n = 0
+    for k in z.files:
+        if k.startswith("gauss.") and k.endswith(".points"):
+            _, strategy, name, _ = k.split(".")
+            got = O.make_gaussmap(z[k], 40, 5, strategy)
+            assert np.array_equal(got, z[f"gauss.{strategy}.{name}.expect"]), k
+            n += 1
+    assert n == 10
+    assert not O.make_gaussmap(None, 40).any()
