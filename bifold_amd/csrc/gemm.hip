@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 struct EpiParams {
     void* c;
     void* c2;
@@ -74,6 +76,85 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
     }
     Vec4<TC>::store(cp, v);
     if (ep.c2) Vec4<bf16_t>::store((bf16_t*)ep.c2 + orow * ep.ldc + n, v);
+}
+
+// 8 consecutive columns of one output row.  A store instruction costs the issuing wave the
+// same whatever its width (measured on gfx950: ~300 cycles per store and wave when every CU
+// stores at once, 512-byte and 1-KB stores alike), so the epilogue moves 16 bytes per lane per
+// instruction wherever the output type allows it.
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const bf16x8 r = *(const bf16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)r[e];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+        *(bf16x8*)p = r;
+    }
+};
+
+template <typename TC, typename TD>
+__device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int n, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
+    if (ep.bias) {
+        float b[8];
+        Vec8<float>::load(ep.bias + n, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+    }
+    size_t orow = (size_t)m;
+    if (ep.rows_in > 0) orow = (size_t)(m / ep.rows_in) * ep.rows_out + ep.row_off + (m % ep.rows_in);
+    if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU || ep.act == BF_ACT_TANH_GELU) {
+        if (ep.pre) Vec8<TD>::store((TD*)ep.pre + orow * ep.ldc + n, v);
+        using AM = ActMath<TD>;
+        if (ep.act == BF_ACT_QUICK_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = AM::quick(v[e]);
+        } else if (ep.act == BF_ACT_TANH_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = AM::tanh_gelu(v[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = AM::erf(v[e]);
+        }
+    } else if (ep.act == BF_ACT_ERF_GELU_GRAD) {
+        using AM = ActMath<TD>;
+        float a[8];
+        Vec8<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= AM::erf_grad(a[e]);
+    }
+    if (ep.residual) {
+        const size_t rr = ep.resid_mod > 0 ? (size_t)(m % ep.resid_mod) : orow;
+        float r[8];
+        Vec8<float>::load(ep.residual + rr * ep.ld_res + n, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+    }
+    TC* cp = (TC*)ep.c + orow * ep.ldc + n;
+    if (ep.accumulate) {
+        float o[8];
+        Vec8<TC>::load(cp, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += o[e];
+    }
+    Vec8<TC>::store(cp, v);
+    if (ep.c2) Vec8<bf16_t>::store((bf16_t*)ep.c2 + orow * ep.ldc + n, v);
 }
 
 #define CT_LD 132   // fp32 staging tile leading dimension (128 + 4 pad)
@@ -510,6 +591,227 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
 }
 
 // =====================================================================================
+//   bf16 MFMA kernel, PERSISTENT 256x256 tile, 8 waves in two staggered groups ("p8")
+// =====================================================================================
+// The 128x128 kernels above top out where their structure does (every K step ends in a
+// vmcnt(0) + barrier; overlap comes only from co-resident workgroups).  This kernel follows
+// the other recipe: ONE workgroup per CU that keeps its LDS-DMA prefetch in flight across
+// barriers.
+//   * 8 waves = 2 (M) x 4 (N), wave tile 128x64 (128 accumulator registers); the two M-groups
+//     sit pairwise on the four SIMDs and run one barrier apart, so while one group issues
+//     its LDS reads / DMA pieces the other issues MFMAs (s_setprio raises the MFMA side).
+//   * K advances in BK = 32 stages through a 4-slot LDS ring (4 x (A 16 KB | B 16 KB) =
+//     128 KB); stage s+2 is issued while stage s is consumed; each wave waits for its own
+//     pieces of stage s+1 with a COUNTED vmcnt one phase before anyone reads them, and the
+//     barrier in between publishes them (a slot is rewritten 3 stages after its last read).
+//   * two phases of 16 MFMAs per stage: phase a reads B (4) + A rows 0-63 (4) fragments and
+//     issues the A pieces of stage s+2, phase b reads A rows 64-127 and issues the B pieces.
+//   * persistent over (split, tile) work items: the next item's first two stages are issued
+//     BEFORE the epilogue of the current one, so the epilogue's loads / stores overlap the
+//     DMA flight, and the stores drain under the next item's main loop.
+#define P8_STAGE 32768
+
+struct P8Item { int m0, n0, kbeg, nk, z; };
+
+#ifdef P8_PROBE
+__device__ unsigned long long p8_probe[16];
+extern "C" int bf_debug_p8_probe(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_probe), sizeof(p8_probe)) == hipSuccess ? 0 : 1;
+}
+#endif
+
+template <bool A_KS, bool B_KS, typename TC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmDims d, EpiParams ep,
+    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles = d.tiles_m * d.tiles_n;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+
+    // round r hands items [r*G, r*G + G) to the G workgroups; blocks with equal bid % 8 share an
+    // XCD and get a contiguous run of items (same split, neighbouring tiles of one group)
+    auto decode = [&](int round, P8Item& w) -> bool {
+        const int base = round * G;
+        const int cnt = min(n_items - base, G);
+        if (bid >= cnt) return false;
+        const int item = base + xcd_remap(bid, cnt);
+        w.z = item / tiles;
+        int tm, tn;
+        tile_coords(item - w.z * tiles, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+        w.m0 = tm * 256; w.n0 = tn * 256;
+        w.kbeg = w.z * d.k_per_split;
+        w.nk = (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 31) >> 5;
+        return true;
+    };
+    auto issue_a = [&](const P8Item& w, int s) {
+        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + s * 32, wave * 2, 2, lane);
+    };
+    auto issue_b = [&](const P8Item& w, int s) {
+        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, d.ldb, w.n0, w.kbeg + s * 32, wave * 2, 2, lane);
+    };
+
+    P8Item w;
+    int round = 0;
+    if (!decode(round, w)) return;
+    // Epilogue stores are a burst (128-512 KB per CU) that the memory system takes at ~2.7 TB/s
+    // chip-wide; with every CU in lock step the bursts coincide and the MFMAs idle meanwhile.
+    // Four phase groups per XCD start a fraction of an epilogue apart, so at any time about a
+    // quarter of the CUs write while the others compute.
+    if (skew_cycles > 0) {
+        const long long wait = (long long)((bid >> 3) & 3) * skew_cycles;
+        const long long t0 = clock64();
+        while ((long long)clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+    issue_a(w, 0); issue_b(w, 0);
+    if (w.nk > 1) { issue_a(w, 1); issue_b(w, 1); }
+
+    while (true) {
+        f32x4 acc[4][8];          // acc[j][i]: n tile j (16 cols), m tile i (16 rows); swapped roles
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#ifdef P8_PROBE
+        const unsigned long long pcw = clock64();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0/1 (and the previous item's stores)
+        __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+        if (bid == 0 && threadIdx.x == 0 && round == 2) p8_probe[6] = clock64() - pcw;
+#endif
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind
+        const int nk = w.nk;
+#ifdef P8_PROBE
+        const unsigned long long pc0 = clock64(), pw0 = wall_clock64();
+#endif
+        for (int s = 0; s < nk; ++s) {
+            const char* la = smem + (s & 3) * P8_STAGE;
+            const char* lb = la + 16384;
+            const bool more = s + 2 < nk;
+            // ---------------- phase a
+            bf16x8 bfr[4], af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS>(la, wm * 128 + i * 16, lane);
+            if (more) issue_a(w, s + 2);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- phase b
+            bf16x8 ag[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ag[i] = bf16_frag32<A_KS>(la, wm * 128 + 64 + i * 16, lane);
+            if (more) {
+                issue_b(w, s + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage s+1 landed (s+2 in flight)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ag[i], acc[j][4 + i], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();          // realign the groups
+#ifdef P8_PROBE
+        const unsigned long long pc1 = clock64(), pw1 = wall_clock64();
+#endif
+
+        // next item's first stages go out before this item's epilogue
+        P8Item nx;
+        const bool has_next = decode(++round, nx);
+        if (has_next) {
+            issue_a(nx, 0); issue_b(nx, 0);
+            if (nx.nk > 1) { issue_a(nx, 1); issue_b(nx, 1); }
+        }
+#ifdef P8_PROBE
+        const unsigned long long pc2 = clock64();
+#endif
+
+        // Epilogue through LDS: in the MFMA layout a wave-instruction's 64 lanes own 16 rows x 4
+        // separate 16-byte groups, i.e. 64 scattered requests per store (measured: ~780 cycles per
+        // store instruction and wave, the epilogue as long as a K = 768 main loop).  Each wave
+        // turns its 128x64 tile around in 32-row chunks through a private 8 KB of ring slots 2-3
+        // (slots 0-1 are receiving the next item), so that 16 adjacent lanes cover 64 consecutive
+        // columns of one row: 4 whole 128/256-byte row segments per store instruction.
+        float* slab = slabs ? slabs + (size_t)w.z * ep.m * ep.n : nullptr;
+        char* stg = smem + 2 * P8_STAGE + wave * 8192;
+        // ONE copy of the epilogue code: fully unrolled (32 copies of every activation / residual
+        // variant, ~100 KB of instructions) it thrashed the 64 KB instruction cache and cost
+        // ~780 cycles per store -- as much as a whole K = 768 main loop per tile.
+        auto stage_chunk = [&](auto cc_) {
+            constexpr int C = decltype(cc_)::value;
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int lr = ii * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cc = j * 4 + (lane >> 4);
+                    *(f32x4*)(stg + lr * 256 + ((cc ^ (lr & 15)) << 4)) = acc[j][2 * C + ii];
+                }
+            }
+        };
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            switch (c) {
+                case 0: stage_chunk(std::integral_constant<int, 0>{}); break;
+                case 1: stage_chunk(std::integral_constant<int, 1>{}); break;
+                case 2: stage_chunk(std::integral_constant<int, 2>{}); break;
+                default: stage_chunk(std::integral_constant<int, 3>{}); break;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+            for (int t = 0; t < 4; ++t) {
+                const int lr = t * 8 + (lane >> 3), c2 = (lane & 7) * 2;
+                const f32x4 q0 = *(const f32x4*)(stg + lr * 256 + ((c2 ^ (lr & 15)) << 4));
+                const f32x4 q1 = *(const f32x4*)(stg + lr * 256 + (((c2 + 1) ^ (lr & 15)) << 4));
+                const int m = w.m0 + wm * 128 + c * 32 + lr;
+                const int n = w.n0 + wn * 64 + c2 * 4;
+                if (m < ep.m && n < ep.n) {
+                    if (slab) {
+                        float* sp = slab + (size_t)m * ep.n + n;
+                        *(f32x4*)sp = q0;
+                        *(f32x4*)(sp + 4) = q1;
+                    } else {
+                        float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+                        epilogue_store8<TC, bf16_t>(ep, m, n, v);
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+#ifdef P8_PROBE
+        if (bid == 0 && threadIdx.x == 0 && round == 1) {
+            p8_probe[0] = pc1 - pc0; p8_probe[1] = pw1 - pw0; p8_probe[2] = nk;
+            p8_probe[3] = clock64() - pc1; p8_probe[4] = wall_clock64() - pw1; p8_probe[5] = pc2 - pc1;
+        }
+#endif
+        if (!has_next) break;
+        w = nx;
+    }
+}
+
+// =====================================================================================
 //                                   exact fp32 MFMA kernel
 // =====================================================================================
 #define F32_LD 132  // [16][128+4] k-major operand tiles
@@ -678,6 +980,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // =====================================================================================
 //                                        host
 // =====================================================================================
+static int pipe_env = -2;   // -2: read BIFOLD_GEMM_PIPE on first use; -1: automatic choice
+
+extern "C" int bf_gemm_set_variant(int variant) {
+    pipe_env = variant < 0 ? -1 : variant;
+    return BF_OK;
+}
+
 extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
     BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
     BF_REQUIRE(g->m > 0 && g->n > 0 && g->k > 0, BF_EINVAL, "bf_gemm: m, n, k must be > 0 (%d %d %d)",
@@ -765,7 +1074,6 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         const size_t b_ext = ((size_t)((g->b_kn ? g->k : g->n) - 1) * g->ldb + (g->b_kn ? g->n : g->k)) * 2;
         const bool dma_ok = ((g->trans_a && g->b_kn) || (g->k % 64) == 0) && a_ext < (1ull << 32) &&
                             b_ext < (1ull << 32) && !getenv("BIFOLD_GEMM_NO_DMA");
-        static int pipe_env = -2;
         if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
         // Kernel choice (measured in-step at B = 256): the BK = 32 kernel runs 4
         // workgroups per CU, which overlaps the epilogue traffic of one tile with the MFMAs of the
@@ -775,8 +1083,45 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         // 256x128 and 256x256 blocks, 128x64 wave tiles, 3/4-deep rings with counted
         // vmcnt -- every one lost to "as many resident workgroups as possible".)
         const bool long_nt = !g->trans_a && !g->b_kn && g->k >= 2048 && (double)g->m * g->n >= 2.0e7;
-        const int variant = pipe_env >= 0 ? pipe_env : (long_nt ? 0 : 4);
-        if (dma_ok && variant == 4) {
+        // The persistent 256x256 kernel wins in-step on the large-M NT GEMMs (vision / fusion
+        // token GEMMs, every epilogue flavour); the text tower's (M = 19.7k, on the side stream
+        // next to the vision tower) and the NN / TN shapes stay with the multi-workgroup kernels.
+        const bool p8_nt = !g->trans_a && !g->b_kn && g->m >= 32768;
+        const int variant = pipe_env >= 0 ? pipe_env : (p8_nt ? 8 : (long_nt ? 0 : 4));
+        if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
+            (!g->aux || (g->ld_aux % 8) == 0)) {
+            const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
+            static int n_cu = 0;
+            if (!n_cu) {
+                int dev = 0;
+                (void)hipGetDevice(&dev);
+                if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+            }
+            GemmDims d8 = d;
+            d8.tiles_m = bf_cdiv(g->m, 256); d8.tiles_n = bf_cdiv(g->n, 256);
+            d8.group_m = d.group_m > 8 ? 8 : d.group_m;
+            const long items = (long)d8.tiles_m * d8.tiles_n * split;
+            BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
+            unsigned g8 = (unsigned)(items < n_cu ? items : n_cu);
+            if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
+            const char* skew_e = getenv("BIFOLD_P8_SKEW");
+            const int skew = skew_e ? atoi(skew_e) : 0;
+#define LAUNCH_P8(AKS, BKS, TC)                                                                     \
+    do {                                                                                          \
+        static bool lds_ok = false;                                                               \
+        if (!lds_ok) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC>,             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE);  \
+            lds_ok = true;                                                                        \
+        }                                                                                         \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC>), dim3(g8), dim3(512), 4 * P8_STAGE, s, A, B, d8, ep, slabs, ab, bb, (int)items, skew); \
+    } while (0)
+            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_P8(false, false, float); else LAUNCH_P8(false, false, bf16_t); }
+            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_P8(false, true, float); else LAUNCH_P8(false, true, bf16_t); }
+            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_P8(true, true, float); else LAUNCH_P8(true, true, bf16_t); }
+            else { if (f32out) LAUNCH_P8(true, false, float); else LAUNCH_P8(true, false, bf16_t); }
+#undef LAUNCH_P8
+        } else if (dma_ok && (variant == 4 || (variant == 8 && !long_nt))) {
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
             // 64-row tiles when they fill the chip's workgroup slots better (256 CUs x 4 vs x 6)
             const long t128 = (long)tiles_m * tiles_n * split;

@@ -134,6 +134,12 @@ typedef struct bf_gemm_args {
 
 int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
 
+/* Tuning hook: force a bf16 kernel variant for every later bf_gemm call of this process
+ * (0 = 128x128x64, 4 = 128x128x32 with 4 workgroups per CU, 8 = persistent 256x256 staggered;
+ * a variant that cannot run a shape falls back to the automatic choice), -1 = automatic.
+ * Same effect as the BIFOLD_GEMM_PIPE environment variable. */
+int bf_gemm_set_variant(int variant);
+
 /* Column sums  out[n] (+)= sum_m x[m, n]  (bias gradients, LayerNorm partials). */
 int bf_colsum(const void* x, int x_dtype, float* out, int rows, int cols, int ld, int accumulate,
               bf_stream_t stream);

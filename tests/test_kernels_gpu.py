@@ -95,6 +95,20 @@ def ref_gemm(a, b, trans_a, b_kn):
     return A @ B
 
 
+@pytest.fixture(params=[-1, 8], ids=["auto", "p8"])
+def gemm_variant(request, L):
+    """Run the bf16 GEMM tests twice: with the automatic kernel choice and with the persistent
+    256x256 kernel forced (bf_gemm_set_variant), which the automatic choice only picks for M >= 32768."""
+    L.lib.bf_gemm_set_variant(request.param)
+    yield request.param
+    L.lib.bf_gemm_set_variant(-1)
+
+
+def _skip_f32_dup(cdt, gemm_variant):
+    if cdt == torch.float32 and gemm_variant != -1:
+        pytest.skip("the exact fp32 kernel has one variant")
+
+
 GEMM_SHAPES = [  # m, n, k
     (197 * 2, 768, 768), (100, 128, 64), (275, 1536, 512), (77 * 3, 512, 2048), (130, 256, 192),
     (1000, 640, 128), (777, 384, 320)]
@@ -103,7 +117,8 @@ GEMM_SHAPES = [  # m, n, k
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt):
+def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt, gemm_variant):
+    _skip_f32_dup(cdt, gemm_variant)
     trans_a = layout[0] == "t"
     b_kn = layout[1] == "n"
     if trans_a and m % 8:          # A stored [K, M]: the leading dimension must stay 16-byte aligned
@@ -122,8 +137,9 @@ def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt):
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("split", [1, 3, 8])
-def test_gemm_splitk_tn(ops, gpu, cdt, split):
+def test_gemm_splitk_tn(ops, gpu, cdt, split, gemm_variant):
     """dW = dY^T X with the token dimension (not a multiple of the K tile) split."""
+    _skip_f32_dup(cdt, gemm_variant)
     g = torch.Generator().manual_seed(5)
     tokens, n_out, k_in = 275 * 3 + 1, 256, 136
     dy = torch.randn(tokens, n_out, generator=g)
@@ -138,7 +154,8 @@ def test_gemm_splitk_tn(ops, gpu, cdt, split):
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", ["none", "quick", "erf", "tanh"])
-def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act):
+def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act, gemm_variant):
+    _skip_f32_dup(cdt, gemm_variant)
     g = torch.Generator().manual_seed(11)
     m, n, k = 200, 384, 128
     a, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) * k ** -0.5
@@ -174,7 +191,8 @@ def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act):
 
 
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
-def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt):
+def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt, gemm_variant):
+    _skip_f32_dup(cdt, gemm_variant)
     g = torch.Generator().manual_seed(13)
     m, n, k = 3 * 17, 256, 64
     dy, w = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)     # dX = dY W, W stored [K,N]
@@ -195,6 +213,27 @@ def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt):
     o = out.reshape(3, 20, n).cpu()
     assert rel_err(o[:, 2:19], ref) < 1e-5
     assert (o[:, :2] == -7).all() and (o[:, 19:] == -7).all()
+
+
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_persistent_rounds(ops, L, gpu, layout):
+    """More 256x256 work items than CUs (the persistent kernel loops, the next item's first
+    stages are in flight during the epilogue), ragged M / N tails, 3 K stages, bf16 and fp32 out."""
+    trans_a, b_kn = layout[0] == "t", layout[1] == "n"
+    m, n, k = 5000, 3592, 96
+    g = torch.Generator().manual_seed(77)
+    a = bf16_round(torch.randn((k, m) if trans_a else (m, k), generator=g))
+    b = bf16_round(torch.randn((k, n) if b_kn else (n, k), generator=g))
+    bias = torch.randn(n, generator=g)
+    ref = ref_gemm(a, b, trans_a, b_kn) + bias.double()
+    L.lib.bf_gemm_set_variant(8)
+    try:
+        for odt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2 ** -8)):
+            out = ops.gemm(a.to(gpu).bfloat16(), b.to(gpu).bfloat16(), trans_a=trans_a, b_kn=b_kn,
+                           bias=bias.to(gpu), out_dtype=odt, split_k=1)
+            assert rel_err(out.float(), ref) < tol
+    finally:
+        L.lib.bf_gemm_set_variant(-1)
 
 
 def test_colsum_and_cast(ops, gpu):

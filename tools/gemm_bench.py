@@ -26,7 +26,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--variants", default="-1", help="comma list of bf_gemm_set_variant values to interleave")
+    ap.add_argument("--check", action="store_true", help="compare every variant with torch.matmul first")
     args = ap.parse_args()
+    variants = [int(v) for v in args.variants.split(",")]
+    from bifold_amd.hip import lib as L
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     cases = []
@@ -38,26 +42,40 @@ def main():
         b = torch.randn((k, n) if bkn else (n, k), device=dev, generator=g).bfloat16()
         out = torch.empty(m, n, device=dev, dtype=torch.float32 if ta else torch.bfloat16)
         cases.append((name, lay, m, n, k, a, b, out, ta, bkn))
-    res = {c[0]: [] for c in cases}
+    if args.check:
+        for name, lay, m, n, k, a, b, out, ta, bkn in cases:
+            ref = ((a.float().t() if ta else a.float()) @ (b.float() if bkn else b.float().t()))
+            for v in variants:
+                L.lib.bf_gemm_set_variant(v)
+                out.zero_()
+                ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out)
+                err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+                print(f"check {name:10s} variant {v:2d}: rel err {err:.2e} {'ok' if err < 1e-2 else 'FAIL'}", flush=True)
+            del ref
+    res = {(c[0], v): [] for c in cases for v in variants}
     for r in range(args.rounds + 1):
         for name, lay, m, n, k, a, b, out, ta, bkn in cases:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out)
-            e1.record()
-            torch.cuda.synchronize()
-            if r > 0:
-                res[name].append(e0.elapsed_time(e1) / 3)
-    tot_ms, tot_fl = 0.0, 0.0
-    for name, lay, m, n, k, *_ in cases:
-        ts = sorted(res[name])
-        med = ts[len(ts) // 2]
-        fl = 2.0 * m * n * k
-        tot_ms += med
-        tot_fl += fl
-        print(f"{name:10s} {lay} {m:6d}x{n:5d}x{k:6d}  {med * 1e3:8.1f} us  {fl / med / 1e9:7.1f} TF/s (min {fl / ts[0] / 1e9:7.1f})")
-    print(f"TOTAL {tot_ms:.3f} ms  {tot_fl / tot_ms / 1e9:.1f} TF/s")
+            for v in variants:
+                L.lib.bf_gemm_set_variant(v)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                if r > 0:
+                    res[(name, v)].append(e0.elapsed_time(e1) / 3)
+    for v in variants:
+        tot_ms, tot_fl = 0.0, 0.0
+        for name, lay, m, n, k, *_ in cases:
+            ts = sorted(res[(name, v)])
+            med = ts[len(ts) // 2]
+            fl = 2.0 * m * n * k
+            tot_ms += med
+            tot_fl += fl
+            print(f"v{v:2d} {name:10s} {lay} {m:6d}x{n:5d}x{k:6d}  {med * 1e3:8.1f} us  {fl / med / 1e9:7.1f} TF/s (min {fl / ts[0] / 1e9:7.1f})")
+        print(f"v{v:2d} TOTAL {tot_ms:.3f} ms  {tot_fl / tot_ms / 1e9:.1f} TF/s")
+    L.lib.bf_gemm_set_variant(-1)
 
 
 if __name__ == "__main__":
