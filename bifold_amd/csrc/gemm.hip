@@ -757,6 +757,63 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // ONE copy of the epilogue code: fully unrolled (32 copies of every activation / residual
         // variant, ~100 KB of instructions) it thrashed the 64 KB instruction cache and cost
         // ~780 cycles per store -- as much as a whole K = 768 main loop per tile.
+        // Plain bf16 outputs (alpha / bias / activation only): do the math in the MFMA layout, turn
+        // the tile around as bf16 (half the LDS bytes: ds_write runs at ~80 B/clk per CU) in two
+        // 64-row halves, and store 8 columns per lane.
+        bool fast16 = false;
+        if constexpr (std::is_same<TC, bf16_t>::value)
+            fast16 = !slab && !ep.residual && !ep.aux && !ep.c2 && !ep.pre && !ep.accumulate && ep.rows_in == 0 &&
+                     ep.act != BF_ACT_ERF_GELU_GRAD;
+        if (fast16) {
+            float4 bj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = w.n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            using AM = ActMath<bf16_t>;
+            auto half_tile = [&](auto h_) {
+                constexpr int H = decltype(h_)::value;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int lr = ii * 16 + (lane & 15);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 a = acc[j][H * 4 + ii];
+                        float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
+                                      fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
+                        if (ep.act == BF_ACT_QUICK_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = AM::quick(v[e]);
+                        } else if (ep.act == BF_ACT_TANH_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = AM::tanh_gelu(v[e]);
+                        } else if (ep.act == BF_ACT_ERF_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
+                        }
+                        bf16x4 pk;
+                        pk[0] = (bf16_t)v[0]; pk[1] = (bf16_t)v[1]; pk[2] = (bf16_t)v[2]; pk[3] = (bf16_t)v[3];
+                        const int cc4 = j * 4 + (lane >> 4);
+                        *(bf16x4*)(stg + lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3)) = pk;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int lr = t * 8 + (lane >> 3), c16 = lane & 7;
+                    const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
+                    const int m = w.m0 + wm * 128 + H * 64 + lr;
+                    const int n = w.n0 + wn * 64 + c16 * 8;
+                    if (m < ep.m && n < ep.n) *(uint4*)((bf16_t*)ep.c + (size_t)m * ep.ldc + n) = q;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            };
+            half_tile(std::integral_constant<int, 0>{});
+            half_tile(std::integral_constant<int, 1>{});
+        } else {
         auto stage_chunk = [&](auto cc_) {
             constexpr int C = decltype(cc_)::value;
 #pragma unroll
@@ -779,7 +836,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
+#pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int lr = t * 8 + (lane >> 3), c2 = (lane & 7) * 2;
                 const f32x4 q0 = *(const f32x4*)(stg + lr * 256 + ((c2 ^ (lr & 15)) << 4));
@@ -800,6 +857,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        }   // general epilogue
 #ifdef P8_PROBE
         if (bid == 0 && threadIdx.x == 0 && round == 1) {
             p8_probe[0] = pc1 - pc0; p8_probe[1] = pw1 - pw0; p8_probe[2] = nk;
