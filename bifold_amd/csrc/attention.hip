@@ -11,6 +11,8 @@
 //    (parity) mode, and the first-correct backward for the bf16 mode.
 #include "common.h"
 
+#include <stdlib.h>
+
 #define KT 64                                 // keys per LDS tile
 
 __device__ __forceinline__ size_t qkv_off(int b, int i, int which, int h, int L, int H, int D) {
@@ -389,6 +391,171 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
     }
 }
 
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+
+// =====================================================================================
+//        bf16 MFMA forward, K / V of the whole (batch, head) resident in LDS
+// =====================================================================================
+// The tiled kernel above restages K and V^T for every 64-key tile: two barriers per tile and
+// eight 2-byte LDS writes per thread to transpose V.  For the sequences of this model family
+// (77 / 197 / 275 tokens) the whole K and V of one (batch, head) fit LDS (<= 74 KB), so they
+// are loaded ONCE, row-major, and every wave then walks all key tiles without a barrier;
+// V^T fragments come from the row-major image by ds_read_b64_tr_b16 (the recipe of the
+// backward kernel's dO^T / Q^T operands).  Same arithmetic, same order as the tiled kernel.
+template <int D, int MASK>
+__global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp) {
+    constexpr int mask_mode = MASK;
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = D / 16;
+    constexpr int DB = DP / 32;
+    constexpr int KROW = D * 2 + 16;          // bytes
+    constexpr int VROW = DP * 2 + 16;         // bytes (pad columns of D = 48 are zero)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* v_lds = smem + (size_t)Lp * KROW;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int q0 = wave * 32;
+    const int qi = q0 + r;
+    const bool q_live = qi < L;
+    const int nthreads = blockDim.x;
+
+    for (int idx = threadIdx.x; idx < Lp * (DP / 8); idx += nthreads) {
+        const int j = idx / (DP / 8), c = idx - j * (DP / 8);
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (j < L && c < D / 8) {
+            kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+            vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+        }
+        if (c < D / 8) *(uint4*)(k_lds + j * KROW + c * 16) = kv;
+        *(uint4*)(v_lds + j * VROW + c * 16) = vv;
+    }
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (q_live) qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
+        }
+    }
+    const bool row_masked = q_live && mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
+
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[db][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
+    __syncthreads();
+
+    for (int j0 = 0; j0 < key_end; j0 += KT) {
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(k_lds + (j0 + kb * 32 + r) * KROW + ks * 32 + hh * 16);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            }
+        }
+        const bool edge = (j0 + KT > L) || (mask_mode == BF_MASK_CAUSAL && j0 + KT - 1 > q0);
+        if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[kb][e] = -100000.0f / scale;
+        }
+        if (edge) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[kb][e] = -INFINITY;
+                }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+        const float m_new = fmaxf(m, tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], sl2, -m_use));
+                sacc[kb][e] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[kb][8 * s + e];
+                const int row0 = j0 + kb * 32 + 16 * s + 4 * hh + q4;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                    const bf16x8 vf = tr_pair(v_lds + row0 * VROW + cb, v_lds + (row0 + 8) * VROW + cb);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                }
+            }
+    }
+
+    if (q_live) {
+        const float inv = 1.0f / l;
+        bf16_t* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)(oacc[db][4 * g + e] * inv);
+                    *(bf16x4*)(op + d0) = o4;
+                }
+            }
+        if (lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
+    }
+}
+
 // =====================================================================================
 //                               bf16 MFMA backward
 // =====================================================================================
@@ -415,16 +582,6 @@ struct BwdCfg {
         return 3 * (lp * ROW + 64) + lp * DP * 4 + (size_t)nw * 32 * 64 + 3 * lp * 4;
     }
 };
-
-typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
-__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p0);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p1);
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
 
 // Generalisation to sequences that do not fit one workgroup: blockIdx.y selects a chunk of
 // 32*nw keys (wave w owns 32 of them); the queries are streamed through LDS in tiles of 32*nw
@@ -695,6 +852,40 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
     hipStream_t s = (hipStream_t)stream;
     if (cdt == BF_BF16) {
         const int nq32 = bf_cdiv(seq, 32);
+        // whole-sequence K / V resident in LDS when they fit and one workgroup can hold every
+        // 32-query wave (the sequences of this model family); otherwise the tiled kernel
+        const int lp = bf_cdiv(seq, 64) * 64;
+        const int dp = (head_dim + 31) / 32 * 32;
+        const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16));
+        static int fwd_res_env = -1;
+        if (fwd_res_env < 0) { const char* e = getenv("BIFOLD_ATTN_FWD_TILED"); fwd_res_env = (e && atoi(e)) ? 0 : 1; }
+        if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024) {
+            dim3 rgrid(batch * heads), rblock(nq32 * 64);
+#define FWD_RES2(DD, MM)                                                                           \
+    do {                                                                                          \
+        static size_t lds_set = 0;                                                                \
+        if (res_lds > lds_set) {                                                                  \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM>,                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
+            lds_set = res_lds;                                                                    \
+        }                                                                                         \
+        hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
+                           (bf16_t*)out, lse, row_mask, seq, heads, scale, lp);                   \
+    } while (0)
+#define FWD_RES(DD)                                                                               \
+    do {                                                                                          \
+        if (mask_mode == BF_MASK_NONE) FWD_RES2(DD, BF_MASK_NONE);                                \
+        else if (mask_mode == BF_MASK_CAUSAL) FWD_RES2(DD, BF_MASK_CAUSAL);                       \
+        else FWD_RES2(DD, BF_MASK_QUERY_ROW);                                                     \
+    } while (0)
+            if (head_dim == 32) FWD_RES(32);
+            else if (head_dim == 48) FWD_RES(48);
+            else FWD_RES(64);
+#undef FWD_RES
+#undef FWD_RES2
+            BF_CHECK_LAUNCH("bf_attention_fwd");
+            return BF_OK;
+        }
         const int chunks = bf_cdiv(nq32, 8);
         const int wpb = bf_cdiv(nq32, chunks);
         dim3 grid(batch * heads, chunks), block(wpb * 64);
@@ -752,7 +943,10 @@ static size_t bwd_lds_of(int head_dim, int nw) {
 // waves (32-key blocks) per workgroup of the MFMA backward for this sequence; 0 = not applicable
 static int bwd_pick_nw(int seq, int head_dim, bool have_ws) {
     const int nw_all = bf_cdiv(seq, 32);
-    const int maxw = head_dim == 32 ? 16 : 8;
+    int maxw = head_dim == 32 ? 16 : 8;
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_NW"); cap = e ? atoi(e) : 0; }
+    if (cap > 0 && cap < maxw && have_ws) maxw = cap;
     if (nw_all <= maxw && bwd_lds_of(head_dim, nw_all) <= 160 * 1024) return nw_all;
     if (!have_ws) return 0;
     int nw = maxw;

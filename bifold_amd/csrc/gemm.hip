@@ -1145,7 +1145,10 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         // token GEMMs, every epilogue flavour); the text tower's (M = 19.7k, on the side stream
         // next to the vision tower) and the NN / TN shapes stay with the multi-workgroup kernels.
         const bool p8_nt = !g->trans_a && !g->b_kn && g->m >= 32768;
-        const int variant = pipe_env >= 0 ? pipe_env : (p8_nt ? 8 : (long_nt ? 0 : 4));
+        // deep dW = dY^T X GEMMs whose (tile, split) items fill the CUs in exactly one round
+        const long items256 = (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) * split;
+        const bool p8_tn = g->trans_a && g->b_kn && split > 1 && items256 > 192 && items256 <= 256;
+        const int variant = pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn) ? 8 : (long_nt ? 0 : 4));
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;

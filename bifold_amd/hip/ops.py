@@ -141,9 +141,15 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
 
 
 # ----------------------------------------------------------------------------- GEMM
-def pick_split_k(m: int, n: int, k: int) -> int:
+def pick_split_k(m: int, n: int, k: int, deep_tn: bool = False) -> int:
     """Split the contraction when the output alone cannot fill the chip (the dW = dY^T X GEMMs:
     16-64 output tiles, 70 k tokens deep)."""
+    if deep_tn and k >= 16384:
+        # bf16 dW GEMMs run on the persistent 256x256 kernel: one (tile, split) item per CU in a
+        # single round (bf_gemm picks that kernel when tiles * split lands in (3/4, 1] x 256)
+        t256 = ((m + 255) // 256) * ((n + 255) // 256)
+        if t256 <= 128:
+            return max(1, min(64, 256 // t256))
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     if tiles >= 256 or k < 1024:
         return 1
@@ -205,7 +211,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
     if want_bf16_copy:
         copy = torch.empty(out.shape, dtype=torch.bfloat16, device=a.device)
         g.c2 = copy.data_ptr()
-    sk = pick_split_k(m, n, k) if split_k is None else split_k
+    sk = (pick_split_k(m, n, k, deep_tn=(trans_a and b_kn and a.dtype == torch.bfloat16))
+          if split_k is None else split_k)
     ws = None
     if sk > 1:
         ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)

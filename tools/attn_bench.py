@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Attention forward / backward microbenchmark on the shapes of the BiFold step (B = 256)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bifold_amd.hip import ops  # noqa: E402
+
+SHAPES = [("vision", 256, 197, 12, 64, 0), ("text", 256, 77, 8, 64, 1), ("fusion", 256, 275, 16, 32, 0)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--bwd", action="store_true")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, B, L, H, D, mode in SHAPES:
+        qkv = torch.randn(B * L, 3 * H * D, device=dev, generator=g).bfloat16()
+        dout = torch.randn(B * L, H * D, device=dev, generator=g).bfloat16()
+        out, lse = ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, None, need_lse=True)
+        fns = {"fwd": lambda: ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, None, need_lse=True)}
+        if args.bwd:
+            fns["bwd"] = lambda: ops.attention_bwd(qkv, out, dout, lse, B, L, H, D, D ** -0.5, mode, None)
+        for tag, fn in fns.items():
+            ts = []
+            for r in range(args.rounds + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                if r:
+                    ts.append(e0.elapsed_time(e1) / 3)
+            ts.sort()
+            fl = (4.0 if tag == "fwd" else 10.0) * B * H * L * L * D * (0.5 if mode == 1 else 1.0)
+            print(f"{name:7s} {tag} B{B} L{L} H{H} D{D} mask{mode}: {ts[len(ts)//2]*1e3:7.1f} us  {fl/ts[len(ts)//2]/1e9:6.1f} TF/s")
+
+
+if __name__ == "__main__":
+    main()

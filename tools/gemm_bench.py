@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--variants", default="-1", help="comma list of bf_gemm_set_variant values to interleave")
+    ap.add_argument("--split", type=int, default=0, help="force split_k (0 = the library default)")
     ap.add_argument("--check", action="store_true", help="compare every variant with torch.matmul first")
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(",")]
@@ -48,7 +49,7 @@ def main():
             for v in variants:
                 L.lib.bf_gemm_set_variant(v)
                 out.zero_()
-                ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out)
+                ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out, split_k=(args.split or None))
                 err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
                 print(f"check {name:10s} variant {v:2d}: rel err {err:.2e} {'ok' if err < 1e-2 else 'FAIL'}", flush=True)
             del ref
@@ -60,7 +61,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(3):
-                    ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out)
+                    ops.gemm(a, b, trans_a=ta, b_kn=bkn, out=out, split_k=(args.split or None))
                 e1.record()
                 torch.cuda.synchronize()
                 if r > 0:
