@@ -1045,7 +1045,81 @@ extern "C" int bf_gemm_set_variant(int variant) {
     return BF_OK;
 }
 
+static int n_cus() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+    }
+    return n_cu;
+}
+
+// The persistent 256x256 kernel hands out whole tiles; when the last round of tiles fills less
+// than ~half of the CUs (N = 768: 591 tiles = 2.3 rounds), the rows of that last round are cut
+// off and run as a split-K problem of their own (tail tiles x sub <= CUs, reduced with the
+// epilogue by splitk_reduce), so the job takes ~2.3 rounds instead of 3.
+struct P8TailPlan { int rows_main; int sub; size_t bytes; };
+static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
+    if (g->cdt != BF_BF16 || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
+        g->accumulate || g->m < 32768 || (g->k % 64) != 0 || (g->n % 8) != 0 || g->k < 2048)
+        return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
+    if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+    if (pipe_env >= 0 && pipe_env != 8) return false;
+    if (g->b_kn && pipe_env != 8) return false;            // NN stays on the 128x128 kernels by default
+    if (getenv("BIFOLD_P8_NO_TAIL")) return false;
+    const int n_cu = n_cus();
+    const long tiles_m = bf_cdiv(g->m, 256), tiles_n = bf_cdiv(g->n, 256);
+    const long items = tiles_m * tiles_n;
+    if (items <= n_cu) return false;
+    const long rem = items % n_cu;
+    if (rem == 0 || rem > (long)(n_cu * 0.55)) return false;
+    const long tm1 = (items - rem) / tiles_n;
+    const long tail_tiles = (tiles_m - tm1) * tiles_n;
+    if (tm1 <= 0 || tail_tiles <= 0 || tail_tiles > n_cu / 2) return false;
+    int sub = (int)(n_cu / tail_tiles);
+    if (sub > 8) sub = 8;
+    const int kps = ((bf_cdiv(g->k, sub) + 63) / 64) * 64;
+    sub = bf_cdiv(g->k, kps);
+    if (sub < 2) return false;
+    plan->rows_main = (int)(tm1 * 256);
+    plan->sub = sub;
+    plan->bytes = (size_t)sub * (size_t)(g->m - plan->rows_main) * g->n * sizeof(float);
+    return true;
+}
+
+extern "C" size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g) {
+    P8TailPlan plan;
+    return (g && p8_tail_plan(g, &plan)) ? plan.bytes : 0;
+}
+
+static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_variant);
+
 extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
+    BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
+    P8TailPlan plan;
+    if (g->split_k <= 1 && g->workspace && p8_tail_plan(g, &plan) && g->workspace_bytes >= plan.bytes &&
+        bf_aligned16(g->workspace)) {
+        bf_gemm_args main = *g, tail = *g;
+        main.m = plan.rows_main; main.workspace = nullptr; main.workspace_bytes = 0; main.split_k = 1;
+        int rc = gemm_impl(&main, stream, 8);
+        if (rc) return rc;
+        const size_t r0 = (size_t)plan.rows_main;
+        const size_t csz = g->c_dtype == BF_F32 ? 4 : 2;
+        tail.m = g->m - plan.rows_main;
+        tail.a = (const char*)g->a + r0 * g->lda * 2;
+        tail.c = (char*)g->c + r0 * g->ldc * csz;
+        if (g->c2) tail.c2 = (char*)g->c2 + r0 * g->ldc * 2;
+        if (g->pre) tail.pre = (char*)g->pre + r0 * g->ldc * 2;
+        if (g->aux) tail.aux = (const char*)g->aux + r0 * g->ld_aux * 2;
+        if (g->residual) tail.residual = g->residual + r0 * g->ld_res;
+        tail.split_k = plan.sub;
+        return gemm_impl(&tail, stream, 8);
+    }
+    return gemm_impl(g, stream, -1);
+}
+
+static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_variant) {
     BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
     BF_REQUIRE(g->m > 0 && g->n > 0 && g->k > 0, BF_EINVAL, "bf_gemm: m, n, k must be > 0 (%d %d %d)",
                g->m, g->n, g->k);
@@ -1148,16 +1222,12 @@ extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
         // deep dW = dY^T X GEMMs whose (tile, split) items fill the CUs in exactly one round
         const long items256 = (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) * split;
         const bool p8_tn = g->trans_a && g->b_kn && split > 1 && items256 > 192 && items256 <= 256;
-        const int variant = pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn) ? 8 : (long_nt ? 0 : 4));
+        const int variant = force_variant >= 0 ? force_variant
+                                               : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn) ? 8 : (long_nt ? 0 : 4)));
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0;
-                (void)hipGetDevice(&dev);
-                if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
-            }
+            const int n_cu = n_cus();
             GemmDims d8 = d;
             d8.tiles_m = bf_cdiv(g->m, 256); d8.tiles_n = bf_cdiv(g->n, 256);
             d8.group_m = d.group_m > 8 ? 8 : d.group_m;

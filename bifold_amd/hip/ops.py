@@ -218,6 +218,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.split_k = sk
+    if sk <= 1 and cdt == L.BF16 and m >= 32768:
+        tail = lib.bf_gemm_tail_workspace_bytes(C.byref(g))
+        if tail:
+            ws = torch.empty(tail // 4, dtype=torch.float32, device=a.device)
+            g.workspace, g.workspace_bytes = ws.data_ptr(), tail
     span = None
     label = f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}"
     if PROFILER is not None and PROFILER.wants(label):

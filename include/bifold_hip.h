@@ -140,6 +140,12 @@ int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
  * Same effect as the BIFOLD_GEMM_PIPE environment variable. */
 int bf_gemm_set_variant(int variant);
 
+/* Optional workspace for an un-split (split_k <= 1) bf16 GEMM: when the persistent 256x256 kernel
+ * would leave most CUs idle in its last round of tiles, bf_gemm cuts the rows of that round off
+ * and runs them split along K through `workspace`.  Returns the bytes to pass (0: not applicable;
+ * passing no workspace is always valid and just skips the optimisation). */
+size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g);
+
 /* Column sums  out[n] (+)= sum_m x[m, n]  (bias gradients, LayerNorm partials). */
 int bf_colsum(const void* x, int x_dtype, float* out, int rows, int cols, int ld, int accumulate,
               bf_stream_t stream);
