@@ -1083,7 +1083,7 @@ static int n_cus() {
 struct P8TailPlan { int rows_main; int sub; size_t bytes; };
 static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
     if (g->cdt != BF_BF16 || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
-        g->accumulate || g->m < 32768 || (g->k % 64) != 0 || (g->n % 8) != 0 || g->k < 2048)
+        g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 || g->k < 2048)
         return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
     if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
     if (pipe_env >= 0 && pipe_env != 8) return false;
@@ -1239,7 +1239,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         // The persistent 256x256 kernel wins in-step on the large-M NT GEMMs (vision / fusion
         // token GEMMs, every epilogue flavour); the text tower's (M = 19.7k, on the side stream
         // next to the vision tower) and the NN / TN shapes stay with the multi-workgroup kernels.
-        const bool p8_nt = !g->trans_a && !g->b_kn && g->m >= 32768;
+        static int p8_min_m = -1;
+        if (p8_min_m < 0) { const char* e = getenv("BIFOLD_P8_MIN_M"); p8_min_m = e ? atoi(e) : 16384; }
+        const bool p8_nt = !g->trans_a && !g->b_kn && g->m >= p8_min_m &&
+                           (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= n_cus();
         // deep dW = dY^T X GEMMs whose (tile, split) items fill the CUs in exactly one round
         const long items256 = (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) * split;
         const bool p8_tn = g->trans_a && g->b_kn && split > 1 && items256 > 192 && items256 <= 256;

@@ -218,7 +218,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.split_k = sk
-    if sk <= 1 and cdt == L.BF16 and m >= 32768:
+    if sk <= 1 and cdt == L.BF16 and m >= 16384:
         tail = lib.bf_gemm_tail_workspace_bytes(C.byref(g))
         if tail:
             ws = torch.empty(tail // 4, dtype=torch.float32, device=a.device)

@@ -8,6 +8,7 @@ stream / statistics; "fp32": exact fp32 MFMA everywhere -- the parity mode) and
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -98,12 +99,16 @@ class RGBOnly(BaseModel):
             self._side_stream = torch.cuda.Stream(device=rgb.device)
         side = self._side_stream
         self.clip_encoder._runtime(cdt)                   # arenas / bf16 copies ready before the fork
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        if os.environ.get("BIFOLD_TEXT_STREAM", "1") == "0":     # both towers on the main stream
             text_feat = self.clip_encoder.encode_text_with_embeddings(instr, cdt)
-        vis_feat = self.clip_encoder.encode_image_with_embeddings(rgb, cdt)
-        main.wait_stream(side)
-        text_feat.record_stream(main)
+            vis_feat = self.clip_encoder.encode_image_with_embeddings(rgb, cdt)
+        else:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_feat = self.clip_encoder.encode_text_with_embeddings(instr, cdt)
+            vis_feat = self.clip_encoder.encode_image_with_embeddings(rgb, cdt)
+            main.wait_stream(side)
+            text_feat.record_stream(main)
         params = [p for _, p in self.trainable_params()]
         heats = RGBTailFn.apply(self, text_feat, vis_feat, *params)
         out = {"attn_weights": None}

@@ -1,7 +1,7 @@
 import ctypes, sys, os, torch
 sys.path.insert(0, "/root/repo")
 from bifold_amd.hip import ops, lib as L
-L.lib.bf_gemm_set_variant(8)
+L.lib.bf_gemm_set_variant(int(os.environ.get("PROBE_VARIANT", "8")))
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 fn = L.lib.bf_debug_p8_probe
