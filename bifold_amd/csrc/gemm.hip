@@ -847,6 +847,53 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 }
             }
         };
+        // dX = (dY W) * gelu'(pre) with a bf16 result (the MLP's input gradient): all 16 rows of
+        // `pre` this lane needs are requested at once (64 registers of raw bf16), so the tile pays
+        // one load latency instead of sixteen; lean body, fully unrolled.
+        bool fastgrad = false;
+        if constexpr (std::is_same<TC, bf16_t>::value)
+            fastgrad = !slab && ep.act == BF_ACT_ERF_GELU_GRAD && !ep.bias && !ep.residual && !ep.c2 && !ep.pre &&
+                       !ep.accumulate && ep.rows_in == 0;
+        if (fastgrad) {
+            using AM = ActMath<bf16_t>;
+            uint4 apre[16];
+#pragma unroll
+            for (int ct = 0; ct < 16; ++ct) {
+                const int m = w.m0 + wm * 128 + ct * 8 + (lane >> 3);
+                const int n = w.n0 + wn * 64 + (lane & 7) * 8;
+                apre[ct] = (m < ep.m && n < ep.n) ? *(const uint4*)((const bf16_t*)ep.aux + (size_t)m * ep.ld_aux + n)
+                                                  : make_uint4(0, 0, 0, 0);
+            }
+            auto grad_chunk = [&](auto cc_) {
+                constexpr int C = decltype(cc_)::value;
+                stage_chunk(cc_);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int lr = t * 8 + (lane >> 3), c2 = (lane & 7) * 2;
+                    const f32x4 q0 = *(const f32x4*)(stg + lr * 256 + ((c2 ^ (lr & 15)) << 4));
+                    const f32x4 q1 = *(const f32x4*)(stg + lr * 256 + (((c2 + 1) ^ (lr & 15)) << 4));
+                    const int m = w.m0 + wm * 128 + C * 32 + lr;
+                    const int n = w.n0 + wn * 64 + c2 * 4;
+                    const uint4 raw = apre[C * 4 + t];
+                    const bf16x8 a8 = *(const bf16x8*)&raw;
+                    bf16x8 o8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o8[e] = (bf16_t)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
+                        o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
+                    }
+                    if (m < ep.m && n < ep.n) *(bf16x8*)((bf16_t*)ep.c + (size_t)m * ep.ldc + n) = o8;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            };
+            grad_chunk(std::integral_constant<int, 0>{});
+            grad_chunk(std::integral_constant<int, 1>{});
+            grad_chunk(std::integral_constant<int, 2>{});
+            grad_chunk(std::integral_constant<int, 3>{});
+        } else
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             switch (c) {
@@ -1246,8 +1293,12 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         // deep dW = dY^T X GEMMs whose (tile, split) items fill the CUs in exactly one round
         const long items256 = (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) * split;
         const bool p8_tn = g->trans_a && g->b_kn && split > 1 && items256 > 192 && items256 <= 256;
+        // dX = dY W (NN): only where the tiles fill at least three rounds (the MLP's 2048-wide
+        // gradient with its GELU' epilogue); the 512-wide ones (2.1 rounds) lose to tile quantisation
+        const bool p8_nn = !g->trans_a && g->b_kn && g->m >= p8_min_m &&
+                           (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= 3L * n_cus();
         const int variant = force_variant >= 0 ? force_variant
-                                               : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn) ? 8 : (long_nt ? 0 : 4)));
+                                               : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn || p8_nn) ? 8 : (long_nt ? 0 : 4)));
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;

@@ -204,6 +204,10 @@ def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt, gemm_variant):
     got = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
                    aux=pre.to(gpu).to(cdt), out_dtype=torch.float32)
     assert rel_err(got, p.grad) < 1e-5
+    if cdt == torch.bfloat16:      # bf16 result (the fused MLP backward): fast erf' + final rounding
+        got16 = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
+                         aux=pre.to(gpu).to(cdt), out_dtype=torch.bfloat16)
+        assert rel_err(got16.float(), p.grad) < 2 ** -7
     # row remap: 3 batches of 17 rows scattered into [3, 20, n] at row offset 2, + broadcast table
     table = torch.randn(17, n, generator=g)
     out = torch.full((3 * 20, n), -7.0, device=gpu)
