@@ -783,7 +783,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // 64-row halves, and store 8 columns per lane.
         bool fast16 = false;
         if constexpr (std::is_same<TC, bf16_t>::value)
-            fast16 = !slab && !ep.residual && !ep.aux && !ep.c2 && !ep.pre && !ep.accumulate && ep.rows_in == 0 &&
+            fast16 = !slab && !ep.residual && !ep.aux && !ep.c2 && !ep.accumulate && ep.rows_in == 0 &&
                      ep.act != BF_ACT_ERF_GELU_GRAD;
         if (fast16) {
             float4 bj[4];
@@ -793,8 +793,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             using AM = ActMath<bf16_t>;
-            auto half_tile = [&](auto h_) {
+            // pass 0 writes the pre-activation copy the backward pass needs (ep.pre), pass 1 the result
+            auto half_tile = [&](auto h_, auto pass_) {
                 constexpr int H = decltype(h_)::value;
+                constexpr int PASS = decltype(pass_)::value;
+                bf16_t* dst = PASS == 0 ? (bf16_t*)ep.pre : (bf16_t*)ep.c;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int lr = ii * 16 + (lane & 15);
@@ -803,15 +806,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                         const f32x4 a = acc[j][H * 4 + ii];
                         float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
                                       fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
-                        if (ep.act == BF_ACT_QUICK_GELU) {
+                        if (PASS == 1) {
+                            if (ep.act == BF_ACT_QUICK_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = AM::quick(v[e]);
-                        } else if (ep.act == BF_ACT_TANH_GELU) {
+                                for (int e = 0; e < 4; ++e) v[e] = AM::quick(v[e]);
+                            } else if (ep.act == BF_ACT_TANH_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = AM::tanh_gelu(v[e]);
-                        } else if (ep.act == BF_ACT_ERF_GELU) {
+                                for (int e = 0; e < 4; ++e) v[e] = AM::tanh_gelu(v[e]);
+                            } else if (ep.act == BF_ACT_ERF_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
+                                for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
+                            }
                         }
                         bf16x4 pk;
                         pk[0] = (bf16_t)v[0]; pk[1] = (bf16_t)v[1]; pk[2] = (bf16_t)v[2]; pk[3] = (bf16_t)v[3];
@@ -827,13 +832,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                     const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
                     const int m = w.m0 + wm * 128 + H * 64 + lr;
                     const int n = w.n0 + wn * 64 + c16 * 8;
-                    if (m < ep.m && n < ep.n) *(uint4*)((bf16_t*)ep.c + (size_t)m * ep.ldc + n) = q;
+                    if (m < ep.m && n < ep.n) *(uint4*)(dst + (size_t)m * ep.ldc + n) = q;
                 }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             };
-            half_tile(std::integral_constant<int, 0>{});
-            half_tile(std::integral_constant<int, 1>{});
+            const bool want_pre = ep.pre && (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU ||
+                                             ep.act == BF_ACT_TANH_GELU);
+            if (want_pre) {
+                half_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                half_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+            }
+            half_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+            half_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
         } else {
         auto stage_chunk = [&](auto cc_) {
             constexpr int C = decltype(cc_)::value;
