@@ -196,7 +196,23 @@ def main():
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                     print(f"{v['ms'] / args.steps:8.3f} ms/step {v['launches'] / args.steps:5.1f}x {v['avg_us']:8.1f} us "
                           f"{v['tflops']:7.1f} TF/s  {k}", file=sys.stderr)
-            d = summ.get(dom)
+            # the dominant DEVICE kernel: the NT GEMM variant with the largest share of the step
+            # (gemm_bf16_nt[p8] = gemm_bf16_p8_kernel<false, false, *> in the rocprof summary)
+            cands = {k: v for k, v in summ.items() if k.split(" ")[0].startswith(dom)}
+            d = None
+            if cands and not args.per_shape:
+                dom = max(cands, key=lambda k: cands[k]["ms"])
+                d = cands[dom]
+            elif cands:
+                agg = {}
+                for k, v in cands.items():
+                    a = agg.setdefault(k.split(" ")[0], {"launches": 0, "ms": 0.0, "flops": 0.0})
+                    for f in ("launches", "ms", "flops"):
+                        a[f] += v[f]
+                dom = max(agg, key=lambda k: agg[k]["ms"])
+                d = agg[dom]
+                d["avg_us"] = 1e3 * d["ms"] / d["launches"]
+                d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12
             if d:
                 peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
                 line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),

@@ -1118,6 +1118,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 //                                        host
 // =====================================================================================
 static int pipe_env = -2;   // -2: read BIFOLD_GEMM_PIPE on first use; -1: automatic choice
+static thread_local int last_variant = -1;
+
+extern "C" int bf_gemm_last_variant(void) { return last_variant; }
 
 extern "C" int bf_gemm_set_variant(int variant) {
     pipe_env = variant < 0 ? -1 : variant;
@@ -1310,8 +1313,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                            (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= 3L * n_cus();
         const int variant = force_variant >= 0 ? force_variant
                                                : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn || p8_nn) ? 8 : (long_nt ? 0 : 4)));
+        last_variant = 1;   // register-staged fallback unless one of the LDS-DMA kernels below takes it
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
+            last_variant = 8;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
             const int n_cu = n_cus();
             GemmDims d8 = d;
@@ -1339,6 +1344,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             else { if (f32out) LAUNCH_P8(true, false, float); else LAUNCH_P8(true, false, bf16_t); }
 #undef LAUNCH_P8
         } else if (dma_ok && (variant == 4 || (variant == 8 && !long_nt))) {
+            last_variant = 4;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
             // 64-row tiles when they fill the chip's workgroup slots better (256 CUs x 4 vs x 6)
             const long t128 = (long)tiles_m * tiles_n * split;
@@ -1366,6 +1372,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             else { if (f32out) LAUNCH_K32(true, false, float); else LAUNCH_K32(true, false, bf16_t); }
 #undef LAUNCH_K32
         } else if (dma_ok) {
+            last_variant = 0;
             const size_t lds2 = 65536;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
 #define LAUNCH_DMA(AKS, BKS, TC)                                                                    \
@@ -1390,6 +1397,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         else { if (f32out) LAUNCH_BF16(true, false, float); else LAUNCH_BF16(true, false, bf16_t); }
 #undef LAUNCH_BF16
     } else {
+        last_variant = -1;
         GemmDimsF d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps};
         const float* A = (const float*)g->a;
         const float* B = (const float*)g->b;

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "bf_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bf_clip_coef": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
     "bf_gemm_set_variant": (c_int, [c_int]),
+    "bf_gemm_last_variant": (c_int, []),
     "bf_gemm_tail_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),
     "bf_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
     "bf_heatmap_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -141,6 +141,9 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
 
 
 # ----------------------------------------------------------------------------- GEMM
+_VARIANT_TAG = {8: "p8", 4: "k32", 0: "bk64", 1: "reg"}
+
+
 def pick_split_k(m: int, n: int, k: int, deep_tn: bool = False) -> int:
     """Split the contraction when the output alone cannot fill the chip (the dW = dY^T X GEMMs:
     16-64 output tiles, 70 k tokens deep)."""
@@ -234,6 +237,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         span = _Span(label, 2.0 * m * n * k)
     check(lib.bf_gemm(C.byref(g), _stream()), "bf_gemm")
     if span is not None:
+        if cdt == L.BF16:          # name the device kernel that ran: gemm_bf16_nt[p8] / [k32] / [bk64] / [reg]
+            span.label = span.label.replace(" ", f"[{_VARIANT_TAG.get(lib.bf_gemm_last_variant(), '?')}] ", 1) \
+                if " " in span.label else span.label + f"[{_VARIANT_TAG.get(lib.bf_gemm_last_variant(), '?')}]"
         span.close()
     if want_pre:
         return out, pre

@@ -139,6 +139,9 @@ int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
  * a variant that cannot run a shape falls back to the automatic choice), -1 = automatic.
  * Same effect as the BIFOLD_GEMM_PIPE environment variable. */
 int bf_gemm_set_variant(int variant);
+/* The bf16 kernel the calling thread's last bf_gemm launched: 8 / 4 / 0 as above, 1 = the
+ * register-staged fallback, -1 = the exact fp32 kernel (profiling label, bench.py). */
+int bf_gemm_last_variant(void);
 
 /* Optional workspace for an un-split (split_k <= 1) bf16 GEMM: when the persistent 256x256 kernel
  * would leave most CUs idle in its last round of tiles, bf_gemm cuts the rows of that round off
