@@ -350,6 +350,56 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
 }
 
+// Any even patch size (ViT-L/14: 14-pixel rows are only 8-byte aligned) and a padded row length:
+// one thread per 2 consecutive kx; columns [3 p^2, ld) are written as zeros so that the GEMM's K
+// can be a multiple of its tile (588 -> 640 for patch 14).
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_ld_kernel(const float* __restrict__ img, T* __restrict__ cols,
+                                                          int batch, int size, int patch, int ld) {
+    const int g = size / patch;
+    const int half = ld >> 1;                           // pairs per output row
+    const int kreal = 3 * patch * patch;
+    const size_t total = (size_t)batch * g * g * half;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pidx = i / half;
+        const int col = (int)(i - pidx * half) * 2;
+        float2 v = make_float2(0.f, 0.f);
+        if (col < kreal) {
+            const int c = col / (patch * patch);
+            const int r = col - c * patch * patch;
+            const int ky = r / patch, kx = r - ky * patch;
+            const int b = (int)(pidx / (g * g));
+            const int pp = (int)(pidx - (size_t)b * g * g);
+            const int py = pp / g, px = pp - py * g;
+            v = *(const float2*)(img + (((size_t)b * 3 + c) * size + (py * patch + ky)) * size + px * patch + kx);
+        }
+        T* dst = cols + pidx * (size_t)ld + col;
+        dst[0] = (T)v.x;
+        dst[1] = (T)v.y;
+    }
+}
+
+extern "C" int bf_patchify_ld(const float* img, void* cols, int cdt, int batch, int size, int patch, int ld,
+                              bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && patch > 0 && (patch & 1) == 0 && size % patch == 0, BF_EINVAL,
+               "bf_patchify_ld: need an even patch and size %% patch == 0 (size=%d patch=%d)", size, patch);
+    BF_REQUIRE(ld >= 3 * patch * patch && (ld & 7) == 0, BF_EINVAL,
+               "bf_patchify_ld: ld must be a multiple of 8 and >= 3 patch^2 (ld=%d)", ld);
+    BF_REQUIRE(bf_aligned16(img) && bf_aligned16(cols), BF_EALIGN, "bf_patchify_ld: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)batch * (size / patch) * (size / patch) * (ld / 2);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    dim3 grid((unsigned)blocks), block(256);
+    if (cdt == BF_F32)
+        hipLaunchKernelGGL(patchify_ld_kernel<float>, grid, block, 0, s, img, (float*)cols, batch, size, patch, ld);
+    else if (cdt == BF_BF16)
+        hipLaunchKernelGGL(patchify_ld_kernel<bf16_t>, grid, block, 0, s, img, (bf16_t*)cols, batch, size, patch, ld);
+    else BF_REQUIRE(false, BF_EINVAL, "bf_patchify_ld: bad dtype %d", cdt);
+    BF_CHECK_LAUNCH("bf_patchify_ld");
+    return BF_OK;
+}
+
 extern "C" int bf_patchify(const float* img, void* cols, int cdt, int batch, int size, int patch,
                            bf_stream_t stream) {
     BF_REQUIRE(batch > 0 && patch > 0 && (patch & 3) == 0 && size % patch == 0, BF_EINVAL,

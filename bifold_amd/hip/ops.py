@@ -315,9 +315,24 @@ def patchify(img: torch.Tensor, patch: int, cdt: torch.dtype):
         raise RuntimeError(f"rgb must be float32 [B,3,S,S], got {img.dtype} {tuple(img.shape)}")
     b, _, s, _ = img.shape
     g = s // patch
-    cols = torch.empty(b * g * g, 3 * patch * patch, dtype=cdt, device=img.device)
-    check(lib.bf_patchify(_ptr(img), _ptr(cols), dtype_code(cols), b, s, patch, _stream()), "bf_patchify")
+    k = 3 * patch * patch
+    if patch % 4 == 0 and k % 64 == 0:
+        cols = torch.empty(b * g * g, k, dtype=cdt, device=img.device)
+        check(lib.bf_patchify(_ptr(img), _ptr(cols), dtype_code(cols), b, s, patch, _stream()), "bf_patchify")
+        return cols
+    # ViT-L/14 and friends: rows padded with zeros to a multiple of 64 (the weight gets zero columns too)
+    ld = patchify_row_length(patch)
+    cols = torch.empty(b * g * g, ld, dtype=cdt, device=img.device)
+    check(lib.bf_patchify_ld(_ptr(img), _ptr(cols), dtype_code(cols), b, s, patch, ld, _stream()),
+          "bf_patchify_ld")
     return cols
+
+
+def patchify_row_length(patch: int) -> int:
+    """Columns of the im2col matrix ops.patchify returns: 3 p^2, rounded up to a multiple of 64 unless
+    the fast path applies (the patch-embed weight must be padded to the same K)."""
+    k = 3 * patch * patch
+    return k if (patch % 4 == 0 and k % 64 == 0) else (k + 63) // 64 * 64
 
 
 def vision_assemble(patches, cls, pos, gamma, beta, batch: int, n_patch: int, eps: float = 1e-5):

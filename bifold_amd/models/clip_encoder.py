@@ -150,6 +150,13 @@ class CLIPEncoder(nn.Module):
         vw = self.vision_width
         cols = ops.patchify(img.contiguous(), self.patch, cdt)
         wconv = self._w("visual.conv1.weight", cdt).view(vw, -1)
+        if cols.shape[1] != wconv.shape[1]:               # patch 14: K padded 588 -> 640, zero columns
+            key = (cdt, cols.shape[1], self.get_parameter("visual.conv1.weight")._version, wconv.data_ptr())
+            if getattr(self, "_wconv_pad_key", None) != key:
+                pad = torch.zeros(vw, cols.shape[1], dtype=cdt, device=wconv.device)
+                pad[:, :wconv.shape[1]] = wconv
+                self._wconv_pad, self._wconv_pad_key = pad, key
+            wconv = self._wconv_pad
         patches = ops.gemm(cols, wconv, out_dtype=torch.float32)
         x = ops.vision_assemble(patches, self._f("visual.class_embedding"),
                                 self._f("visual.positional_embedding"), self._f("visual.ln_pre.weight"),

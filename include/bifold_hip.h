@@ -191,6 +191,10 @@ int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const f
  * conv1.weight.flatten(1), row order = row-major patches. */
 int bf_patchify(const float* img, void* cols, int cdt, int batch, int size, int patch,
                 bf_stream_t stream);
+/* Same for any EVEN patch size (ViT-L/14) with a padded row length: cols [B*g*g, ld], columns
+ * [3 p^2, ld) zero, so that the patch-embed GEMM's K is a multiple of its tile (588 -> 640). */
+int bf_patchify_ld(const float* img, void* cols, int cdt, int batch, int size, int patch, int ld,
+                   bf_stream_t stream);
 
 /* Vision-token assembly + ln_pre (models/clip/model.py:300-309):
  * x[b,0,:] = cls + pos[0]; x[b,1+p,:] = patches[b*n+p,:] + pos[1+p]; x = LN(x). */

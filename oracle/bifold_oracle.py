@@ -526,7 +526,7 @@ def gaussian_heatmaps(centres: torch.Tensor, size: int, sigma: float = 5.0):
 
 
 def synthetic_sample(batch: int, gen: torch.Generator, *, size=224, context=77, vocab=49408,
-                     real_tokens=32, is_bimanual=False) -> Dict[str, torch.Tensor]:
+                     real_tokens=32, is_bimanual=False, heat_size=None) -> Dict[str, torch.Tensor]:
     rgb = torch.randn(batch, 3, size, size, generator=gen)
     instr = torch.zeros(batch, context, dtype=torch.int32)
     instr[:, 0] = vocab - 2                                   # <|startoftext|> 49406
@@ -535,8 +535,11 @@ def synthetic_sample(batch: int, gen: torch.Generator, *, size=224, context=77, 
     instr[:, real_tokens - 1] = vocab - 1                     # <|endoftext|> 49407
     sample = {"rgb": rgb, "instruction": instr}
     for n in decoder_heads(is_bimanual):
-        c = torch.randint(0, size, (batch, 2), generator=gen)
-        sample[f"{n}_heatmap"] = gaussian_heatmaps(c, size)
+        # the decoder always upsamples the patch grid x16 (modules.py:68-69): with a patch size other
+        # than 16 (ViT-L/14) the heatmaps are 16 * grid pixels wide, not the image size
+        hs = heat_size or size
+        c = torch.randint(0, hs, (batch, 2), generator=gen)
+        sample[f"{n}_heatmap"] = gaussian_heatmaps(c, hs)
     return sample
 
 

@@ -190,13 +190,16 @@ TINY_MODEL = dict(image_size=64, is_bimanual=False, requires_graph=False, text_e
                   fusion_model="concat_transformer")
 
 
-def tiny_end_to_end(is_bimanual: bool, fname: str, seed: int):
-    print(f"== tiny end-to-end, bimanual={is_bimanual}")
-    mk = dict(TINY_MODEL, is_bimanual=is_bimanual)
-    model = build_ref_rgbonly(TINY_CLIP, mk, seed)
+def tiny_end_to_end(is_bimanual: bool, fname: str, seed: int, patch: int = 16):
+    """patch = 14 is the ViT-L/14 geometry in miniature (BASELINE configs[3]): 56-pixel images, a 4x4
+    patch grid, K = 588 in the patch embedding, and 64-pixel heatmaps (the decoder upsamples x16)."""
+    print(f"== tiny end-to-end, bimanual={is_bimanual}, patch={patch}")
+    size = 4 * patch
+    mk = dict(TINY_MODEL, is_bimanual=is_bimanual, image_size=size, patch_size=patch)
+    model = build_ref_rgbonly(dict(TINY_CLIP, image_resolution=size, vision_patch_size=patch), mk, seed)
     state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     gen = torch.Generator().manual_seed(seed + 7)
-    sample = O.synthetic_sample(3, gen, size=64, vocab=512, is_bimanual=is_bimanual)
+    sample = O.synthetic_sample(3, gen, size=size, vocab=512, is_bimanual=is_bimanual, heat_size=64)
 
     # intermediates from the reference
     with torch.no_grad():
@@ -594,12 +597,17 @@ def main():
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-siglip", action="store_true")
     ap.add_argument("--only-postproc", action="store_true")
+    ap.add_argument("--only-patch14", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if args.only_patch14:
+        tiny_end_to_end(False, "tiny_patch14.npz", seed=3414, patch=14)
+        return
     postproc_fixture(seed=3413)
     if args.only_postproc:
         return
+    tiny_end_to_end(False, "tiny_patch14.npz", seed=3414, patch=14)
     siglip_fixture(False, "tiny_siglip.npz", seed=3411)
     siglip_fixture(True, "tiny_siglip_sequential.npz", seed=3412)
     if args.only_siglip:

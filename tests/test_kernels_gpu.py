@@ -327,6 +327,20 @@ def test_patchify_matches_conv(ops, gpu, cdt):
                                             else cols.cpu()))
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_patchify_patch14_padded(ops, gpu, cdt):
+    """ViT-L/14: 14-pixel patches, im2col rows padded with zeros from 588 to 640 columns."""
+    g = torch.Generator().manual_seed(24)
+    img = torch.randn(2, 3, 56, 56, generator=g)
+    w = torch.randn(24, 3, 14, 14, generator=g)
+    cols = ops.patchify(img.to(gpu), 14, cdt)
+    assert cols.shape == (2 * 16, 640) and ops.patchify_row_length(14) == 640
+    c = cols.float().cpu()
+    assert (c[:, 588:] == 0).all()
+    ref = F.conv2d(img, w, stride=14).flatten(2).transpose(1, 2).reshape(-1, 24)
+    assert rel_err(c[:, :588] @ w.flatten(1).t(), ref) < (1e-5 if cdt == torch.float32 else 1e-2)
+
+
 def test_vision_assemble_embed_fusion(ops, gpu):
     g = torch.Generator().manual_seed(29)
     B, n, W = 3, 16, 128

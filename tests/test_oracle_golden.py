@@ -23,7 +23,7 @@ def close(a, b, rtol=2e-5, atol=2e-6):
     return (a - b).abs().max().item() <= atol + rtol * b.abs().max().item()
 
 
-@pytest.mark.parametrize("fixture", ["tiny_unimanual.npz", "tiny_bimanual.npz"])
+@pytest.mark.parametrize("fixture", ["tiny_unimanual.npz", "tiny_bimanual.npz", "tiny_patch14.npz"])
 def test_end_to_end_step_matches_reference(golden_dir, fixture):
     fx = load(golden_dir, fixture)
     bim = bool(int(fx["meta"]["is_bimanual"]))
