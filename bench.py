@@ -35,7 +35,8 @@ GF_PER_SAMPLE = 91.49          # 57.89 fwd + 33.60 bwd
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
-def synthetic_batch(batch: int, device, seed: int, size: int = 224, ctx: int = 77, vocab: int = 49408):
+def synthetic_batch(batch: int, device, seed: int, size: int = 224, ctx: int = 77, vocab: int = 49408,
+                    heat_size: int = 0):
     """SURVEY.md §8d inputs, generated directly in HBM."""
     g = torch.Generator(device=device).manual_seed(seed)
     rgb = torch.randn(batch, 3, size, size, generator=g, device=device)
@@ -44,10 +45,11 @@ def synthetic_batch(batch: int, device, seed: int, size: int = 224, ctx: int = 7
     instr[:, 1:31] = torch.randint(1, vocab - 2, (batch, 30), generator=g, device=device).int()
     instr[:, 31] = vocab - 1
     sample = {"rgb": rgb, "instruction": instr}
-    ys = torch.arange(size, device=device, dtype=torch.float32).view(1, size, 1)
-    xs = torch.arange(size, device=device, dtype=torch.float32).view(1, 1, size)
+    hs = heat_size or size      # the decoder upsamples the patch grid x16: 384 for ViT-L/14 @336
+    ys = torch.arange(hs, device=device, dtype=torch.float32).view(1, hs, 1)
+    xs = torch.arange(hs, device=device, dtype=torch.float32).view(1, 1, hs)
     for name in ("pick", "place"):
-        c = torch.randint(0, size, (batch, 2), generator=g, device=device).float()
+        c = torch.randint(0, hs, (batch, 2), generator=g, device=device).float()
         sample[f"{name}_heatmap"] = torch.exp(-((xs - c[:, 0].view(-1, 1, 1)) ** 2 +
                                                 (ys - c[:, 1].view(-1, 1, 1)) ** 2) / 50.0).contiguous()
     return sample
@@ -94,6 +96,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="diagnostic: time every GEMM shape separately")
     ap.add_argument("--all-kernels", action="store_true", help="time every matrix kernel, not just the dominant one")
+    ap.add_argument("--config", default="a", choices=["a", "vitl14"],
+                    help="a: BASELINE configs[1] (the metric); vitl14: configs[3], ViT-L/14 @336 (diagnostic line: "
+                         "no roofline, run with --batch 64)")
     args = ap.parse_args()
 
     from bifold_amd import dist as bdist
@@ -111,8 +116,10 @@ def main():
     from bifold_amd.optim import Optimizers
 
     torch.manual_seed(3407)                       # identical replicas on every rank
-    cfg = dict(name="rgb_clip", image_size=224, is_bimanual=False, requires_graph=False,
-               text_encoder="ViT-B/16", patch_size=16, depth=8, heads=16, mlp_ratio=4, dropout=0.0,
+    big = args.config == "vitl14"
+    cfg = dict(name="rgb_clip", image_size=336 if big else 224, is_bimanual=False, requires_graph=False,
+               text_encoder="ViT-L/14@336px" if big else "ViT-B/16", patch_size=14 if big else 16, depth=8,
+               heads=16, mlp_ratio=4, dropout=0.0,
                text_dropout=0.0, rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
                fusion_model="concat_transformer", dtype=args.dtype)
     with warnings.catch_warnings():
@@ -122,7 +129,8 @@ def main():
     loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))
     opt = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
                                  params=[p for p in model.parameters() if p.requires_grad])
-    sample = synthetic_batch(args.batch, dev, seed=3407 + rank)
+    sample = synthetic_batch(args.batch, dev, seed=3407 + rank, size=336 if big else 224,
+                             heat_size=384 if big else 0)
 
     sync = None
     if world > 1 or os.environ.get("BIFOLD_FORCE_PG") == "1":
@@ -174,16 +182,19 @@ def main():
         global_batch = args.batch * world
         ms = 1e3 * elapsed / args.steps
         value = global_batch * args.steps / elapsed
-        step_tflops = value * GF_PER_SAMPLE / 1e3
+        step_tflops = value * GF_PER_SAMPLE / 1e3 if not big else 0.0
         line = {
             "metric": "train samples/sec (224x224 RGB + 32-tok instr)",
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
-                                   "fusion 8x512 (16 heads) + 2 conv decoders, BCE, Adam; frozen encoders; "
-                                   "random-init weights", "per_gpu_batch": args.batch,
+            "config": {"workload": ("BASELINE configs[3] (diagnostic): rgb_clip ViT-L/14@336 (577 tokens, 24 layers, "
+                                    "width 1024) + CLIP text + fusion 8x768 (16 heads), 384-px heatmaps"
+                                    if big else
+                                    "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
+                                    "fusion 8x512 (16 heads) + 2 conv decoders, BCE, Adam; frozen encoders; "
+                                    "random-init weights"), "per_gpu_batch": args.batch,
                        "global_batch": global_batch, "parallelism": f"dp{world}", "final_loss": final_loss},
             "step_roofline": {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
@@ -223,7 +234,10 @@ def main():
                                    "tflops": round(v["tflops"], 1),
                                    "share_of_step": round(v["ms"] / (1e3 * elapsed), 4)}
                                for k, v in sorted(summ.items())}
-        if world == 1 and not args.no_cpu_baseline:
+        if big:
+            line.pop("step_roofline", None)
+            line.pop("roofline", None)
+        if world == 1 and not args.no_cpu_baseline and not big:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
 
