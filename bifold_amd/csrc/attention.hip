@@ -815,6 +815,296 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
     }
 }
 
+// =====================================================================================
+//      bf16 MFMA backward, split in two barrier-free kernels (whole sequence in LDS)
+// =====================================================================================
+// The single-kernel backward above keeps dK/dV per wave and reduces dQ across waves through
+// LDS: a read-add-write chain of 16 x DB LDS accesses and a workgroup barrier per step, 128 KB
+// of LDS (one workgroup per CU, 2.25 waves per SIMD) -- measured ~6 k cycles per 32x32 block
+// against ~1.5 k of instructions.  For sequences whose K+V (or Q+dO) fit LDS the work is split:
+//   attn_bwd_q_kernel  : QUERY on the lane, like the forward kernel.  One wave per 32 queries,
+//       K and V of the (batch, head) resident in LDS, recomputes S^T = K Q^T and
+//       dP^T = V dO^T per key block, dS^T = P^T (dP^T - delta) scale stays in the accumulator
+//       registers and is the B operand of dQ^T += K^T dS^T (K^T by transposed LDS reads).
+//       Also writes delta = rowsum(dO * O) for the second kernel.  No barrier after the load.
+//   attn_bwd_kv_kernel : KEY on the lane, the dK / dV half of the kernel above without the dQ
+//       part: Q and dO of the (batch, head) resident in LDS, no dS image, no dQ accumulation,
+//       no per-step barrier; 46 KB of LDS at L = 275, d = 32 (two to three workgroups per CU).
+// S and dP are computed twice (14 instead of 10 MFMAs per block, exp twice); both kernels read
+// their operands once more from HBM.  Same arithmetic per element as the single kernel.
+template <int D, int MASK>
+__global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    float* __restrict__ delta_ws, int L, int H, float scale, int Lp) {
+    constexpr int mask_mode = MASK;
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = D / 16;
+    constexpr int DB = DP / 32;
+    constexpr int KROW = DP * 2 + 16;         // K rows padded to DP columns (zero) for the transposed reads
+    constexpr int VROW = D * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* v_lds = smem + (size_t)Lp * KROW;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    // blockIdx.y: the 32-query blocks of a (batch, head) are spread over several workgroups of
+    // ~5 waves, each with its own K / V image: 9-wave workgroups left 7 of a CU's 16 wave slots idle
+    const int q0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 32;
+    const int qi = q0 + r;
+    const bool q_live = qi < L;
+    const int nthreads = blockDim.x;
+
+    for (int idx = threadIdx.x; idx < Lp * (DP / 8); idx += nthreads) {
+        const int j = idx / (DP / 8), c = idx - j * (DP / 8);
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (j < L && c < D / 8) {
+            kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+            vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+        }
+        *(uint4*)(k_lds + j * KROW + c * 16) = kv;
+        if (c < D / 8) *(uint4*)(v_lds + j * VROW + c * 16) = vv;
+    }
+
+    bf16x8 qf[KS], dof[KS];
+    float delta = 0.f, lse_q = 1e30f;
+    bool row_masked = false;
+    if (q_live) {
+        const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+            dof[ks] = *(const bf16x8*)(dout + oo + ks * 16 + hh * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
+            const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta = fmaf((float)ov[e], (float)gv[e], delta);
+        }
+        lse_q = lse[((size_t)b * H + h) * L + qi];
+        row_masked = mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
+        if (hh == 0) delta_ws[((size_t)b * H + h) * L + qi] = delta;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qf[ks][e] = (bf16_t)0.f; dof[ks][e] = (bf16_t)0.f; }
+    }
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const float s_init = -lse_q * inv_scale;
+
+    f32x16 dqacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqacc[db][e] = 0.f;
+    const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
+    __syncthreads();
+    if (q0 >= L) return;                          // spare wave of the last workgroup
+
+    for (int j0 = 0; j0 < key_end; j0 += 32) {
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *(const bf16x8*)(k_lds + (j0 + r) * KROW + ks * 32 + hh * 16);
+            const bf16x8 vf = *(const bf16x8*)(v_lds + (j0 + r) * VROW + ks * 32 + hh * 16);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+        }
+        // dS^T (rows = keys, lane = query); masked scores carry no gradient
+        const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float ds = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * pacc[e] * scale;
+            if (edge) {
+                const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) ds = 0.f;
+            }
+            sacc[e] = ds;
+        }
+        if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[8 * s + e];
+            const int row0 = j0 + 16 * s + 4 * hh + q4;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                const bf16x8 kt = tr_pair(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
+                dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, pf, dqacc[db], 0, 0, 0);
+            }
+        }
+    }
+
+    if (q_live) {
+        bf16_t* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)dqacc[db][4 * g + e];
+                    *(bf16x4*)(dq + d0) = o4;
+                }
+            }
+    }
+}
+
+template <int D, int MASK>
+__global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    int L, int H, float scale) {
+    constexpr int mask_mode = MASK;
+    using Cf = BwdCfg<D>;
+    constexpr int KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nw = (L + 31) >> 5;                 // 32-query blocks of the sequence (all resident in LDS)
+    const int Lp = nw * 32;
+    char* q_lds = smem;
+    char* do_lds = q_lds + (size_t)Lp * ROW + 64;
+    float* lse_s = (float*)(do_lds + (size_t)Lp * ROW + 64);
+    float* del_s = lse_s + Lp;
+    int* msk_s = (int*)(del_s + Lp);
+
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);   // this wave's 32-key block
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int nthreads = blockDim.x;
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+
+    for (int idx = threadIdx.x; idx < Lp * (D / 8); idx += nthreads) {
+        const int i = idx / (D / 8), c = idx - i * (D / 8);
+        uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
+        if (i < L) {
+            qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
+            dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
+        }
+        *(uint4*)(q_lds + i * ROW + c * 16) = qv;
+        *(uint4*)(do_lds + i * ROW + c * 16) = dv;
+    }
+    for (int i = threadIdx.x; i < Lp; i += nthreads) {
+        float dl = 0.f, ls = 1e30f;
+        int mk = 0;
+        if (i < L) {
+            ls = lse[((size_t)b * H + h) * L + i];
+            dl = delta_ws[((size_t)b * H + h) * L + i];
+            mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
+        }
+        lse_s[i] = ls; del_s[i] = dl; msk_s[i] = mk;
+    }
+    const int key = w * 32 + r;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (key < L) {
+            kf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
+            vf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[ks][e] = (bf16_t)0.f; vf[ks][e] = (bf16_t)0.f; }
+        }
+    }
+    f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[db][e] = 0.f; dvacc[db][e] = 0.f; }
+    const float inv_len = 1.0f / (float)L;
+    const float lane_on = key < L ? 1.0f : 0.0f;
+    __syncthreads();
+    if (w >= nw) return;                          // spare wave of the last workgroup
+
+    for (int t = 0; t < nw; ++t) {
+        int qb = w + t;                           // start at the diagonal: spreads the LDS rows touched per step
+        if (qb >= nw) qb -= nw;
+        const int qrow0 = qb * 32;
+        if (qrow0 >= L || ((mask_mode == BF_MASK_CAUSAL) && (qrow0 + 31 < w * 32))) continue;
+        f32x16 sacc, pacc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 l4 = *(const float4*)(lse_s + qrow0 + 8 * g + 4 * hh);
+            const float4 d4 = *(const float4*)(del_s + qrow0 + 8 * g + 4 * hh);
+            sacc[4 * g + 0] = -l4.x * inv_scale; sacc[4 * g + 1] = -l4.y * inv_scale;
+            sacc[4 * g + 2] = -l4.z * inv_scale; sacc[4 * g + 3] = -l4.w * inv_scale;
+            pacc[4 * g + 0] = -d4.x; pacc[4 * g + 1] = -d4.y; pacc[4 * g + 2] = -d4.z; pacc[4 * g + 3] = -d4.w;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qa = *(const bf16x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+            const bf16x8 da = *(const bf16x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float p = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * lane_on;
+            float ds = p * pacc[e] * scale;
+            if (mask_mode != BF_MASK_NONE) {
+                const int ql = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (mask_mode == BF_MASK_QUERY_ROW && msk_s[ql]) { p = inv_len * lane_on; ds = 0.f; }
+                if (mask_mode == BF_MASK_CAUSAL && key > ql) { p = 0.f; ds = 0.f; }
+            }
+            sacc[e] = p;
+            pacc[e] = ds;
+        }
+        bf16x8 pb[2], dsb[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int row0 = qrow0 + 16 * s + 4 * hh + q4;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                const bf16x8 qtt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
+                dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtt, dsb[s], dkacc[db], 0, 0, 0);
+            }
+        }
+    }
+
+    if (key < L) {
+        bf16_t* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+        bf16_t* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 k4, v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { k4[e] = (bf16_t)dkacc[db][4 * g + e]; v4[e] = (bf16_t)dvacc[db][4 * g + e]; }
+                    *(bf16x4*)(dkp + d0) = k4;
+                    *(bf16x4*)(dvp + d0) = v4;
+                }
+            }
+    }
+}
+
 // dq_ws fp32 [B, L, H*D] -> the Q slot of dqkv [B, L, 3, H, D] (bf16)
 __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, bf16_t* __restrict__ dqkv,
                                                            size_t rows, int hd) {
@@ -972,6 +1262,59 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     // MFMA kernel geometry: one chunk of 32*nw keys per workgroup.  Short sequences run as ONE chunk
     // (whole sequence in LDS, dQ stored directly); longer ones use the largest nw whose LDS image
     // fits 160 KB and accumulate dQ across key chunks through dq_ws.
+    // Sequences whose K+V / Q+dO fit LDS: two barrier-free kernels (dQ with the query on the lane,
+    // then dK/dV with the key on the lane); longer ones: the single tiled kernel below.
+    {
+        const int nq32 = bf_cdiv(seq, 32), lp = nq32 * 32;
+        const int dp = (head_dim + 31) / 32 * 32, row = head_dim * 2 + 16;
+        const size_t lds_q = (size_t)lp * ((dp * 2 + 16) + row);
+        const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4;
+        static int split_env = -1;
+        if (split_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SINGLE"); split_env = (e && atoi(e)) ? 0 : 1; }
+        // (short causal sequences stay on the single kernel: 72 vs 116 us at L = 77)
+        if (cdt == BF_BF16 && split_env && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
+            !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
+            // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);
+            // with larger images (d = 64: two workgroups per CU either way) one workgroup per (batch, head)
+            const size_t lds_max = lds_q > lds_kv ? lds_q : lds_kv;
+            const int n_split = (lds_max * 3 <= 160 * 1024 && nq32 > 5) ? bf_cdiv(nq32, 5) : 1;
+            const int wpb = bf_cdiv(nq32, n_split);
+            dim3 grid(batch * heads, n_split), block(wpb * 64);
+#define BWD_SPLIT2(DD, MM)                                                                          \
+    do {                                                                                            \
+        static size_t set_q = 0, set_kv = 0;                                                        \
+        if (lds_q > set_q) {                                                                        \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DD, MM>,                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
+            set_q = lds_q;                                                                          \
+        }                                                                                           \
+        if (lds_kv > set_kv) {                                                                      \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
+            set_kv = lds_kv;                                                                        \
+        }                                                                                           \
+        hipLaunchKernelGGL((attn_bwd_q_kernel<DD, MM>), grid, block, lds_q, s, (const bf16_t*)qkv,  \
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,   \
+                           delta_ws, seq, heads, scale, lp);                                        \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM>), grid, block, lds_kv, s, (const bf16_t*)qkv, \
+                           (const bf16_t*)dout, lse, (const float*)delta_ws, row_mask,              \
+                           (bf16_t*)dqkv, seq, heads, scale);                                       \
+    } while (0)
+#define BWD_SPLIT(DD)                                                                               \
+    do {                                                                                            \
+        if (mask_mode == BF_MASK_NONE) BWD_SPLIT2(DD, BF_MASK_NONE);                                \
+        else if (mask_mode == BF_MASK_CAUSAL) BWD_SPLIT2(DD, BF_MASK_CAUSAL);                       \
+        else BWD_SPLIT2(DD, BF_MASK_QUERY_ROW);                                                     \
+    } while (0)
+            if (head_dim == 32) BWD_SPLIT(32);
+            else if (head_dim == 48) BWD_SPLIT(48);
+            else BWD_SPLIT(64);
+#undef BWD_SPLIT
+#undef BWD_SPLIT2
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            return BF_OK;
+        }
+    }
     const int nw = bwd_pick_nw(seq, head_dim, dq_ws != nullptr);
     auto lds_of = [&](int n) { return bwd_lds_of(head_dim, n); };
     if (cdt == BF_BF16 && nw > 0) {
