@@ -37,6 +37,7 @@ struct EpiParams {
     int act;
     int accumulate;
     float alpha;
+    float* colsum;      // fused column sums of the stored result (atomicAdd into a zeroed [n]) or null
 };
 
 template <typename TC, typename TD>
@@ -875,6 +876,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 apre[ct] = (m < ep.m && n < ep.n) ? *(const uint4*)((const bf16_t*)ep.aux + (size_t)m * ep.ld_aux + n)
                                                   : make_uint4(0, 0, 0, 0);
             }
+            float cs[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[e] = 0.f;
             auto grad_chunk = [&](auto cc_) {
                 constexpr int C = decltype(cc_)::value;
                 stage_chunk(cc_);
@@ -895,7 +899,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                         o8[e] = (bf16_t)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
                         o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
                     }
-                    if (m < ep.m && n < ep.n) *(bf16x8*)((bf16_t*)ep.c + (size_t)m * ep.ldc + n) = o8;
+                    if (m < ep.m && n < ep.n) {
+                        *(bf16x8*)((bf16_t*)ep.c + (size_t)m * ep.ldc + n) = o8;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) cs[e] += (float)o8[e];      // sums of the STORED values
+                    }
                 }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -904,6 +912,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             grad_chunk(std::integral_constant<int, 1>{});
             grad_chunk(std::integral_constant<int, 2>{});
             grad_chunk(std::integral_constant<int, 3>{});
+            if (ep.colsum) {        // 128 rows of this wave -> one atomic per column
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    cs[e] += __shfl_xor(cs[e], 8, 64);
+                    cs[e] += __shfl_xor(cs[e], 16, 64);
+                    cs[e] += __shfl_xor(cs[e], 32, 64);
+                }
+                const int n = w.n0 + wn * 64 + (lane & 7) * 8;
+                if (lane < 8 && n < ep.n) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) atomicAdd(ep.colsum + n + e, cs[e]);
+                }
+            }
         } else
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
@@ -1144,7 +1165,7 @@ static int n_cus() {
 struct P8TailPlan { int rows_main; int sub; size_t bytes; };
 static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
     if (g->cdt != BF_BF16 || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
-        g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 || g->k < 2048)
+        g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 || g->k < 2048 || g->colsum_out)
         return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
     if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
     if (pipe_env >= 0 && pipe_env != 8) return false;
@@ -1257,6 +1278,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     ep.ld_res = g->ld_res; ep.resid_mod = g->resid_mod; ep.rows_in = g->rows_in;
     ep.rows_out = g->rows_out; ep.row_off = g->row_off; ep.act = g->act;
     ep.accumulate = g->accumulate; ep.alpha = g->alpha;
+    ep.colsum = nullptr;
+    bool colsum_fused = false;
+    BF_REQUIRE(!g->colsum_out || (g->rows_in == 0 && bf_aligned16(g->colsum_out)), BF_EINVAL,
+               "bf_gemm: colsum_out needs rows_in == 0 and a 16-byte aligned pointer");
 
     hipStream_t s = (hipStream_t)stream;
     const int tiles_m = bf_cdiv(g->m, 128), tiles_n = bf_cdiv(g->n, 128);
@@ -1317,6 +1342,14 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
             last_variant = 8;
+            // column sums fused into the bf16 GELU-grad epilogue (same predicate as the kernel's `fastgrad`)
+            if (g->colsum_out && !slabs && !f32out && g->act == BF_ACT_ERF_GELU_GRAD && !g->bias && !g->residual &&
+                !g->c2 && !g->pre && !g->accumulate && g->rows_in == 0) {
+                BF_REQUIRE(hipMemsetAsync(g->colsum_out, 0, (size_t)g->n * sizeof(float), s) == hipSuccess, BF_ELAUNCH,
+                           "bf_gemm: memset of colsum_out failed");
+                ep.colsum = g->colsum_out;
+                colsum_fused = true;
+            }
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
             const int n_cu = n_cus();
             GemmDims d8 = d;
@@ -1436,5 +1469,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         }
         BF_CHECK_LAUNCH("bf_gemm/splitk_reduce");
     }
+    if (g->colsum_out && !colsum_fused)
+        return bf_colsum(g->c, g->c_dtype, g->colsum_out, g->m, g->n, g->ldc, 0, stream);
     return BF_OK;
 }

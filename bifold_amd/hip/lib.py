@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU = 0, 1, 2, 3, 4
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, MAX_TARGET_POINTS = 0, 1, 16
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
         ("c2", c_void_p),
         ("split_k", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
+        ("colsum_out", c_void_p),
     ]
 
 

@@ -166,7 +166,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
          resid_mod: int = 0, out: Optional[torch.Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, rows_in: int = 0, rows_out: int = 0,
          row_off: int = 0, accumulate: bool = False, want_bf16_copy: bool = False,
-         alpha: float = 1.0, split_k: Optional[int] = None):
+         alpha: float = 1.0, split_k: Optional[int] = None, colsum_out: Optional[torch.Tensor] = None):
     """C = epilogue(alpha * op(A) op(B)); see include/bifold_hip.h for the epilogue order.
     Returns C, or (C, pre) / (C, copy) when asked for."""
     a, ar, ac, lda = _rows2d(a, "A")
@@ -214,6 +214,10 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
     if want_bf16_copy:
         copy = torch.empty(out.shape, dtype=torch.bfloat16, device=a.device)
         g.c2 = copy.data_ptr()
+    if colsum_out is not None:
+        if colsum_out.dtype != torch.float32 or colsum_out.numel() != n or not colsum_out.is_contiguous():
+            raise RuntimeError("colsum_out must be a contiguous float32 [n] tensor")
+        g.colsum_out = colsum_out.data_ptr()
     sk = (pick_split_k(m, n, k, deep_tn=(trans_a and b_kn and a.dtype == torch.bfloat16))
           if split_k is None else split_k)
     ws = None

@@ -153,11 +153,11 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
-    da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD, aux=S["a_pre"])
+    da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD, aux=S["a_pre"],
+                      colsum_out=g(P["bb1"]))          # d bias1 = column sums of da_pre, fused into the epilogue
     ops.gemm(op3, S["a"], trans_a=True, b_kn=True, out=g(P["w2"]))
     dh2 = ops.gemm(da_pre, A.operand(P["w1"], cdt), b_kn=True)
     ops.gemm(da_pre, S["h2"], trans_a=True, b_kn=True, out=g(P["w1"]))
-    ops.colsum(da_pre, out=g(P["bb1"]))
     # the LayerNorm backward streams dx3 (in) and dx2 (out): it also emits their column sums,
     # i.e. the bias gradients of net.3 and to_out
     dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]),

@@ -208,6 +208,13 @@ def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt, gemm_variant):
         got16 = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
                          aux=pre.to(gpu).to(cdt), out_dtype=torch.bfloat16)
         assert rel_err(got16.float(), p.grad) < 2 ** -7
+    # fused bias gradient: column sums of the STORED result, whatever kernel ran (fused in the persistent
+    # kernel's GELU-grad epilogue, a bf_colsum launch otherwise)
+    for odt in ((torch.float32, torch.bfloat16) if cdt == torch.bfloat16 else (torch.float32,)):
+        cs = torch.full((n,), 123.0, device=gpu)
+        o = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
+                     aux=pre.to(gpu).to(cdt), out_dtype=odt, colsum_out=cs)
+        assert rel_err(cs, o.double().sum(0)) < 1e-5
     # row remap: 3 batches of 17 rows scattered into [3, 20, n] at row offset 2, + broadcast table
     table = torch.randn(17, n, generator=g)
     out = torch.full((3 * 20, n), -7.0, device=gpu)
