@@ -222,3 +222,21 @@ def test_select_arms_matches_reference_action(golden_dir):
     assert np.array_equal(keep, ref_keep)
     assert keep.any(axis=0).all()           # at least one arm always acts
     assert (~keep).any()
+
+
+def test_bench_contract_helpers():
+    """bench.py is the driver's measurement contract: it must import without a GPU, price the step with
+    SURVEY 8d's FLOP count against the dense bf16 peak, and find the committed PMC summary it quotes."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.GF_PER_SAMPLE == pytest.approx(91.49) and bench.PEAK_BF16_TFLOPS == 2500.0
+    traffic = bench.profiled_traffic("gemm_bf16_nt[p8]")
+    assert traffic is not None and 1e8 < traffic[0] < 2e9 and "profiles/" in traffic[1]
+    assert bench.profiled_traffic("gemm_bf16_nt[k32]") is None
+    src = open(os.path.join(root, "bench.py")).read()
+    for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
+                '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
+        assert key in src, key
