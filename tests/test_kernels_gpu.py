@@ -247,6 +247,27 @@ def test_gemm_persistent_rounds(ops, L, gpu, layout):
         L.lib.bf_gemm_set_variant(-1)
 
 
+def test_gemm_tail_split_of_last_round(ops, L, gpu):
+    """270 tiles of 256x256 on 256 CUs: bf_gemm cuts the rows of the under-filled last round off and runs
+    them split along K through the workspace ops.gemm passes (bf_gemm_tail_workspace_bytes); the result
+    must not depend on that (bias + fp32 residual epilogue, deep K)."""
+    m, n, k = 256 * 90, 768, 2048
+    g = torch.Generator(device=gpu).manual_seed(91)
+    a = torch.randn(m, k, device=gpu, generator=g).bfloat16()
+    b = (torch.randn(n, k, device=gpu, generator=g) * k ** -0.5).bfloat16()
+    bias = torch.randn(n, device=gpu, generator=g)
+    res = torch.randn(m, n, device=gpu, generator=g)
+    args = L.GemmArgs()
+    args.m, args.n, args.k, args.lda, args.ldb, args.ldc = m, n, k, k, k, n
+    args.cdt, args.c_dtype, args.split_k = L.BF16, L.F32, 1
+    assert L.lib.bf_gemm_tail_workspace_bytes(args) > 0          # the plan applies to this shape
+    ref = a.float() @ b.float().t() + bias + res
+    out = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    assert rel_err(out, ref) < 1e-5
+    out1 = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, split_k=1)
+    assert rel_err(out1, ref) < 1e-5
+
+
 def test_colsum_and_cast(ops, gpu):
     g = torch.Generator().manual_seed(17)
     x = torch.randn(1234, 768, generator=g)
