@@ -61,6 +61,7 @@ PROTOTYPES = {
                                  c_int, c_int, c_void_p]),
     "bf_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "bf_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "bf_colsum_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bf_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_int, c_void_p]),
     "bf_attention_bwd_needs_dq_ws": (c_int, [c_int, c_int]),

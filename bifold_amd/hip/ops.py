@@ -132,11 +132,9 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
                                _ptr(dres), _ptr(dx), _ptr(dx_c), L.BF16 if dx_c is not None else L.F32,
                                _ptr(parts[0]), _ptr(parts[1]), _ptr(parts[2]) if want else None,
                                _ptr(parts[3]) if want else None, rows, cols, _stream()), "bf_layernorm_bwd")
-    colsum(parts[0], out=dgamma_out)
-    colsum(parts[1], out=dbeta_out)
-    if want:
-        colsum(parts[2], out=dres_sum_out)
-        colsum(parts[3], out=dx_sum_out)
+    check(lib.bf_colsum_multi(_ptr(parts), 4 if want else 2, nparts, cols, _ptr(dgamma_out), _ptr(dbeta_out),
+                              _ptr(dres_sum_out) if want else None, _ptr(dx_sum_out) if want else None,
+                              _stream()), "bf_colsum_multi")
     return dx, dx_c
 
 

@@ -156,6 +156,11 @@ size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g);
 /* Column sums  out[n] (+)= sum_m x[m, n]  (bias gradients, LayerNorm partials). */
 int bf_colsum(const void* x, int x_dtype, float* out, int rows, int cols, int ld, int accumulate,
               bf_stream_t stream);
+/* Column sums of up to four stacked fp32 partial arrays parts[n_arrays][nparts][cols] in one launch,
+ * each written (not accumulated) to its own out vector [cols]: the reduction of bf_layernorm_bwd's
+ * dgamma / dbeta / dres-sum / dx-sum partials. */
+int bf_colsum_multi(const float* parts, int n_arrays, int nparts, int cols, float* out0, float* out1,
+                    float* out2, float* out3, bf_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Multi-head attention on a packed QKV buffer.
