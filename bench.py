@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--per-shape", action="store_true", help="diagnostic: time every GEMM shape separately")
     ap.add_argument("--all-kernels", action="store_true", help="time every matrix kernel, not just the dominant one")
+    ap.add_argument("--host-fed", action="store_true",
+                    help="diagnostic: the batch starts in pinned HOST memory every step (H2D copy on a side stream, "
+                         "double-buffered) -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
     ap.add_argument("--config", default="a", choices=["a", "vitl14"],
                     help="a: BASELINE configs[1] (the metric); vitl14: configs[3], ViT-L/14 @336 (diagnostic line: "
                          "no roofline, run with --batch 64)")
@@ -157,7 +160,24 @@ def main():
     if world > 1 or os.environ.get("BIFOLD_FORCE_PG") == "1":
         sync = bdist.gradient_sync_for(model)
 
+    host, copy_stream, staged = None, None, None
+    if args.host_fed:
+        host = {k: v.cpu().pin_memory() for k, v in sample.items()}
+        copy_stream = torch.cuda.Stream(device=dev)
+
+        def stage_next():
+            with torch.cuda.stream(copy_stream):
+                return {k: v.to(dev, non_blocking=True) for k, v in host.items()}
+        staged = stage_next()
+
     def step():
+        nonlocal staged, sample
+        if args.host_fed:                          # consume the staged batch, start copying the next one
+            torch.cuda.current_stream().wait_stream(copy_stream)
+            sample = staged
+            for v in sample.values():
+                v.record_stream(torch.cuda.current_stream())
+            staged = stage_next()
         out = model(sample)
         loss, _ = loss_fn(out, sample)
         opt.zero_grad()
@@ -209,7 +229,8 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bf16" else "f32", "data": "synthetic",
+            "dtype": "bf16" if args.dtype == "bf16" else "f32",
+            "data": "synthetic (pinned host memory, H2D copy every step)" if args.host_fed else "synthetic",
             "config": {"workload": ("BASELINE configs[3] (diagnostic): rgb_clip ViT-L/14@336 (577 tokens, 24 layers, "
                                     "width 1024) + CLIP text + fusion 8x768 (16 heads), 384-px heatmaps"
                                     if big else
