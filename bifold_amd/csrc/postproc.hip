@@ -168,7 +168,49 @@ __global__ __launch_bounds__(PP_THREADS) void gaussian_targets_kernel(const floa
     }
 }
 
+// raw camera frames -> the network's input: mask fill (value 77, processor.py:257), uint8 -> [0,1]
+// (v2.ToDtype(scale=True)), per-channel (x - mean) / std (v2.Normalize), HWC -> CHW.  For frames that
+// already have the model's resolution (v2.Resize / CenterCrop are then the identity); resizing is not built.
+__global__ __launch_bounds__(256) void preprocess_rgb_kernel(const uint8_t* __restrict__ raw, const float* __restrict__ mask,
+                                                             float* __restrict__ out, int batch, int size, float m0,
+                                                             float m1, float m2, float is0, float is1, float is2) {
+    const size_t pixels = (size_t)size * size;
+    const size_t total = (size_t)batch * pixels;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / pixels, p = i - b * pixels;
+        const uint8_t* px = raw + i * 3;
+        float r = px[0], g = px[1], bl = px[2];
+        if (mask) {
+            // (rgb * mask + (1 - mask) * 77).astype(uint8): the mask is 0/1 in every shipped dataset; a
+            // fractional value truncates like numpy's cast
+            const float mk = mask[i];
+            r = floorf(r * mk + (1.0f - mk) * 77.0f);
+            g = floorf(g * mk + (1.0f - mk) * 77.0f);
+            bl = floorf(bl * mk + (1.0f - mk) * 77.0f);
+        }
+        float* o = out + b * 3 * pixels + p;
+        o[0] = (r / 255.0f - m0) * is0;
+        o[pixels] = (g / 255.0f - m1) * is1;
+        o[2 * pixels] = (bl / 255.0f - m2) * is2;
+    }
+}
+
 }  // namespace
+
+extern "C" int bf_preprocess_rgb(const uint8_t* raw, const float* mask, float* out, int batch, int size,
+                                 const float* mean3, const float* std3, bf_stream_t stream) {
+    BF_REQUIRE(raw && out && mean3 && std3, BF_EINVAL, "bf_preprocess_rgb: null pointer");
+    BF_REQUIRE(batch >= 0 && size > 0 && size <= 32768, BF_EINVAL, "bf_preprocess_rgb: bad shape");
+    BF_REQUIRE(std3[0] > 0.f && std3[1] > 0.f && std3[2] > 0.f, BF_EINVAL, "bf_preprocess_rgb: std must be positive");
+    if (batch == 0) return BF_OK;
+    const size_t total = (size_t)batch * size * size;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(preprocess_rgb_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, raw, mask, out,
+                       batch, size, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1], 1.0f / std3[2]);
+    BF_CHECK_LAUNCH("bf_preprocess_rgb");
+    return BF_OK;
+}
 
 extern "C" int bf_heatmap_pick(const float* heat, const float* mask, int32_t* xy, float* conf, int n_maps,
                                int size, bf_stream_t stream) {

@@ -106,6 +106,8 @@ PROTOTYPES = {
     "bf_gemm_last_variant": (c_int, []),
     "bf_gemm_tail_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),
     "bf_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
+    "bf_preprocess_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float),
+                                  c_void_p]),
     "bf_heatmap_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "bf_gaussian_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int,
                                     c_void_p]),

@@ -528,3 +528,23 @@ def gaussian_targets(points: torch.Tensor, counts: Optional[torch.Tensor], size:
     check(lib.bf_gaussian_targets(_ptr(points), _ptr(counts), _ptr(heat), n, p, size, float(sigma),
                                   codes[strategy], _stream()), "bf_gaussian_targets")
     return heat
+
+
+def preprocess_rgb(raw: torch.Tensor, mask: Optional[torch.Tensor], mean, std) -> torch.Tensor:
+    """raw uint8 [B, S, S, 3] (+ mask [B, S, S] / [B, 1, S, S], 1 = keep) -> fp32 [B, 3, S, S]: mask fill 77, /255,
+    (x - mean) / std -- the tensor half of Processor.__call__ for frames already at the model's resolution."""
+    if raw.dtype != torch.uint8 or raw.dim() != 4 or raw.shape[3] != 3 or raw.shape[1] != raw.shape[2]:
+        raise RuntimeError(f"raw must be uint8 [B, S, S, 3], got {raw.dtype} {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    _dev(raw, "raw")
+    b, s = raw.shape[0], raw.shape[1]
+    if mask is not None:
+        if mask.numel() != b * s * s:
+            raise RuntimeError("mask must have one value per pixel")
+        mask = mask.reshape(b, s, s).to(torch.float32).contiguous()
+        _dev(mask, "mask")
+    out = torch.empty(b, 3, s, s, dtype=torch.float32, device=raw.device)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.bf_preprocess_rgb(_ptr(raw), _ptr(mask), _ptr(out), b, s, m3, s3, _stream()), "bf_preprocess_rgb")
+    return out

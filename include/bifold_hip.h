@@ -350,6 +350,13 @@ int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t cou
  * ---------------------------------------------------------------------- */
 #define BF_MAX_TARGET_POINTS 16
 enum { BF_TARGETS_FIRST = 0, BF_TARGETS_GMM = 1 };
+/* bf_preprocess_rgb: camera frames raw uint8 [B, S, S, 3] (+ optional 0/1 mask fp32 [B, S, S]) -> network
+ *   input fp32 [B, 3, S, S]: mask fill with 77 (bifold/data/processor.py:255-258), scale to [0, 1] and
+ *   per-channel normalisation (:87-95; mean3 / std3 are HOST pointers to the 3 values of
+ *   conf/processor/default.yaml).  Frames must already have the model's resolution (v2.Resize /
+ *   CenterCrop are then the identity); resizing is not built. */
+int bf_preprocess_rgb(const uint8_t* raw, const float* mask, float* out, int batch, int size,
+                      const float* mean3, const float* std3, bf_stream_t stream);
 int bf_heatmap_pick(const float* heat, const float* mask, int32_t* xy, float* conf, int n_maps,
                     int size, bf_stream_t stream);
 int bf_gaussian_targets(const float* points, const int32_t* counts, float* heat, int n_maps,

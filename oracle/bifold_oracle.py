@@ -612,3 +612,18 @@ def make_gaussmap(points, size: int, sigma: float = 5.0, strategy: str = "gmm"):
     else:
         raise ValueError(f"Strategy {strategy} is not restated (only first / gmm)")
     return g.astype(np.float32)
+
+
+def preprocess_rgb(raw, mask, mean, std):
+    """uint8 [S,S,3] (+ 0/1 mask [S,S]) -> fp32 [3,S,S]: mask fill 77 (bifold/data/processor.py:255-258), then
+    rgb_transform (:87-95) for a frame already at the model's resolution, where v2.Resize / CenterCrop are the
+    identity: ToDtype(float32, scale=True) = x / 255, Normalize = (x - mean) / std.  torchvision is absent in
+    this container, so this formula is restated from the transform definitions (parity unpinned for it)."""
+    raw = np.asarray(raw)
+    if mask is not None:
+        m = np.asarray(mask)
+        raw = (raw * m[:, :, None] + (1 - m[:, :, None]) * 77).astype(np.uint8)
+    x = raw.astype(np.float32).transpose(2, 0, 1) / np.float32(255.0)
+    mean = np.asarray(mean, dtype=np.float32)[:, None, None]
+    std = np.asarray(std, dtype=np.float32)[:, None, None]
+    return ((x - mean) / std).astype(np.float32)

@@ -622,3 +622,20 @@ def test_gaussian_targets_full_size_properties(ops):
             assert torch.allclose(maps[i], exp, rtol=2.4e-7, atol=1e-37)
     with pytest.raises(ValueError):
         ops.gaussian_targets(pts.cuda(), cnt.cuda(), 224, 5.0, "fit")
+
+
+def test_preprocess_rgb_matches_oracle(ops, gpu):
+    """Mask fill + scale + normalise (the tensor half of the reference's Processor) against the numpy
+    restatement: fp32, tolerance 2 ulp (1 / std is applied as a multiplication)."""
+    import numpy as np
+    from oracle import bifold_oracle as O
+    rng = np.random.default_rng(7)
+    raw = rng.integers(0, 256, (3, 48, 48, 3), dtype=np.uint8)
+    mask = (rng.random((3, 48, 48)) > 0.4).astype(np.float32)
+    mean, std = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+    for mk in (None, mask):
+        got = ops.preprocess_rgb(torch.from_numpy(raw).to(gpu), None if mk is None else torch.from_numpy(mk).to(gpu),
+                                 mean, std).cpu().numpy()
+        for i in range(3):
+            exp = O.preprocess_rgb(raw[i], None if mk is None else mk[i], mean, std)
+            assert np.allclose(got[i], exp, rtol=3e-7, atol=3e-7)
