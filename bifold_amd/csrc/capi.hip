@@ -17,3 +17,27 @@ void bf_set_error(int hip_code, const char* fmt, ...) {
 extern "C" int bf_abi_version(void) { return BF_ABI_VERSION; }
 extern "C" const char* bf_last_error(void) { return g_err; }
 extern "C" int bf_last_hip_error(void) { return g_hip_err; }
+
+// Test hook: `blocks` workgroups that each hold a whole CU's worth of LDS (a stand-in for a
+// collective's long-running kernels) and spin for `cycles` shader clocks, then exit.  Used by
+// tools/gemm_disturb.py to measure how the persistent GEMM behaves when some CUs are taken.
+__global__ __launch_bounds__(256) void spin_kernel(long long cycles, int* sink) {
+    extern __shared__ char hold[];
+    hold[threadIdx.x] = (char)threadIdx.x;
+    __syncthreads();
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(16);
+    if (sink && hold[(threadIdx.x + 1) & 255] == 77 && cycles < 0) sink[0] = 1;
+}
+
+extern "C" int bf_debug_spin(int blocks, long long cycles, bf_stream_t stream) {
+    BF_REQUIRE(blocks > 0 && blocks <= 256 && cycles >= 0 && cycles < (1LL << 34), BF_EINVAL, "bf_debug_spin: bad arguments");
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void*)spin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(256), 150 * 1024, (hipStream_t)stream, cycles, (int*)nullptr);
+    BF_CHECK_LAUNCH("bf_debug_spin");
+    return BF_OK;
+}

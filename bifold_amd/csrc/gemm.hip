@@ -21,6 +21,7 @@
 
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 struct EpiParams {
@@ -624,8 +625,9 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 template <bool A_KS, bool B_KS, typename TC>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmDims d, EpiParams ep,
-    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB)
+    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
+    unsigned* __restrict__ tk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB) + 16 B
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -634,13 +636,24 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
 
-    // round r hands items [r*G, r*G + G) to the G workgroups; blocks with equal bid % 8 share an
-    // XCD and get a contiguous run of items (same split, neighbouring tiles of one group)
-    auto decode = [&](int round, P8Item& w) -> bool {
-        const int base = round * G;
-        const int cnt = min(n_items - base, G);
-        if (bid >= cnt) return false;
-        const int item = base + xcd_remap(bid, cnt);
+    // Work distribution.  Items (split, tile) are cut into one contiguous range per XCD (blocks with
+    // equal bid % 8 share an XCD and therefore an L2: neighbouring tiles, the same A / W panels).  Inside
+    // a range the workgroups DRAW items from a ticket counter in global memory instead of owning a
+    // fixed stride: a CU that is not available (held by a collective's resident kernel, or by the other
+    // tower's kernels on the side stream) then simply draws nothing, instead of leaving its share
+    // for a second pass -- with the fixed stride 8 busy CUs cost +44 % (tools/gemm_disturb.py).
+    // tk[0..7]: tickets per XCD lane, tk[8]: workgroups finished (the last one zeroes the set for the
+    // next launch on this stream).  The draw for the item after next is issued at an item boundary
+    // and published through LDS at the next one, so its latency sits under the epilogue.
+    const int NX = G < 8 ? G : 8;
+    const int xl = bid % NX;
+    const int per = (n_items + NX - 1) / NX;
+    const int x_base = xl * per;
+    const int x_cnt = max(0, min(per, n_items - x_base));
+    volatile unsigned* bcast = (volatile unsigned*)(smem + 4 * P8_STAGE);
+    auto decode = [&](unsigned ticket, P8Item& w) -> bool {
+        if (ticket >= (unsigned)x_cnt) return false;
+        const int item = x_base + (int)ticket;
         w.z = item / tiles;
         int tm, tn;
         tile_coords(item - w.z * tiles, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
@@ -648,6 +661,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         w.kbeg = w.z * d.k_per_split;
         w.nk = (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 31) >> 5;
         return true;
+    };
+    auto finish = [&]() {              // every workgroup exactly once, after its last draw
+        if (threadIdx.x == 0 && atomicAdd(tk + 8, 1u) == (unsigned)G - 1u) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tk[i] = 0u;
+        }
     };
     auto issue_a = [&](const P8Item& w, int s) {
         dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + s * 32, wave * 2, 2, lane);
@@ -657,8 +676,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     };
 
     P8Item w;
-    int round = 0;
-    if (!decode(round, w)) return;
+    int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
+    unsigned pend = 0;                 // thread 0: the ticket drawn for the item after next
+    if (threadIdx.x == 0) {
+        bcast[0] = atomicAdd(tk + xl, 1u);
+        pend = atomicAdd(tk + xl, 1u);
+    }
+    __syncthreads();
+    const unsigned first = bcast[0];
+    unsigned nxt = 0;
+    if (!decode(first, w)) { finish(); return; }
     // Epilogue stores are a burst (128-512 KB per CU) that the memory system takes at ~2.7 TB/s
     // chip-wide; with every CU in lock step the bursts coincide and the MFMAs idle meanwhile.
     // Four phase groups per XCD start a fraction of an epilogue apart, so at any time about a
@@ -700,8 +727,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 #ifdef P8_PROBE
         const unsigned long long pcw = clock64();
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0/1 (and the previous item's stores)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0/1 (and the previous item's stores, the draw)
+        if (threadIdx.x == 0) bcast[0] = pend;             // ticket of the item after this one
         __builtin_amdgcn_s_barrier();
+        nxt = bcast[0];
 #ifdef P8_PROBE
         if (bid == 0 && threadIdx.x == 0 && round == 2) p8_probe[6] = clock64() - pcw;
 #endif
@@ -757,10 +786,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 
         // next item's first stages go out before this item's epilogue
         P8Item nx;
-        const bool has_next = decode(++round, nx);
+        ++round;
+        const bool has_next = decode(nxt, nx);
         if (has_next) {
             issue_a(nx, 0); issue_b(nx, 0);
             if (nx.nk > 1) { issue_a(nx, 1); issue_b(nx, 1); }
+            if (threadIdx.x == 0) pend = atomicAdd(tk + xl, 1u);   // lands during the epilogue
         }
 #ifdef P8_PROBE
         const unsigned long long pc2 = clock64();
@@ -967,6 +998,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         if (!has_next) break;
         w = nx;
     }
+    finish();
 }
 
 // =====================================================================================
@@ -1198,6 +1230,32 @@ extern "C" size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g) {
 
 static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_variant);
 
+// Ticket sets of the persistent kernel: 9 counters per launch (8 XCD lanes + finished workgroups), zero at
+// rest (the last workgroup of a launch zeroes its set).  Launches on one stream run in order, so a per-stream
+// ring of sets can never be shared by two running kernels; concurrent streams get rings of their own.
+#define P8_TK_STREAMS 16
+#define P8_TK_RING 64
+__device__ unsigned p8_ticket_sets[P8_TK_STREAMS * P8_TK_RING * 16];
+static unsigned* p8_ticket_set(hipStream_t s) {
+    static unsigned* base = nullptr;
+    static hipStream_t owners[P8_TK_STREAMS];
+    static unsigned next[P8_TK_STREAMS];
+    static int n_owner = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(p8_ticket_sets)) != hipSuccess) return nullptr;
+    int slot = -1;
+    for (int i = 0; i < n_owner; ++i) if (owners[i] == s) { slot = i; break; }
+    if (slot < 0) {
+        if (n_owner == P8_TK_STREAMS) return nullptr;          // more streams than rings: caller falls back
+        slot = n_owner++;
+        owners[slot] = s;
+        next[slot] = 0;
+    }
+    const unsigned set = next[slot]++ % P8_TK_RING;
+    return base + ((size_t)slot * P8_TK_RING + set) * 16;
+}
+
 extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
     BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
     P8TailPlan plan;
@@ -1361,6 +1419,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
             unsigned g8 = (unsigned)(items < n_cu ? items : n_cu);
             if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
+            unsigned* tk8 = p8_ticket_set(s);
+            BF_REQUIRE(tk8 != nullptr, BF_ELAUNCH, "bf_gemm: no ticket set for this stream (more than %d streams)", P8_TK_STREAMS);
             const char* skew_e = getenv("BIFOLD_P8_SKEW");
             const int skew = skew_e ? atoi(skew_e) : 0;
 #define LAUNCH_P8(AKS, BKS, TC)                                                                     \
@@ -1368,10 +1428,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         static bool lds_ok = false;                                                               \
         if (!lds_ok) {                                                                            \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC>,             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE);  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE + 16);  \
             lds_ok = true;                                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC>), dim3(g8), dim3(512), 4 * P8_STAGE, s, A, B, d8, ep, slabs, ab, bb, (int)items, skew); \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, A, B, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
     } while (0)
             if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_P8(false, false, float); else LAUNCH_P8(false, false, bf16_t); }
             else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_P8(false, true, float); else LAUNCH_P8(false, true, bf16_t); }

@@ -102,6 +102,7 @@ PROTOTYPES = {
                              c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "bf_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bf_clip_coef": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
+    "bf_debug_spin": (c_int, [c_int, C.c_longlong, c_void_p]),
     "bf_gemm_set_variant": (c_int, [c_int]),
     "bf_gemm_last_variant": (c_int, []),
     "bf_gemm_tail_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),

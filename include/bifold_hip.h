@@ -142,6 +142,10 @@ int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
  * (0 = 128x128x64, 4 = 128x128x32 with 4 workgroups per CU, 8 = persistent 256x256 staggered;
  * a variant that cannot run a shape falls back to the automatic choice), -1 = automatic.
  * Same effect as the BIFOLD_GEMM_PIPE environment variable. */
+/* Test hook: launches `blocks` (<= 256) workgroups that each take one CU (150 KB of LDS) and spin for `cycles`
+ * shader clocks -- a stand-in for a collective's resident kernels when measuring how bf_gemm behaves with part
+ * of the chip taken (tools/gemm_disturb.py). */
+int bf_debug_spin(int blocks, long long cycles, bf_stream_t stream);
 int bf_gemm_set_variant(int variant);
 /* The bf16 kernel the calling thread's last bf_gemm launched: 8 / 4 / 0 as above, 1 = the
  * register-staged fallback, -1 = the exact fp32 kernel (profiling label, bench.py). */
