@@ -643,13 +643,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     // tower's kernels on the side stream) then simply draws nothing, instead of leaving its share
     // for a second pass -- with the fixed stride 8 busy CUs cost +44 % (tools/gemm_disturb.py).
     // tk[0..7]: tickets per XCD lane, tk[8]: workgroups finished (the last one zeroes the set for the
-    // next launch on this stream).  The draw for the item after next is issued at an item boundary
-    // and published through LDS at the next one, so its latency sits under the epilogue.
+    // next launch on this stream).  The draw for the next item is issued by one thread a few stages before
+    // the end of the main loop and published through LDS at the item boundary.
     const int NX = G < 8 ? G : 8;
     const int xl = bid % NX;
-    const int per = (n_items + NX - 1) / NX;
-    const int x_base = xl * per;
-    const int x_cnt = max(0, min(per, n_items - x_base));
+    // ranges proportional to the workgroups a lane has (G need not be a multiple of 8): with exactly one
+    // item per workgroup no lane may hold more items than workgroups
+    auto lane_start = [&](int x) { return (int)((long long)n_items * (x * (G / NX) + min(x, G % NX)) / G); };
+    const int x_base = lane_start(xl);
+    const int x_cnt = lane_start(xl + 1) - x_base;
     volatile unsigned* bcast = (volatile unsigned*)(smem + 4 * P8_STAGE);
     auto decode = [&](unsigned ticket, P8Item& w) -> bool {
         if (ticket >= (unsigned)x_cnt) return false;
@@ -677,11 +679,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 
     P8Item w;
     int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
-    unsigned pend = 0;                 // thread 0: the ticket drawn for the item after next
-    if (threadIdx.x == 0) {
-        bcast[0] = atomicAdd(tk + xl, 1u);
-        pend = atomicAdd(tk + xl, 1u);
-    }
+    unsigned pend = 0;                 // thread 0: the ticket drawn for the next item
+    if (threadIdx.x == 0) bcast[0] = atomicAdd(tk + xl, 1u);
     __syncthreads();
     const unsigned first = bcast[0];
     unsigned nxt = 0;
@@ -727,10 +726,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 #ifdef P8_PROBE
         const unsigned long long pcw = clock64();
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0/1 (and the previous item's stores, the draw)
-        if (threadIdx.x == 0) bcast[0] = pend;             // ticket of the item after this one
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stages 0/1 (and the previous item's stores)
         __builtin_amdgcn_s_barrier();
-        nxt = bcast[0];
 #ifdef P8_PROBE
         if (bid == 0 && threadIdx.x == 0 && round == 2) p8_probe[6] = clock64() - pcw;
 #endif
@@ -739,10 +736,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 #ifdef P8_PROBE
         const unsigned long long pc0 = clock64(), pw0 = wall_clock64();
 #endif
+        // The next item is drawn LATE (8 stages before the end of this one: enough for the atomic to return
+        // under the remaining MFMAs): a workgroup that drew two items up front would take work from
+        // one that has not started yet, and with one item per CU (the split dW GEMMs) half the CUs idled.
+        const int draw_stage = nk > 8 ? nk - 8 : 0;
         for (int s = 0; s < nk; ++s) {
             const char* la = smem + (s & 3) * P8_STAGE;
             const char* lb = la + 16384;
             const bool more = s + 2 < nk;
+            if (s == draw_stage && threadIdx.x == 0) pend = atomicAdd(tk + xl, 1u);
             // ---------------- phase a
             bf16x8 bfr[4], af[4];
 #pragma unroll
@@ -787,11 +789,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // next item's first stages go out before this item's epilogue
         P8Item nx;
         ++round;
+        if (threadIdx.x == 0) bcast[0] = pend;             // publish the draw made during the main loop
+        __builtin_amdgcn_s_barrier();
+        nxt = bcast[0];
         const bool has_next = decode(nxt, nx);
         if (has_next) {
             issue_a(nx, 0); issue_b(nx, 0);
             if (nx.nk > 1) { issue_a(nx, 1); issue_b(nx, 1); }
-            if (threadIdx.x == 0) pend = atomicAdd(tk + xl, 1u);   // lands during the epilogue
         }
 #ifdef P8_PROBE
         const unsigned long long pc2 = clock64();
@@ -1417,7 +1421,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             d8.group_m = p8_group;
             const long items = (long)d8.tiles_m * d8.tiles_n * split;
             BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
-            unsigned g8 = (unsigned)(items < n_cu ? items : n_cu);
+            unsigned g8 = (unsigned)(n_cu & ~7);      // every CU draws; workgroups that find no ticket exit
             if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
             unsigned* tk8 = p8_ticket_set(s);
             BF_REQUIRE(tk8 != nullptr, BF_ELAUNCH, "bf_gemm: no ticket set for this stream (more than %d streams)", P8_TK_STREAMS);
