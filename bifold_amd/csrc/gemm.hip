@@ -1398,8 +1398,12 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         // gradient with its GELU' epilogue); the 512-wide ones (2.1 rounds) lose to tile quantisation
         const bool p8_nn = !g->trans_a && g->b_kn && g->m >= p8_min_m &&
                            (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= 3L * n_cus();
-        const int variant = force_variant >= 0 ? force_variant
-                                               : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn || p8_nn) ? 8 : (long_nt ? 0 : 4)));
+        int variant = force_variant >= 0 ? force_variant
+                                         : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn || p8_nn) ? 8 : (long_nt ? 0 : 4)));
+        // the persistent kernel draws its items from a per-stream ring of ticket sets; a process that uses
+        // more streams than there are rings runs the extra streams' GEMMs on the other kernels
+        unsigned* tk8 = variant == 8 ? p8_ticket_set(s) : nullptr;
+        if (variant == 8 && !tk8) variant = long_nt ? 0 : 4;
         last_variant = 1;   // register-staged fallback unless one of the LDS-DMA kernels below takes it
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
@@ -1423,8 +1427,6 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
             unsigned g8 = (unsigned)(n_cu & ~7);      // every CU draws; workgroups that find no ticket exit
             if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
-            unsigned* tk8 = p8_ticket_set(s);
-            BF_REQUIRE(tk8 != nullptr, BF_ELAUNCH, "bf_gemm: no ticket set for this stream (more than %d streams)", P8_TK_STREAMS);
             const char* skew_e = getenv("BIFOLD_P8_SKEW");
             const int skew = skew_e ? atoi(skew_e) : 0;
 #define LAUNCH_P8(AKS, BKS, TC)                                                                     \
