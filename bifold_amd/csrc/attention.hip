@@ -338,15 +338,22 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
         // m_new is finite for every live query: tile 0 always holds an unmasked key
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m - m_use);
-        float psum = 0.f;
+        // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
+        // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], sl2, -m_use));
-                sacc[kb][e] = p;
-                psum += p;
+            for (int e = 0; e < 16; e += 2) {
+                f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
+                t = __builtin_elementwise_fma(t, sl2v, mneg);
+                f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                sacc[kb][e] = p2[0];
+                sacc[kb][e + 1] = p2[1];
+                psum2 += p2;
             }
+        float psum = psum2[0] + psum2[1];
         psum += __shfl_xor(psum, 32, 64);
         l = l * alpha + psum;
         m = m_new;
@@ -503,15 +510,22 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         const float m_new = fmaxf(m, tmax);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m - m_use);
-        float psum = 0.f;
+        // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
+        // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
+        f32x2 psum2 = {0.f, 0.f};
+        const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][e], sl2, -m_use));
-                sacc[kb][e] = p;
-                psum += p;
+            for (int e = 0; e < 16; e += 2) {
+                f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
+                t = __builtin_elementwise_fma(t, sl2v, mneg);
+                f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                sacc[kb][e] = p2[0];
+                sacc[kb][e + 1] = p2[1];
+                psum2 += p2;
             }
+        float psum = psum2[0] + psum2[1];
         psum += __shfl_xor(psum, 32, 64);
         l = l * alpha + psum;
         m = m_new;
@@ -921,14 +935,21 @@ __global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
         }
         // dS^T (rows = keys, lane = query); masked scores carry no gradient
         const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
+        const f32x2 sl2v = {sl2, sl2}, scalev = {scale, scale};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float ds = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * pacc[e] * scale;
+        for (int e = 0; e < 16; e += 2) {                   // packed fp32: two scores per VALU instruction
+            const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+            const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
             if (edge) {
-                const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) ds = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int key = j0 + ((e + u) & 3) + 8 * ((e + u) >> 2) + 4 * hh;
+                    if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) ds2[u] = 0.f;
+                }
             }
-            sacc[e] = ds;
+            sacc[e] = ds2[0];
+            sacc[e + 1] = ds2[1];
         }
         if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
 #pragma unroll
@@ -1055,17 +1076,22 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
             pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
         }
+        const f32x2 sl2v = {sl2, sl2}, onv = {lane_on, lane_on}, scalev = {scale, scale};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float p = __builtin_amdgcn_exp2f(sl2 * sacc[e]) * lane_on;
-            float ds = p * pacc[e] * scale;
+        for (int e = 0; e < 16; e += 2) {                   // packed fp32: two scores per VALU instruction
+            const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+            f32x2 p2 = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * onv;
+            f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
             if (mask_mode != BF_MASK_NONE) {
-                const int ql = qrow0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                if (mask_mode == BF_MASK_QUERY_ROW && msk_s[ql]) { p = inv_len * lane_on; ds = 0.f; }
-                if (mask_mode == BF_MASK_CAUSAL && key > ql) { p = 0.f; ds = 0.f; }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ql = qrow0 + ((e + u) & 3) + 8 * ((e + u) >> 2) + 4 * hh;
+                    if (mask_mode == BF_MASK_QUERY_ROW && msk_s[ql]) { p2[u] = inv_len * lane_on; ds2[u] = 0.f; }
+                    if (mask_mode == BF_MASK_CAUSAL && key > ql) { p2[u] = 0.f; ds2[u] = 0.f; }
+                }
             }
-            sacc[e] = p;
-            pacc[e] = ds;
+            sacc[e] = p2[0]; sacc[e + 1] = p2[1];
+            pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
         }
         bf16x8 pb[2], dsb[2];
 #pragma unroll
