@@ -622,7 +622,11 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 }
 #endif
 
-template <bool A_KS, bool B_KS, typename TC>
+// EPI: which epilogue this instantiation carries (the host evaluates the same predicates): 0 = general
+// (any output type, residual / aux / copies / row remap / split-K slabs), 1 = plain bf16 (alpha, bias,
+// activation, optional pre-activation copy), 2 = bf16 GELU-grad.  One kernel with all three paths sat at
+// the 256-register limit and spilled differently with every edit.
+template <bool A_KS, bool B_KS, typename TC, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmDims d, EpiParams ep,
     float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     unsigned pend = 0;                 // thread 0: the ticket drawn for the next item
     if (threadIdx.x == 0) bcast[0] = atomicAdd(tk + xl, 1u);
     __syncthreads();
-    const unsigned first = bcast[0];
+    const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);   // wave-uniform: keeps the item in SGPRs
     unsigned nxt = 0;
     if (!decode(first, w)) { finish(); return; }
     // Epilogue stores are a burst (128-512 KB per CU) that the memory system takes at ~2.7 TB/s
@@ -740,11 +744,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // under the remaining MFMAs): a workgroup that drew two items up front would take work from
         // one that has not started yet, and with one item per CU (the split dW GEMMs) half the CUs idled.
         const int draw_stage = nk > 8 ? nk - 8 : 0;
+        // (the address goes through an opaque per-lane zero: with a provably uniform address hipcc's atomic
+        // optimiser rewrites the draw into a wave-aggregated atomic and waits vmcnt(0) for it on the spot,
+        // which drained the DMA ring once per item)
+        unsigned lane_zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
         for (int s = 0; s < nk; ++s) {
             const char* la = smem + (s & 3) * P8_STAGE;
             const char* lb = la + 16384;
             const bool more = s + 2 < nk;
-            if (s == draw_stage && threadIdx.x == 0) pend = atomicAdd(tk + xl, 1u);
+            if (s == draw_stage && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
             // ---------------- phase a
             bf16x8 bfr[4], af[4];
 #pragma unroll
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         ++round;
         if (threadIdx.x == 0) bcast[0] = pend;             // publish the draw made during the main loop
         __builtin_amdgcn_s_barrier();
-        nxt = bcast[0];
+        nxt = __builtin_amdgcn_readfirstlane(bcast[0]);
         const bool has_next = decode(nxt, nx);
         if (has_next) {
             issue_a(nx, 0); issue_b(nx, 0);
@@ -817,11 +826,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // Plain bf16 outputs (alpha / bias / activation only): do the math in the MFMA layout, turn
         // the tile around as bf16 (half the LDS bytes: ds_write runs at ~80 B/clk per CU) in two
         // 64-row halves, and store 8 columns per lane.
-        bool fast16 = false;
-        if constexpr (std::is_same<TC, bf16_t>::value)
-            fast16 = !slab && !ep.residual && !ep.aux && !ep.c2 && !ep.accumulate && ep.rows_in == 0 &&
-                     ep.act != BF_ACT_ERF_GELU_GRAD;
-        if (fast16) {
+        constexpr bool fast16 = EPI == 1;
+        if constexpr (fast16) {
             float4 bj[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -897,11 +903,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // dX = (dY W) * gelu'(pre) with a bf16 result (the MLP's input gradient): all 16 rows of
         // `pre` this lane needs are requested at once (64 registers of raw bf16), so the tile pays
         // one load latency instead of sixteen; lean body, fully unrolled.
-        bool fastgrad = false;
-        if constexpr (std::is_same<TC, bf16_t>::value)
-            fastgrad = !slab && ep.act == BF_ACT_ERF_GELU_GRAD && !ep.bias && !ep.residual && !ep.c2 && !ep.pre &&
-                       !ep.accumulate && ep.rows_in == 0;
-        if (fastgrad) {
+        constexpr bool fastgrad = EPI == 2;
+        if constexpr (fastgrad) {
             using AM = ActMath<bf16_t>;
             uint4 apre[16];
 #pragma unroll
@@ -960,7 +963,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                     for (int e = 0; e < 8; ++e) atomicAdd(ep.colsum + n + e, cs[e]);
                 }
             }
-        } else
+        } else {
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             switch (c) {
@@ -991,6 +994,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+        }
         }
         }   // general epilogue
 #ifdef P8_PROBE
@@ -1410,7 +1414,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             last_variant = 8;
             // column sums fused into the bf16 GELU-grad epilogue (same predicate as the kernel's `fastgrad`)
             if (g->colsum_out && !slabs && !f32out && g->act == BF_ACT_ERF_GELU_GRAD && !g->bias && !g->residual &&
-                !g->c2 && !g->pre && !g->accumulate && g->rows_in == 0) {
+                !g->c2 && !g->pre && !g->accumulate && g->rows_in == 0) {   // == the EPI 2 instantiation below
                 BF_REQUIRE(hipMemsetAsync(g->colsum_out, 0, (size_t)g->n * sizeof(float), s) == hipSuccess, BF_ELAUNCH,
                            "bf_gemm: memset of colsum_out failed");
                 ep.colsum = g->colsum_out;
@@ -1429,20 +1433,34 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
             const char* skew_e = getenv("BIFOLD_P8_SKEW");
             const int skew = skew_e ? atoi(skew_e) : 0;
-#define LAUNCH_P8(AKS, BKS, TC)                                                                     \
+            // which epilogue instantiation (the predicates of the kernel's EPI paths)
+            int epi = 0;
+            if (!f32out && !slabs && !g->residual && !g->c2 && !g->accumulate && g->rows_in == 0) {
+                if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD) epi = 1;
+                else if (g->act == BF_ACT_ERF_GELU_GRAD && !g->bias && !g->pre) epi = 2;
+            }
+#define LAUNCH_P8E(AKS, BKS, TC, EPI)                                                               \
     do {                                                                                          \
         static bool lds_ok = false;                                                               \
         if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC>,             \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC, EPI>,        \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE + 16);  \
             lds_ok = true;                                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, A, B, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC, EPI>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, A, B, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
     } while (0)
-            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_P8(false, false, float); else LAUNCH_P8(false, false, bf16_t); }
-            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_P8(false, true, float); else LAUNCH_P8(false, true, bf16_t); }
-            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_P8(true, true, float); else LAUNCH_P8(true, true, bf16_t); }
-            else { if (f32out) LAUNCH_P8(true, false, float); else LAUNCH_P8(true, false, bf16_t); }
+#define LAUNCH_P8(AKS, BKS)                                                                         \
+    do {                                                                                          \
+        if (f32out) LAUNCH_P8E(AKS, BKS, float, 0);                                               \
+        else if (epi == 1) LAUNCH_P8E(AKS, BKS, bf16_t, 1);                                       \
+        else if (epi == 2) LAUNCH_P8E(AKS, BKS, bf16_t, 2);                                       \
+        else LAUNCH_P8E(AKS, BKS, bf16_t, 0);                                                     \
+    } while (0)
+            if (!g->trans_a && !g->b_kn) LAUNCH_P8(false, false);
+            else if (!g->trans_a && g->b_kn) LAUNCH_P8(false, true);
+            else if (g->trans_a && g->b_kn) LAUNCH_P8(true, true);
+            else LAUNCH_P8(true, false);
+#undef LAUNCH_P8E
 #undef LAUNCH_P8
         } else if (dma_ok && (variant == 4 || (variant == 8 && !long_nt))) {
             last_variant = 4;
