@@ -1393,15 +1393,17 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         // next to the vision tower) and the NN / TN shapes stay with the multi-workgroup kernels.
         static int p8_min_m = -1;
         if (p8_min_m < 0) { const char* e = getenv("BIFOLD_P8_MIN_M"); p8_min_m = e ? atoi(e) : 16384; }
+        static int p8_min_tiles = -1;      // at least this many 256x256 tiles (default: one per two CUs)
+        if (p8_min_tiles < 0) { const char* e = getenv("BIFOLD_P8_MIN_TILES"); p8_min_tiles = e ? atoi(e) : n_cus() / 2; }
         const bool p8_nt = !g->trans_a && !g->b_kn && g->m >= p8_min_m &&
-                           (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= n_cus();
+                           (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= p8_min_tiles;
         // deep dW = dY^T X GEMMs whose (tile, split) items fill the CUs in exactly one round
         const long items256 = (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) * split;
         const bool p8_tn = g->trans_a && g->b_kn && split > 1 && items256 > 192 && items256 <= 256;
         // dX = dY W (NN): like NT (with the spill-free instantiations the 512-wide ones win too, in spite of
         // their 2.1 rounds of tiles)
         const bool p8_nn = !g->trans_a && g->b_kn && g->m >= p8_min_m &&
-                           (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= n_cus();
+                           (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= p8_min_tiles;
         int variant = force_variant >= 0 ? force_variant
                                          : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn || p8_nn) ? 8 : (long_nt ? 0 : 4)));
         // the persistent kernel draws its items from a per-stream ring of ticket sets; a process that uses
