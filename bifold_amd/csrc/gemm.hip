@@ -109,16 +109,14 @@ template <> struct Vec8<bf16_t> {
     }
 };
 
+// bias8: this lane's 8 bias values, loaded ONCE per tile by the caller (zeros without a bias).  A load inside
+// the per-row loop makes every iteration wait -- through the in-order vmcnt -- for the previous iteration's
+// stores as well: 16 exposed store latencies per tile.
 template <typename TC, typename TD>
-__device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int n, float (&v)[8]) {
+__device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int n, float (&v)[8],
+                                                const float (&bias8)[8]) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] *= ep.alpha;
-    if (ep.bias) {
-        float b[8];
-        Vec8<float>::load(ep.bias + n, b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b[e];
-    }
+    for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], ep.alpha, bias8[e]);
     size_t orow = (size_t)m;
     if (ep.rows_in > 0) orow = (size_t)(m / ep.rows_in) * ep.rows_out + ep.row_off + (m % ep.rows_in);
     if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU || ep.act == BF_ACT_TANH_GELU) {
@@ -964,6 +962,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 }
             }
         } else {
+        float b8[8];                   // the lane's 8 columns are the same for every row of the tile
+        {
+            const int n = w.n0 + wn * 64 + (lane & 7) * 8;
+            if (ep.bias && !slab && n < ep.n) Vec8<float>::load(ep.bias + n, b8);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) b8[e] = 0.f;
+            }
+        }
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             switch (c) {
@@ -988,7 +995,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                         *(f32x4*)(sp + 4) = q1;
                     } else {
                         float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                        epilogue_store8<TC, bf16_t>(epi, m, n, v);
+                        epilogue_store8<TC, bf16_t>(epi, m, n, v, b8);
                     }
                 }
             }
