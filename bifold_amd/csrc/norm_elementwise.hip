@@ -60,6 +60,83 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x,
     }
 }
 
+// Exact-width variant (cols == NC * 256): no per-chunk bounds tests, and each wave carries R rows
+// at once so 2 * NC 16-byte loads are in flight per lane before the first reduction (the one-row
+// kernel above is latency-bound at ~3.9 TB/s on the 50 k x 768 encoder activations).
+template <typename TX, typename TY, int NC, int R>
+__global__ __launch_bounds__(256) void ln_fwd_rows_kernel(const TX* __restrict__ x,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          TY* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, int rows, float eps) {
+    constexpr int cols = NC * 256;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    float4 v[R][NC];
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = min(row0 + r, rows - 1);
+        const TX* xr = x + (size_t)row * cols;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) v[r][i] = Vec4<TX>::load(xr + (lane + i * 64) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
+    }
+    float mu[R], q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mu[r] = s[r] / (float)cols;
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float a = v[r][i].x - mu[r], b = v[r][i].y - mu[r], c = v[r][i].z - mu[r],
+                        d = v[r][i].w - mu[r];
+            q[r] += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o, 64);
+    }
+    float4 g[NC], bt[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        g[i] = *(const float4*)(gamma + (lane + i * 64) * 4);
+        bt[i] = *(const float4*)(beta + (lane + i * 64) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= rows) break;
+        const float rs = rsqrtf(q[r] / (float)cols + eps);
+        TY* yr = y + (size_t)(row0 + r) * cols;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            float4 o;
+            o.x = (v[r][i].x - mu[r]) * rs * g[i].x + bt[i].x;
+            o.y = (v[r][i].y - mu[r]) * rs * g[i].y + bt[i].y;
+            o.z = (v[r][i].z - mu[r]) * rs * g[i].z + bt[i].z;
+            o.w = (v[r][i].w - mu[r]) * rs * g[i].w + bt[i].w;
+            Vec4<TY>::store(yr + (lane + i * 64) * 4, o);
+        }
+        if (lane == 0) {
+            if (mean) mean[row0 + r] = mu[r];
+            if (rstd) rstd[row0 + r] = rs;
+        }
+    }
+}
+
 extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float* beta,
                                 void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
                                 float eps, bf_stream_t stream) {
@@ -70,6 +147,24 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
                BF_EALIGN, "bf_layernorm_fwd: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bf_cdiv(rows, 4)), block(256);
+    static const int ln_rows = []() { const char* e = getenv("BIFOLD_LN_ROWS"); return e ? atoi(e) : 2; }();
+    if (x_dtype == BF_F32 && (cols == 512 || cols == 768 || cols == 1024) && ln_rows > 1 &&
+        (y_dtype == BF_BF16 || y_dtype == BF_F32)) {
+#define LN_ROWS(TY, NC, R)                                                                       \
+    hipLaunchKernelGGL((ln_fwd_rows_kernel<float, TY, NC, R>), dim3(bf_cdiv(rows, 4 * R)), block, 0, \
+                       s, (const float*)x, gamma, beta, (TY*)y, mean, rstd, rows, eps)
+#define LN_ROWS_NC(TY, R)                                                                       \
+    do {                                                                                        \
+        if (cols == 512) LN_ROWS(TY, 2, R); else if (cols == 768) LN_ROWS(TY, 3, R);            \
+        else LN_ROWS(TY, 4, R);                                                                 \
+    } while (0)
+        if (y_dtype == BF_BF16) { if (ln_rows >= 4) LN_ROWS_NC(bf16_t, 4); else LN_ROWS_NC(bf16_t, 2); }
+        else { if (ln_rows >= 4) LN_ROWS_NC(float, 4); else LN_ROWS_NC(float, 2); }
+#undef LN_ROWS_NC
+#undef LN_ROWS
+        BF_CHECK_LAUNCH("bf_layernorm_fwd");
+        return BF_OK;
+    }
 #define LN_LAUNCH(TX, TY)                                                                       \
     hipLaunchKernelGGL((ln_fwd_kernel<TX, TY>), grid, block, 0, s, (const TX*)x, gamma, beta,  \
                        (TY*)y, mean, rstd, rows, cols, eps)
