@@ -197,15 +197,15 @@ class CLIPEncoder(nn.Module):
 def load(name: str, device="cpu", checkpoint: Optional[str] = None, **_):
     """Stand-in for clip.load (clip/__init__.py:117-176), which downloads weights: there is
     no network here, so the tower is built from its hyper-parameters and filled from
-    `checkpoint` (a state dict saved with torch.save) when one is given."""
+    `checkpoint` when one is given: OpenAI's TorchScript archive for that name, or a plain
+    state dict (checkpoint_io.read_state_dict lists the accepted files)."""
     if name not in CLIP_CONFIGS:
         raise RuntimeError(f"Model {name} not found; available models = {list(CLIP_CONFIGS)}")
     model = CLIPEncoder(**CLIP_CONFIGS[name])
     if checkpoint:
-        sd = torch.load(checkpoint, map_location="cpu")
-        sd = {k: v.float() for k, v in sd.items() if k not in ("input_resolution", "context_length", "vocab_size")}
-        model.load_state_dict(sd, strict=False)
+        from .checkpoint_io import load_into, read_state_dict
+        load_into(model, read_state_dict(checkpoint), f"CLIP {name}")
     else:
         warnings.warn(f"CLIP {name}: no checkpoint given, using random initialisation "
-                      f"(set model.clip_checkpoint=<state_dict.pt> to load weights)")
+                      f"(set model.clip_checkpoint=<ViT-*.pt | state_dict.pt> to load weights)")
     return model.eval(), None

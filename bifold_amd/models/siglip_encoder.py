@@ -183,15 +183,17 @@ class SiglipTowers(nn.Module):
 
 def from_pretrained(name: str, checkpoint: Optional[str] = None) -> SiglipTowers:
     """Stand-in for AutoModel.from_pretrained (no network): build the towers from the named
-    checkpoint's hyper-parameters and fill them from a local state dict when one is given."""
+    checkpoint's hyper-parameters and fill them from a local copy when one is given: the
+    Hugging Face snapshot directory, its model.safetensors, or a state dict with the same
+    (transformers SiglipModel) key names -- see checkpoint_io.read_state_dict."""
     if name not in SIGLIP_CONFIGS:
         raise ValueError(f"unknown SigLIP model {name!r}; known: {sorted(SIGLIP_CONFIGS)}")
     cfg = SIGLIP_CONFIGS[name]
     model = SiglipTowers(cfg["vision"], cfg["text"])
     if checkpoint:
-        sd = torch.load(checkpoint, map_location="cpu")
-        model.load_state_dict({k: v.float() for k, v in sd.items()}, strict=False)
+        from .checkpoint_io import load_into, read_state_dict
+        load_into(model, read_state_dict(checkpoint), f"SigLIP {name}")
     else:
         warnings.warn(f"SigLIP {name}: no checkpoint given, using random initialisation "
-                      f"(set model.siglip_checkpoint=<state_dict.pt> to load weights)")
+                      f"(set model.siglip_checkpoint=<snapshot dir | model.safetensors | state_dict.pt>)")
     return model.eval()
