@@ -130,16 +130,29 @@ __device__ __forceinline__ float tanh_gelu_fast(float x) {       // tanh(u) = 1 
     return 0.5f * x * (1.0f + t);
 }
 
+// d/dx [0.5 x (1 + tanh u)],  u = c (x + 0.044715 x^3):  0.5 (1 + t) + 0.5 x (1 - t^2) c (1 + 0.134145 x^2)
+__device__ __forceinline__ float tanh_gelu_grad_f(float x) {
+    const float t = tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x));
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 0.134145f * x * x);
+}
+__device__ __forceinline__ float tanh_gelu_grad_fast(float x) {
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+    const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+    return fmaf(0.5f * x * (1.0f - t * t), 0.7978845608028654f * fmaf(0.134145f * x, x, 1.0f), 0.5f * (1.0f + t));
+}
+
 template <typename TD> struct ActMath;      // TD = compute dtype of the call
 template <> struct ActMath<float> {
     static __device__ __forceinline__ float quick(float x) { return quick_gelu_f(x); }
     static __device__ __forceinline__ float erf(float x) { return erf_gelu_f(x); }
     static __device__ __forceinline__ float erf_grad(float x) { return erf_gelu_grad_f(x); }
     static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_f(x); }
+    static __device__ __forceinline__ float tanh_grad(float x) { return tanh_gelu_grad_f(x); }
 };
 template <> struct ActMath<bf16_t> {
     static __device__ __forceinline__ float quick(float x) { return quick_gelu_fast(x); }
     static __device__ __forceinline__ float erf(float x) { return erf_gelu_fast(x); }
     static __device__ __forceinline__ float erf_grad(float x) { return erf_gelu_grad_fast(x); }
     static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_fast(x); }
+    static __device__ __forceinline__ float tanh_grad(float x) { return tanh_gelu_grad_fast(x); }
 };

@@ -65,6 +65,11 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
         const float4 a = Vec4<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n);
         v.x *= AM::erf_grad(a.x); v.y *= AM::erf_grad(a.y);
         v.z *= AM::erf_grad(a.z); v.w *= AM::erf_grad(a.w);
+    } else if (ep.act == BF_ACT_TANH_GELU_GRAD) {
+        using AM = ActMath<TD>;
+        const float4 a = Vec4<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n);
+        v.x *= AM::tanh_grad(a.x); v.y *= AM::tanh_grad(a.y);
+        v.z *= AM::tanh_grad(a.z); v.w *= AM::tanh_grad(a.w);
     }
     if (ep.residual) {
         const size_t rr = ep.resid_mod > 0 ? (size_t)(m % ep.resid_mod) : orow;
@@ -138,6 +143,12 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int 
         Vec8<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n, a);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= AM::erf_grad(a[e]);
+    } else if (ep.act == BF_ACT_TANH_GELU_GRAD) {
+        using AM = ActMath<TD>;
+        float a[8];
+        Vec8<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= AM::tanh_grad(a[e]);
     }
     if (ep.residual) {
         const size_t rr = ep.resid_mod > 0 ? (size_t)(m % ep.resid_mod) : orow;
@@ -1305,8 +1316,9 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                "bf_gemm: fp32 operands produce fp32 output only");
     BF_REQUIRE(!(g->accumulate && g->c_dtype != BF_F32), BF_EINVAL,
                "bf_gemm: accumulate needs an fp32 C");
-    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_TANH_GELU, BF_EINVAL, "bf_gemm: bad act");
-    BF_REQUIRE(g->act != BF_ACT_ERF_GELU_GRAD || g->aux, BF_EINVAL, "bf_gemm: GELU_GRAD needs aux");
+    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_TANH_GELU_GRAD, BF_EINVAL, "bf_gemm: bad act");
+    BF_REQUIRE((g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD) || g->aux, BF_EINVAL,
+               "bf_gemm: the GELU_GRAD activations need aux");
     const int vec = g->cdt == BF_BF16 ? 8 : 4;
     BF_REQUIRE((g->n & 3) == 0 && (g->ldc & 3) == 0 && g->ldc >= g->n, BF_EINVAL,
                "bf_gemm: n and ldc must be multiples of 4 (n=%d ldc=%d)", g->n, g->ldc);
@@ -1445,7 +1457,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             // which epilogue instantiation (the predicates of the kernel's EPI paths)
             int epi = 0;
             if (!f32out && !slabs && !g->residual && !g->c2 && !g->accumulate && g->rows_in == 0) {
-                if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD) epi = 1;
+                if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD) epi = 1;
                 else if (g->act == BF_ACT_ERF_GELU_GRAD && !g->bias && !g->pre) epi = 2;
             }
 #define LAUNCH_P8E(AKS, BKS, TC, EPI)                                                               \

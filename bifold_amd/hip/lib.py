@@ -15,10 +15,10 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t
 import torch  # noqa: F401
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TANH_GELU_GRAD = 0, 1, 2, 3, 4, 5
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, MAX_TARGET_POINTS = 0, 1, 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(

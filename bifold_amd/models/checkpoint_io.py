@@ -62,14 +62,16 @@ def read_state_dict(path: str) -> Dict[str, torch.Tensor]:
 
 
 def load_into(module: nn.Module, sd: Dict[str, torch.Tensor], what: str, prefix: str = "",
-              optional: Iterable[str] = ()) -> None:
+              optional: Iterable[str] = (), optional_containing: Iterable[str] = ()) -> None:
     """Copy `sd` into `module` (keys optionally under `prefix`, e.g. a tower saved inside a full
-    model).  Missing parameters and shape mismatches raise; extra entries only warn."""
+    model).  Missing parameters and shape mismatches raise -- except names starting with one of
+    `optional` or containing one of `optional_containing` (LoRA adapters absent from a base-model
+    file); extra entries only warn."""
     if prefix:
         sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     own = module.state_dict()
-    optional = tuple(optional)
-    missing = [k for k in own if k not in sd and not k.startswith(optional)]
+    optional, inside = tuple(optional), tuple(optional_containing)
+    missing = [k for k in own if k not in sd and not k.startswith(optional) and not any(t in k for t in inside)]
     if missing:
         raise KeyError(f"{what}: checkpoint lacks {len(missing)} of {len(own)} tensors, e.g. {missing[:4]}")
     bad = [(k, tuple(sd[k].shape), tuple(own[k].shape)) for k in own if k in sd and sd[k].shape != own[k].shape]

@@ -357,6 +357,7 @@ class SegmentTailFn(torch.autograd.Function):
                 d_pos = g(prm).view(-1, dim)[row0:row0 + 1 + sg["n"]]
             ops.segment_assemble_bwd(dx, g(sg["lead"]).view(-1), d_pos, d_type[sg["modality"]], c.batch, sg["n"],
                                      c.seq, sg["row_off"])
+        model.tower_backward(dx, c.segments, c.batch, c.seq)    # LoRA adapters of the towers (no-op when frozen)
         model._grad_ready(-1)
         ctx.c = None
         return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))

@@ -2,10 +2,16 @@
 heatmaps (reference bifold/models/siglip.py:10-137; `siglip_sequential` is the reference's
 default model and BASELINE config 3).
 
-Constructor kwargs are the YAML keys of conf/model/siglip*.yaml.  `lora: true` is NOT built:
-LoRA's arithmetic lives in the third-party `peft` package, absent from this image, so there is
-nothing to pin it against ("parity unpinned"); `lora: false` (frozen towers,
-models/siglip.py:41-43) is the supported mode.  New optional keys: `dtype`, `siglip_checkpoint`.
+Constructor kwargs are the YAML keys of conf/model/siglip*.yaml.  `lora: false` freezes the
+towers (models/siglip.py:41-43).  `lora: true` (models/siglip.py:33-40, the reference's default)
+adds rank-r adapters to `target_modules` of BOTH towers and trains them: the towers then keep
+their activations and `tower_backward` continues the fused tail's backward through them
+(siglip_encoder.SiglipTowers).  LoRA's arithmetic lives in the third-party `peft` package, absent
+from this image: that mode follows PEFT's published definition and is PARITY UNPINNED (checked
+against oracle/lora_oracle.py, a torch-autograd restatement, not against the reference);
+`lora_dropout` must be 0 -- the adapters are merged into the in-projection weights, which a
+dropout on the adapter's input alone does not allow.  New optional keys: `dtype`,
+`siglip_checkpoint`.
 """
 from __future__ import annotations
 
@@ -26,22 +32,26 @@ class SigLip(BaseModel):
     def __init__(self, patch_size, dim, lora, r, lora_alpha, lora_dropout, automodel_name, target_modules,
                  pick_place_model, dtype="bf16", siglip_checkpoint=None, **kwargs):
         super().__init__(**kwargs)
-        if lora:
-            raise NotImplementedError(
-                "lora=true needs a restatement of peft's LoRA (third-party, absent here: parity unpinned); "
-                "use lora=false (frozen towers)")
+        if lora and float(lora_dropout) != 0.0:
+            raise ValueError(
+                f"lora_dropout={lora_dropout}: the adapters are merged into the projection weights "
+                f"(W + alpha/r B A), which is PEFT's forward only without dropout on the adapter input; "
+                f"set model.lora_dropout=0 (the reference's 0.01 drops 1 % of the adapter's inputs)")
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
         self.compute_dtype = _DTYPES[dtype]
         self.patch_size = patch_size
-        self.siglip_model = from_pretrained(automodel_name, siglip_checkpoint)
+        self.lora = bool(lora)
+        adapters = dict(r=r, alpha=lora_alpha, targets=list(target_modules), adapter="siglip_adapter") if lora else None
+        self.siglip_model = from_pretrained(automodel_name, siglip_checkpoint, lora=adapters)
         self.hidden_size = dim
         assert self.hidden_size == self.siglip_model.vcfg["hidden_size"]
         assert self.hidden_size == self.siglip_model.tcfg["hidden_size"]
         self.num_patches = (self.image_size // self.patch_size) ** 2
         if self.siglip_model.grid ** 2 != self.num_patches:
             raise ValueError("image_size / patch_size do not match the SigLIP vision tower")
-        self.frozen_submodule("siglip_model")
+        if not lora:
+            self.frozen_submodule("siglip_model")
         self.text_token = nn.Parameter(torch.randn(1, 1, dim))
         self.image_token = nn.Parameter(torch.randn(1, 1, dim))
         self.pick_place = Components.get_by_name(pick_place_model, dim=dim, patch_size=patch_size,
@@ -51,7 +61,7 @@ class SigLip(BaseModel):
 
     # ---- same runtime plumbing as RGBOnly ---------------------------------------------------
     def trainable_params(self):
-        return [(n, p) for n, p in self.named_parameters() if "siglip_model" not in n]
+        return [(n, p) for n, p in self.named_parameters() if "siglip_model" not in n or ".lora_" in n]
 
     def trainable_arena(self) -> ParamArena:
         a = self._train_arena
@@ -78,17 +88,38 @@ class SigLip(BaseModel):
                                f"restatement lives in oracle/ for tests)")
         cdt = self.compute_dtype
         self.trainable_arena().sync_shadow()
-        img = self.siglip_model.vision_tokens(rgb, cdt)                       # [B*n, W] fp32
+        img = self._vision(x, cdt)                                            # [B*n, W] fp32
         txt = self.siglip_model.text_tokens(x["instruction"], cdt)            # [B*L, W] fp32
         return img, txt
+
+    def _vision(self, x, cdt):
+        return self.siglip_model.vision_tokens(x["rgb"], cdt)
 
     def _segments(self, x, img, txt):
         b = x["rgb"].shape[0]
         n_txt = txt.shape[0] // b
         n_img = self.num_patches
         d = self.hidden_size
-        return [dict(src=txt, bstride=n_txt * d, n=n_txt, batch=b, lead=self.text_token, pos=None, modality=0),
-                dict(src=img, bstride=n_img * d, n=n_img, batch=b, lead=self.image_token, pos=None, modality=1)], None
+        return [dict(src=txt, bstride=n_txt * d, n=n_txt, batch=b, lead=self.text_token, pos=None, modality=0,
+                     role="txt"),
+                dict(src=img, bstride=n_img * d, n=n_img, batch=b, lead=self.image_token, pos=None, modality=1,
+                     role="img")], None
+
+    # ---- LoRA: the tail's backward continues into the towers -----------------------------------
+    def tower_backward(self, dx: torch.Tensor, segments, batch: int, seq: int) -> None:
+        """dx fp32 [B*seq, dim] = d loss / d (assembled fusion input).  A segment's tower tokens sit
+        one row after its lead token and enter the sum unscaled, so their gradient is that slice."""
+        if not self.lora:
+            return
+        d = self.hidden_size
+        dxv = dx.view(batch, seq, d)
+        by_role = {sg["role"]: dxv[:, sg["row_off"] + 1: sg["row_off"] + 1 + sg["n"]] for sg in segments}
+        g = self.trainable_arena().grad_view
+        self.siglip_model.backward("vision_model", self._vision_grad(by_role, batch), g)
+        self.siglip_model.backward("text_model", by_role["txt"].reshape(-1, d), g)
+
+    def _vision_grad(self, by_role, batch: int) -> torch.Tensor:
+        return by_role["img"].reshape(-1, self.hidden_size)
 
     def forward(self, x):
         img, txt = self._towers(x)
@@ -109,18 +140,24 @@ class SiglipSequential(SigLip):
             torch.randn(1, context_length * (self.num_patches + 1), self.hidden_size))
 
     def _segments(self, x, img, txt):
-        (seg_txt, seg_img), _ = super()._segments(x, img, txt)
         ctx = x["rgb_context"]
         b, t = ctx.shape[:2]
         if t != self.context_length:
             raise ValueError(f"rgb_context has {t} frames, model was built with context_length={self.context_length}")
         n, d = self.num_patches, self.hidden_size
-        cf = self.siglip_model.vision_tokens(ctx.flatten(0, 1), self.compute_dtype)      # [(b t) n, W]
-        cf = cf.view(b, t, n, d)
+        if self.lora:
+            # ONE pass of the vision tower over [current image | context frames]: the reference runs the
+            # (LoRA-wrapped) vision_model twice (models/siglip.py:57,102-104); images are independent, so
+            # the tokens are the same and the adapters' gradient is accumulated by a single backward
+            cf = img[b * n:].view(b, t, n, d)
+            img = img[:b * n]
+        else:
+            cf = self.siglip_model.vision_tokens(ctx.flatten(0, 1), self.compute_dtype).view(b, t, n, d)
+        (seg_txt, seg_img), _ = super()._segments(x, img, txt)
         segs = [seg_txt]
         for f in range(t):        # frame f: src offset f*n*d inside each sample's T*n*d block
             segs.append(dict(src=cf[:, f], bstride=t * n * d, n=n, batch=b, lead=self.image_token,
-                             pos=(self.context_pos_embedding, f * (n + 1)), modality=1))
+                             pos=(self.context_pos_embedding, f * (n + 1)), modality=1, role=("ctx", f)))
         segs.append(seg_img)
         # query-row mask [ones | ctx_mask repeated n+1 | ones]  (models/siglip.py:118-130)
         m = x["context_attention_mask"].to(torch.int32)
@@ -128,3 +165,13 @@ class SiglipSequential(SigLip):
                               m.repeat_interleave(n + 1, dim=1),
                               torch.ones(b, n + 1, dtype=torch.int32, device=m.device)], dim=1).contiguous()
         return segs, row_mask
+
+    def _vision(self, x, cdt):
+        if not self.lora:
+            return super()._vision(x, cdt)
+        return self.siglip_model.vision_tokens(torch.cat([x["rgb"], x["rgb_context"].flatten(0, 1)], dim=0), cdt)
+
+    def _vision_grad(self, by_role, batch: int) -> torch.Tensor:
+        d, t = self.hidden_size, self.context_length
+        ctx = torch.stack([by_role[("ctx", f)] for f in range(t)], dim=1)       # [B, T, n, d]
+        return torch.cat([by_role["img"].reshape(-1, d), ctx.reshape(-1, d)], dim=0)

@@ -7,12 +7,25 @@ also computes are discarded, so they are not computed here.  Parameter names are
 (`vision_model.embeddings.patch_embedding.weight`, `text_model.encoder.layers.{i}.self_attn.q_proj.weight`
 ...; full list pinned by tests/golden/tiny_siglip.npz), so a SiglipModel state dict loads with
 `load_state_dict`.  Block = pre-LN (eps 1e-6), q/k/v/out projections with bias, tanh-GELU MLP; no
-class token, no attention mask.  Forward-only (the towers are frozen when lora=false).
+class token, no attention mask.
+
+`lora=None`: frozen towers, forward only (models/siglip.py:41-43).  With a `lora` dict (the
+reference's default, models/siglip.py:33-40: `LoraModel(siglip_model, LoraConfig(r, lora_alpha,
+target_modules=[q_proj, v_proj], lora_dropout), "siglip_adapter")`) every targeted projection of
+BOTH towers gains `lora_A [r, in]` (Kaiming-uniform) and `lora_B [out, r]` (zeros), the forward
+runs with `W + (alpha / r) B A` merged into the packed in-projection (identical to PEFT's
+`Wx + b + (alpha / r) B A x` at lora_dropout = 0), activations are kept, and `backward()` walks
+both towers in reverse to produce the adapters' gradients.  Parameter names then follow PEFT's
+wrapping (`base_model.model.` prefix, `<proj>.base_layer.{weight,bias}`,
+`<proj>.lora_{A,B}.<adapter>.weight`).  PARITY UNPINNED for this mode: `peft` is not in the
+image, so the arithmetic follows PEFT's published definition and is checked against a torch
+autograd restatement of it (oracle/lora_oracle.py), not against the reference itself.
 """
 from __future__ import annotations
 
+import math
 import warnings
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import torch
 from torch import nn
@@ -20,7 +33,8 @@ from torch import nn
 from ..hip import lib as L
 from ..hip import ops
 from .arena import ParamArena
-from .params import add_param, layernorm_init, linear_init
+from .params import add_param as _register
+from .params import get_param, layernorm_init, linear_init
 
 _BASE = dict(hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12)
 # Hyper-parameters of the published checkpoints the reference's configs name
@@ -33,47 +47,87 @@ SIGLIP_CONFIGS: Dict[str, Dict] = {
 LN_EPS = 1e-6
 
 
+_MERGEABLE = ("q_proj", "k_proj", "v_proj")      # projections folded into the packed in-projection
+
+
 class SiglipTowers(nn.Module):
-    def __init__(self, vision: Dict, text: Dict):
+    def __init__(self, vision: Dict, text: Dict, lora: Optional[Dict] = None):
         super().__init__()
         self.vcfg, self.tcfg = dict(vision), dict(text)
+        self.lora = None
+        self._real: Dict[str, str] = {}               # HF parameter name -> registered path
+        self._prefix = ""
+        if lora:
+            targets = tuple(lora["targets"])
+            bad = [t for t in targets if t not in _MERGEABLE]
+            if bad:
+                raise NotImplementedError(f"LoRA target_modules {bad}: only {list(_MERGEABLE)} are built")
+            if int(lora["r"]) % 4 != 0 or int(lora["r"]) <= 0:
+                raise ValueError(f"LoRA rank r={lora['r']} must be a positive multiple of 4 (fp32 GEMM row alignment)")
+            self.lora = dict(r=int(lora["r"]), alpha=float(lora["alpha"]), targets=targets,
+                             adapter=str(lora.get("adapter", "siglip_adapter")))
+            self._prefix = "base_model.model."
         vw, tw = vision["hidden_size"], text["hidden_size"]
         p = vision["patch_size"]
         self.grid = vision["image_size"] // p
         self.patch = p
         n = self.grid ** 2
         for k, v in linear_init(vw, 3 * p * p).items():
-            add_param(self, f"vision_model.embeddings.patch_embedding.{k}", v.view(vw, 3, p, p) if k == "weight" else v)
-        add_param(self, "vision_model.embeddings.position_embedding.weight", torch.randn(n, vw) * vw ** -0.5)
+            self._add(f"vision_model.embeddings.patch_embedding.{k}", v.view(vw, 3, p, p) if k == "weight" else v)
+        self._add("vision_model.embeddings.position_embedding.weight", torch.randn(n, vw) * vw ** -0.5)
         self._layers("vision_model", vision)
         for k, v in layernorm_init(vw).items():
-            add_param(self, f"vision_model.post_layernorm.{k}", v)
+            self._add(f"vision_model.post_layernorm.{k}", v)
         # attention-pooling head: part of the checkpoint schema, never evaluated (its output is unused)
-        add_param(self, "vision_model.head.probe", torch.randn(1, 1, vw))
-        add_param(self, "vision_model.head.attention.in_proj_weight", torch.randn(3 * vw, vw) * vw ** -0.5)
-        add_param(self, "vision_model.head.attention.in_proj_bias", torch.zeros(3 * vw))
+        self._add("vision_model.head.probe", torch.randn(1, 1, vw))
+        self._add("vision_model.head.attention.in_proj_weight", torch.randn(3 * vw, vw) * vw ** -0.5)
+        self._add("vision_model.head.attention.in_proj_bias", torch.zeros(3 * vw))
         for k, v in linear_init(vw, vw).items():
-            add_param(self, f"vision_model.head.attention.out_proj.{k}", v)
+            self._add(f"vision_model.head.attention.out_proj.{k}", v)
         for k, v in layernorm_init(vw).items():
-            add_param(self, f"vision_model.head.layernorm.{k}", v)
+            self._add(f"vision_model.head.layernorm.{k}", v)
         for k, v in linear_init(vision["intermediate_size"], vw).items():
-            add_param(self, f"vision_model.head.mlp.fc1.{k}", v)
+            self._add(f"vision_model.head.mlp.fc1.{k}", v)
         for k, v in linear_init(vw, vision["intermediate_size"]).items():
-            add_param(self, f"vision_model.head.mlp.fc2.{k}", v)
-        add_param(self, "text_model.embeddings.token_embedding.weight", torch.randn(text["vocab_size"], tw) * tw ** -0.5)
-        add_param(self, "text_model.embeddings.position_embedding.weight",
+            self._add(f"vision_model.head.mlp.fc2.{k}", v)
+        self._add("text_model.embeddings.token_embedding.weight", torch.randn(text["vocab_size"], tw) * tw ** -0.5)
+        self._add("text_model.embeddings.position_embedding.weight",
                   torch.randn(text["max_position_embeddings"], tw) * tw ** -0.5)
         self._layers("text_model", text)
         for k, v in layernorm_init(tw).items():
-            add_param(self, f"text_model.final_layer_norm.{k}", v)
+            self._add(f"text_model.final_layer_norm.{k}", v)
         for k, v in linear_init(tw, tw).items():
-            add_param(self, f"text_model.head.{k}", v)
-        add_param(self, "logit_scale", torch.zeros(1))
-        add_param(self, "logit_bias", torch.zeros(1))
+            self._add(f"text_model.head.{k}", v)
+        self._add("logit_scale", torch.zeros(1))
+        self._add("logit_bias", torch.zeros(1))
         self._arena: Optional[ParamArena] = None
         self._packed: Dict[str, torch.Tensor] = {}
         self._packed_version = -1
         self._err_flag: Optional[torch.Tensor] = None
+        self._saved: Dict[str, Dict] = {}             # per tower: what backward() needs
+        if self.lora:                                 # PEFT: only the adapters train
+            for n, p in self.named_parameters():
+                p.requires_grad_(".lora_" in n)
+
+    def _add(self, name: str, value: torch.Tensor) -> nn.Parameter:
+        """Register the parameter HF calls `name` under the path the checkpoint schema uses."""
+        real = self._prefix + name
+        if self.lora:
+            for t in self.lora["targets"]:
+                tag = f".self_attn.{t}."
+                if tag in name:
+                    real = self._prefix + name.replace(tag, tag + "base_layer.")
+        self._real[name] = real
+        return _register(self, real, value)
+
+    def _p(self, name: str) -> nn.Parameter:
+        return get_param(self, self._real[name])
+
+    def lora_params(self, tower: str, layer: int, proj: str):
+        """(lora_A [r, in], lora_B [out, r]) of one adapted projection."""
+        base = f"{self._prefix}{tower}.encoder.layers.{layer}.self_attn.{proj}."
+        ad = self.lora["adapter"]
+        return get_param(self, f"{base}lora_A.{ad}.weight"), get_param(self, f"{base}lora_B.{ad}.weight")
 
     def _layers(self, tower: str, cfg: Dict):
         w, inter = cfg["hidden_size"], cfg["intermediate_size"]
@@ -81,20 +135,29 @@ class SiglipTowers(nn.Module):
             b = f"{tower}.encoder.layers.{i}."
             for ln in ("layer_norm1", "layer_norm2"):
                 for k, v in layernorm_init(w).items():
-                    add_param(self, f"{b}{ln}.{k}", v)
+                    self._add(f"{b}{ln}.{k}", v)
             for proj in ("k_proj", "v_proj", "q_proj", "out_proj"):          # HF's registration order
                 for k, v in linear_init(w, w).items():
-                    add_param(self, f"{b}self_attn.{proj}.{k}", v)
+                    self._add(f"{b}self_attn.{proj}.{k}", v)
+                if self.lora and proj in self.lora["targets"]:
+                    # peft LoraLayer.reset_lora_parameters: A ~ kaiming_uniform(a=sqrt(5)) = U(+-1/sqrt(in)), B = 0
+                    r, ad = self.lora["r"], self.lora["adapter"]
+                    base = f"{self._prefix}{b}self_attn.{proj}."
+                    bound = 1.0 / math.sqrt(w)
+                    _register(self, f"{base}lora_A.{ad}.weight", torch.empty(r, w).uniform_(-bound, bound))
+                    _register(self, f"{base}lora_B.{ad}.weight", torch.zeros(w, r))
             for k, v in linear_init(inter, w).items():
-                add_param(self, f"{b}mlp.fc1.{k}", v)
+                self._add(f"{b}mlp.fc1.{k}", v)
             for k, v in linear_init(w, inter).items():
-                add_param(self, f"{b}mlp.fc2.{k}", v)
+                self._add(f"{b}mlp.fc2.{k}", v)
 
     # ------------------------------------------------------------------ runtime
     def _runtime(self, cdt: torch.dtype) -> ParamArena:
         a = self._arena
         if a is None or not a.still_bound() or (cdt != torch.float32 and a.shadow is None):
-            a = ParamArena(self.named_parameters(), with_grad=False, with_shadow=(cdt != torch.float32))
+            # the adapters live in the MODEL's trainable arena (gradients, Adam state), not here
+            a = ParamArena([(n, p) for n, p in self.named_parameters() if ".lora_" not in n],
+                           with_grad=False, with_shadow=(cdt != torch.float32))
             self._arena = a
             self._packed_version = -1
         a.sync_shadow()
@@ -106,74 +169,187 @@ class SiglipTowers(nn.Module):
             for tower, cfg in (("vision_model", self.vcfg), ("text_model", self.tcfg)):
                 for i in range(cfg["num_hidden_layers"]):
                     b = f"{tower}.encoder.layers.{i}.self_attn."
-                    ws = [a.operand(self.get_parameter(f"{b}{n}_proj.weight"), cdt) for n in "qkv"]
-                    bs = [self.get_parameter(f"{b}{n}_proj.bias").data for n in "qkv"]
+                    ws = [a.operand(self._p(f"{b}{n}_proj.weight"), cdt) for n in "qkv"]
+                    bs = [self._p(f"{b}{n}_proj.bias").data for n in "qkv"]
                     self._packed[b + "w"] = torch.cat(ws, dim=0).contiguous()
                     self._packed[b + "b"] = torch.cat(bs, dim=0).contiguous()
             self._packed_version = ver
+        if self.lora:
+            self._merge_adapters(cdt)
         return a
 
+    def _merge_adapters(self, cdt: torch.dtype) -> None:
+        """Packed in-projection rows of every adapted projection <- W + (alpha / r) B A (fp32 math on
+        the fp32 masters, then one rounding to the compute dtype).  Runs every forward: the adapters
+        change every optimiser step, the base weights never."""
+        scale = self.lora["alpha"] / self.lora["r"]
+        for tower, cfg in (("vision_model", self.vcfg), ("text_model", self.tcfg)):
+            w = cfg["hidden_size"]
+            for i in range(cfg["num_hidden_layers"]):
+                b = f"{tower}.encoder.layers.{i}.self_attn."
+                pw = self._packed[b + "w"]
+                for slot, n in enumerate("qkv"):
+                    if f"{n}_proj" not in self.lora["targets"]:
+                        continue
+                    la, lb = self.lora_params(tower, i, f"{n}_proj")
+                    rows = pw[slot * w:(slot + 1) * w]
+                    base = self._p(f"{b}{n}_proj.weight").data
+                    if cdt == torch.float32:
+                        ops.gemm(lb.data, la.data, b_kn=True, alpha=scale, residual=base, out=rows)
+                    else:
+                        _, c16 = ops.gemm(lb.data, la.data, b_kn=True, alpha=scale, residual=base,
+                                          want_bf16_copy=True)
+                        rows.copy_(c16)
+
     def _w(self, name: str, cdt):
-        return self._arena.operand(self.get_parameter(name), cdt)
+        return self._arena.operand(self._p(name), cdt)
 
     def _f(self, name: str):
-        return self.get_parameter(name).data
+        return self._p(name).data
 
-    def _encoder(self, x, tower: str, cfg: Dict, batch: int, seq: int, cdt):
+    def _encoder(self, x, tower: str, cfg: Dict, batch: int, seq: int, cdt, saved: Optional[List] = None):
+        """The pre-LN blocks.  `saved` (a list) receives per layer what _encoder_bwd needs; without it
+        the residual stream is updated in place."""
         heads = cfg["num_attention_heads"]
         d = cfg["hidden_size"] // heads
+        keep = saved is not None
         for i in range(cfg["num_hidden_layers"]):
             b = f"{tower}.encoder.layers.{i}."
-            h, _, _ = ops.layernorm_fwd(x, self._f(b + "layer_norm1.weight"), self._f(b + "layer_norm1.bias"), cdt,
-                                        eps=LN_EPS)
-            qkv = ops.gemm(h, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
-            o, _ = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, L.MASK_NONE)
-            ops.gemm(o, self._w(b + "self_attn.out_proj.weight", cdt), bias=self._f(b + "self_attn.out_proj.bias"),
-                     residual=x, out=x)
-            h, _, _ = ops.layernorm_fwd(x, self._f(b + "layer_norm2.weight"), self._f(b + "layer_norm2.bias"), cdt,
-                                        eps=LN_EPS)
-            a = ops.gemm(h, self._w(b + "mlp.fc1.weight", cdt), bias=self._f(b + "mlp.fc1.bias"),
-                         act=L.ACT_TANH_GELU)
-            ops.gemm(a, self._w(b + "mlp.fc2.weight", cdt), bias=self._f(b + "mlp.fc2.bias"), residual=x, out=x)
+            h1, m1, r1 = ops.layernorm_fwd(x, self._f(b + "layer_norm1.weight"), self._f(b + "layer_norm1.bias"), cdt,
+                                           save_stats=keep, eps=LN_EPS)
+            qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
+            o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, L.MASK_NONE, need_lse=keep)
+            xm = ops.gemm(o, self._w(b + "self_attn.out_proj.weight", cdt), bias=self._f(b + "self_attn.out_proj.bias"),
+                          residual=x, out=None if keep else x, out_dtype=torch.float32)
+            h2, m2, r2 = ops.layernorm_fwd(xm, self._f(b + "layer_norm2.weight"), self._f(b + "layer_norm2.bias"), cdt,
+                                           save_stats=keep, eps=LN_EPS)
+            if keep:
+                a, pre = ops.gemm(h2, self._w(b + "mlp.fc1.weight", cdt), bias=self._f(b + "mlp.fc1.bias"),
+                                  act=L.ACT_TANH_GELU, want_pre=True)
+            else:
+                a, pre = ops.gemm(h2, self._w(b + "mlp.fc1.weight", cdt), bias=self._f(b + "mlp.fc1.bias"),
+                                  act=L.ACT_TANH_GELU), None
+            xo = ops.gemm(a, self._w(b + "mlp.fc2.weight", cdt), bias=self._f(b + "mlp.fc2.bias"), residual=xm,
+                          out=None if keep else xm, out_dtype=torch.float32)
+            if keep:      # h2 and a feed only frozen weights' gradients: not kept
+                saved.append(dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, xm=xm, m2=m2, r2=r2, pre=pre))
+            x = xo
         return x
 
-    @torch.no_grad()
+    def _encoder_bwd(self, dx: torch.Tensor, dx_c: Optional[torch.Tensor], saved: List, tower: str, cfg: Dict,
+                     batch: int, seq: int, cdt, grad_view) -> None:
+        """dx fp32 [M, W] (+ its compute-dtype copy) = d loss / d (last block's output).  Walks the blocks in reverse; the only
+        parameter gradients produced are the adapters' (everything else is frozen):
+        with W_eff = W + s B A,   dB = s dW_eff A^T,   dA = s B^T dW_eff,   dW_eff = dY^T h1."""
+        heads = cfg["num_attention_heads"]
+        w = cfg["hidden_size"]
+        d = w // heads
+        scale = self.lora["alpha"] / self.lora["r"]
+        dev = dx.device
+        junk_g = torch.empty(w, dtype=torch.float32, device=dev)       # LayerNorm weight/bias gradients: frozen
+        junk_b = torch.empty(w, dtype=torch.float32, device=dev)
+        dw = torch.empty(3 * w, w, dtype=torch.float32, device=dev)
+        for i in reversed(range(cfg["num_hidden_layers"])):
+            b = f"{tower}.encoder.layers.{i}."
+            S = saved[i]
+            op = dx_c if dx_c is not None else dx
+            # MLP:  xo = xm + gelu_tanh(h2 W1^T + b1) W2^T + b2
+            dpre = ops.gemm(op, self._w(b + "mlp.fc2.weight", cdt), b_kn=True, act=L.ACT_TANH_GELU_GRAD, aux=S["pre"])
+            dh2 = ops.gemm(dpre, self._w(b + "mlp.fc1.weight", cdt), b_kn=True)
+            dxm, dxm_c = ops.layernorm_bwd(dh2, S["xm"], self._f(b + "layer_norm2.weight"), S["m2"], S["r2"], dx, cdt,
+                                           junk_g, junk_b)
+            del dpre, dh2
+            op2 = dxm_c if dxm_c is not None else dxm
+            # attention:  xm = x + attn(h1 Wqkv_eff^T + b) Wo^T + bo
+            do = ops.gemm(op2, self._w(b + "self_attn.out_proj.weight", cdt), b_kn=True)
+            dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, L.MASK_NONE, None)
+            ops.gemm(dqkv, S["h1"], trans_a=True, b_kn=True, out=dw)
+            for slot, n in enumerate("qkv"):
+                if f"{n}_proj" not in self.lora["targets"]:
+                    continue
+                la, lb = self.lora_params(tower, i, f"{n}_proj")
+                dwp = dw[slot * w:(slot + 1) * w]
+                ops.gemm(dwp, la.data, alpha=scale, out=grad_view(lb))                            # [out, in] [r, in]^T
+                ops.gemm(lb.data, dwp, trans_a=True, b_kn=True, alpha=scale, out=grad_view(la))  # [out, r]^T [out, in]
+            dh1 = ops.gemm(dqkv, self._packed[b + "self_attn.w"], b_kn=True)
+            dx, dx_c = ops.layernorm_bwd(dh1, S["x"], self._f(b + "layer_norm1.weight"), S["m1"], S["r1"], dxm, cdt,
+                                         junk_g, junk_b)
+            saved[i] = None                                # free this block's activations early
+        # the embeddings below are frozen: the walk ends here
+
+    def _final_norm(self, x, name: str, keep: bool):
+        y, m, r = ops.layernorm_fwd(x, self._f(name + ".weight"), self._f(name + ".bias"), torch.float32,
+                                    save_stats=keep, eps=LN_EPS)
+        return y, (x, m, r)
+
+    def _keep(self) -> bool:
+        return self.lora is not None and torch.is_grad_enabled()
+
     def vision_tokens(self, img: torch.Tensor, cdt: torch.dtype) -> torch.Tensor:
         """[N,3,S,S] fp32 -> post_layernorm(tokens) fp32 [N*(S/p)^2, W]."""
-        self._runtime(cdt)
-        nimg, _, size, _ = img.shape
-        if size != self.grid * self.patch:
-            raise ValueError(f"image size {size} != {self.grid * self.patch} expected by the SigLIP vision tower")
-        n = self.grid * self.grid
-        vw = self.vcfg["hidden_size"]
-        cols = ops.patchify(img.contiguous(), self.patch, cdt)
-        wconv = self._w("vision_model.embeddings.patch_embedding.weight", cdt).view(vw, -1)
-        x = torch.empty(nimg * n, vw, dtype=torch.float32, device=img.device)
-        # conv bias and the learned position table ride in the GEMM epilogue (table row = patch index)
-        ops.gemm(cols, wconv, bias=self._f("vision_model.embeddings.patch_embedding.bias"),
-                 residual=self._f("vision_model.embeddings.position_embedding.weight"), resid_mod=n, out=x)
-        x = self._encoder(x, "vision_model", self.vcfg, nimg, n, cdt)
-        y, _, _ = ops.layernorm_fwd(x, self._f("vision_model.post_layernorm.weight"),
-                                    self._f("vision_model.post_layernorm.bias"), torch.float32, eps=LN_EPS)
+        keep = self._keep()
+        with torch.no_grad():
+            self._runtime(cdt)
+            nimg, _, size, _ = img.shape
+            if size != self.grid * self.patch:
+                raise ValueError(f"image size {size} != {self.grid * self.patch} expected by the SigLIP vision tower")
+            n = self.grid * self.grid
+            vw = self.vcfg["hidden_size"]
+            cols = ops.patchify(img.contiguous(), self.patch, cdt)
+            wconv = self._w("vision_model.embeddings.patch_embedding.weight", cdt).view(vw, -1)
+            x = torch.empty(nimg * n, vw, dtype=torch.float32, device=img.device)
+            # conv bias and the learned position table ride in the GEMM epilogue (table row = patch index)
+            ops.gemm(cols, wconv, bias=self._f("vision_model.embeddings.patch_embedding.bias"),
+                     residual=self._f("vision_model.embeddings.position_embedding.weight"), resid_mod=n, out=x)
+            del cols
+            layers: Optional[List] = [] if keep else None
+            x = self._encoder(x, "vision_model", self.vcfg, nimg, n, cdt, layers)
+            y, fin = self._final_norm(x, "vision_model.post_layernorm", keep)
+            if keep:
+                self._saved["vision_model"] = dict(layers=layers, fin=fin, batch=nimg, seq=n, cdt=cdt)
+        return y
+
+    def text_tokens(self, ids: torch.Tensor, cdt: torch.dtype) -> torch.Tensor:
+        """[B,L] int -> final_layer_norm(tokens) fp32 [B*L, W]."""
+        keep = self._keep()
+        with torch.no_grad():
+            self._runtime(cdt)
+            ids = ids.to(torch.int32).contiguous()
+            batch, ctx = ids.shape
+            if ctx > self.tcfg["max_position_embeddings"]:
+                raise ValueError(f"instruction length {ctx} exceeds the SigLIP text tower's "
+                                 f"{self.tcfg['max_position_embeddings']} positions")
+            if self._err_flag is None or self._err_flag.device != ids.device:
+                self._err_flag = torch.zeros(1, dtype=torch.int32, device=ids.device)
+            x = ops.embed_tokens(ids, self._f("text_model.embeddings.token_embedding.weight"),
+                                 self._f("text_model.embeddings.position_embedding.weight"), self._err_flag)
+            layers: Optional[List] = [] if keep else None
+            x = self._encoder(x, "text_model", self.tcfg, batch, ctx, cdt, layers)
+            y, fin = self._final_norm(x, "text_model.final_layer_norm", keep)
+            if keep:
+                self._saved["text_model"] = dict(layers=layers, fin=fin, batch=batch, seq=ctx, cdt=cdt)
         return y
 
     @torch.no_grad()
-    def text_tokens(self, ids: torch.Tensor, cdt: torch.dtype) -> torch.Tensor:
-        """[B,L] int -> final_layer_norm(tokens) fp32 [B*L, W]."""
-        self._runtime(cdt)
-        ids = ids.to(torch.int32).contiguous()
-        batch, ctx = ids.shape
-        if ctx > self.tcfg["max_position_embeddings"]:
-            raise ValueError(f"instruction length {ctx} exceeds the SigLIP text tower's "
-                             f"{self.tcfg['max_position_embeddings']} positions")
-        if self._err_flag is None or self._err_flag.device != ids.device:
-            self._err_flag = torch.zeros(1, dtype=torch.int32, device=ids.device)
-        x = ops.embed_tokens(ids, self._f("text_model.embeddings.token_embedding.weight"),
-                             self._f("text_model.embeddings.position_embedding.weight"), self._err_flag)
-        x = self._encoder(x, "text_model", self.tcfg, batch, ctx, cdt)
-        y, _, _ = ops.layernorm_fwd(x, self._f("text_model.final_layer_norm.weight"),
-                                    self._f("text_model.final_layer_norm.bias"), torch.float32, eps=LN_EPS)
-        return y
+    def backward(self, tower: str, d_tokens: torch.Tensor, grad_view) -> None:
+        """Adapter gradients of one tower from d loss / d (its output tokens), fp32 [M, W] in the row
+        order of the last vision_tokens / text_tokens call.  `grad_view(param)` names the buffer
+        each gradient is WRITTEN to (the model's gradient arena)."""
+        if not self.lora:
+            raise RuntimeError("SiglipTowers.backward: the towers are frozen (lora=None)")
+        S = self._saved.pop(tower, None)
+        if S is None:
+            raise RuntimeError(f"SiglipTowers.backward({tower}): no forward with gradients enabled preceded it")
+        cfg = self.vcfg if tower == "vision_model" else self.tcfg
+        fin_name = "vision_model.post_layernorm" if tower == "vision_model" else "text_model.final_layer_norm"
+        cdt = S["cdt"]
+        x, m, r = S["fin"]
+        w = cfg["hidden_size"]
+        junk_g = torch.empty(w, dtype=torch.float32, device=x.device)
+        junk_b = torch.empty(w, dtype=torch.float32, device=x.device)
+        dx, dx_c = ops.layernorm_bwd(d_tokens.contiguous(), x, self._f(fin_name + ".weight"), m, r, None, cdt,
+                                     junk_g, junk_b)
+        self._encoder_bwd(dx, dx_c, S["layers"], tower, cfg, S["batch"], S["seq"], cdt, grad_view)
 
     def check_token_ids(self) -> None:
         if self._err_flag is not None and int(self._err_flag.item()) != 0:
@@ -181,7 +357,7 @@ class SiglipTowers(nn.Module):
             raise IndexError("instruction contains a token id outside the SigLIP vocabulary")
 
 
-def from_pretrained(name: str, checkpoint: Optional[str] = None) -> SiglipTowers:
+def from_pretrained(name: str, checkpoint: Optional[str] = None, lora: Optional[Dict] = None) -> SiglipTowers:
     """Stand-in for AutoModel.from_pretrained (no network): build the towers from the named
     checkpoint's hyper-parameters and fill them from a local copy when one is given: the
     Hugging Face snapshot directory, its model.safetensors, or a state dict with the same
@@ -189,10 +365,13 @@ def from_pretrained(name: str, checkpoint: Optional[str] = None) -> SiglipTowers
     if name not in SIGLIP_CONFIGS:
         raise ValueError(f"unknown SigLIP model {name!r}; known: {sorted(SIGLIP_CONFIGS)}")
     cfg = SIGLIP_CONFIGS[name]
-    model = SiglipTowers(cfg["vision"], cfg["text"])
+    model = SiglipTowers(cfg["vision"], cfg["text"], lora=lora)
     if checkpoint:
         from .checkpoint_io import load_into, read_state_dict
-        load_into(model, read_state_dict(checkpoint), f"SigLIP {name}")
+        # a published (HF-named) file fills the base weights of a LoRA-wrapped tower too; the adapters
+        # keep their initialisation unless the file (a PEFT-named fine-tuned checkpoint) carries them
+        sd = {model._real.get(k, k): v for k, v in read_state_dict(checkpoint).items()}
+        load_into(model, sd, f"SigLIP {name}", optional_containing=(".lora_",))
     else:
         warnings.warn(f"SigLIP {name}: no checkpoint given, using random initialisation "
                       f"(set model.siglip_checkpoint=<snapshot dir | model.safetensors | state_dict.pt>)")

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 2
+#define BF_ABI_VERSION 3
 
 enum { BF_F32 = 0, BF_BF16 = 1 };
 
@@ -96,7 +96,8 @@ int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
  *   act: BF_ACT_NONE | BF_ACT_QUICK_GELU (x*sigmoid(1.702x), clip/model.py:187-189)
  *        | BF_ACT_ERF_GELU (nn.GELU, modules.py:23); `pre` (cdt, optional) receives v
  *        before the activation (saved for backward);
- *        BF_ACT_ERF_GELU_GRAD: v *= gelu'(aux[m,n]) (aux = saved pre-activation, cdt)
+ *        BF_ACT_ERF_GELU_GRAD / BF_ACT_TANH_GELU_GRAD: v *= gelu'(aux[m,n]) (aux = saved
+ *        pre-activation, cdt)
  *   v += residual[r(m), n]  (fp32; row r = m % resid_mod if resid_mod > 0, else the
  *        output row)
  *   out row = (m / rows_in) * rows_out + row_off + m % rows_in   (rows_in = 0: identity)
@@ -104,7 +105,8 @@ int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
  *   c2 (optional, BF16) receives a bf16 copy of v at the same position.
  * ---------------------------------------------------------------------- */
 enum { BF_ACT_NONE = 0, BF_ACT_QUICK_GELU = 1, BF_ACT_ERF_GELU = 2, BF_ACT_ERF_GELU_GRAD = 3,
-       BF_ACT_TANH_GELU = 4 /* gelu_pytorch_tanh: the MLP of transformers' SiglipModel */ };
+       BF_ACT_TANH_GELU = 4 /* gelu_pytorch_tanh: the MLP of transformers' SiglipModel */,
+       BF_ACT_TANH_GELU_GRAD = 5 /* v *= d/dx gelu_pytorch_tanh at aux[m,n] (LoRA: tower backward) */ };
 
 typedef struct bf_gemm_args {
     const void* a;
@@ -119,7 +121,7 @@ typedef struct bf_gemm_args {
     const float* bias;       /* [n] or NULL                                        */
     int act;
     void* pre;               /* optional [m, ldc] cdt                              */
-    const void* aux;         /* BF_ACT_ERF_GELU_GRAD: [m, ld_aux] cdt              */
+    const void* aux;         /* BF_ACT_*_GELU_GRAD: [m, ld_aux] cdt                */
     int ld_aux;
     const float* residual;   /* optional fp32, leading dimension ld_res            */
     int ld_res;

@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
     for name in declared:
         assert hasattr(L.lib, name)
-    assert L.lib.bf_abi_version() == 2
+    assert L.lib.bf_abi_version() == L.ABI_VERSION == 3
 
 
 def test_c_abi_rejects_bad_arguments_before_launching():
@@ -195,10 +195,31 @@ def test_siglip_state_dict_schema_matches_reference(golden_dir, name, fixture, e
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = Models.get_by_name(dict(cfg), device=torch.device("cpu"))
-        with pytest.raises(NotImplementedError, match="peft"):
+        with pytest.raises(ValueError, match="lora_dropout"):       # merged adapters: no dropout on their input
             Models.get_by_name(dict(cfg, lora=True), device=torch.device("cpu"))
+        ml = Models.get_by_name(dict(cfg, lora=True, lora_dropout=0.0), device=torch.device("cpu"))
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
     assert all("siglip_model" in n for n, p in m.named_parameters() if not p.requires_grad)
+    # lora=True: PEFT's key layout after LoraModel(model, config, "siglip_adapter") (models/siglip.py:33-40) --
+    # base_model.model. prefix, adapted Linears under .base_layer, adapters under lora_{A,B}.<adapter>
+    def peft_name(k):
+        if not k.startswith("siglip_model."):
+            return k
+        k = "siglip_model.base_model.model." + k[len("siglip_model."):]
+        for t in ("q_proj", "v_proj"):
+            k = k.replace(f".self_attn.{t}.", f".self_attn.{t}.base_layer.")
+        return k
+    want = {peft_name(k): v for k, v in ref.items()}
+    for tower in ("vision_model", "text_model"):
+        for i in range(2):
+            for t in ("q_proj", "v_proj"):
+                base = f"siglip_model.base_model.model.{tower}.encoder.layers.{i}.self_attn.{t}."
+                want[base + "lora_A.siglip_adapter.weight"] = (8, 64)
+                want[base + "lora_B.siglip_adapter.weight"] = (64, 8)
+    assert {k: tuple(v.shape) for k, v in ml.state_dict().items()} == want
+    train = {n for n, p in ml.named_parameters() if p.requires_grad}
+    assert {n for n in train if "siglip_model" in n} == {k for k in want if ".lora_" in k}
+    assert all(float(p.abs().max()) == 0 for n, p in ml.named_parameters() if ".lora_B." in n)
 
 
 def test_siglip_config_resolves():
