@@ -269,8 +269,10 @@ class SiglipTowers(nn.Module):
                     continue
                 la, lb = self.lora_params(tower, i, f"{n}_proj")
                 dwp = dw[slot * w:(slot + 1) * w]
-                ops.gemm(dwp, la.data, alpha=scale, out=grad_view(lb))                            # [out, in] [r, in]^T
-                ops.gemm(lb.data, dwp, trans_a=True, b_kn=True, alpha=scale, out=grad_view(la))  # [out, r]^T [out, in]
+                # 8-wide outputs: a handful of tiles, so the contraction is split to occupy more CUs
+                sk = 8 if w % 256 == 0 else 1
+                ops.gemm(dwp, la.data, alpha=scale, out=grad_view(lb), split_k=sk)                            # dW A^T
+                ops.gemm(lb.data, dwp, trans_a=True, b_kn=True, alpha=scale, out=grad_view(la), split_k=sk)  # B^T dW
             dh1 = ops.gemm(dqkv, self._packed[b + "self_attn.w"], b_kn=True)
             dx, dx_c = ops.layernorm_bwd(dh1, S["x"], self._f(b + "layer_norm1.weight"), S["m1"], S["r1"], dxm, cdt,
                                          junk_g, junk_b)
