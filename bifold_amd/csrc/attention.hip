@@ -1146,6 +1146,318 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
     }
 }
 
+// =====================================================================================
+//   The split pair for sequences that do NOT fit LDS (SigLIP towers at 384 px: 576 tokens;
+//   the sequential fusion: 642 - 2 950 tokens): same two kernels, the resident operand streamed
+// =====================================================================================
+// attn_bwd_mfma_kernel handles these lengths with key chunks across workgroups, query tiles
+// restaged per chunk, one barrier per 32-query step and dQ reduced through LDS and fp32 atomics:
+// 218 TFLOP/s at 2 373 x 48.  Here the wave keeps ITS 32 queries (or keys) in registers for the
+// whole kernel, exactly as in attn_bwd_q_kernel / attn_bwd_kv_kernel, and the other operand walks
+// through LDS in chunks of CH rows: two barriers per CHUNK, no dQ reduction, no atomics, no dq_ws.
+template <int D, int MASK>
+__global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_q_stream_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    float* __restrict__ delta_ws, int L, int H, float scale, int CH) {
+    constexpr int mask_mode = MASK;
+    constexpr int DP = (D + 31) / 32 * 32;
+    constexpr int KS = D / 16;
+    constexpr int DB = DP / 32;
+    constexpr int KROW = DP * 2 + 16;         // K rows padded to DP columns (zero) for the transposed reads
+    constexpr int VROW = D * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* v_lds = smem + (size_t)CH * KROW;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int nwaves = blockDim.x >> 6;
+    const int q0 = (blockIdx.y * nwaves + wave) * 32;
+    const int qi = q0 + r;
+    const bool q_live = qi < L;
+    const bool wave_live = q0 < L;
+    const int nthreads = blockDim.x;
+
+    bf16x8 qf[KS], dof[KS];
+    float delta = 0.f, lse_q = 1e30f;
+    bool row_masked = false;
+    if (q_live) {
+        const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+            dof[ks] = *(const bf16x8*)(dout + oo + ks * 16 + hh * 8);
+        }
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
+            const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta = fmaf((float)ov[e], (float)gv[e], delta);
+        }
+        lse_q = lse[((size_t)b * H + h) * L + qi];
+        row_masked = mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
+        if (hh == 0) delta_ws[((size_t)b * H + h) * L + qi] = delta;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qf[ks][e] = (bf16_t)0.f; dof[ks][e] = (bf16_t)0.f; }
+    }
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const float s_init = -lse_q * inv_scale;
+
+    f32x16 dqacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dqacc[db][e] = 0.f;
+    const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
+    // keys any wave of this workgroup needs (uniform: every wave walks the same chunks)
+    const int wg_key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, (int)(blockIdx.y + 1) * nwaves * 32) : L;
+
+    for (int c0 = 0; c0 < wg_key_end; c0 += CH) {
+        __syncthreads();                          // the previous chunk is consumed
+        for (int idx = threadIdx.x; idx < CH * (DP / 8); idx += nthreads) {
+            const int jl = idx / (DP / 8), c = idx - jl * (DP / 8);
+            const int j = c0 + jl;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (j < L && c < D / 8) {
+                kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+                vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+            }
+            *(uint4*)(k_lds + jl * KROW + c * 16) = kv;
+            if (c < D / 8) *(uint4*)(v_lds + jl * VROW + c * 16) = vv;
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+        const int kend = min(key_end, c0 + CH);
+        for (int j0 = c0; j0 < kend; j0 += 32) {
+            const int jl = j0 - c0;
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(k_lds + (jl + r) * KROW + ks * 32 + hh * 16);
+                const bf16x8 vf = *(const bf16x8*)(v_lds + (jl + r) * VROW + ks * 32 + hh * 16);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+            }
+            const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
+            const f32x2 sl2v = {sl2, sl2}, scalev = {scale, scale};
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
+                if (edge) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int key = j0 + ((e + u) & 3) + 8 * ((e + u) >> 2) + 4 * hh;
+                        if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) ds2[u] = 0.f;
+                    }
+                }
+                sacc[e] = ds2[0];
+                sacc[e + 1] = ds2[1];
+            }
+            if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[8 * s + e];
+                const int row0 = jl + 16 * s + 4 * hh + q4;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                    const bf16x8 kt = tr_pair(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
+                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, pf, dqacc[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (q_live) {
+        bf16_t* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)dqacc[db][4 * g + e];
+                    *(bf16x4*)(dq + d0) = o4;
+                }
+            }
+    }
+}
+
+template <int D, int MASK>
+__global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_kv_stream_kernel(
+    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    int L, int H, float scale, int CH) {
+    constexpr int mask_mode = MASK;
+    using Cf = BwdCfg<D>;
+    constexpr int KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* q_lds = smem;
+    char* do_lds = q_lds + (size_t)CH * ROW + 64;
+    float* lse_s = (float*)(do_lds + (size_t)CH * ROW + 64);
+    float* del_s = lse_s + CH;
+    int* msk_s = (int*)(del_s + CH);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int w = blockIdx.y * nwaves + wave;     // this wave's 32-key block
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int nthreads = blockDim.x;
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const bool wave_live = w * 32 < L;
+    const int nblk = CH >> 5;                     // 32-query blocks per chunk
+
+    const int key = w * 32 + r;
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (key < L) {
+            kf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
+            vf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[ks][e] = (bf16_t)0.f; vf[ks][e] = (bf16_t)0.f; }
+        }
+    }
+    f32x16 dkacc[DB], dvacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[db][e] = 0.f; dvacc[db][e] = 0.f; }
+    const float inv_len = 1.0f / (float)L;
+    const float lane_on = key < L ? 1.0f : 0.0f;
+    const int wg_first_key = (int)blockIdx.y * nwaves * 32;
+
+    for (int c0 = 0; c0 < L; c0 += CH) {
+        // causal: queries before the workgroup's first key see none of its keys
+        if (mask_mode == BF_MASK_CAUSAL && c0 + CH - 1 < wg_first_key) continue;
+        __syncthreads();                          // the previous chunk is consumed
+        for (int idx = threadIdx.x; idx < CH * (D / 8); idx += nthreads) {
+            const int il = idx / (D / 8), c = idx - il * (D / 8);
+            const int i = c0 + il;
+            uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
+            if (i < L) {
+                qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
+                dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
+            }
+            *(uint4*)(q_lds + il * ROW + c * 16) = qv;
+            *(uint4*)(do_lds + il * ROW + c * 16) = dv;
+        }
+        for (int il = threadIdx.x; il < CH; il += nthreads) {
+            float dl = 0.f, ls = 1e30f;
+            int mk = 0;
+            const int i = c0 + il;
+            if (i < L) {
+                ls = lse[((size_t)b * H + h) * L + i];
+                dl = delta_ws[((size_t)b * H + h) * L + i];
+                mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
+            }
+            lse_s[il] = ls; del_s[il] = dl; msk_s[il] = mk;
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+
+        for (int t = 0; t < nblk; ++t) {
+            int qb = wave + t;                    // staggered start: spreads the LDS rows touched per step
+            if (qb >= nblk) qb -= nblk;
+            if (qb >= nblk) qb -= nblk;
+            const int lq0 = qb * 32;              // row inside the chunk
+            const int qrow0 = c0 + lq0;           // query index
+            if (qrow0 >= L || ((mask_mode == BF_MASK_CAUSAL) && (qrow0 + 31 < w * 32))) continue;
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *(const float4*)(lse_s + lq0 + 8 * g + 4 * hh);
+                const float4 d4 = *(const float4*)(del_s + lq0 + 8 * g + 4 * hh);
+                sacc[4 * g + 0] = -l4.x * inv_scale; sacc[4 * g + 1] = -l4.y * inv_scale;
+                sacc[4 * g + 2] = -l4.z * inv_scale; sacc[4 * g + 3] = -l4.w * inv_scale;
+                pacc[4 * g + 0] = -d4.x; pacc[4 * g + 1] = -d4.y; pacc[4 * g + 2] = -d4.z; pacc[4 * g + 3] = -d4.w;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 qa = *(const bf16x8*)(q_lds + (lq0 + r) * ROW + ks * 32 + hh * 16);
+                const bf16x8 da = *(const bf16x8*)(do_lds + (lq0 + r) * ROW + ks * 32 + hh * 16);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+            }
+            const f32x2 sl2v = {sl2, sl2}, onv = {lane_on, lane_on}, scalev = {scale, scale};
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2 tt = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+                f32x2 p2 = (f32x2){__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])} * onv;
+                f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
+                if (mask_mode != BF_MASK_NONE) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int lql = lq0 + ((e + u) & 3) + 8 * ((e + u) >> 2) + 4 * hh;
+                        if (mask_mode == BF_MASK_QUERY_ROW && msk_s[lql]) { p2[u] = inv_len * lane_on; ds2[u] = 0.f; }
+                        if (mask_mode == BF_MASK_CAUSAL && key > c0 + lql) { p2[u] = 0.f; ds2[u] = 0.f; }
+                    }
+                }
+                sacc[e] = p2[0]; sacc[e + 1] = p2[1];
+                pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
+            }
+            bf16x8 pb[2], dsb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int row0 = lq0 + 16 * s + 4 * hh + q4;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                    const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                    const bf16x8 qtt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
+                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtt, dsb[s], dkacc[db], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if (key < L) {
+        bf16_t* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+        bf16_t* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = db * 32 + 8 * g + 4 * hh;
+                if (d0 < D) {
+                    bf16x4 k4, v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { k4[e] = (bf16_t)dkacc[db][4 * g + e]; v4[e] = (bf16_t)dvacc[db][4 * g + e]; }
+                    *(bf16x4*)(dkp + d0) = k4;
+                    *(bf16x4*)(dvp + d0) = v4;
+                }
+            }
+    }
+}
+
 // dq_ws fp32 [B, L, H*D] -> the Q slot of dqkv [B, L, 3, H, D] (bf16)
 __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, bf16_t* __restrict__ dqkv,
                                                            size_t rows, int hd) {
@@ -1352,6 +1664,59 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             else BWD_SPLIT(64);
 #undef BWD_SPLIT
 #undef BWD_SPLIT2
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            return BF_OK;
+        }
+    }
+    {   // longer sequences: the same pair with the resident operand streamed through LDS in chunks
+        static int stream_env = -1;
+        if (stream_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_STREAM"); stream_env = e ? atoi(e) : 1; }
+        const int nq32 = bf_cdiv(seq, 32);
+        if (cdt == BF_BF16 && stream_env && nq32 > 8) {
+            // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
+            // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)
+            static int ch_env = -1, wpb_env = -1;
+            if (ch_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_CH"); ch_env = e ? atoi(e) : 0; }
+            if (wpb_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_WPB"); wpb_env = e ? atoi(e) : 0; }
+            // measured at 2 373 x 48 and 576 x 64 (tools/attn_bench.py --family siglip): 128-row chunks with
+            // 4-wave workgroups 1.85 / 0.47 ms, 256-row chunks 1.99 / 0.52, 8 waves 1.91-1.98 / 0.53
+            const int CH = (ch_env >= 32 && ch_env <= 512 && ch_env % 32 == 0) ? ch_env : (head_dim == 32 ? 256 : 128);
+            const int wpb = (wpb_env >= 1 && wpb_env <= (head_dim == 32 ? 16 : 8)) ? wpb_env : (head_dim == 32 ? 8 : 4);
+            const int dp = (head_dim + 31) / 32 * 32, row = head_dim * 2 + 16;
+            const size_t lds_q = (size_t)CH * ((dp * 2 + 16) + row);
+            const size_t lds_kv = 2 * ((size_t)CH * row + 64) + 3 * (size_t)CH * 4;
+            dim3 grid(batch * heads, bf_cdiv(nq32, wpb)), block(wpb * 64);
+#define BWD_STREAM2(DD, MM)                                                                         \
+    do {                                                                                            \
+        static size_t set_q = 0, set_kv = 0;                                                        \
+        if (lds_q > set_q) {                                                                        \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_stream_kernel<DD, MM>,                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
+            set_q = lds_q;                                                                          \
+        }                                                                                           \
+        if (lds_kv > set_kv) {                                                                      \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_stream_kernel<DD, MM>,               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
+            set_kv = lds_kv;                                                                        \
+        }                                                                                           \
+        hipLaunchKernelGGL((attn_bwd_q_stream_kernel<DD, MM>), grid, block, lds_q, s, (const bf16_t*)qkv, \
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,   \
+                           delta_ws, seq, heads, scale, CH);                                        \
+        hipLaunchKernelGGL((attn_bwd_kv_stream_kernel<DD, MM>), grid, block, lds_kv, s, (const bf16_t*)qkv, \
+                           (const bf16_t*)dout, lse, (const float*)delta_ws, row_mask,              \
+                           (bf16_t*)dqkv, seq, heads, scale, CH);                                   \
+    } while (0)
+#define BWD_STREAM(DD)                                                                              \
+    do {                                                                                            \
+        if (mask_mode == BF_MASK_NONE) BWD_STREAM2(DD, BF_MASK_NONE);                               \
+        else if (mask_mode == BF_MASK_CAUSAL) BWD_STREAM2(DD, BF_MASK_CAUSAL);                      \
+        else BWD_STREAM2(DD, BF_MASK_QUERY_ROW);                                                    \
+    } while (0)
+            if (head_dim == 32) BWD_STREAM(32);
+            else if (head_dim == 48) BWD_STREAM(48);
+            else BWD_STREAM(64);
+#undef BWD_STREAM
+#undef BWD_STREAM2
             BF_CHECK_LAUNCH("bf_attention_bwd");
             return BF_OK;
         }

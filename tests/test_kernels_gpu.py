@@ -320,7 +320,11 @@ def test_attention_fwd(ops, gpu, B, Lq, H, D, mode, cdt):
                                             (2, 90, 2, 48, 2), (1, 512, 2, 32, 0), (2, 130, 3, 32, 1),
                                             (1, 200, 2, 48, 0), (1, 300, 1, 64, 0), (1, 600, 1, 32, 2),
                                             (1, 853, 2, 48, 2), (2, 400, 2, 32, 1), (1, 1000, 1, 64, 0),
-                                            (1, 353, 1, 32, 0), (1, 225, 1, 48, 1)])
+                                            (1, 353, 1, 32, 0), (1, 225, 1, 48, 1),
+                                            # streamed split pair (sequences beyond LDS): causal across chunks,
+                                            # ragged last chunk, every head width
+                                            (1, 700, 2, 64, 1), (1, 577, 2, 48, 1), (1, 900, 1, 32, 0),
+                                            (2, 576, 2, 64, 0), (1, 1290, 1, 48, 2)])
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_attention_bwd(ops, gpu, B, Lq, H, D, mode, cdt):
     g = torch.Generator().manual_seed(Lq + D)

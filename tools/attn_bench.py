@@ -12,20 +12,27 @@ from bifold_amd.hip import ops  # noqa: E402
 SHAPES = [("vision", 256, 197, 12, 64, 0), ("text", 256, 77, 8, 64, 1), ("fusion", 256, 275, 16, 32, 0)]
 
 
+SIGLIP_SHAPES = [("vision384", 64, 576, 12, 64, 0), ("text", 16, 64, 12, 64, 0), ("fusion", 16, 2373, 16, 48, 2)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--family", default="clip", choices=["clip", "siglip"],
+                    help="siglip: the long sequences of siglip_sequential at 384 px (B = 16, T = 3)")
     args = ap.parse_args()
+    shapes = SHAPES if args.family == "clip" else SIGLIP_SHAPES
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
-    for name, B, L, H, D, mode in SHAPES:
+    for name, B, L, H, D, mode in shapes:
         qkv = torch.randn(B * L, 3 * H * D, device=dev, generator=g).bfloat16()
         dout = torch.randn(B * L, H * D, device=dev, generator=g).bfloat16()
-        out, lse = ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, None, need_lse=True)
-        fns = {"fwd": lambda: ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, None, need_lse=True)}
+        rm = (torch.rand(B, L, device=dev, generator=g) > 0.25).int() if mode == 2 else None
+        out, lse = ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, rm, need_lse=True)
+        fns = {"fwd": lambda: ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, rm, need_lse=True)}
         if args.bwd:
-            fns["bwd"] = lambda: ops.attention_bwd(qkv, out, dout, lse, B, L, H, D, D ** -0.5, mode, None)
+            fns["bwd"] = lambda: ops.attention_bwd(qkv, out, dout, lse, B, L, H, D, D ** -0.5, mode, rm)
         for tag, fn in fns.items():
             ts = []
             for r in range(args.rounds + 1):
