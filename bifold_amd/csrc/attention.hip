@@ -1155,17 +1155,35 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
 // 218 TFLOP/s at 2 373 x 48.  Here the wave keeps ITS 32 queries (or keys) in registers for the
 // whole kernel, exactly as in attn_bwd_q_kernel / attn_bwd_kv_kernel, and the other operand walks
 // through LDS in chunks of CH rows: two barriers per CHUNK, no dQ reduction, no atomics, no dq_ws.
+// Geometry of the streamed pair (measured, tools/attn_bench.py --family siglip: 128-row chunks and
+// 4-wave workgroups 1.85 / 0.47 ms at 2 373 x 48 / 576 x 64; 256 rows 1.99 / 0.52; 8 waves 1.91 / 0.53).
+// With the next chunk's rows held in registers the kernels need 190 - 245 registers, so a CU runs 8 waves as
+// two workgroups of 4 (one stages while the other computes).  Compile-time so that the prefetch lives in a
+// fixed set of registers.
+template <int D>
+struct StreamCfg {
+    static constexpr int CH = 128;                          // rows per chunk
+    static constexpr int WPB = 4;                           // waves per workgroup
+    static constexpr int NT = WPB * 64;
+    static constexpr int DP = (D + 31) / 32 * 32;
+    static constexpr int NPF_Q = CH * (DP / 8) / NT;        // 16-byte pieces per thread and operand (q kernel: K, V)
+    static constexpr int NPF_KV = (CH * (D / 8) + NT - 1) / NT;   // (kv kernel: Q, dO)
+};
+
 template <int D, int MASK>
-__global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_q_stream_kernel(
+__global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
-    float* __restrict__ delta_ws, int L, int H, float scale, int CH) {
+    float* __restrict__ delta_ws, int L, int H, float scale) {
     constexpr int mask_mode = MASK;
+    using SC = StreamCfg<D>;
+    constexpr int CH = SC::CH, NPF = SC::NPF_Q, NT = SC::NT;
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;
     constexpr int DB = DP / 32;
     constexpr int KROW = DP * 2 + 16;         // K rows padded to DP columns (zero) for the transposed reads
     constexpr int VROW = D * 2 + 16;
+    constexpr int CPR = DP / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
     char* v_lds = smem + (size_t)CH * KROW;
@@ -1174,12 +1192,37 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_q_stream_kernel
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
-    const int nwaves = blockDim.x >> 6;
+    const int nwaves = SC::WPB;
     const int q0 = (blockIdx.y * nwaves + wave) * 32;
     const int qi = q0 + r;
     const bool q_live = qi < L;
     const bool wave_live = q0 < L;
-    const int nthreads = blockDim.x;
+
+    // The NEXT chunk's K / V rows travel in registers while the current chunk is being consumed:
+    // unconditional loads from clamped addresses (the compiler then counts vmcnt instead of draining
+    // it), zeros substituted when the registers are written to LDS.
+    uint4 pk[NPF], pv[NPF];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int j = min(c0 + idx / CPR, L - 1), c = min(idx % CPR, D / 8 - 1);
+            pk[i] = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+            pv[i] = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+        }
+    };
+    auto stash = [&](int c0) {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int jl = idx / CPR, c = idx - jl * CPR;
+            uint4 kq = pk[i], vq = pv[i];
+            if (!(c0 + jl < L && c < D / 8)) { kq = z4; vq = z4; }
+            *(uint4*)(k_lds + jl * KROW + c * 16) = kq;
+            if (c < D / 8) *(uint4*)(v_lds + jl * VROW + c * 16) = vq;
+        }
+    };
 
     bf16x8 qf[KS], dof[KS];
     float delta = 0.f, lse_q = 1e30f;
@@ -1220,20 +1263,12 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_q_stream_kernel
     // keys any wave of this workgroup needs (uniform: every wave walks the same chunks)
     const int wg_key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, (int)(blockIdx.y + 1) * nwaves * 32) : L;
 
+    fetch(0);
     for (int c0 = 0; c0 < wg_key_end; c0 += CH) {
         __syncthreads();                          // the previous chunk is consumed
-        for (int idx = threadIdx.x; idx < CH * (DP / 8); idx += nthreads) {
-            const int jl = idx / (DP / 8), c = idx - jl * (DP / 8);
-            const int j = c0 + jl;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (j < L && c < D / 8) {
-                kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
-                vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
-            }
-            *(uint4*)(k_lds + jl * KROW + c * 16) = kv;
-            if (c < D / 8) *(uint4*)(v_lds + jl * VROW + c * 16) = vv;
-        }
+        stash(c0);
         __syncthreads();
+        if (c0 + CH < wg_key_end) fetch(c0 + CH); // in flight under this chunk's MFMAs
         if (!wave_live) continue;
         const int kend = min(key_end, c0 + CH);
         for (int j0 = c0; j0 < kend; j0 += 32) {
@@ -1303,13 +1338,16 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_q_stream_kernel
 }
 
 template <int D, int MASK>
-__global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_kv_stream_kernel(
+__global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
-    int L, int H, float scale, int CH) {
+    int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
+    using SC = StreamCfg<D>;
+    constexpr int CH = SC::CH, NPF = SC::NPF_KV, NT = SC::NT;
     constexpr int KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
+    constexpr int CPR = D / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* q_lds = smem;
     char* do_lds = q_lds + (size_t)CH * ROW + 64;
@@ -1318,16 +1356,55 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_kv_stream_kerne
     int* msk_s = (int*)(del_s + CH);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwaves = blockDim.x >> 6;
+    const int nwaves = SC::WPB;
     const int w = blockIdx.y * nwaves + wave;     // this wave's 32-key block
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
-    const int nthreads = blockDim.x;
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
     const bool wave_live = w * 32 < L;
-    const int nblk = CH >> 5;                     // 32-query blocks per chunk
+    constexpr int nblk = CH >> 5;                 // 32-query blocks per chunk
+
+    // next chunk's Q / dO rows (+ lse, delta, mask of its first CH <= NT rows) in registers, as in the q kernel
+    static_assert(CH <= NT, "one lse / delta / mask entry per thread");
+    uint4 pq[NPF], pd[NPF];
+    float p_ls = 1e30f, p_dl = 0.f;
+    int p_mk = 0;
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = min((int)threadIdx.x + i * NT, CH * CPR - 1);
+            const int il = idx / CPR, c = idx - il * CPR;
+            const int i_g = min(c0 + il, L - 1);
+            pq[i] = *(const uint4*)(qkv + qkv_off(b, i_g, 0, h, L, H, D) + c * 8);
+            pd[i] = *(const uint4*)(dout + ((size_t)b * L + i_g) * (size_t)H * D + (size_t)h * D + c * 8);
+        }
+        const int i_g = min(c0 + (int)threadIdx.x, L - 1);
+        p_ls = lse[((size_t)b * H + h) * L + i_g];
+        p_dl = delta_ws[((size_t)b * H + h) * L + i_g];
+        if (mask_mode == BF_MASK_QUERY_ROW) p_mk = row_mask[(size_t)b * L + i_g] == 0;
+    };
+    auto stash = [&](int c0) {
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int idx = threadIdx.x + i * NT;
+            const int il = idx / CPR, c = idx - il * CPR;
+            uint4 qv = pq[i], dv = pd[i];
+            if (!(c0 + il < L)) { qv = z4; dv = z4; }
+            if (idx < CH * CPR) {
+                *(uint4*)(q_lds + il * ROW + c * 16) = qv;
+                *(uint4*)(do_lds + il * ROW + c * 16) = dv;
+            }
+        }
+        if ((int)threadIdx.x < CH) {
+            const bool live = c0 + (int)threadIdx.x < L;
+            lse_s[threadIdx.x] = live ? p_ls : 1e30f;
+            del_s[threadIdx.x] = live ? p_dl : 0.f;
+            msk_s[threadIdx.x] = live ? p_mk : 0;
+        }
+    };
 
     const int key = w * 32 + r;
     bf16x8 kf[KS], vf[KS];
@@ -1350,33 +1427,14 @@ __global__ __launch_bounds__(D == 32 ? 1024 : 512) void attn_bwd_kv_stream_kerne
     const float lane_on = key < L ? 1.0f : 0.0f;
     const int wg_first_key = (int)blockIdx.y * nwaves * 32;
 
-    for (int c0 = 0; c0 < L; c0 += CH) {
-        // causal: queries before the workgroup's first key see none of its keys
-        if (mask_mode == BF_MASK_CAUSAL && c0 + CH - 1 < wg_first_key) continue;
+    // causal: query chunks before the workgroup's first key see none of its keys
+    const int c_first = (mask_mode == BF_MASK_CAUSAL) ? (wg_first_key / CH) * CH : 0;
+    fetch(c_first);
+    for (int c0 = c_first; c0 < L; c0 += CH) {
         __syncthreads();                          // the previous chunk is consumed
-        for (int idx = threadIdx.x; idx < CH * (D / 8); idx += nthreads) {
-            const int il = idx / (D / 8), c = idx - il * (D / 8);
-            const int i = c0 + il;
-            uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
-            if (i < L) {
-                qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
-                dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
-            }
-            *(uint4*)(q_lds + il * ROW + c * 16) = qv;
-            *(uint4*)(do_lds + il * ROW + c * 16) = dv;
-        }
-        for (int il = threadIdx.x; il < CH; il += nthreads) {
-            float dl = 0.f, ls = 1e30f;
-            int mk = 0;
-            const int i = c0 + il;
-            if (i < L) {
-                ls = lse[((size_t)b * H + h) * L + i];
-                dl = delta_ws[((size_t)b * H + h) * L + i];
-                mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
-            }
-            lse_s[il] = ls; del_s[il] = dl; msk_s[il] = mk;
-        }
+        stash(c0);
         __syncthreads();
+        if (c0 + CH < L) fetch(c0 + CH);          // in flight under this chunk's MFMAs
         if (!wave_live) continue;
 
         for (int t = 0; t < nblk; ++t) {
@@ -1675,13 +1733,8 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         if (cdt == BF_BF16 && stream_env && nq32 > 8) {
             // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
             // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)
-            static int ch_env = -1, wpb_env = -1;
-            if (ch_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_CH"); ch_env = e ? atoi(e) : 0; }
-            if (wpb_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_WPB"); wpb_env = e ? atoi(e) : 0; }
-            // measured at 2 373 x 48 and 576 x 64 (tools/attn_bench.py --family siglip): 128-row chunks with
-            // 4-wave workgroups 1.85 / 0.47 ms, 256-row chunks 1.99 / 0.52, 8 waves 1.91-1.98 / 0.53
-            const int CH = (ch_env >= 32 && ch_env <= 512 && ch_env % 32 == 0) ? ch_env : (head_dim == 32 ? 256 : 128);
-            const int wpb = (wpb_env >= 1 && wpb_env <= (head_dim == 32 ? 16 : 8)) ? wpb_env : (head_dim == 32 ? 8 : 4);
+            const int CH = head_dim == 32 ? StreamCfg<32>::CH : StreamCfg<64>::CH;       // see StreamCfg
+            const int wpb = head_dim == 32 ? StreamCfg<32>::WPB : StreamCfg<64>::WPB;
             const int dp = (head_dim + 31) / 32 * 32, row = head_dim * 2 + 16;
             const size_t lds_q = (size_t)CH * ((dp * 2 + 16) + row);
             const size_t lds_kv = 2 * ((size_t)CH * row + 64) + 3 * (size_t)CH * 4;
@@ -1701,10 +1754,10 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         }                                                                                           \
         hipLaunchKernelGGL((attn_bwd_q_stream_kernel<DD, MM>), grid, block, lds_q, s, (const bf16_t*)qkv, \
                            (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,   \
-                           delta_ws, seq, heads, scale, CH);                                        \
+                           delta_ws, seq, heads, scale);                                            \
         hipLaunchKernelGGL((attn_bwd_kv_stream_kernel<DD, MM>), grid, block, lds_kv, s, (const bf16_t*)qkv, \
                            (const bf16_t*)dout, lse, (const float*)delta_ws, row_mask,              \
-                           (bf16_t*)dqkv, seq, heads, scale, CH);                                   \
+                           (bf16_t*)dqkv, seq, heads, scale);                                       \
     } while (0)
 #define BWD_STREAM(DD)                                                                              \
     do {                                                                                            \
