@@ -1683,7 +1683,14 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         static int split_env = -1;
         if (split_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SINGLE"); split_env = (e && atoi(e)) ? 0 : 1; }
         // (short causal sequences stay on the single kernel: 72 vs 116 us at L = 77)
-        if (cdt == BF_BF16 && split_env && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
+        static int res_wide_env = -1;     // d = 48 / 64 resident kernels spill at their 128-register cap: A/B switch
+        if (res_wide_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_RESIDENT_WIDE"); res_wide_env = e ? atoi(e) : 0; }
+        static int stream_min_env = -1;
+        if (stream_min_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_MIN_Q32"); stream_min_env = e ? atoi(e) : 1; }
+        static int stream_d32_env = -1;
+        if (stream_d32_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_D32"); stream_d32_env = e ? atoi(e) : 0; }
+        const bool wide_ok = (head_dim == 32 && !stream_d32_env) || res_wide_env || nq32 < stream_min_env;
+        if (cdt == BF_BF16 && split_env && wide_ok && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
             !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
             // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);
             // with larger images (d = 64: two workgroups per CU either way) one workgroup per (batch, head)
@@ -1730,7 +1737,11 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         static int stream_env = -1;
         if (stream_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_STREAM"); stream_env = e ? atoi(e) : 1; }
         const int nq32 = bf_cdiv(seq, 32);
-        if (cdt == BF_BF16 && stream_env && nq32 > 8) {
+        static int stream_min_env = -1;
+        if (stream_min_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_MIN_Q32"); stream_min_env = e ? atoi(e) : 1; }
+        static int stream_d32_env = -1;
+        if (stream_d32_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_D32"); stream_d32_env = e ? atoi(e) : 0; }
+        if (cdt == BF_BF16 && stream_env && nq32 >= ((head_dim == 32 && !stream_d32_env) ? 9 : stream_min_env)) {
             // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
             // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)
             const int CH = head_dim == 32 ? StreamCfg<32>::CH : StreamCfg<64>::CH;       // see StreamCfg

@@ -12,7 +12,7 @@ from bifold_amd.hip import ops  # noqa: E402
 SHAPES = [("vision", 256, 197, 12, 64, 0), ("text", 256, 77, 8, 64, 1), ("fusion", 256, 275, 16, 32, 0)]
 
 
-SIGLIP_SHAPES = [("vision384", 64, 576, 12, 64, 0), ("text", 16, 64, 12, 64, 0), ("fusion", 16, 2373, 16, 48, 2)]
+SIGLIP_SHAPES = [("vis224", 64, 196, 12, 64, 0), ("txt64", 64, 64, 12, 64, 0), ("fus224", 32, 262, 16, 48, 0), ("fus300", 32, 300, 12, 64, 0), ("vision384", 64, 576, 12, 64, 0), ("text", 16, 64, 12, 64, 0), ("fusion", 16, 2373, 16, 48, 2)]
 
 
 def main():
