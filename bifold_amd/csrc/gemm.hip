@@ -691,7 +691,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     };
 
     P8Item w;
-    int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
+    [[maybe_unused]] int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
     unsigned pend = 0;                 // thread 0: the ticket drawn for the next item
     if (threadIdx.x == 0) bcast[0] = atomicAdd(tk + xl, 1u);
     __syncthreads();
