@@ -1260,16 +1260,22 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqacc[db][e] = 0.f;
     const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
+    // query-row mask: a masked row's scores are the constant -1e5 (transformer.py:35), so nothing flows to
+    // Q or K through it; when all 32 rows of the wave are masked (whole context frames are) the wave only
+    // keeps the barriers company
+    const bool wave_masked = mask_mode == BF_MASK_QUERY_ROW && __all(row_masked || !q_live);
     // keys any wave of this workgroup needs (uniform: every wave walks the same chunks)
     const int wg_key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, (int)(blockIdx.y + 1) * nwaves * 32) : L;
 
-    fetch(0);
-    for (int c0 = 0; c0 < wg_key_end; c0 += CH) {
+    // a workgroup whose 128 queries are all masked (inside a masked context frame) streams nothing
+    const bool wg_idle = mask_mode == BF_MASK_QUERY_ROW && __syncthreads_and(wave_masked || !wave_live);
+    if (!wg_idle) fetch(0);
+    for (int c0 = 0; c0 < wg_key_end && !wg_idle; c0 += CH) {
         __syncthreads();                          // the previous chunk is consumed
         stash(c0);
         __syncthreads();
         if (c0 + CH < wg_key_end) fetch(c0 + CH); // in flight under this chunk's MFMAs
-        if (!wave_live) continue;
+        if (!wave_live || wave_masked) continue;  // masked query rows receive no gradient: dQ stays 0
         const int kend = min(key_end, c0 + CH);
         for (int j0 = c0; j0 < kend; j0 += 32) {
             const int jl = j0 - c0;
@@ -1444,6 +1450,27 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
             const int lq0 = qb * 32;              // row inside the chunk
             const int qrow0 = c0 + lq0;           // query index
             if (qrow0 >= L || ((mask_mode == BF_MASK_CAUSAL) && (qrow0 + 31 < w * 32))) continue;
+            if (mask_mode == BF_MASK_QUERY_ROW) {
+                // all 32 query rows masked (rows beyond L count as masked: their dO rows are zero): P = 1/L for
+                // every (query, key), dS = 0 -> only dV^T += dO^T P is left, no scores, no exp, no dK
+                const int qrow = qrow0 + r;
+                if (__all(msk_s[lq0 + r] != 0 || qrow >= L)) {
+                    bf16x8 pconst;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pconst[e] = (bf16_t)(inv_len * lane_on);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int row0 = lq0 + 16 * s + 4 * hh + q4;
+#pragma unroll
+                        for (int db = 0; db < DB; ++db) {
+                            const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                            const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pconst, dvacc[db], 0, 0, 0);
+                        }
+                    }
+                    continue;
+                }
+            }
             f32x16 sacc, pacc;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

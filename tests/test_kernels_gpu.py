@@ -345,6 +345,32 @@ def test_attention_bwd(ops, gpu, B, Lq, H, D, mode, cdt):
     assert rel_err(dqkv.float(), leaf.grad) < (2e-5 if cdt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("B,Lq,H,D,spans", [(2, 600, 2, 48, [(64, 256)]), (1, 1290, 1, 64, [(0, 33), (577, 1154)]),
+                                            (2, 700, 1, 32, [(100, 420), (650, 700)])])
+def test_attention_bwd_with_whole_masked_segments(ops, gpu, B, Lq, H, D, spans):
+    """siglip_sequential masks whole context frames (query rows, models/siglip.py:118-130): the streamed
+    backward skips 32-query blocks that are masked entirely (dQ = 0, dK untouched, dV += dO / L).  Spans
+    are chosen to start and end inside blocks as well as on their boundaries."""
+    g = torch.Generator().manual_seed(Lq * 3 + D)
+    qkv = bf16_round(torch.randn(B * Lq, 3 * H * D, generator=g))
+    dout = bf16_round(torch.randn(B * Lq, H * D, generator=g))
+    row_mask = torch.ones(B, Lq, dtype=torch.int32)
+    for a, b in spans:
+        row_mask[:, a:b] = 0
+    row_mask[0, 5] = 0                                    # and a lone masked row in a live block
+    leaf = qkv.double().requires_grad_(True)
+    ref_o, _ = ref_attention(leaf, B, Lq, H, D, D ** -0.5, 2, row_mask)
+    ref_o.backward(dout.double())
+    qg, rm = qkv.to(gpu).bfloat16(), row_mask.to(gpu)
+    out, lse = ops.attention_fwd(qg, B, Lq, H, D, D ** -0.5, 2, rm, need_lse=True)
+    assert rel_err(out.float(), ref_o.detach()) < 1.5e-2
+    dqkv = ops.attention_bwd(qg, out, dout.to(gpu).bfloat16(), lse, B, Lq, H, D, D ** -0.5, 2, rm)
+    assert rel_err(dqkv.float(), leaf.grad) < 2e-2
+    dq = dqkv.float().view(B, Lq, 3, H * D)[:, :, 0]
+    for a, b in spans:
+        assert float(dq[:, a:b].abs().max()) == 0.0       # masked queries receive exactly no gradient
+
+
 # ------------------------------------------------------------------ token plumbing
 @pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
 def test_patchify_matches_conv(ops, gpu, cdt):

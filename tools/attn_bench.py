@@ -28,7 +28,13 @@ def main():
     for name, B, L, H, D, mode in shapes:
         qkv = torch.randn(B * L, 3 * H * D, device=dev, generator=g).bfloat16()
         dout = torch.randn(B * L, H * D, device=dev, generator=g).bfloat16()
-        rm = (torch.rand(B, L, device=dev, generator=g) > 0.25).int() if mode == 2 else None
+        rm = None
+        if mode == 2:       # siglip_sequential's mask: [text | T context frames of 577 rows | current frame], the
+            rm = torch.ones(B, L, dtype=torch.int32, device=dev)      # first k ~ U{0..T} context frames valid
+            t = max((L - 65 - 577) // 577, 0)
+            k = torch.randint(0, t + 1, (B,), generator=torch.Generator().manual_seed(1))
+            for bi in range(B):
+                rm[bi, 65 + int(k[bi]) * 577: 65 + t * 577] = 0
         out, lse = ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, rm, need_lse=True)
         fns = {"fwd": lambda: ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, rm, need_lse=True)}
         if args.bwd:
