@@ -55,6 +55,26 @@ def synthetic_batch(batch: int, device, seed: int, size: int = 224, ctx: int = 7
     return sample
 
 
+def synthetic_sequential_batch(batch: int, device, seed: int, size: int = 384, frames: int = 4):
+    """SURVEY.md §8d inputs of configs[2] (siglip_sequential, bimanual): SigLIP ids (32 tokens + 32 pads of id 1,
+    int64), T context frames with the first k ~ U{0..T} valid, four Gaussian target maps."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sample = {"rgb": torch.randn(batch, 3, size, size, generator=g, device=device),
+              "rgb_context": torch.randn(batch, frames, 3, size, size, generator=g, device=device)}
+    instr = torch.ones(batch, 64, dtype=torch.int64, device=device)
+    instr[:, :32] = torch.randint(0, 32000, (batch, 32), generator=g, device=device)
+    sample["instruction"] = instr
+    k = torch.randint(0, frames + 1, (batch, 1), generator=g, device=device)
+    sample["context_attention_mask"] = (torch.arange(frames, device=device).view(1, -1) < k).long()
+    ys = torch.arange(size, device=device, dtype=torch.float32).view(1, size, 1)
+    xs = torch.arange(size, device=device, dtype=torch.float32).view(1, 1, size)
+    for name in ("left_pick", "left_place", "right_pick", "right_place"):
+        c = torch.randint(0, size, (batch, 2), generator=g, device=device).float()
+        sample[f"{name}_heatmap"] = torch.exp(-((xs - c[:, 0].view(-1, 1, 1)) ** 2 +
+                                                (ys - c[:, 1].view(-1, 1, 1)) ** 2) / 50.0).contiguous()
+    return sample
+
+
 def profiled_traffic(dom: str):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE /
     WRITE_SIZE passes are separate runs of this same command, as MI355X_MICROARCH.md prescribes, so they cannot be
@@ -120,9 +140,12 @@ def main():
     ap.add_argument("--host-fed", action="store_true",
                     help="diagnostic: the batch starts in pinned HOST memory every step (H2D copy on a side stream, "
                          "double-buffered) -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
-    ap.add_argument("--config", default="a", choices=["a", "vitl14"],
+    ap.add_argument("--config", default="a", choices=["a", "vitl14", "siglip_seq"],
                     help="a: BASELINE configs[1] (the metric); vitl14: configs[3], ViT-L/14 @336 (diagnostic line: "
-                         "no roofline, run with --batch 64)")
+                         "no roofline, run with --batch 64); siglip_seq: configs[2], siglip_sequential @384 with 4 "
+                         "context frames (diagnostic line, run with --batch 128; --lora trains the adapters)")
+    ap.add_argument("--lora", action="store_true", help="siglip_seq: LoRA adapters on q/v of both towers (the "
+                                                         "reference's default) instead of frozen towers")
     args = ap.parse_args()
 
     from bifold_amd import dist as bdist
@@ -141,20 +164,30 @@ def main():
 
     torch.manual_seed(3407)                       # identical replicas on every rank
     big = args.config == "vitl14"
+    seq = args.config == "siglip_seq"
     cfg = dict(name="rgb_clip", image_size=336 if big else 224, is_bimanual=False, requires_graph=False,
                text_encoder="ViT-L/14@336px" if big else "ViT-B/16", patch_size=14 if big else 16, depth=8,
                heads=16, mlp_ratio=4, dropout=0.0,
                text_dropout=0.0, rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
                fusion_model="concat_transformer", dtype=args.dtype)
+    if seq:
+        cfg = dict(name="siglip_sequential", image_size=384, is_bimanual=True, requires_graph=False, patch_size=16,
+                   automodel_name="google/siglip-base-patch16-384", dim=768, emb_dropout=0.0, lora=args.lora, r=8,
+                   lora_alpha=32, lora_dropout=0.0, target_modules=["q_proj", "v_proj"], threshold=0.5,
+                   text_encoder=None, pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer",
+                   depth=8, heads=16, mlp_ratio=4, dropout=0.0, dtype=args.dtype, context_length=4)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")           # random-init CLIP (no network for weights)
         model = Models.get_by_name(cfg, device=dev).to(dev)
     model.train()
-    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))
+    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=seq, mask_pick_heatmap=False))
     opt = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
                                  params=[p for p in model.parameters() if p.requires_grad])
-    sample = synthetic_batch(args.batch, dev, seed=3407 + rank, size=336 if big else 224,
-                             heat_size=384 if big else 0)
+    if seq:
+        sample = synthetic_sequential_batch(args.batch, dev, seed=3407 + rank)
+    else:
+        sample = synthetic_batch(args.batch, dev, seed=3407 + rank, size=336 if big else 224,
+                                 heat_size=384 if big else 0)
 
     sync = None
     if world > 1 or os.environ.get("BIFOLD_FORCE_PG") == "1":
@@ -223,15 +256,22 @@ def main():
         global_batch = args.batch * world
         ms = 1e3 * elapsed / args.steps
         value = global_batch * args.steps / elapsed
-        step_tflops = value * GF_PER_SAMPLE / 1e3 if not big else 0.0
+        # configs[2] at T = 4 is 2 271.8 GF/sample with frozen towers, 2 836.6 with LoRA
+        gf = (2836.6 if args.lora else 2271.8) if seq else GF_PER_SAMPLE
+        step_tflops = value * gf / 1e3 if not big else 0.0
         line = {
-            "metric": "train samples/sec (224x224 RGB + 32-tok instr)",
+            "metric": ("train samples/sec (384x384 RGB + 4 context frames + 64-tok instr)" if seq else
+                       "train samples/sec (224x224 RGB + 32-tok instr)"),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.dtype == "bf16" else "f32",
             "data": "synthetic (pinned host memory, H2D copy every step)" if args.host_fed else "synthetic",
-            "config": {"workload": ("BASELINE configs[3] (diagnostic): rgb_clip ViT-L/14@336 (577 tokens, 24 layers, "
+            "config": {"workload": ("BASELINE configs[2] (diagnostic): siglip_sequential, SigLIP-base/16 @384 (576 patches), "
+                                    "4 context frames with a random valid prefix, fusion 8x768 over 2 950 tokens, 4 "
+                                    "decoders; " + ("LoRA r=8 on q/v of both towers" if args.lora else "frozen towers")
+                                    if seq else
+                                    "BASELINE configs[3] (diagnostic): rgb_clip ViT-L/14@336 (577 tokens, 24 layers, "
                                     "width 1024) + CLIP text + fusion 8x768 (16 heads), 384-px heatmaps"
                                     if big else
                                     "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
@@ -240,7 +280,7 @@ def main():
                        "global_batch": global_batch, "parallelism": f"dp{world}", "final_loss": final_loss},
             "step_roofline": {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
-                              "flops_per_sample": GF_PER_SAMPLE * 1e9},
+                              "flops_per_sample": gf * 1e9},
         }
         if timer is not None:
             summ = timer.summary()
@@ -281,8 +321,9 @@ def main():
                                for k, v in sorted(summ.items())}
         if big:
             line.pop("step_roofline", None)
+        if big or seq:
             line.pop("roofline", None)
-        if world == 1 and not args.no_cpu_baseline and not big:
+        if world == 1 and not args.no_cpu_baseline and not big and not seq:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
 
