@@ -31,12 +31,24 @@ def _worker(rank, world, port, out):
         names.append(n); offsets[n] = (off, cnt); off += (cnt + 63) // 64 * 64
     grad = torch.full((off,), float(rank + 1)) + torch.arange(off) * (rank + 1) * 1e-3
     expect = (torch.full((off,), 1.5) + torch.arange(off) * 1.5e-3)
+    ok = True
+    for coalesce in (1, 2, 3, None):              # one all-reduce per layer ... everything in the final one
+        g = grad.clone()
+        s2 = bdist.GradSync(g, bdist.layer_buckets(names, offsets, depth, off), depth, coalesce=coalesce)
+        sent = sorted(sum(list(s2.plan.values()), []) + s2.final)
+        ok = ok and sent[0][0] == 0 and sent[-1][1] == off and all(sent[i][1] == sent[i + 1][0]
+                                                                  for i in range(len(sent) - 1))
+        for layer in reversed(range(depth)):
+            s2.on_ready(layer)
+        s2.on_ready(-1)
+        s2.finish()
+        ok = ok and torch.allclose(g, expect, rtol=1e-6)
     sync = bdist.GradSync(grad, bdist.layer_buckets(names, offsets, depth, off), depth)
     for layer in reversed(range(depth)):          # the order the fused backward reports completion
         sync.on_ready(layer)
     sync.on_ready(-1)
     sync.finish()
-    ok = torch.allclose(grad, expect, rtol=1e-6)
+    ok = ok and torch.allclose(grad, expect, rtol=1e-6)
     # a second step must work identically (state reset by finish())
     grad.copy_(torch.full((off,), float(10 * (rank + 1))))
     for layer in reversed(range(depth)):
