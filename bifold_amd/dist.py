@@ -25,6 +25,7 @@ import torch.distributed as dist
 def init_process_group_from_env(device_backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, local_rank, world).  Reads the torchrun environment; a bare `python bench.py`
     is world 1 and needs no process group."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # see bifold_amd/__init__.py (before the first HIP call)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -92,9 +93,9 @@ class GradSync:
     `buckets` (layer_buckets) are adjacent arena slices in backward order; `coalesce` consecutive
     layers travel in ONE all-reduce (default 4, env BIFOLD_DDP_COALESCE): 105 MB of gradients take
     ~0.6 ms on xGMI, so two or three large collectives hide as well under the remaining backward as
-    ten small ones with a third of the launches, stream waits and CU grabs.  (Measured with the RCCL path
-    forced at world 1, BIFOLD_FORCE_PG=1: a process group that exists but reduces nothing already costs
-    3.1 % of the step, the all-reduces add 1.5 % more whether they are 10, 3 or 1 -- see DESIGN.md §7.)
+    ten small ones with a third of the launches, stream waits and CU grabs (with the RCCL path forced at
+    world 1 the step costs the same for 10, 3 or 1 collectives; what did cost 4.6 % was stream-to-queue
+    aliasing, fixed by GPU_MAX_HW_QUEUES=8 -- DESIGN.md §7).
     """
 
     def __init__(self, flat_grad: torch.Tensor, buckets: List[Tuple[int, int]], depth: int,
