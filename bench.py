@@ -80,7 +80,7 @@ def profiled_traffic(dom: str):
     WRITE_SIZE passes are separate runs of this same command, as MI355X_MICROARCH.md prescribes, so they cannot be
     collected inside the timed run): launch-weighted mean over the kernel's instantiations, reads with the
     guide's x2 gfx950 correction."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc_v2.txt")
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc_v3.txt")
     if "[p8]" not in dom or "_nt" not in dom or not os.path.isfile(path):
         return None
     tot_n, tot_b = 0, 0.0
@@ -92,7 +92,7 @@ def profiled_traffic(dom: str):
             tot_b += n * (read_corr + write) * 1e6
     if not tot_n:
         return None
-    return round(tot_b / tot_n), ("bytes per launch, profiles/r01_hbm_traffic_pmc_v2.txt (separate --pmc FETCH_SIZE / "
+    return round(tot_b / tot_n), ("bytes per launch, profiles/r01_hbm_traffic_pmc_v3.txt (separate --pmc FETCH_SIZE / "
                                   "WRITE_SIZE passes of this command; reads x2 per the gfx950 correction)")
 
 
