@@ -15,6 +15,20 @@
 
 #define KT 64                                 // keys per LDS tile
 
+// Workgroup -> (batch, head).  Consecutive workgroup ids go to consecutive XCDs (8 private L2s).  With
+// d = 32 a head's slice of a token row is 64 bytes, half a 128-byte line: the other half belongs to the
+// neighbouring head, whose workgroup runs on ANOTHER XCD and fetches the same line from HBM again
+// (PMC: 432 MB read per forward launch for 216 MB of Q / K / V, 885 - 1 015 MB per backward kernel for
+// 360).  Pairing heads 2p and 2p+1 on one XCD, in adjacent dispatch slots, lets the second hit in L2.
+// d = 48: four heads span exactly three lines (384 bytes), so groups of four.  d = 64: a head is a line.
+template <int D>
+__device__ __forceinline__ int paired_bh(int i, int n) {
+    constexpr int G = D == 32 ? 2 : (D == 48 ? 4 : 1);
+    if (G == 1 || (n % (8 * G))) return i;
+    const int xcd = i & 7, s = i >> 3, t = s % G;
+    return ((s / G) * 8 + xcd) * G + t;
+}
+
 __device__ __forceinline__ size_t qkv_off(int b, int i, int which, int h, int L, int H, int D) {
     return (((size_t)b * L + i) * 3 + which) * (size_t)H * D + (size_t)h * D;
 }
@@ -243,7 +257,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     const int q0 = (blockIdx.y * waves_per_block + wave) * 32;   // first query of this wave
     const int nthreads = blockDim.x;
     const int qi = q0 + r;                                        // this lane's query
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     const int q0 = wave * 32;
     const int qi = q0 + r;
     const bool q_live = qi < L;
@@ -879,7 +893,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     // blockIdx.y: the 32-query blocks of a (batch, head) are spread over several workgroups of
     // ~5 waves, each with its own K / V image: 9-wave workgroups left 7 of a CU's 16 wave slots idle
     const int q0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 32;
@@ -1023,7 +1037,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
     const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);   // this wave's 32-key block
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     const int nthreads = blockDim.x;
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
@@ -1191,7 +1205,7 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     const int nwaves = SC::WPB;
     const int q0 = (blockIdx.y * nwaves + wave) * 32;
     const int qi = q0 + r;
@@ -1366,7 +1380,7 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
     const int w = blockIdx.y * nwaves + wave;     // this wave's 32-key block
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
     const bool wave_live = w * 32 < L;
