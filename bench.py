@@ -148,7 +148,7 @@ def main():
                                                          "reference's default) instead of frozen towers")
     args = ap.parse_args()
 
-    from bifold_amd import dist as bdist
+    from bifold import dist as bdist
     rank, local_rank, world = bdist.init_process_group_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -158,9 +158,9 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from bifold_amd.hip import ops
-    from bifold_amd.losses import Losses
-    from bifold_amd.models import Models
-    from bifold_amd.optim import Optimizers
+    from bifold.losses import Losses
+    from bifold.models import Models
+    from bifold.optim import Optimizers
 
     torch.manual_seed(3407)                       # identical replicas on every rank
     big = args.config == "vitl14"

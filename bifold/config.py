@@ -1,11 +1,13 @@
-"""Minimal Hydra-style config composition for `python -m bifold_amd`.
+"""Minimal Hydra-style config composition for `python -m bifold`.
 
 The reference's entrypoint is `@hydra.main(config_path="conf", config_name="config")`
 (bifold/__main__.py:24).  hydra-core/omegaconf are used when installed; this module is the
 fallback for images without them (this one), covering exactly what the conf tree uses:
 `defaults:` lists with `group: option` and `group@package: option` entries, `group=option`
 and `key.path=value` command-line overrides, `${a.b}` / `${.sibling}` / `${oc.env:VAR}`
-interpolation.  Nodes behave like the OmegaConf nodes the factories expect: attribute and
+interpolation, and the `hydra:` block of conf/config.yaml (run directory keyed by
+`hydra.job.override_dirname`, `job.chdir`), so a run lands in the directory the reference's
+Hydra would have picked and auto-resume finds the same `checkpoints/last.pth`.  Nodes behave like the OmegaConf nodes the factories expect: attribute and
 item access, `del cfg.name`, and `**cfg` splatting.
 """
 from __future__ import annotations
@@ -118,7 +120,25 @@ def _resolve(root: Dict) -> None:
     walk(root, "")
 
 
-def compose(config_dir: str, overrides: Optional[List[str]] = None, config_name: str = "config") -> ConfigNode:
+def override_dirname(overrides: List[str], exclude_keys=(), item_sep: str = ",", kv_sep: str = "=") -> str:
+    """Hydra's `hydra.job.override_dirname`: the task overrides whose key (or config group, for
+    `group@package=option`) is not excluded, sorted, joined by `item_sep`."""
+    lines = []
+    for ov in overrides:
+        key = ov.partition("=")[0].lstrip("+~")
+        group = key.partition("@")[0]
+        if key in exclude_keys or group in exclude_keys:
+            continue
+        lines.append(ov)
+    lines.sort()
+    return item_sep.join(lines).replace("=", kv_sep)
+
+
+def compose(config_dir: str, overrides: Optional[List[str]] = None, config_name: str = "config",
+            return_hydra: bool = False):
+    """The task config (without the `hydra` node, as Hydra hands it to the task function); with
+    `return_hydra` also the resolved `hydra` node (`run.dir`, `job.chdir`, `job.override_dirname`,
+    `overrides.task`)."""
     overrides = list(overrides or [])
     base = _load_yaml(os.path.join(config_dir, config_name + ".yaml"))
     defaults = base.pop("defaults", [])
@@ -153,5 +173,16 @@ def compose(config_dir: str, overrides: Optional[List[str]] = None, config_name:
         cfg[package] = _load_yaml(path)
     for key, val in values:
         _set_path(cfg, key, val)
+    hydra = cfg.setdefault("hydra", {}) or {}
+    cfg["hydra"] = hydra
+    job = hydra.setdefault("job", {})
+    od = ((job.get("config") or {}).get("override_dirname") or {})
+    job["override_dirname"] = override_dirname(overrides, tuple(od.get("exclude_keys") or ()),
+                                               od.get("item_sep", ","), od.get("kv_sep", "="))
+    job.setdefault("chdir", False)
+    hydra.setdefault("run", {}).setdefault("dir", ".")
+    hydra["overrides"] = {"task": list(overrides)}
     _resolve(cfg)
-    return _wrap(cfg)
+    hydra = _wrap(cfg.pop("hydra"))
+    out = _wrap(cfg)
+    return (out, hydra) if return_hydra else out

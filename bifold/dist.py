@@ -61,11 +61,27 @@ def layer_buckets(names: List[str], offsets, depth: int, count: int) -> List[Tup
     # start of the first parameter after the last layer
     after = min((offsets[n][0] for n in names if marker not in n and offsets[n][0] > starts[depth - 1]),
                 default=count)
-    buckets = [(after, count)]
+    # bucket 0 leaves as soon as the LAST fusion layer reports: it may only hold parameters whose gradients
+    # the backward has written by then, i.e. the decoders.  Anything else registered behind the fusion layers
+    # (a new head, an arena built in another order) goes with the final bucket instead of being averaged stale.
+    late = [n for n in names if marker not in n and offsets[n][0] >= after and "_decoder." not in n]
+    if late:
+        after_dec = min(offsets[n][0] for n in late)
+        early = [n for n in names if offsets[n][0] >= after_dec and "_decoder." in n]
+        if early:
+            raise ValueError(f"decoder parameters {early[:2]}... are interleaved with {late[:2]}... behind the "
+                             f"fusion layers: cannot bucket the gradient arena in backward order")
+        buckets = [(after, after_dec)]
+        tail_extra = (after_dec, count)
+    else:
+        buckets = [(after, count)]
+        tail_extra = None
     for i in reversed(range(depth)):
         end = starts[i + 1] if i + 1 < depth else after
         buckets.append((starts[i], end))
     buckets.append((0, starts[0]))
+    if tail_extra is not None:
+        buckets.append(tail_extra)
     return buckets
 
 
@@ -108,7 +124,6 @@ class GradSync:
         self.on_gpu = flat_grad.is_cuda
         self.side = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
         self.pending: List = []
-        self.avg_native = self.on_gpu        # RCCL implements ReduceOp.AVG; gloo does not
         if coalesce is None:
             coalesce = int(os.environ.get("BIFOLD_DDP_COALESCE", "4"))
         self.coalesce = max(1, coalesce)
@@ -124,7 +139,7 @@ class GradSync:
             if layers_in >= self.coalesce:
                 groups.append(cur)
                 cur = []
-        tail = cur + [len(buckets) - 1]                   # remainder + input-side parameters
+        tail = cur + list(range(1 + depth, len(buckets)))  # remainder + input-side (+ late) parameters
         for g in groups:
             last_layer = depth - 1 - (g[-1] - 1)
             self.plan[last_layer] = self._merge([buckets[j] for j in g])

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import torch
 
-from ..hip import ops
+from bifold_amd.hip import ops
 
 
 def _pop_name(cfg):

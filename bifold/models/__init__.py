@@ -98,7 +98,7 @@ def _picks_to_host(picks):
 
 
 def _device_pick(heatmap: torch.Tensor, mask=None):
-    from ..hip import ops
+    from bifold_amd.hip import ops
     if not heatmap.is_cuda:
         raise RuntimeError("sample_from_heatmap runs on the MI355X (bf_heatmap_pick); the numpy restatement "
                            "of the reference lives in oracle/ for tests")

@@ -56,6 +56,7 @@ class ParamArena:
             p._bf_name = n
         self._by_id = {id(p): n for n, p in items}
         self._versions = -1
+        self.grads_pending = False        # a backward wrote gradients that no step()/zero_grad() consumed yet
         self.sync_shadow(force=True)
 
     # -- views -----------------------------------------------------------------
@@ -82,6 +83,16 @@ class ParamArena:
         o, cnt = self.offsets[self._by_id[id(p)]]
         return self.shadow[o:o + cnt].view(p.shape)
 
+    def begin_backward(self) -> None:
+        """The fused backward OVERWRITES the gradient arena; a second backward before the optimiser
+        consumed the first (gradient accumulation, two losses on one model) would silently drop
+        gradients, so it raises instead.  Clearing `.grad` (`model.zero_grad()`) also counts as consumed."""
+        if self.grads_pending and all(p.grad is not None for p in self.params if p.requires_grad):
+            raise RuntimeError(
+                "backward() was called twice without optimizer.step() / zero_grad() in between: the fused "
+                "backward overwrites the gradient arena, gradient accumulation is not supported on the HIP path")
+        self.grads_pending = True
+
     # -- consistency -----------------------------------------------------------
     def still_bound(self) -> bool:
         base = self.flat.data_ptr()
@@ -97,7 +108,7 @@ class ParamArena:
             return
         ver = sum(p._version for p in self.params)
         if force or ver != self._versions:
-            from ..hip import ops
+            from bifold_amd.hip import ops
             ops.cast(self.flat, torch.bfloat16, out=self.shadow)
             self._versions = ver
 

@@ -16,8 +16,8 @@ from typing import Dict, Optional
 import torch
 from torch import nn
 
-from ..hip import lib as L
-from ..hip import ops
+from bifold_amd.hip import lib as L
+from bifold_amd.hip import ops
 from .arena import ParamArena
 from .params import add_param, layernorm_init
 

@@ -20,8 +20,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 from torch import nn
 
-from ..hip import lib as L
-from ..hip import ops
+from bifold_amd.hip import lib as L
+from bifold_amd.hip import ops
 from . import Components
 from .arena import ParamArena
 from .decoder_math import upsample_operator
@@ -280,6 +280,7 @@ class RGBTailFn(torch.autograd.Function):
         model = c.model
         pp: PickPlaceConvDecoder = model.pick_place
         A: ParamArena = model.trainable_arena()
+        A.begin_backward()
         cdt = model.compute_dtype
         g = A.grad_view
         dim = pp.dim
@@ -341,6 +342,7 @@ class SegmentTailFn(torch.autograd.Function):
         model = c.model
         pp: PickPlaceConvDecoder = model.pick_place
         A: ParamArena = model.trainable_arena()
+        A.begin_backward()
         cdt = model.compute_dtype
         g = A.grad_view
         dim = pp.dim

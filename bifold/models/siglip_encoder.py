@@ -30,8 +30,8 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
-from ..hip import lib as L
-from ..hip import ops
+from bifold_amd.hip import lib as L
+from bifold_amd.hip import ops
 from .arena import ParamArena
 from .params import add_param as _register
 from .params import get_param, layernorm_init, linear_init

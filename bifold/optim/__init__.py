@@ -14,7 +14,7 @@ from typing import Dict, Iterable, List, Optional
 
 import torch
 
-from ..hip import ops
+from bifold_amd.hip import ops
 from ..models.arena import ParamArena, arena_of
 
 
@@ -59,15 +59,16 @@ class FusedAdam:
     # -- Trainer-facing API ---------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
         """Gradients are OVERWRITTEN by every backward pass of the fused tail (they are not
-        accumulated across backward calls), so there is nothing to clear."""
+        accumulated across backward calls), so there is nothing to clear; the call marks the
+        arena's gradients as consumed (a second backward without it or step() raises)."""
         self.grad_scale = None
+        self.arena.grads_pending = False
 
     def clip_grad_norm_(self, max_norm: float) -> torch.Tensor:
-        """torch.nn.utils.clip_grad_norm_ (bifold/__main__.py:148-149) without a host sync: the
-        coefficient stays on the device and is applied inside the Adam kernel."""
-        ss = ops.sumsq(self.arena.grad)
-        self.grad_scale = ops.clip_coef(ss, float(max_norm))
-        return ss
+        """torch.nn.utils.clip_grad_norm_ (bifold/__main__.py:148-149) on the flat gradient arena:
+        three launches, no host sync; scales `.grad` in place and returns the total norm like torch.
+        `torch.nn.utils.clip_grad_norm_(model.parameters(), c)` itself lands here (see below)."""
+        return ops.clip_grad_norm_(self.arena.grad, float(max_norm))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -79,6 +80,7 @@ class FusedAdam:
                       self.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                       self.decoupled, self.grad_scale)
         self.arena.mark_synced()
+        self.arena.grads_pending = False
 
     # -- checkpoint format of torch.optim.Adam --------------------------------------------
     def state_dict(self) -> Dict:
@@ -108,6 +110,50 @@ class FusedAdam:
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ; FusedAdam keeps one step counter")
         self.step_count = steps.pop() if steps else 0
+
+
+# ---- torch.nn.utils.clip_grad_norm_(model.parameters(), c), unchanged at the call site -----------
+# The reference trainer clips with the torch utility (bifold/__main__.py:148-149).  On arena-backed
+# gradients that call would still work -- it sees ~110 `.grad` views -- but as a per-tensor foreach norm,
+# a stack, a second norm and a foreach multiply.  Importing this module wraps the utility: when every
+# gradient it is handed is a view of ONE ParamArena (and the call asks for the plain L2 norm), the three
+# launches of bf_clip_grad_norm run over the flat buffer instead; anything else goes to torch's own
+# implementation untouched.
+_torch_clip_grad_norm_ = getattr(torch.nn.utils.clip_grad_norm_, "_bifold_original", torch.nn.utils.clip_grad_norm_)
+
+
+def _arena_behind(params: List[torch.Tensor]) -> Optional[ParamArena]:
+    """The ParamArena whose gradient buffer backs `.grad` of EVERY parameter that has one, provided
+    those parameters are all of the arena's; None otherwise."""
+    with_grad = [p for p in params if p.grad is not None]
+    if not with_grad:
+        return None
+    arena = getattr(with_grad[0], "_bf_arena", None)
+    if arena is None or arena.grad is None or len(with_grad) != len(arena.params):
+        return None
+    base, ids = arena.grad.data_ptr(), {id(p) for p in arena.params}
+    for p in with_grad:
+        if id(p) not in ids or p.grad.data_ptr() != base + 4 * arena.offsets[arena.name_of(p)][0]:
+            return None
+    return arena
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=False, foreach=None):
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    params = list(parameters)
+    if float(norm_type) == 2.0 and not error_if_nonfinite:
+        arena = _arena_behind(params)
+        if arena is not None:
+            return ops.clip_grad_norm_(arena.grad, float(max_norm))
+    return _torch_clip_grad_norm_(params, max_norm, norm_type=norm_type, error_if_nonfinite=error_if_nonfinite,
+                                  foreach=foreach)
+
+
+clip_grad_norm_._bifold_original = _torch_clip_grad_norm_
+torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
+if getattr(torch.nn.utils, "clip_grad", None) is not None:
+    torch.nn.utils.clip_grad.clip_grad_norm_ = clip_grad_norm_
 
 
 class Optimizers:

@@ -12,7 +12,7 @@ from typing import Dict, Mapping, Optional, Sequence
 
 import torch
 
-from .hip import ops
+from bifold_amd.hip import ops
 
 HEADS = {False: ("pick", "place"), True: ("left_pick", "left_place", "right_pick", "right_place")}
 

@@ -122,3 +122,54 @@ extern "C" int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_s
     BF_CHECK_LAUNCH("bf_clip_coef");
     return BF_OK;
 }
+
+// torch.nn.utils.clip_grad_norm_ over the flat gradient arena, entirely on the device:
+// ws[0..1023] partial sums, ws[1024] = total norm, ws[1025] = clip coefficient.
+__global__ __launch_bounds__(256) void clip_finish_kernel(float* __restrict__ ws, int n, float max_norm,
+                                                          float* __restrict__ norm_out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += ws[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        ws[SUMSQ_BLOCKS] = norm;
+        ws[SUMSQ_BLOCKS + 1] = fminf(1.0f, max_norm / (norm + 1e-6f));
+        norm_out[0] = norm;
+    }
+}
+__global__ __launch_bounds__(256) void scale_inplace_kernel(float* __restrict__ x, size_t n4, size_t count,
+                                                            const float* __restrict__ coef) {
+    const float c = coef[0];
+    if (c >= 1.0f) return;                       // torch multiplies by the clamped 1.0: the identity
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ((float4*)x)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        ((float4*)x)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) x[n4 * 4 + threadIdx.x] *= c;
+}
+
+extern "C" int bf_clip_grad_norm(float* grad, size_t count, float max_norm, float* ws, float* norm_out,
+                                 bf_stream_t stream) {
+    BF_REQUIRE(grad && ws && norm_out && count > 0 && max_norm > 0.f, BF_EINVAL, "bf_clip_grad_norm: bad args");
+    BF_REQUIRE(bf_aligned16(grad), BF_EALIGN, "bf_clip_grad_norm: unaligned pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grad, n4, count, ws);
+    BF_CHECK_LAUNCH("bf_clip_grad_norm/1");
+    hipLaunchKernelGGL(clip_finish_kernel, dim3(1), dim3(256), 0, s, ws, (int)blocks, max_norm, norm_out);
+    BF_CHECK_LAUNCH("bf_clip_grad_norm/2");
+    size_t sblocks = (n4 + 255) / 256;
+    if (sblocks > 4096) sblocks = 4096;
+    if (sblocks < 1) sblocks = 1;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)sblocks), dim3(256), 0, s, grad, n4, count,
+                       ws + SUMSQ_BLOCKS + 1);
+    BF_CHECK_LAUNCH("bf_clip_grad_norm/3");
+    return BF_OK;
+}

@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TANH_GELU_GRAD = 0, 1, 2, 3, 4, 5
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, MAX_TARGET_POINTS = 0, 1, 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
@@ -102,6 +102,7 @@ PROTOTYPES = {
                              c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "bf_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bf_clip_coef": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),
+    "bf_clip_grad_norm": (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p, c_void_p]),
     "bf_debug_spin": (c_int, [c_int, C.c_longlong, c_void_p]),
     "bf_gemm_set_variant": (c_int, [c_int]),
     "bf_gemm_last_variant": (c_int, []),

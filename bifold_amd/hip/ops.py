@@ -487,6 +487,17 @@ def clip_coef(sumsq_t: torch.Tensor, max_norm: float) -> torch.Tensor:
     return out
 
 
+def clip_grad_norm_(flat_grad: torch.Tensor, max_norm: float) -> torch.Tensor:
+    """In-place torch.nn.utils.clip_grad_norm_ of a flat fp32 gradient arena; returns the total norm
+    as a 0-dim device tensor (what torch returns), no host sync."""
+    _dev(flat_grad, "grad")
+    ws = torch.empty(1026, dtype=torch.float32, device=flat_grad.device)
+    norm = torch.empty(1, dtype=torch.float32, device=flat_grad.device)
+    check(lib.bf_clip_grad_norm(_ptr(flat_grad), flat_grad.numel(), float(max_norm), _ptr(ws), _ptr(norm),
+                                _stream()), "bf_clip_grad_norm")
+    return norm.view(())
+
+
 # ----------------------------------------------------------------------------- either side of the step
 def heatmap_pick(heat: torch.Tensor, mask: Optional[torch.Tensor] = None):
     """heat fp32 [n, S, S]; mask [n, S, S] / [n, 1, S, S] (non-zero = allowed) or None ->

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 3
+#define BF_ABI_VERSION 4
 
 enum { BF_F32 = 0, BF_BF16 = 1 };
 
@@ -331,6 +331,12 @@ int bf_sumsq(const float* x, size_t count, float* partial_ws, float* out, bf_str
 /* clip coefficient: out[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))
  * (torch.nn.utils.clip_grad_norm_, __main__.py:148-149). */
 int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) (__main__.py:148-149) for gradients that
+ * live in ONE flat fp32 arena: norm_out[0] = ||grad||_2 (the value torch returns), then
+ * grad *= min(1, max_norm / (norm + 1e-6)) in place; nothing crosses to the host.
+ * ws: fp32 scratch >= 1026 floats. */
+int bf_clip_grad_norm(float* grad, size_t count, float max_norm, float* ws, float* norm_out,
+                      bf_stream_t stream);
 
 /* Elementwise cast between fp32 and bf16 (count elements). */
 int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,

@@ -8,10 +8,10 @@ import pytest
 import torch
 from torch import nn
 
-from bifold_amd.models import checkpoint_io as cio
-from bifold_amd.models.clip_encoder import CLIPEncoder
-from bifold_amd.models.params import add_param
-from bifold_amd.models.siglip_encoder import SiglipTowers
+from bifold.models import checkpoint_io as cio
+from bifold.models.clip_encoder import CLIPEncoder
+from bifold.models.params import add_param
+from bifold.models.siglip_encoder import SiglipTowers
 
 TINY_CLIP = dict(embed_dim=32, image_resolution=32, vision_layers=2, vision_width=64, vision_patch_size=8,
                  context_length=77, vocab_size=512, transformer_width=32, transformer_heads=2,

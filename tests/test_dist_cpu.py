@@ -20,7 +20,7 @@ def _free_port():
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
-    from bifold_amd import dist as bdist
+    from bifold import dist as bdist
     r, lr, w = bdist.init_process_group_from_env("gloo")
     assert (r, w) == (rank, world)
     depth = 3

@@ -17,7 +17,7 @@ TINY_CLIP = dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_widt
 
 
 def tiny_cfg(**over):
-    from bifold_amd.models.clip_encoder import CLIP_CONFIGS
+    from bifold.models.clip_encoder import CLIP_CONFIGS
     CLIP_CONFIGS["tiny-test"] = TINY_CLIP
     cfg = dict(name="rgb_clip", image_size=64, is_bimanual=False, requires_graph=False, text_encoder="tiny-test",
                patch_size=16, depth=2, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
     for name in declared:
         assert hasattr(L.lib, name)
-    assert L.lib.bf_abi_version() == L.ABI_VERSION == 3
+    assert L.lib.bf_abi_version() == L.ABI_VERSION == 4
 
 
 def test_c_abi_rejects_bad_arguments_before_launching():
@@ -58,9 +58,9 @@ def test_missing_library_fails_loudly(tmp_path):
 
 
 def test_factories_and_error_behaviour():
-    from bifold_amd.losses import Losses
-    from bifold_amd.models import Components, Models
-    from bifold_amd.optim import Optimizers, Schedulers
+    from bifold.losses import Losses
+    from bifold.models import Components, Models
+    from bifold.optim import Optimizers, Schedulers
     with pytest.raises(ValueError, match="not recognized"):
         Models.get_by_name(dict(name="nope"))
     with pytest.raises(ValueError, match="not recognized"):
@@ -95,7 +95,7 @@ def test_factories_and_error_behaviour():
 
 @pytest.mark.parametrize("fixture,bim", [("tiny_unimanual.npz", False), ("tiny_bimanual.npz", True)])
 def test_state_dict_schema_matches_reference(golden_dir, fixture, bim):
-    from bifold_amd.models import Models
+    from bifold.models import Models
     z = np.load(os.path.join(golden_dir, fixture))
     ref = {k[6:]: tuple(z[k].shape) for k in z.files if k.startswith("state/")}
     with warnings.catch_warnings():
@@ -106,7 +106,7 @@ def test_state_dict_schema_matches_reference(golden_dir, fixture, bim):
 
 
 def test_linear_warmup_reproduces_reference_trace(golden_dir):
-    from bifold_amd.optim import Schedulers
+    from bifold.optim import Schedulers
 
     class FakeOpt:
         param_groups = [{"lr": 1e-4}]
@@ -126,7 +126,7 @@ def test_linear_warmup_reproduces_reference_trace(golden_dir):
 
 def test_upsample_operator_matches_interpolate():
     import torch.nn.functional as F
-    from bifold_amd.models.decoder_math import upsample_operator
+    from bifold.models.decoder_math import upsample_operator
     for g in (3, 14, 24):
         U = upsample_operator(g).double()
         x = torch.randn(2, 1, g, g, dtype=torch.float64)
@@ -138,15 +138,22 @@ def test_upsample_operator_matches_interpolate():
         assert torch.allclose(U.sum(1), torch.ones(16 * g, dtype=torch.float64), atol=1e-6)
 
 
+CONF = os.path.join(ROOT, "bifold", "conf")
+
+
 def test_config_composition_and_overrides():
-    from bifold_amd.config import compose
-    conf = os.path.join(ROOT, "bifold_amd", "conf")
-    cfg = compose(conf, [])
-    assert cfg.model.name == "rgb_clip" and cfg.model.is_bimanual is False
+    from bifold.config import compose
+    cfg = compose(CONF, [])
+    # the reference's defaults, unchanged (bifold/conf/config.yaml:2-33)
+    assert cfg.model.name == "siglip_sequential" and cfg.train_dataset.name == "bimanual_sequential"
+    assert cfg.model.lora is True and cfg.model.lora_dropout == 0.01 and cfg.model.context_length == 3
+    assert cfg.use_wandb is True and cfg.simulator == "softgym" and cfg.batch_size == 2 and "hydra" not in cfg
     assert cfg.optim.lr == 1e-4 and isinstance(cfg.optim.lr, float)
-    assert cfg.loss.is_bimanual is False and cfg.scheduler.name is None
+    assert cfg.loss.is_bimanual is True and cfg.scheduler.name is None
+    cfg = compose(CONF, ["model=rgb_clip", "dataset@train_dataset=synthetic"])
+    assert cfg.model.name == "rgb_clip" and cfg.model.is_bimanual is False
     assert cfg.processor.model_image_size == 224 and cfg.processor.text_encoder == "ViT-B/16"
-    cfg = compose(conf, ["optim=adamw", "scheduler=linear_warmup", "batch_size=8", "model.depth=4",
+    cfg = compose(CONF, ["model=rgb_clip", "optim=adamw", "scheduler=linear_warmup", "batch_size=8", "model.depth=4",
                          "dataset@train_dataset=single", "train_dataset.n_samples=1000"])
     assert cfg.optim.name == "adamw" and cfg.optim.weight_decay == 0.01
     assert cfg.scheduler.warmup_portion == 0.1 and cfg.batch_size == 8 and cfg.model.depth == 4
@@ -155,11 +162,55 @@ def test_config_composition_and_overrides():
     del node.name
     assert "name" not in node and dict(**node)["lr"] == 1e-4
     with pytest.raises(FileNotFoundError):
-        compose(conf, ["model=does_not_exist"])
+        compose(CONF, ["model=does_not_exist"])
+
+
+def test_conf_tree_carries_every_reference_file_and_value():
+    """bifold/conf holds the reference's 20 YAML files; every key the reference sets keeps its value (new keys
+    are allowed, changed values are not).  The expected values below are the reference's (conf/**), restated."""
+    import yaml
+    want_files = {"config.yaml", "dataset/bimanual.yaml", "dataset/bimanual_sequential.yaml", "dataset/none.yaml",
+                  "dataset/real.yaml", "dataset/single.yaml", "dataset/single_sequential.yaml",
+                  "loss/bce_gaussmap.yaml", "loss/bce_mask.yaml", "loss/composed.yaml", "loss/composed_dice_focal.yaml",
+                  "model/rgb_clip.yaml", "model/siglip.yaml", "model/siglip_sequential.yaml", "model/text_unet.yaml",
+                  "optim/adam.yaml", "optim/adamw.yaml", "processor/default.yaml", "scheduler/linear_warmup.yaml",
+                  "scheduler/none.yaml"}
+    have = {os.path.relpath(os.path.join(d, f), CONF) for d, _, fs in os.walk(CONF) for f in fs}
+    assert want_files <= have, want_files - have
+    top = yaml.safe_load(open(os.path.join(CONF, "config.yaml")))
+    assert top["defaults"][:8] == ["_self_", {"model": "siglip_sequential"},
+                                   {"dataset@train_dataset": "bimanual_sequential"}, {"dataset@test_dataset": "none"},
+                                   {"processor": "default"}, {"loss": "bce_gaussmap"}, {"optim": "adam"},
+                                   {"scheduler": "none"}]
+    for k, v in dict(seed=3407, eval_only=False, eval_epochs=20, save_epochs=None, load_best=False, use_wandb=True,
+                     num_workers=6, batch_size=2, gradient_clip=None, test_batch_size=2, epochs=100, debug=False,
+                     num_evals=50, use_cpu=False, simulator="softgym").items():
+        assert top[k] == v, k
+    assert top["hydra"]["run"]["dir"] == "${oc.env:HOME}/bifold/outputs/${train_dataset.name}/${hydra.job.override_dirname}"
+    assert top["hydra"]["job"]["chdir"] is True and "seed" in top["hydra"]["job"]["config"]["override_dirname"]["exclude_keys"]
+    sig = yaml.safe_load(open(os.path.join(CONF, "model", "siglip_sequential.yaml")))
+    assert sig["lora"] is True and sig["lora_dropout"] == 0.01 and sig["r"] == 8 and sig["lora_alpha"] == 32
+    assert sig["target_modules"] == ["q_proj", "v_proj"] and sig["context_length"] == "${train_dataset.max_context_length}"
+
+
+def test_run_directory_follows_hydra_override_dirname(monkeypatch):
+    """hydra.run.dir = ~/bifold/outputs/<dataset>/<sorted, non-excluded overrides joined by ','>
+    (conf/config.yaml:34-59): two runs with different models / learning rates land in different directories,
+    the same command line lands where the reference's Hydra would have put it."""
+    from bifold.config import compose, override_dirname
+    monkeypatch.setenv("HOME", "/home/u")
+    ov = ["model=rgb_clip", "dataset@train_dataset=synthetic", "seed=7", "optim.lr=0.001", "batch_size=64", "debug=true"]
+    cfg, hydra = compose(CONF, ov, return_hydra=True)
+    assert hydra.job.override_dirname == "batch_size=64,model=rgb_clip,optim.lr=0.001"
+    assert hydra.run.dir == "/home/u/bifold/outputs/synthetic/batch_size=64,model=rgb_clip,optim.lr=0.001"
+    assert hydra.job.chdir is True and hydra.overrides.task == ov
+    _, h2 = compose(CONF, ["model=siglip", "dataset@train_dataset=synthetic"], return_hydra=True)
+    assert h2.run.dir != hydra.run.dir
+    assert override_dirname(["+a.b=1", "z=2", "seed=3"], ("seed",)) == "+a.b=1,z=2"
 
 
 def test_layer_buckets_tile_the_arena():
-    from bifold_amd.dist import layer_buckets
+    from bifold.dist import layer_buckets
     names, offsets, off = [], {}, 0
     def add(n, cnt):
         nonlocal off
@@ -171,6 +222,12 @@ def test_layer_buckets_tile_the_arena():
     add("pick_place.pick_decoder.decoder_net.0.weight", 500)
     b = layer_buckets(names, offsets, 3, off)
     assert len(b) == 5 and b[0][1] == off and b[-1][0] == 0
+    # a parameter registered BEHIND the decoders (not a decoder) must ride in the final bucket, never in the
+    # decoders' bucket that leaves first (stale gradients would be averaged)
+    add("late_head.weight", 100)
+    b2 = layer_buckets(names, offsets, 3, off)
+    assert len(b2) == 6 and b2[0] == (b[0][0], offsets["late_head.weight"][0]) and b2[-1] == (offsets["late_head.weight"][0], off)
+    names.pop(); off = offsets.pop("late_head.weight")[0]
     covered = sorted(b)
     assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(4)) and covered[-1][1] == off
     assert b[1] == (offsets[names[6]][0], b[0][0])             # layer 2 comes right after the decoders
@@ -179,8 +236,8 @@ def test_layer_buckets_tile_the_arena():
 @pytest.mark.parametrize("name,fixture,extra", [("siglip", "tiny_siglip.npz", {}),
                                                 ("siglip_sequential", "tiny_siglip_sequential.npz", {"context_length": 2})])
 def test_siglip_state_dict_schema_matches_reference(golden_dir, name, fixture, extra):
-    from bifold_amd.models import Models
-    from bifold_amd.models.siglip_encoder import SIGLIP_CONFIGS
+    from bifold.models import Models
+    from bifold.models.siglip_encoder import SIGLIP_CONFIGS
     SIGLIP_CONFIGS["tiny"] = dict(
         vision=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16),
         text=dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=100,
@@ -223,9 +280,8 @@ def test_siglip_state_dict_schema_matches_reference(golden_dir, name, fixture, e
 
 
 def test_siglip_config_resolves():
-    from bifold_amd.config import compose
-    cfg = compose(os.path.join(ROOT, "bifold_amd", "conf"),
-                  ["model=siglip_sequential", "dataset@train_dataset=synthetic_bimanual_sequential"])
+    from bifold.config import compose
+    cfg = compose(CONF, ["model=siglip_sequential", "dataset@train_dataset=synthetic_bimanual_sequential"])
     assert cfg.model.automodel_name == "google/siglip-base-patch16-384"
     assert cfg.model.context_length == 3 and cfg.model.is_bimanual is True and cfg.loss.is_bimanual is True
 
@@ -233,7 +289,7 @@ def test_siglip_config_resolves():
 def test_select_arms_matches_reference_action(golden_dir):
     """The arm-selection rule of get_action (models/__init__.py:118-131) on the golden
     confidences: which arms the reference kept is visible as non-dummy picks."""
-    from bifold_amd.models import select_arms
+    from bifold.models import select_arms
     from oracle import bifold_oracle as O
     z = np.load(os.path.join(golden_dir, "postproc.npz"))
     mask = z["mask"]

@@ -483,7 +483,7 @@ def test_segment_assemble_and_backward(ops, gpu):
 @pytest.mark.parametrize("dim,grid,heads", [(512, 14, 2), (96, 3, 4), (768, 24, 1)])
 def test_decoder_collapsed_matches_as_written(ops, gpu, dim, grid, heads):
     from oracle import bifold_oracle as O
-    from bifold_amd.models.decoder_math import upsample_operator
+    from bifold.models.decoder_math import upsample_operator
     g = torch.Generator().manual_seed(dim + grid)
     B = 2
     state = {k: v for k, v in O.make_tail_state(g, dim=dim, depth=0, is_bimanual=(heads == 4)).items()

@@ -11,9 +11,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-from bifold_amd.losses import Losses  # noqa: E402
-from bifold_amd.models import Models  # noqa: E402
-from bifold_amd.optim import Optimizers  # noqa: E402
+from bifold.losses import Losses  # noqa: E402
+from bifold.models import Models  # noqa: E402
+from bifold.optim import Optimizers  # noqa: E402
 
 dev = torch.device("cuda", 0)
 torch.manual_seed(3407)
