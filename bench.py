@@ -2,7 +2,9 @@
 """Throughput of BiFold's VLM training step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a torchrun environment: this process starts `python -m torch.distributed.run --nnodes=1
+     --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>` as a CHILD -- before it has touched the
+     GPU itself -- relays rank 0's JSON line and exits with the child's status; under torchrun it is a rank)
 
 One "step" = one full optimisation step on one synthetic batch per GPU: frozen CLIP ViT-B/16
 image tower + CLIP text tower forward, project + 8-layer fusion transformer + 2 heatmap
@@ -75,14 +77,68 @@ def synthetic_sequential_batch(batch: int, device, seed: int, size: int = 384, f
     return sample
 
 
+def pmc_summary_path():
+    """The newest committed HBM-traffic summary (profiles/rNN_hbm_traffic_pmc*.txt, produced by tools/pmc_summary.py)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hbm_traffic_pmc*.txt")))
+    return found[-1] if found else None
+
+
+def kernel_stats_path():
+    """The newest committed `rocprofv3 --kernel-trace --stats` summary of this command (tools/prof_summary.py)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats*.txt")))
+    return found[-1] if found else None
+
+
+def rocprof_nt_average_us():
+    """Launch-weighted average duration of the NT instantiations of gemm_bf16_p8_kernel in the committed rocprof
+    summary: what `roofline.avg_us` (HIP events around the host call) has to agree with."""
+    path = kernel_stats_path()
+    if path is None:
+        return None
+    calls, ms = 0.0, 0.0
+    for line in open(path):
+        if "gemm_bf16_p8_kernel<false, false," in line or "gemm_bf16_p8_kernelILb0ELb0E" in line:
+            f = line.split()
+            ms += float(f[0])
+            calls += float(f[2])
+    if not calls:
+        return None
+    return {"file": os.path.relpath(path, ROOT), "device_launches_per_step": calls,
+            "avg_us": round(1e3 * ms / calls, 2), "ms_per_step": round(ms, 3)}
+
+
+def host_cpu():
+    """(model name, physical cores, logical cpus) of the machine the CPU baseline runs on."""
+    model, pairs, logical, phys, core = "unknown", set(), 0, None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+                pairs.add((phys, core))
+    except OSError:
+        pass
+    return model, (len(pairs) or None), logical
+
+
 def profiled_traffic(dom: str):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE /
     WRITE_SIZE passes are separate runs of this same command, as MI355X_MICROARCH.md prescribes, so they cannot be
     collected inside the timed run): launch-weighted mean over the kernel's instantiations, reads with the
     guide's x2 gfx950 correction."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc_v3.txt")
-    if "[p8]" not in dom or "_nt" not in dom or not os.path.isfile(path):
+    path = pmc_summary_path()
+    if "[p8]" not in dom or "_nt" not in dom or path is None:
         return None
+    rel = os.path.relpath(path, ROOT)
     tot_n, tot_b = 0, 0.0
     for line in open(path):
         if line.startswith("gemm_bf16_p8_kernel<0,0,") or line.startswith("gemm_bf16_p8_kernel<false, false,"):
@@ -92,13 +148,15 @@ def profiled_traffic(dom: str):
             tot_b += n * (read_corr + write) * 1e6
     if not tot_n:
         return None
-    return round(tot_b / tot_n), ("bytes per launch, profiles/r01_hbm_traffic_pmc_v3.txt (separate --pmc FETCH_SIZE / "
-                                  "WRITE_SIZE passes of this command; reads x2 per the gfx950 correction)")
+    return round(tot_b / tot_n), (f"bytes per DEVICE launch, launch-weighted over the NT instantiations of {rel} "
+                                  f"(separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command; reads x2 per the "
+                                  f"gfx950 correction)")
 
 
-def cpu_baseline(steps: int = 2, batch: int = 4):
-    """The CPU oracle (a port of the reference path, pinned against it by tests/golden) on the
-    same workload at B = 4 (BASELINE.json configs[0]), fwd + loss + bwd + Adam, all host cores."""
+def cpu_baseline(steps: int = 10, warmup: int = 3, batch: int = 4):
+    """The CPU oracle (a port of the reference path, pinned against it by tests/golden) on the same workload at
+    B = 4 (BASELINE.json configs[0]): fwd + loss + bwd + Adam, fp32, all host cores; BASELINE.md §3's procedure --
+    3 warm-up + 10 timed full steps, median."""
     from oracle import bifold_oracle as O
     gen = torch.Generator().manual_seed(3407)
     state = {**O.make_clip_state(gen), **O.make_tail_state(gen)}
@@ -107,7 +165,7 @@ def cpu_baseline(steps: int = 2, batch: int = 4):
     m = {k: torch.zeros_like(state[k]) for k in keys}
     v = {k: torch.zeros_like(state[k]) for k in keys}
     times = []
-    for it in range(steps + 1):
+    for it in range(warmup + steps):
         t0 = time.perf_counter()
         for k in keys:
             state[k] = state[k].detach().requires_grad_(True)
@@ -118,12 +176,55 @@ def cpu_baseline(steps: int = 2, batch: int = 4):
             for k, gr in zip(keys, grads):
                 state[k], m[k], v[k] = O.adam_update(state[k].detach(), gr, m[k], v[k], it + 1, 1e-4)
         times.append(time.perf_counter() - t0)
-    timed = sorted(times[1:])
-    med = timed[len(timed) // 2]
+    timed = sorted(times[warmup:])
+    med = 0.5 * (timed[(len(timed) - 1) // 2] + timed[len(timed) // 2])
+    model, physical, logical = host_cpu()
     return {"value": round(batch / med, 4), "unit": "samples/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"config A at B={batch} fp32 (BASELINE configs[0]), 1 warm-up + {steps} timed full "
-                      f"steps, median {med:.2f} s/step"}
+            "kind": "port", "host_cpu": model, "physical_cores": physical, "logical_cpus": logical,
+            "sample": f"config A at B={batch} fp32 (BASELINE configs[0]), {warmup} warm-up + {steps} timed full "
+                      f"steps, median {med:.2f} s/step, torch threads = cores"}
+
+
+def parity_vs_oracle(model, sample, n: int = 4):
+    """north_star's accuracy gate on the benchmarked configuration itself: the first `n` samples of the timed batch
+    (samples are independent in the forward) through the CPU oracle in fp32 with the model's current weights,
+    against the heatmaps the HIP path produced for them INSIDE the full batch."""
+    from oracle import bifold_oracle as O
+    model.eval()
+    with torch.no_grad():
+        out = model(sample)
+    state = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    sub = {k: v[:n].detach().cpu() for k, v in sample.items() if isinstance(v, torch.Tensor)}
+    with torch.no_grad():
+        ref = O.rgb_clip_forward(state, sub, heads=model.pick_place.fusion.heads)
+    worst_rel, worst_abs, mse = 0.0, 0.0, 0.0
+    for k in ("pick_heatmap", "place_heatmap"):
+        got, want = out[k][:n].double().cpu(), ref[k].double()
+        worst_abs = max(worst_abs, (got - want).abs().max().item())
+        worst_rel = max(worst_rel, ((got - want).abs().max() / (want.abs().max() + 1e-30)).item())
+        mse = max(mse, ((got - want) ** 2).mean().item())
+    model.train()
+    return {"heatmap_max_rel": float(f"{worst_rel:.3e}"), "heatmap_max_abs": float(f"{worst_abs:.3e}"),
+            "heatmap_mse": float(f"{mse:.3e}"), "gate_rel": 1e-3, "within_gate": bool(worst_rel <= 1e-3),
+            "samples_checked": n, "against": "oracle/bifold_oracle.py, fp32 CPU, same weights and inputs; "
+                                             "rel = max|diff| / max|ref| per head"}
+
+
+def self_launch(args_list, gpus: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a child `torch.distributed.run`, relay what
+    they print, return their exit status.  Called before this process has made any GPU call (a process that has
+    initialised HIP must never exec another program on this pool, and does not need to: it only waits)."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -146,12 +247,16 @@ def main():
                          "context frames (diagnostic line, run with --batch 128; --lora trains the adapters)")
     ap.add_argument("--lora", action="store_true", help="siglip_seq: LoRA adapters on q/v of both towers (the "
                                                          "reference's default) instead of frozen towers")
+    ap.add_argument("--no-parity", action="store_true", help="skip the 4-sample oracle check of the timed batch")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
 
     from bifold import dist as bdist
     rank, local_rank, world = bdist.init_process_group_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the torchrun environment disagrees with --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -277,7 +382,10 @@ def main():
                                     "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
                                     "fusion 8x512 (16 heads) + 2 conv decoders, BCE, Adam; frozen encoders; "
                                     "random-init weights"), "per_gpu_batch": args.batch,
-                       "global_batch": global_batch, "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "global_batch": global_batch, "parallelism": f"dp{world}", "final_loss": final_loss,
+                       "collective": (f"RCCL all-reduce(AVG) of the gradient arena over {torch.distributed.get_world_size()} "
+                                      f"ranks, {len(sync.plan) + 1} bucketed launches per step on a side stream"
+                                      if sync is not None else "none (single process)")},
             "step_roofline": {"bound": "mfma", "achieved": round(step_tflops / world, 2), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
                               "flops_per_sample": gf * 1e9},
@@ -314,7 +422,11 @@ def main():
                                     "traffic": traffic[0] if traffic else None,
                                     "traffic_note": traffic[1] if traffic else "no PMC summary under profiles/",
                                     "launches": d["launches"], "avg_us": round(d["avg_us"], 2),
-                                    "share_of_step": round(d["ms"] / (1e3 * elapsed), 4)}
+                                    "share_of_step": round(d["ms"] / (1e3 * elapsed), 4),
+                                    "timing": "HIP events on the launching stream around each bf_gemm host call "
+                                              "(one host call = 1 device launch, or 2 when the last round of tiles "
+                                              "runs as a split-K tail)",
+                                    "rocprof": rocprof_nt_average_us()}
             line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
                                    "tflops": round(v["tflops"], 1),
                                    "share_of_step": round(v["ms"] / (1e3 * elapsed), 4)}
@@ -323,6 +435,8 @@ def main():
             line.pop("step_roofline", None)
         if big or seq:
             line.pop("roofline", None)
+        if world == 1 and not args.no_parity and not big and not seq and args.dtype == "bf16":
+            line["parity"] = parity_vs_oracle(model, sample)
         if world == 1 and not args.no_cpu_baseline and not big and not seq:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

@@ -47,6 +47,7 @@ class ConcatTransformer(nn.Module):
         if dim % heads:
             raise ValueError("dim must be divisible by heads")
         self.dim, self.heads, self.depth = dim, heads, depth
+        self.compute_dtype = torch.bfloat16       # standalone forward only; the models pass their own dtype
         self.dim_head = dim // heads
         self.mlp_dim = dim * mlp_ratio
         self.num_modalities = num_modalities
@@ -73,8 +74,26 @@ class ConcatTransformer(nn.Module):
                     bb1=f.fn.net._modules["0"].bias, w2=f.fn.net._modules["3"].weight,
                     bb2=f.fn.net._modules["3"].bias)
 
-    def forward(self, *inputs, **kwargs):
-        raise NotImplementedError("ConcatTransformer runs inside PickPlaceConvDecoder's fused tail")
+    def forward(self, *inputs, modalities=None, attention_masks=None, **kwargs):
+        """Standalone use of the component (models/fusion.py:35-64): fp32 CUDA inputs [B, n_i, dim] ->
+        (features of the LAST input's tokens [B, n_last, dim], None).  Like the reference the type
+        embedding is added to the inputs IN PLACE (fusion.py:52).  The models never call this: RGBOnly /
+        SigLip run the same layers inside their fused tail (RGBTailFn / SegmentTailFn), which also fuses
+        the token assembly and the decoders."""
+        if modalities is None:
+            modalities = range(len(inputs))
+        modalities = [int(m) for m in modalities]
+        assert len(inputs) == len(modalities)
+        if any(not t.is_cuda for t in inputs):
+            raise RuntimeError("ConcatTransformer runs on the MI355X only (there is no CPU path)")
+        mask = None
+        if attention_masks is not None:
+            mask = attention_masks.to(torch.int32).contiguous()
+        with torch.no_grad():                              # the reference's in-place `inp += type_embeddings`;
+            for mod, inp in zip(modalities, inputs):       # its gradient is produced by _FusionStackFn.backward
+                inp.add_(self.token_type_embeddings.weight[mod].to(inp.dtype))
+        out = _FusionStackFn.apply(self, tuple(modalities), mask, len(inputs), *inputs, *self.parameters())
+        return out[:, -inputs[-1].shape[1]:, :], None
 
 
 class PickPlaceConvDecoder(nn.Module):
@@ -112,7 +131,17 @@ class PickPlaceConvDecoder(nn.Module):
         return self._U
 
     def forward(self, *inputs, **kwargs):
-        raise NotImplementedError("use RGBOnly.forward: the fusion/decoder tail is fused with its inputs")
+        """Standalone use of the component (models/pickplace.py:59-124): `*inputs` / `**kwargs` go to the
+        fusion model, the last input's tokens (minus its lead token) feed the decoders.  Returns the
+        reference's dict: "attn_weights" (None) and one `[B, S, S]` heatmap per head."""
+        component_arena(self)                              # one arena for fusion + decoders, before either runs
+        fused, attn = self.fusion(*inputs, **kwargs)
+        heats = _DecoderHeadsFn.apply(self, fused.contiguous(), *[p for n, p in self.named_parameters()
+                                                                   if "_decoder." in n])
+        out = {"attn_weights": attn}
+        for name, h in zip(self.heads_out, heats):
+            out[f"{name}_heatmap"] = h
+        return out
 
 
 # ======================================================================================
@@ -172,18 +201,36 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
 
 
-def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch: int, seq: int,
-                       mask_mode: int, row_mask, save: bool):
-    """x fp32 [B*seq, dim] (the assembled fusion input) -> heat [n_heads, B, S, S] and what the
-    backward needs.  The LAST n_patches+1 tokens of every sequence are the image modality whose
-    tokens feed the decoders (models/fusion.py:62-63, models/pickplace.py:71)."""
-    fus: ConcatTransformer = pp.fusion
-    dim, nh = pp.dim, len(pp.heads_out)
-    dev = x.device
+def fusion_stack_fwd(fus: "ConcatTransformer", A: ParamArena, cdt, x, batch: int, seq: int, mask_mode: int,
+                     row_mask, save: bool):
+    """depth x fusion_layer_fwd on x fp32 [B*seq, dim]; returns (x_out, per-layer saved activations)."""
     layers = []
     for i in range(fus.depth):
         x, s = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, mask_mode, row_mask, save)
         layers.append(s)
+    return x, layers
+
+
+def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, batch: int, seq: int, mask_mode: int,
+                     row_mask, on_layer_done=None):
+    """Backward of fusion_stack_fwd: dx fp32 [B*seq, dim] w.r.t. the stack's output -> w.r.t. its input;
+    every layer's parameter gradients go straight into the arena."""
+    dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
+    for i in reversed(range(fus.depth)):
+        dx, dx_c = fusion_layer_bwd(dx, dx_c, layers[i], fus.layer_params(i), A, cdt, batch, seq, fus.heads,
+                                    mask_mode, row_mask)
+        layers[i] = None                                   # free this layer's activations early
+        if on_layer_done is not None:
+            on_layer_done(i)
+    return dx
+
+
+def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride: int, batch: int):
+    """tok: fp32 view [B, n_patches+1, dim] of the image-modality tokens (batch stride tok_bstride
+    elements, used in place) -> heat [n_heads, B, S, S] + (w_eff, rows_ws) for the backward
+    (models/pickplace.py:71-123 with ConvDecoder collapsed, models/modules.py:58-71)."""
+    dim, nh = pp.dim, len(pp.heads_out)
+    dev = tok.device
     w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
     b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
     rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
@@ -191,12 +238,46 @@ def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch:
         ws, bs = pp.decoder_params(name)
         ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
                                  rows_ws[h])
-    first = seq - (pp.num_patches + 1)
-    img_tok = x.view(batch, seq, dim)[:, first:]           # used in place through its batch stride
-    low = ops.decoder_project(img_tok, seq * dim, w_eff, b_eff, batch, nh, pp.num_patches, dim)
+    low = ops.decoder_project(tok, tok_bstride, w_eff, b_eff, batch, nh, pp.num_patches, dim)
     heat = ops.decoder_upsample_sigmoid(low, pp.upsample_matrix(dev), nh * batch, pp.grid)
     size = pp.grid * 16
-    heat = heat.view(nh, batch, size, size)
+    return heat.view(nh, batch, size, size), w_eff, rows_ws
+
+
+def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstride: int, heat, w_eff, rows_ws,
+                      d_heats, d_tok, dtok_bstride: int, batch: int):
+    """Backward of decoder_heads_fwd: writes d_tok (fp32 view like tok; token 0 gets zeros) and every
+    decoder parameter gradient into the arena."""
+    g = A.grad_view
+    dim, nh = pp.dim, len(pp.heads_out)
+    dev = tok.device
+    U = pp.upsample_matrix(dev)
+    g_low = torch.empty(nh, batch, pp.grid * pp.grid, dtype=torch.float32, device=dev)
+    for h in range(nh):
+        if d_heats[h] is None:                             # a head the loss ignores
+            g_low[h].zero_()
+        else:
+            ops.decoder_upsample_sigmoid_bwd(heat[h], d_heats[h].contiguous(), U, batch, pp.grid, out=g_low[h])
+    g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+    g_b = torch.empty(nh, dtype=torch.float32, device=dev)
+    ops.decoder_project_bwd(tok, tok_bstride, w_eff, g_low, d_tok, dtok_bstride, g_w, g_b, batch, nh,
+                            pp.num_patches, dim)
+    for h, name in enumerate(pp.heads_out):
+        ws, bs = pp.decoder_params(name)
+        ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], rows_ws[h], g_w[h],
+                                 g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
+
+
+def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch: int, seq: int,
+                       mask_mode: int, row_mask, save: bool):
+    """x fp32 [B*seq, dim] (the assembled fusion input) -> heat [n_heads, B, S, S] and what the
+    backward needs.  The LAST n_patches+1 tokens of every sequence are the image modality whose
+    tokens feed the decoders (models/fusion.py:62-63, models/pickplace.py:71)."""
+    dim = pp.dim
+    x, layers = fusion_stack_fwd(pp.fusion, A, cdt, x, batch, seq, mask_mode, row_mask, save)
+    first = seq - (pp.num_patches + 1)
+    img_tok = x.view(batch, seq, dim)[:, first:]           # used in place through its batch stride
+    heat, w_eff, rows_ws = decoder_heads_fwd(pp, img_tok, seq * dim, batch)
     saved = None
     if save:
         saved = dict(layers=layers, x_out=x, w_eff=w_eff, rows_ws=rows_ws, heat=heat, batch=batch, seq=seq,
@@ -207,39 +288,102 @@ def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch:
 def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heats, on_layer_done=None):
     """Backward of fusion_decoder_fwd: writes every fusion / decoder parameter gradient into the
     arena and returns d(fusion input) fp32 [B*seq, dim]."""
-    fus: ConcatTransformer = pp.fusion
-    g = A.grad_view
-    dim, nh = pp.dim, len(pp.heads_out)
+    dim = pp.dim
     batch, seq = S["batch"], S["seq"]
-    dev = S["x_out"].device
-    U = pp.upsample_matrix(dev)
-    gg = pp.grid * pp.grid
-    g_low = torch.empty(nh, batch, gg, dtype=torch.float32, device=dev)
-    for h in range(nh):
-        if d_heats[h] is None:                             # a head the loss ignores
-            g_low[h].zero_()
-        else:
-            ops.decoder_upsample_sigmoid_bwd(S["heat"][h], d_heats[h].contiguous(), U, batch, pp.grid, out=g_low[h])
-    dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=dev)
-    g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
-    g_b = torch.empty(nh, dtype=torch.float32, device=dev)
+    dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=S["x_out"].device)
     first = seq - (pp.num_patches + 1)
     xv = S["x_out"].view(batch, seq, dim)
     dxv = dx.view(batch, seq, dim)
-    ops.decoder_project_bwd(xv[:, first:], seq * dim, S["w_eff"], g_low, dxv[:, first:], seq * dim, g_w, g_b,
-                            batch, nh, pp.num_patches, dim)
-    for h, name in enumerate(pp.heads_out):
-        ws, bs = pp.decoder_params(name)
-        ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], S["rows_ws"][h], g_w[h],
-                                 g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
-    dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
-    for i in reversed(range(fus.depth)):
-        dx, dx_c = fusion_layer_bwd(dx, dx_c, S["layers"][i], fus.layer_params(i), A, cdt, batch, seq, fus.heads,
-                                    S["mask_mode"], S["row_mask"])
-        S["layers"][i] = None                              # free this layer's activations early
-        if on_layer_done is not None:
-            on_layer_done(i)
-    return dx
+    decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"], d_heats,
+                      dxv[:, first:], seq * dim, batch)
+    return fusion_stack_bwd(pp.fusion, A, cdt, dx, S["layers"], batch, seq, S["mask_mode"], S["row_mask"],
+                            on_layer_done)
+
+
+def component_arena(module: nn.Module) -> ParamArena:
+    """The arena behind a component used on its own: the model's arena when the parameters already live
+    in one (a component taken out of a built model), otherwise a new arena over the module's parameters."""
+    params = [p for p in module.parameters()]
+    a = getattr(params[0], "_bf_arena", None)
+    if a is not None and a.grad is not None and a.still_bound() and all(getattr(p, "_bf_arena", None) is a
+                                                                        for p in params):
+        return a
+    return ParamArena(list(module.named_parameters()), with_grad=True, with_shadow=True)
+
+
+class _FusionStackFn(torch.autograd.Function):
+    """ConcatTransformer.forward on its own: type-embedding add + concat (torch glue, a few MB) around the
+    HIP fusion layers.  Gradients of the inputs are returned to autograd; parameter gradients are
+    written into the arena (overwritten per backward, like the fused tails)."""
+
+    @staticmethod
+    def forward(ctx, fus, modalities, row_mask, n_in, *tensors):
+        inputs = tensors[:n_in]
+        A = component_arena(fus)
+        A.sync_shadow()
+        cdt = fus.compute_dtype
+        x = torch.cat([t.float() for t in inputs], dim=1)
+        batch, seq, dim = x.shape
+        save = any(ctx.needs_input_grad)
+        mode = L.MASK_QUERY_ROW if row_mask is not None else L.MASK_NONE
+        y, layers = fusion_stack_fwd(fus, A, cdt, x.view(batch * seq, dim), batch, seq, mode, row_mask, save)
+        if save:
+            c = _Ctx()
+            c.fus, c.A, c.layers, c.mode, c.row_mask = fus, A, layers, mode, row_mask
+            c.batch, c.seq, c.modalities = batch, seq, modalities
+            c.lens = [t.shape[1] for t in inputs]
+            c.dtypes = [t.dtype for t in inputs]
+            ctx.c = c
+        ctx.n_in = n_in
+        return y.view(batch, seq, dim)
+
+    @staticmethod
+    def backward(ctx, dy):
+        c: _Ctx = ctx.c
+        fus, A = c.fus, c.A
+        dim = fus.dim
+        dx = fusion_stack_bwd(fus, A, fus.compute_dtype, dy.contiguous().view(-1, dim).float(), c.layers, c.batch,
+                              c.seq, c.mode, c.row_mask)
+        dxv = dx.view(c.batch, c.seq, dim)
+        d_type = A.grad_view(fus.token_type_embeddings.weight)
+        d_type.zero_()
+        d_inputs, off = [], 0
+        for mod, n, dt in zip(c.modalities, c.lens, c.dtypes):
+            seg = dxv[:, off:off + n]
+            d_type[mod] += seg.sum(dim=(0, 1))
+            d_inputs.append(seg.to(dt))
+            off += n
+        ctx.c = None
+        n_par = len(ctx.needs_input_grad) - 4 - ctx.n_in
+        return (None, None, None, None) + tuple(d_inputs) + tuple(None for _ in range(n_par))
+
+
+class _DecoderHeadsFn(torch.autograd.Function):
+    """The decoders of PickPlaceConvDecoder.forward on their own (models/pickplace.py:71-123)."""
+
+    @staticmethod
+    def forward(ctx, pp, fused, *params):
+        batch, n, dim = fused.shape
+        if n != pp.num_patches + 1:
+            raise RuntimeError(f"expected {pp.num_patches + 1} tokens from the fusion model, got {n}")
+        tok = fused.float().contiguous()
+        heat, w_eff, rows_ws = decoder_heads_fwd(pp, tok, n * dim, batch)
+        if any(ctx.needs_input_grad):
+            c = _Ctx()
+            c.pp, c.tok, c.heat, c.w_eff, c.rows_ws, c.batch, c.dtype = pp, tok, heat, w_eff, rows_ws, batch, fused.dtype
+            ctx.c = c
+        return tuple(heat[h] for h in range(len(pp.heads_out)))
+
+    @staticmethod
+    def backward(ctx, *d_heats):
+        c: _Ctx = ctx.c
+        pp = c.pp
+        A = component_arena(pp)
+        d_tok = torch.empty_like(c.tok)
+        n, dim = c.tok.shape[1], c.tok.shape[2]
+        decoder_heads_bwd(pp, A, c.tok, n * dim, c.heat, c.w_eff, c.rows_ws, d_heats, d_tok, n * dim, c.batch)
+        ctx.c = None
+        return (None, d_tok.to(c.dtype)) + tuple(None for _ in range(len(ctx.needs_input_grad) - 2))
 
 
 class RGBTailFn(torch.autograd.Function):

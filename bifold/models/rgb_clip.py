@@ -52,6 +52,7 @@ class RGBOnly(BaseModel):
         self.rgb_pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
         self.pick_place = Components.get_by_name(pick_place_model, dim=dim, patch_size=patch_size,
                                                  num_patches=num_patches, **kwargs)
+        self.pick_place.fusion.compute_dtype = self.compute_dtype
         self._train_arena: Optional[ParamArena] = None
         self._grad_hooks: List[Callable[[int], None]] = []
         self._side_stream = None

@@ -56,6 +56,7 @@ class SigLip(BaseModel):
         self.image_token = nn.Parameter(torch.randn(1, 1, dim))
         self.pick_place = Components.get_by_name(pick_place_model, dim=dim, patch_size=patch_size,
                                                  num_patches=self.num_patches, **kwargs)
+        self.pick_place.fusion.compute_dtype = self.compute_dtype
         self._train_arena: Optional[ParamArena] = None
         self._grad_hooks: List[Callable[[int], None]] = []
 

@@ -67,3 +67,100 @@ def test_gradsync_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+class _HostArena:
+    """The memory layout of models/arena.ParamArena on the host (the real one lives in HBM and casts its bf16
+    shadow with a HIP kernel): enough for dist.gradient_sync_for -- `.grad`, `.offsets`, `.name_of`, `.count`."""
+
+    def __init__(self, named):
+        self.offsets, self._by_id, off = {}, {}, 0
+        for n, p in named:
+            self.offsets[n] = (off, p.numel())
+            self._by_id[id(p)] = n
+            off += (p.numel() + 63) // 64 * 64
+        self.count = off
+        self.grad = torch.zeros(off)
+
+    def name_of(self, p):
+        return self._by_id[id(p)]
+
+
+def _hook_worker(rank, world, port, out):
+    """A REAL RGBOnly (tiny, on the host) whose `register_grad_ready_hook` / `_grad_ready` drive GradSync exactly as
+    its fused backward does on the GPU: layers depth-1 ... 0, then -1.  Each layer's gradients are written just
+    before its report, so a bucket that left too early would be averaged stale and the check below would fail."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from bifold import dist as bdist
+    from bifold.models import Models
+    from bifold.models.clip_encoder import CLIP_CONFIGS
+    bdist.init_process_group_from_env("gloo")
+    CLIP_CONFIGS["tiny-ddp"] = dict(embed_dim=32, image_resolution=64, vision_layers=1, vision_width=64,
+                                    vision_patch_size=16, context_length=77, vocab_size=64, transformer_width=64,
+                                    transformer_heads=1, transformer_layers=1)
+    cfg = dict(name="rgb_clip", image_size=64, is_bimanual=True, requires_graph=False, text_encoder="tiny-ddp",
+               patch_size=16, depth=5, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
+               pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype="bf16")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = Models.get_by_name(cfg, device=torch.device("cpu"))
+    arena = _HostArena(model.trainable_params())
+    model.trainable_arena = lambda: arena
+    ok = True
+    for coalesce in ("1", "2", "4", "8"):
+        os.environ["BIFOLD_DDP_COALESCE"] = coalesce
+        model._grad_hooks.clear()
+        sync = bdist.gradient_sync_for(model)
+        assert model._grad_hooks == [sync.on_ready]
+        depth = model.pick_place.fusion.depth
+        for step in range(2):
+            arena.grad.fill_(float("nan"))             # anything averaged before it was written stays NaN
+            value = lambda n: (rank + 1) * (1 + step) * (1 + (hash(n) % 97) / 97.0)
+            def write(pred):
+                for n, p in model.trainable_params():
+                    if pred(n):
+                        o, cnt = arena.offsets[n]
+                        arena.grad[o:o + (cnt + 63) // 64 * 64] = value(n)
+            write(lambda n: "_decoder." in n)          # the backward starts with the decoders ...
+            for i in reversed(range(depth)):           # ... then fusion layers depth-1 ... 0 ...
+                write(lambda n, i=i: f"layers.{i}." in n)
+                model._grad_ready(i)
+            write(lambda n: "_decoder." not in n and "layers." not in n)   # ... then the input side
+            model._grad_ready(-1)
+            sync.finish()
+            for n, p in model.trainable_params():
+                o, cnt = arena.offsets[n]
+                want = 1.5 * (1 + step) * (1 + (hash(n) % 97) / 97.0)
+                ok = ok and bool(torch.allclose(arena.grad[o:o + cnt], torch.full((cnt,), want), rtol=1e-6))
+    out[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_model_hooks_drive_gradsync_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    os.environ["PYTHONHASHSEED"] = "0"               # hash(name) must agree across the two ranks
+    mp.spawn(_hook_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no torchrun environment must start its two ranks itself (the driver's
+    command).  Without a GPU each rank stops at "needs an MI355X" -- AFTER it has joined the 2-rank rendezvous the
+    parent set up -- and the parent relays the failure as its exit status."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        assert r.returncode == 0 and '"n_gpus": 2' in r.stdout, r.stderr[-3000:]
+    else:
+        assert r.returncode != 0
+        assert "disagrees" not in r.stderr and "launch with" not in r.stderr
+        assert r.stderr.count("needs an MI355X") >= 2 or "device" in r.stderr.lower(), r.stderr[-3000:]

@@ -1,0 +1,246 @@
+"""The Trainer of `python -m bifold` on the MI355X: gradient clipping through the
+UNCHANGED torch call, LinearWarmup inside the loop, periodic evaluation (`get_action` -> pixel metrics ->
+best.pth), checkpoints in the reference's schema, auto-resume from the Hydra-style run directory, and the
+data-parallel hooks with a live RCCL group (world size 1, BIFOLD_FORCE_PG=1)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY_CLIP = dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+                 context_length=77, vocab_size=49408, transformer_width=64, transformer_heads=1, transformer_layers=2)
+OVERRIDES = ["model=rgb_clip", "dataset@train_dataset=synthetic", "model.text_encoder=tiny-trainer",
+             "model.image_size=64", "train_dataset.image_size=64", "train_dataset.length=64", "model.depth=2",
+             "model.heads=2", "batch_size=8", "test_batch_size=8", "epochs=3", "gradient_clip=0.05",
+             "scheduler=linear_warmup", "save_epochs=1", "eval_epochs=1", "simulator=null", "use_wandb=false",
+             "model.dtype=fp32", "ddp=false"]
+
+
+@pytest.fixture()
+def run_home(tmp_path, monkeypatch):
+    from bifold.models.clip_encoder import CLIP_CONFIGS
+    CLIP_CONFIGS["tiny-trainer"] = TINY_CLIP
+    monkeypatch.setenv("HOME", str(tmp_path))
+    cwd = os.getcwd()
+    yield tmp_path
+    os.chdir(cwd)
+
+
+def _trainer(overrides):
+    import bifold.__main__ as M
+    from bifold.config import compose
+    cfg, hydra = compose(M.CONF_DIR, overrides, return_hydra=True)
+    os.makedirs(hydra.run.dir, exist_ok=True)
+    os.chdir(hydra.run.dir)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return M.Trainer(cfg, overrides), hydra
+
+
+def test_trainer_clip_warmup_eval_save_and_resume(gpu, run_home, monkeypatch):
+    import bifold.__main__ as M
+    import bifold.optim as BO
+    from bifold_amd.hip import ops
+    calls = {"fused": 0}
+    real = ops.clip_grad_norm_
+
+    def counting(flat, max_norm):
+        calls["fused"] += 1
+        return real(flat, max_norm)
+    monkeypatch.setattr(ops, "clip_grad_norm_", counting)
+
+    # ---- an uninterrupted 3-epoch run through main(): clip + warm-up + eval each epoch + checkpoints
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = M.main(list(OVERRIDES))
+    run_dir = os.getcwd()
+    assert run_dir.startswith(str(run_home)) and "model=rgb_clip" in os.path.basename(run_dir)
+    assert "seed" not in os.path.basename(run_dir) and "use_wandb" not in os.path.basename(run_dir)
+    assert os.path.isfile("config.yaml") and os.path.isfile("checkpoints/last.pth") and os.path.isfile("checkpoints/best.pth")
+    assert os.path.isfile("eval_synthetic.yaml")
+    steps = 3 * len(t.train_dataloader)
+    assert calls["fused"] == steps          # torch.nn.utils.clip_grad_norm_(model.parameters(), c) took the arena path
+    assert torch.nn.utils.clip_grad_norm_ is BO.clip_grad_norm_
+    ck = torch.load("checkpoints/last.pth", map_location="cpu", weights_only=False)
+    # the reference's schema (bifold/__main__.py:304-325)
+    assert set(ck) >= {"epoch", "random_states", "model", "optimizer", "scheduler", "best_eval"}
+    assert ck["epoch"] == 3 and len(ck["random_states"]) == 4
+    assert isinstance(ck["random_states"][2], torch.Tensor) and isinstance(ck["random_states"][3], torch.Tensor)
+    assert ck["scheduler"]["last_step"] == t.scheduler.last_step and "optimizer" not in ck["scheduler"]
+    assert ck["optimizer"]["state"][0]["step"].item() == steps
+    final = {k: v.clone() for k, v in t.model.state_dict().items()}
+    assert t.metrics.best_eval is not None and np.isfinite(t.metrics.best_eval)
+
+    # ---- the same command again: auto-resume finds the finished run, trains nothing, evaluates
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t2 = M.main(list(OVERRIDES))
+    assert os.getcwd() == run_dir and t2.start_epoch == 3
+    for k, v in final.items():
+        assert torch.equal(t2.model.state_dict()[k].cpu(), v.cpu()), k
+
+    # ---- an interrupted run: epoch 0, save, new process state, resume -> same parameters as 2 straight epochs
+    ov = [o for o in OVERRIDES if not o.startswith("epochs=")] + ["epochs=2", "eval_epochs=null"]
+    ta, _ = _trainer(ov)
+    ta.prepare_train()
+    ta.train()
+    straight = {k: v.clone() for k, v in ta.model.state_dict().items() if "clip_encoder" not in k}
+    os.remove("checkpoints/last.pth")
+    tb, _ = _trainer(ov)
+    tb.prepare_train()
+    tb.train_epoch(0)
+    tb.save_model(0)
+    tc, _ = _trainer(ov)
+    tc.prepare_train()
+    assert tc.start_epoch == 1 and tc.optimizer.step_count == len(tc.train_dataloader)
+    assert tc.scheduler.last_step == tb.scheduler.last_step
+    tc.train()
+    for k, v in straight.items():
+        got = tc.model.state_dict()[k]
+        assert (got - v).abs().max().item() <= 1e-6 * (v.abs().max().item() + 1e-12) + 1e-9, k
+
+
+def test_a_reference_shaped_checkpoint_resumes(gpu, run_home):
+    """A `last.pth` written by the reference's Trainer.save_model (torch.optim.Adam state, `epoch` = next epoch,
+    `random_states` 4-tuple) loads: start epoch, RNG streams, weights, optimiser moments."""
+    import random
+    ov = [o for o in OVERRIDES if not o.startswith(("scheduler=", "gradient_clip="))] + ["scheduler=none"]
+    t, _ = _trainer(ov)
+    t.prepare_train()
+    params = [p for p in t.model.parameters() if p.requires_grad]
+    ref_opt = torch.optim.Adam([p.detach().clone().requires_grad_(True) for p in params], lr=1e-4)
+    for p in ref_opt.param_groups[0]["params"]:
+        p.grad = torch.full_like(p, 1e-3)
+    ref_opt.step()
+    random.seed(5); np.random.seed(6); torch.manual_seed(7); torch.cuda.manual_seed(8)
+    want_py, want_np, want_t = random.getstate(), np.random.get_state(), torch.get_rng_state()
+    want_cuda = torch.cuda.get_rng_state()
+    os.makedirs("checkpoints", exist_ok=True)
+    torch.save({"epoch": 2, "random_states": (want_py, want_np, want_t, want_cuda),
+                "model": t.model.state_dict(), "optimizer": ref_opt.state_dict(), "best_eval": 12.5},
+               "checkpoints/last.pth")
+    random.seed(0); np.random.seed(0); torch.manual_seed(0); torch.cuda.manual_seed(0)
+    t2, _ = _trainer(ov)
+    t2.prepare_train()
+    assert t2.start_epoch == 2 and t2.metrics.best_eval == 12.5 and t2.optimizer.step_count == 1
+    assert random.getstate() == want_py and torch.equal(torch.get_rng_state(), want_t)
+    assert torch.equal(torch.cuda.get_rng_state().cpu(), want_cuda.cpu())
+    assert np.array_equal(np.random.get_state()[1], want_np[1])
+    assert float(t2.optimizer.exp_avg.abs().max()) > 0
+
+
+def test_torch_clip_grad_norm_on_arena_gradients_equals_torch(gpu, golden_dir):
+    """`torch.nn.utils.clip_grad_norm_(model.parameters(), c)` -- the reference's line, unchanged -- on a model whose
+    gradients live in the arena: same total norm and same clipped gradients as torch's own implementation; tensors
+    that are not arena-backed still go to torch."""
+    import bifold.optim as BO
+    from test_model_gpu import build_tiny, load_fixture
+    from bifold.losses import Losses
+    fx = load_fixture(golden_dir, "tiny_unimanual.npz")
+    model = build_tiny(False, "fp32", gpu)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in fx["state"].items()}, strict=True)
+    model = model.to(gpu).train()
+    sample = {k: torch.from_numpy(v).to(gpu) for k, v in fx["sample"].items()}
+    loss, _ = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))(model(sample), sample)
+    loss.backward()
+    named = [(n, p) for n, p in model.named_parameters() if p.grad is not None]
+    copies = [p.detach().clone().requires_grad_(True) for _, p in named]
+    for c, (_, p) in zip(copies, named):
+        c.grad = p.grad.detach().clone()
+    for max_norm in (1e-3, 1e9):                      # clipping active / inactive
+        want = BO._torch_clip_grad_norm_(copies, max_norm)
+        got = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        assert got.shape == want.shape and abs(got.item() - want.item()) <= 1e-5 * want.item()
+        for c, (n, p) in zip(copies, named):
+            assert torch.allclose(p.grad, c.grad, rtol=1e-5, atol=1e-12), n
+    loose = [torch.nn.Parameter(torch.randn(7, device=gpu)) for _ in range(2)]
+    for p in loose:
+        p.grad = torch.ones_like(p)
+    n = torch.nn.utils.clip_grad_norm_(loose, 1.0)
+    assert abs(n.item() - (14 ** 0.5)) < 1e-5 and abs(loose[0].grad[0].item() - 14 ** -0.5) < 1e-5
+
+
+def test_second_backward_without_step_raises(gpu, golden_dir):
+    from test_model_gpu import build_tiny, load_fixture
+    from bifold.losses import Losses
+    from bifold.optim import Optimizers
+    fx = load_fixture(golden_dir, "tiny_unimanual.npz")
+    model = build_tiny(False, "fp32", gpu).to(gpu).train()
+    sample = {k: torch.from_numpy(v).to(gpu) for k, v in fx["sample"].items()}
+    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))
+    opt = Optimizers.get_by_name(dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
+                                 [p for p in model.parameters() if p.requires_grad])
+    loss_fn(model(sample), sample)[0].backward()
+    with pytest.raises(RuntimeError, match="gradient accumulation"):
+        loss_fn(model(sample), sample)[0].backward()
+    opt.zero_grad()
+    loss_fn(model(sample), sample)[0].backward()     # consumed -> fine again
+    opt.step()
+    loss_fn(model(sample), sample)[0].backward()
+
+
+DDP_SCRIPT = r"""
+import os, sys, warnings
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from bifold import dist as bdist
+from bifold.losses import Losses
+from bifold.models import Models
+from bifold.models.clip_encoder import CLIP_CONFIGS
+rank, local, world = bdist.init_process_group_from_env()
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" and world == 1
+dev = torch.device("cuda", 0)
+CLIP_CONFIGS["t"] = dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+                         context_length=77, vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
+cfg = dict(name="rgb_clip", image_size=64, is_bimanual=False, requires_graph=False, text_encoder="t", patch_size=16,
+           depth=3, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
+           pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype="fp32")
+torch.manual_seed(0)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    model = Models.get_by_name(cfg, device=dev).to(dev).train()
+g = torch.Generator().manual_seed(1)
+sample = {"rgb": torch.randn(4, 3, 64, 64, generator=g).to(dev), "instruction": torch.randint(1, 500, (4, 77), generator=g).int().to(dev)}
+for k in ("pick", "place"):
+    sample[k + "_heatmap"] = torch.rand(4, 64, 64, generator=g).to(dev)
+loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))
+loss_fn(model(sample), sample)[0].backward()
+torch.cuda.synchronize()
+plain = model.trainable_arena().grad.clone()
+model.trainable_arena().grads_pending = False
+sync = bdist.gradient_sync_for(model)                # registers on_ready through register_grad_ready_hook
+launched = []
+orig = sync._launch
+sync._launch = lambda spans: (launched.append(list(spans)), orig(spans))[1]
+loss_fn(model(sample), sample)[0].backward()         # the real fused backward drives the hooks
+sync.finish()
+torch.cuda.synchronize()
+flat = sorted(sum(launched, []))
+assert flat[0][0] == 0 and flat[-1][1] == model.trainable_arena().count
+assert all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)), flat
+assert len(launched) >= 2                             # at least one bucket left before the end of backward
+got = model.trainable_arena().grad
+assert torch.allclose(got, plain, rtol=1e-6, atol=1e-12), float((got - plain).abs().max())
+torch.distributed.destroy_process_group()
+print("DDP-HOOKS-OK", len(launched))
+"""
+
+
+def test_backward_hooks_drive_rccl_allreduce_world1(gpu, tmp_path):
+    """World-size-1 RCCL group (BIFOLD_FORCE_PG=1) in a child process: the REAL fused backward reports layers through
+    register_grad_ready_hook, GradSync all-reduces every arena slice exactly once on its side stream while the
+    backward is still running, and the averaged gradients equal the un-synchronised ones."""
+    script = tmp_path / "ddp_world1.py"
+    script.write_text(DDP_SCRIPT)
+    env = dict(os.environ, BIFOLD_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="1", RANK="0",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", BIFOLD_DDP_COALESCE="1")
+    r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP-HOOKS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
