@@ -85,9 +85,10 @@ def test_config_a_batch_256_bf16_matches_oracle_and_exact_mode(gpu, observed):
              loss_rel_bf16_vs_fp32=loss_rel, worst_grad_rel=grad_err[worst], worst_grad=worst,
              median_grad_rel=float(np.median(list(grad_err.values()))))
     assert err["fp32"] < 1e-3                       # the exact mode meets north_star's gate at the bench shapes
-    assert err["bf16"] < 3e-2                       # FIRST-RUN placeholder, tightened to ~3x observed below
-    assert loss_rel < 1e-3
-    assert grad_err[worst] < 0.15, (worst, grad_err[worst])
+    # observed on MI355X: heatmaps 2.4e-4, loss 2.2e-5, worst gradient tensor 6.8e-3 (median 2.8e-3)
+    assert err["bf16"] < 1e-3                       # the bf16 mode meets north_star's 1e-3 gate at the bench shapes
+    assert loss_rel < 1e-4
+    assert grad_err[worst] < 2e-2, (worst, grad_err[worst])
 
 
 def test_reference_per_op_fixtures_through_the_hip_kernels(gpu, golden_dir, observed):
@@ -154,7 +155,7 @@ def test_reference_per_op_fixtures_through_the_hip_kernels(gpu, golden_dir, obse
     # nn.BCELoss incl. the -100 clamp at p = 0 / p = 1 (losses/__init__.py:61)
     bce = fx["bce"]
     loss = bce_mean(torch.from_numpy(bce["p"]).view(1, -1).to(gpu), torch.from_numpy(bce["t"]).view(1, -1).to(gpu))
-    seen["bce"] = abs(loss.item() - float(bce["loss"][""])) / abs(float(bce["loss"][""]))
+    seen["bce"] = abs(loss.item() - float(bce["loss"])) / abs(float(bce["loss"]))
     assert seen["bce"] < 1e-6
     # four Adam steps (optim/__init__.py:7-12 -> torch.optim.Adam)
     ad = fx["adam"]
