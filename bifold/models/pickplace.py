@@ -403,13 +403,21 @@ class RGBTailFn(torch.autograd.Function):
         batch = vis_feat.shape[0] // n_rgb
         n_text = text_feat.shape[0] // batch
         seq = 1 + n_text + n_rgb
-        rgb_feat = ops.gemm(vis_feat, A.operand(model.project.weight, cdt), bias=model.project.bias.data,
-                            out_dtype=torch.float32)
-        x = ops.fusion_assemble(text_feat, rgb_feat, model.text_token.data.view(-1),
-                                model.text_pos_embedding.data.view(-1, dim),
-                                model.rgb_pos_embedding.data.view(-1, dim),
-                                fus.token_type_embeddings.weight.data, batch, n_text, n_rgb)
-        del rgb_feat
+        # K8: the fusion input X [B, 1 + n_text + n_rgb, dim] is written in place by its two
+        # producers -- no rgb_feat round trip through HBM, no separate assembly pass over the image rows:
+        #   rows 0 .. n_text      text_token / frozen text features + text_pos + type[0]   (bf_segment_assemble)
+        #   rows 1 + n_text ..    project(vis_feat) + bias + (rgb_pos + type[1]): the GEMM's epilogue adds the
+        #                         per-token table as a residual indexed m % n_rgb and remaps row m of the
+        #                         [B * n_rgb] problem to row (m / n_rgb) * seq + 1 + n_text + m % n_rgb
+        # (models/rgb_clip.py:52-66 + models/fusion.py:45-56).
+        type_w = fus.token_type_embeddings.weight.data
+        x = torch.empty(batch * seq, dim, dtype=torch.float32, device=vis_feat.device)
+        ops.segment_assemble(text_feat, n_text * dim, model.text_token.data.view(-1),
+                             model.text_pos_embedding.data.view(-1, dim)[:1 + n_text], type_w[0], x, batch,
+                             n_text, seq, 0)
+        rgb_table = model.rgb_pos_embedding.data.view(-1, dim) + type_w[1]          # [n_rgb, dim], 400 KB of glue
+        ops.gemm(vis_feat, A.operand(model.project.weight, cdt), bias=model.project.bias.data,
+                 residual=rgb_table, resid_mod=n_rgb, out=x, rows_in=n_rgb, rows_out=seq, row_off=1 + n_text)
         heat, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, L.MASK_NONE, None, save)
         if save:
             c = _Ctx()

@@ -9,8 +9,9 @@ their activations and `tower_backward` continues the fused tail's backward throu
 (siglip_encoder.SiglipTowers).  LoRA's arithmetic lives in the third-party `peft` package, absent
 from this image: that mode follows PEFT's published definition and is PARITY UNPINNED (checked
 against oracle/lora_oracle.py, a torch-autograd restatement, not against the reference);
-`lora_dropout` must be 0 -- the adapters are merged into the in-projection weights, which a
-dropout on the adapter's input alone does not allow.  New optional keys: `dtype`,
+`lora_dropout` > 0 (the reference ships 0.01) runs the adapters unmerged in training with a
+device-generated, replayable mask per adapted Linear (siglip_encoder.SiglipTowers); in eval mode or at
+0 they are merged into the in-projection weights.  New optional keys: `dtype`,
 `siglip_checkpoint`.
 """
 from __future__ import annotations
@@ -32,17 +33,13 @@ class SigLip(BaseModel):
     def __init__(self, patch_size, dim, lora, r, lora_alpha, lora_dropout, automodel_name, target_modules,
                  pick_place_model, dtype="bf16", siglip_checkpoint=None, **kwargs):
         super().__init__(**kwargs)
-        if lora and float(lora_dropout) != 0.0:
-            raise ValueError(
-                f"lora_dropout={lora_dropout}: the adapters are merged into the projection weights "
-                f"(W + alpha/r B A), which is PEFT's forward only without dropout on the adapter input; "
-                f"set model.lora_dropout=0 (the reference's 0.01 drops 1 % of the adapter's inputs)")
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
         self.compute_dtype = _DTYPES[dtype]
         self.patch_size = patch_size
         self.lora = bool(lora)
-        adapters = dict(r=r, alpha=lora_alpha, targets=list(target_modules), adapter="siglip_adapter") if lora else None
+        adapters = (dict(r=r, alpha=lora_alpha, targets=list(target_modules), adapter="siglip_adapter",
+                         dropout=float(lora_dropout)) if lora else None)
         self.siglip_model = from_pretrained(automodel_name, siglip_checkpoint, lora=adapters)
         self.hidden_size = dim
         assert self.hidden_size == self.siglip_model.vcfg["hidden_size"]
@@ -89,6 +86,7 @@ class SigLip(BaseModel):
                                f"restatement lives in oracle/ for tests)")
         cdt = self.compute_dtype
         self.trainable_arena().sync_shadow()
+        self.siglip_model.begin_step()
         img = self._vision(x, cdt)                                            # [B*n, W] fp32
         txt = self.siglip_model.text_tokens(x["instruction"], cdt)            # [B*L, W] fp32
         return img, txt

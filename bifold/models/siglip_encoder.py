@@ -12,10 +12,17 @@ class token, no attention mask.
 `lora=None`: frozen towers, forward only (models/siglip.py:41-43).  With a `lora` dict (the
 reference's default, models/siglip.py:33-40: `LoraModel(siglip_model, LoraConfig(r, lora_alpha,
 target_modules=[q_proj, v_proj], lora_dropout), "siglip_adapter")`) every targeted projection of
-BOTH towers gains `lora_A [r, in]` (Kaiming-uniform) and `lora_B [out, r]` (zeros), the forward
-runs with `W + (alpha / r) B A` merged into the packed in-projection (identical to PEFT's
-`Wx + b + (alpha / r) B A x` at lora_dropout = 0), activations are kept, and `backward()` walks
-both towers in reverse to produce the adapters' gradients.  Parameter names then follow PEFT's
+BOTH towers gains `lora_A [r, in]` (Kaiming-uniform) and `lora_B [out, r]` (zeros), activations are
+kept, and `backward()` walks both towers in reverse to produce the adapters' gradients.  Two forms
+of PEFT's `Wx + b + (alpha / r) B A dropout(x)`:
+  * merged -- `W + (alpha / r) B A` folded into the packed in-projection: exact when the dropout is
+    the identity, i.e. at lora_dropout = 0 and, as in PEFT, whenever the module is in eval mode
+    or gradients are off;
+  * unmerged (training with lora_dropout > 0, the reference's shipped 0.01): the base projection
+    plus, per adapted projection, `u = dropout(h) A^T` (an [M, r] GEMM) and a rank-r GEMM that
+    ACCUMULATES `(alpha / r) u B^T` into that projection's columns of the packed QKV buffer.  Every
+    adapted Linear draws its own mask, regenerated from a seed in the backward pass
+    (bf_dropout); `last_dropout_seeds` lets a checker replay the masks.  Parameter names then follow PEFT's
 wrapping (`base_model.model.` prefix, `<proj>.base_layer.{weight,bias}`,
 `<proj>.lora_{A,B}.<adapter>.weight`).  PARITY UNPINNED for this mode: `peft` is not in the
 image, so the arithmetic follows PEFT's published definition and is checked against a torch
@@ -64,8 +71,11 @@ class SiglipTowers(nn.Module):
                 raise NotImplementedError(f"LoRA target_modules {bad}: only {list(_MERGEABLE)} are built")
             if int(lora["r"]) % 4 != 0 or int(lora["r"]) <= 0:
                 raise ValueError(f"LoRA rank r={lora['r']} must be a positive multiple of 4 (fp32 GEMM row alignment)")
+            p_drop = float(lora.get("dropout", 0.0))
+            if not 0.0 <= p_drop < 1.0:
+                raise ValueError(f"lora_dropout must be in [0, 1), got {p_drop}")
             self.lora = dict(r=int(lora["r"]), alpha=float(lora["alpha"]), targets=targets,
-                             adapter=str(lora.get("adapter", "siglip_adapter")))
+                             adapter=str(lora.get("adapter", "siglip_adapter")), dropout=p_drop)
             self._prefix = "base_model.model."
         vw, tw = vision["hidden_size"], text["hidden_size"]
         p = vision["patch_size"]
@@ -105,6 +115,11 @@ class SiglipTowers(nn.Module):
         self._packed_version = -1
         self._err_flag: Optional[torch.Tensor] = None
         self._saved: Dict[str, Dict] = {}             # per tower: what backward() needs
+        self._packed_merged = False
+        # (tower, call index within the step, layer, projection) -> seed of that Linear's dropout mask in the
+        # most recent training forward; bf_dropout_mask(seed) replays it
+        self.last_dropout_seeds: Dict = {}
+        self._calls: Dict[str, int] = {}
         if self.lora:                                 # PEFT: only the adapters train
             for n, p in self.named_parameters():
                 p.requires_grad_(".lora_" in n)
@@ -174,9 +189,24 @@ class SiglipTowers(nn.Module):
                     self._packed[b + "w"] = torch.cat(ws, dim=0).contiguous()
                     self._packed[b + "b"] = torch.cat(bs, dim=0).contiguous()
             self._packed_version = ver
-        if self.lora:
+            self._packed_merged = False
+        if self.lora and not self._unmerged():
             self._merge_adapters(cdt)
+            self._packed_merged = True
+        elif self._packed_merged:                         # back to the base rows for the unmerged form
+            self._packed_version = -1
+            return self._runtime(cdt)
         return a
+
+    def _unmerged(self) -> bool:
+        """PEFT's training-mode forward with an active dropout: the adapters cannot be folded into W."""
+        return (self.lora is not None and self.lora["dropout"] > 0.0 and self.training and torch.is_grad_enabled())
+
+    def begin_step(self) -> None:
+        """Called by the model at the top of each forward: resets the per-step call counters that key the
+        dropout seeds (the vision tower runs twice per step in SiglipSequential)."""
+        self._calls = {}
+        self.last_dropout_seeds = {}
 
     def _merge_adapters(self, cdt: torch.dtype) -> None:
         """Packed in-projection rows of every adapted projection <- W + (alpha / r) B A (fp32 math on
@@ -211,13 +241,38 @@ class SiglipTowers(nn.Module):
         """The pre-LN blocks.  `saved` (a list) receives per layer what _encoder_bwd needs; without it
         the residual stream is updated in place."""
         heads = cfg["num_attention_heads"]
-        d = cfg["hidden_size"] // heads
+        w = cfg["hidden_size"]
+        d = w // heads
         keep = saved is not None
+        unmerged = keep and self._unmerged()
+        if unmerged:
+            if cdt != torch.float32 and self.lora["r"] % 8:
+                raise ValueError(f"lora_dropout > 0 in bf16 needs a LoRA rank that is a multiple of 8 (the adapter "
+                                 f"branch is a K = r bf16 GEMM), got r={self.lora['r']}")
+            call = self._calls.get(tower, 0)
+            self._calls[tower] = call + 1
+            # one host-side draw per tower call from torch's CPU generator (seeded by cfg.seed): no device sync
+            base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            p_drop, scale = self.lora["dropout"], self.lora["alpha"] / self.lora["r"]
         for i in range(cfg["num_hidden_layers"]):
             b = f"{tower}.encoder.layers.{i}."
             h1, m1, r1 = ops.layernorm_fwd(x, self._f(b + "layer_norm1.weight"), self._f(b + "layer_norm1.bias"), cdt,
                                            save_stats=keep, eps=LN_EPS)
             qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
+            drop = None
+            if unmerged:
+                drop = {}
+                for slot, n in enumerate("qkv"):
+                    if f"{n}_proj" not in self.lora["targets"]:
+                        continue
+                    seed = (base_seed + 16 * i + slot) & (2 ** 63 - 1)
+                    self.last_dropout_seeds[(tower, call, i, f"{n}_proj")] = seed
+                    la, lb = self.lora_params(tower, i, f"{n}_proj")
+                    hd = ops.dropout(h1, p_drop, seed)
+                    u = ops.gemm(hd, la.data.to(cdt))                          # [M, r]
+                    ops.gemm(u, lb.data.to(cdt), alpha=scale, out=qkv[:, slot * w:(slot + 1) * w], accumulate=True)
+                    drop[n] = (u, seed)
+                    del hd
             o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, L.MASK_NONE, need_lse=keep)
             xm = ops.gemm(o, self._w(b + "self_attn.out_proj.weight", cdt), bias=self._f(b + "self_attn.out_proj.bias"),
                           residual=x, out=None if keep else x, out_dtype=torch.float32)
@@ -232,7 +287,8 @@ class SiglipTowers(nn.Module):
             xo = ops.gemm(a, self._w(b + "mlp.fc2.weight", cdt), bias=self._f(b + "mlp.fc2.bias"), residual=xm,
                           out=None if keep else xm, out_dtype=torch.float32)
             if keep:      # h2 and a feed only frozen weights' gradients: not kept
-                saved.append(dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, xm=xm, m2=m2, r2=r2, pre=pre))
+                saved.append(dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, xm=xm, m2=m2, r2=r2, pre=pre,
+                                  drop=drop))
             x = xo
         return x
 
@@ -263,17 +319,38 @@ class SiglipTowers(nn.Module):
             # attention:  xm = x + attn(h1 Wqkv_eff^T + b) Wo^T + bo
             do = ops.gemm(op2, self._w(b + "self_attn.out_proj.weight", cdt), b_kn=True)
             dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, L.MASK_NONE, None)
-            ops.gemm(dqkv, S["h1"], trans_a=True, b_kn=True, out=dw)
-            for slot, n in enumerate("qkv"):
-                if f"{n}_proj" not in self.lora["targets"]:
-                    continue
-                la, lb = self.lora_params(tower, i, f"{n}_proj")
-                dwp = dw[slot * w:(slot + 1) * w]
-                # 8-wide outputs: a handful of tiles, so the contraction is split to occupy more CUs
-                sk = 8 if w % 256 == 0 else 1
-                ops.gemm(dwp, la.data, alpha=scale, out=grad_view(lb), split_k=sk)                            # dW A^T
-                ops.gemm(lb.data, dwp, trans_a=True, b_kn=True, alpha=scale, out=grad_view(la), split_k=sk)  # B^T dW
-            dh1 = ops.gemm(dqkv, self._packed[b + "self_attn.w"], b_kn=True)
+            if S["drop"] is None:
+                # merged form: dW_eff = dY^T h1, dB = s dW_eff A^T, dA = s B^T dW_eff
+                ops.gemm(dqkv, S["h1"], trans_a=True, b_kn=True, out=dw)
+                for slot, n in enumerate("qkv"):
+                    if f"{n}_proj" not in self.lora["targets"]:
+                        continue
+                    la, lb = self.lora_params(tower, i, f"{n}_proj")
+                    dwp = dw[slot * w:(slot + 1) * w]
+                    # 8-wide outputs: a handful of tiles, so the contraction is split to occupy more CUs
+                    sk = 8 if w % 256 == 0 else 1
+                    ops.gemm(dwp, la.data, alpha=scale, out=grad_view(lb), split_k=sk)                            # dW A^T
+                    ops.gemm(lb.data, dwp, trans_a=True, b_kn=True, alpha=scale, out=grad_view(la), split_k=sk)  # B^T dW
+                dh1 = ops.gemm(dqkv, self._packed[b + "self_attn.w"], b_kn=True)
+            else:
+                # unmerged form, per adapted projection with its own mask D (regenerated from the seed):
+                #   y += s u B^T, u = (D h1) A^T   =>   du = s dy B,  dB = s dy^T u,  dA = du^T (D h1),
+                #   dh1 += D (du A)
+                dh1 = ops.gemm(dqkv, self._packed[b + "self_attn.w"], b_kn=True)      # base rows
+                p_drop = self.lora["dropout"]
+                for slot, n in enumerate("qkv"):
+                    if n not in S["drop"]:
+                        continue
+                    u, seed = S["drop"][n]
+                    la, lb = self.lora_params(tower, i, f"{n}_proj")
+                    dy = dqkv[:, slot * w:(slot + 1) * w]
+                    du = ops.gemm(dy, lb.data.to(cdt), b_kn=True, alpha=scale)                    # [M, r]
+                    ops.gemm(dy, u, trans_a=True, b_kn=True, alpha=scale, out=grad_view(lb))      # [w, r]
+                    hd = ops.dropout(S["h1"], p_drop, seed)
+                    ops.gemm(du, hd, trans_a=True, b_kn=True, out=grad_view(la))                  # [r, w]
+                    t = ops.gemm(du, la.data.to(cdt), b_kn=True)                                  # [M, w]
+                    ops.dropout(t, p_drop, seed, out=dh1, accumulate=True)
+                    del hd, t, du
             dx, dx_c = ops.layernorm_bwd(dh1, S["x"], self._f(b + "layer_norm1.weight"), S["m1"], S["r1"], dxm, cdt,
                                          junk_g, junk_b)
             saved[i] = None                                # free this block's activations early

@@ -1314,8 +1314,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     BF_REQUIRE(g->c_dtype == BF_F32 || g->c_dtype == BF_BF16, BF_EINVAL, "bf_gemm: bad c_dtype");
     BF_REQUIRE(!(g->cdt == BF_F32 && g->c_dtype != BF_F32), BF_EINVAL,
                "bf_gemm: fp32 operands produce fp32 output only");
-    BF_REQUIRE(!(g->accumulate && g->c_dtype != BF_F32), BF_EINVAL,
-               "bf_gemm: accumulate needs an fp32 C");
+    BF_REQUIRE(!(g->accumulate && g->split_k > 1 && g->c_dtype != BF_F32), BF_EINVAL,
+               "bf_gemm: accumulate into a bf16 C cannot be combined with split_k");
     BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_TANH_GELU_GRAD, BF_EINVAL, "bf_gemm: bad act");
     BF_REQUIRE((g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD) || g->aux, BF_EINVAL,
                "bf_gemm: the GELU_GRAD activations need aux");

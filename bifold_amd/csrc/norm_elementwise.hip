@@ -851,3 +851,71 @@ extern "C" int bf_segment_assemble_bwd(const float* dx, float* d_lead, float* d_
     BF_CHECK_LAUNCH("bf_segment_assemble_bwd/2");
     return BF_OK;
 }
+
+// ----------------------------------------------------------------------------------------
+// Dropout with a REPLAYABLE mask (LoRA's `lora_dropout` on the adapter input, reference
+// bifold/models/siglip.py:33-40 -> peft LoraLayer: lora_B(lora_A(dropout(x)))).  The keep decision of
+// element i is a pure function of (seed, i): splitmix64 -> 24 bits >= p * 2^24, so the backward pass
+// (and a CPU oracle, through bf_dropout_mask) regenerates the mask instead of storing it.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dropout_keep(unsigned long long idx, unsigned long long seed, unsigned thr) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 40) >= thr;
+}
+
+template <typename T, bool ACC>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n4,
+                                                      unsigned thr, float inv_keep, unsigned long long seed) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = Vec4<T>::load(x + i * 4);
+        float* vp = (float*)&v;
+        float4 o = ACC ? Vec4<T>::load(y + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* op = (float*)&o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            op[e] += dropout_keep(i * 4 + e, seed, thr) ? vp[e] * inv_keep : 0.f;
+        Vec4<T>::store(y + i * 4, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ mask, size_t n, unsigned thr,
+                                                           unsigned long long seed) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        mask[i] = dropout_keep(i, seed, thr) ? 1 : 0;
+}
+
+static inline unsigned dropout_threshold(float p) { return (unsigned)((double)p * 16777216.0); }
+
+extern "C" int bf_dropout(const void* x, void* y, int dtype, size_t count, float p, unsigned long long seed,
+                          int accumulate, bf_stream_t stream) {
+    BF_REQUIRE(x && y && count > 0 && (count & 3) == 0, BF_EINVAL, "bf_dropout: count must be a positive multiple of 4");
+    BF_REQUIRE(p >= 0.f && p < 1.f, BF_EINVAL, "bf_dropout: p must be in [0, 1) (got %f)", (double)p);
+    BF_REQUIRE(dtype == BF_F32 || dtype == BF_BF16, BF_EINVAL, "bf_dropout: bad dtype");
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(y), BF_EALIGN, "bf_dropout: unaligned pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const unsigned thr = dropout_threshold(p);
+    const float inv_keep = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+#define BF_DROP(T, ACC) hipLaunchKernelGGL((dropout_kernel<T, ACC>), dim3((unsigned)blocks), dim3(256), 0, s, \
+                                           (const T*)x, (T*)y, n4, thr, inv_keep, seed)
+    if (dtype == BF_F32) { if (accumulate) BF_DROP(float, true); else BF_DROP(float, false); }
+    else { if (accumulate) BF_DROP(bf16_t, true); else BF_DROP(bf16_t, false); }
+#undef BF_DROP
+    BF_CHECK_LAUNCH("bf_dropout");
+    return BF_OK;
+}
+
+extern "C" int bf_dropout_mask(uint8_t* mask, size_t count, float p, unsigned long long seed, bf_stream_t stream) {
+    BF_REQUIRE(mask && count > 0 && p >= 0.f && p < 1.f, BF_EINVAL, "bf_dropout_mask: bad args");
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, count,
+                       dropout_threshold(p), seed);
+    BF_CHECK_LAUNCH("bf_dropout_mask");
+    return BF_OK;
+}

@@ -108,6 +108,8 @@ PROTOTYPES = {
     "bf_gemm_last_variant": (c_int, []),
     "bf_gemm_tail_workspace_bytes": (c_size_t, [POINTER(GemmArgs)]),
     "bf_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
+    "bf_dropout": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, C.c_ulonglong, c_int, c_void_p]),
+    "bf_dropout_mask": (c_int, [c_void_p, c_size_t, c_float, C.c_ulonglong, c_void_p]),
     "bf_preprocess_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p]),
     "bf_heatmap_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -267,6 +267,28 @@ def cast(src: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = No
     return dst
 
 
+def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """y (+)= keep(seed, i) ? x / (1 - p) : 0 with the replayable mask of bf_dropout."""
+    _dev(x, "x")
+    y = out if out is not None else torch.empty_like(x)
+    if accumulate and out is None:
+        raise RuntimeError("accumulate needs an `out` to add into")
+    _dev(y, "out")
+    if y.shape != x.shape or y.dtype != x.dtype:
+        raise RuntimeError("dropout: out must match x")
+    check(lib.bf_dropout(_ptr(x), _ptr(y), dtype_code(x), x.numel(), float(p), int(seed) & (2 ** 64 - 1),
+                         int(accumulate), _stream()), "bf_dropout")
+    return y
+
+
+def dropout_mask(shape, p: float, seed: int, device) -> torch.Tensor:
+    """The keep decisions of ops.dropout(x, p, seed) for a tensor of `shape`, as uint8 (1 = kept)."""
+    mask = torch.empty(shape, dtype=torch.uint8, device=device)
+    check(lib.bf_dropout_mask(_ptr(mask), mask.numel(), float(p), int(seed) & (2 ** 64 - 1), _stream()),
+          "bf_dropout_mask")
+    return mask
+
+
 # ----------------------------------------------------------------------------- attention
 def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale: float,
                   mask_mode: int = L.MASK_NONE, row_mask: Optional[torch.Tensor] = None,

@@ -101,7 +101,8 @@ int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
  *   v += residual[r(m), n]  (fp32; row r = m % resid_mod if resid_mod > 0, else the
  *        output row)
  *   out row = (m / rows_in) * rows_out + row_off + m % rows_in   (rows_in = 0: identity)
- *   C[out row, n] (c_dtype) = v   (or += v when accumulate != 0, fp32 C only);
+ *   C[out row, n] (c_dtype) = v   (or += v when accumulate != 0: fp32 math on the stored value, one more
+ *        rounding for a bf16 C);
  *   c2 (optional, BF16) receives a bf16 copy of v at the same position.
  * ---------------------------------------------------------------------- */
 enum { BF_ACT_NONE = 0, BF_ACT_QUICK_GELU = 1, BF_ACT_ERF_GELU = 2, BF_ACT_ERF_GELU_GRAD = 3,
@@ -337,6 +338,16 @@ int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_stream_t str
  * ws: fp32 scratch >= 1026 floats. */
 int bf_clip_grad_norm(float* grad, size_t count, float max_norm, float* ws, float* norm_out,
                       bf_stream_t stream);
+
+/* Inverted dropout with a replayable mask: y[i] (+)= keep(seed, i) ? x[i] / (1 - p) : 0, keep = a pure function
+ * of (seed, element index) (splitmix64, 24 bits against p * 2^24), so the backward pass regenerates the mask from
+ * the seed instead of storing it.  Replaces the nn.Dropout(lora_dropout) PEFT puts in front of lora_A
+ * (models/siglip.py:33-40 -> LoraConfig(lora_dropout=...)).  x, y: dtype BF_F32 / BF_BF16, count % 4 == 0;
+ * accumulate != 0 adds into y (the backward: dX += mask * dT / (1 - p)).  bf_dropout_mask writes the same
+ * decisions as bytes (1 = kept) for a checker that has to replay them. */
+int bf_dropout(const void* x, void* y, int dtype, size_t count, float p, unsigned long long seed, int accumulate,
+               bf_stream_t stream);
+int bf_dropout_mask(uint8_t* mask, size_t count, float p, unsigned long long seed, bf_stream_t stream);
 
 /* Elementwise cast between fp32 and bf16 (count elements). */
 int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,

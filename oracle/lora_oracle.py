@@ -12,8 +12,9 @@ file restates PEFT's published definition of a LoRA-wrapped nn.Linear
         y = base_layer(x) + lora_B(lora_A(lora_dropout(x))) * (lora_alpha / r)
 
 (peft.tuners.lora.layer.Linear.forward; lora_A: Linear(in, r, bias=False) initialised
-kaiming_uniform(a=sqrt(5)), lora_B: Linear(r, out, bias=False) initialised to zero; dropout is the
-identity at p = 0 / in eval mode) and PEFT's parameter naming after wrapping
+kaiming_uniform(a=sqrt(5)), lora_B: Linear(r, out, bias=False) initialised to zero; lora_dropout is
+nn.Dropout(p) on the adapter branch's input -- the identity at p = 0 / in eval mode, and with a
+replayed mask here, see lora_linear) and PEFT's parameter naming after wrapping
 (`base_model.model.<hf name>`, `<proj>.base_layer.{weight,bias}`,
 `<proj>.lora_{A,B}.<adapter>.weight`).  It deliberately applies the adapter UNMERGED, as PEFT does in
 training, so that it is an independent check of the product's merged-weight formulation; gradients
@@ -34,12 +35,21 @@ PEFT_PREFIX = "siglip_model.base_model.model."
 
 
 def lora_linear(state: State, pfx: str, x: torch.Tensor, scale: float, adapter: str):
-    """`pfx` = "...self_attn.q_proj." -- adapted when the state holds lora_A for it."""
+    """`pfx` = "...self_attn.q_proj." -- adapted when the state holds lora_A for it.
+
+    Training-mode dropout (`lora_dropout` > 0): nn.Dropout's mask is random, so a checker must REPLAY the
+    mask the implementation under test drew.  `state["__dropout__"]` (optional) = (p, {pfx: [mask, ...]}):
+    the keep masks (1 = kept, shaped like x) of that Linear in call order; each call consumes one and
+    applies inverted dropout, x * mask / (1 - p), to the adapter branch only -- the base branch sees x."""
     a_key = f"{pfx}lora_A.{adapter}.weight"
     if a_key not in state:
         return F.linear(x, state[pfx + "weight"], state[pfx + "bias"])
     y = F.linear(x, state[pfx + "base_layer.weight"], state[pfx + "base_layer.bias"])
-    return y + F.linear(F.linear(x, state[a_key]), state[f"{pfx}lora_B.{adapter}.weight"]) * scale
+    xa = x
+    if "__dropout__" in state:
+        p, masks = state["__dropout__"]
+        xa = x * masks[pfx].pop(0).to(x.dtype).reshape(x.shape) / (1.0 - p)
+    return y + F.linear(F.linear(xa, state[a_key]), state[f"{pfx}lora_B.{adapter}.weight"]) * scale
 
 
 def siglip_layer(state: State, pfx: str, x: torch.Tensor, heads: int, scale: float, adapter: str,
@@ -112,4 +122,4 @@ def siglip_sequential_forward(state: State, sample, tower_heads: int, fusion_hea
 def trainable_keys(state: State) -> Sequence[str]:
     """PEFT freezes everything inside the wrapped model except the adapters; the rest of SigLip
     (tokens, context positions, fusion, decoders) trains as before."""
-    return [k for k in state if not k.startswith("siglip_model.") or ".lora_" in k]
+    return [k for k in state if k != "__dropout__" and (not k.startswith("siglip_model.") or ".lora_" in k)]

@@ -252,9 +252,8 @@ def test_siglip_state_dict_schema_matches_reference(golden_dir, name, fixture, e
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         m = Models.get_by_name(dict(cfg), device=torch.device("cpu"))
-        with pytest.raises(ValueError, match="lora_dropout"):       # merged adapters: no dropout on their input
-            Models.get_by_name(dict(cfg, lora=True), device=torch.device("cpu"))
-        ml = Models.get_by_name(dict(cfg, lora=True, lora_dropout=0.0), device=torch.device("cpu"))
+        ml = Models.get_by_name(dict(cfg, lora=True), device=torch.device("cpu"))      # the shipped lora_dropout = 0.01
+        assert ml.siglip_model.lora["dropout"] == 0.01
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == ref
     assert all("siglip_model" in n for n, p in m.named_parameters() if not p.requires_grad)
     # lora=True: PEFT's key layout after LoraModel(model, config, "siglip_adapter") (models/siglip.py:33-40) --
