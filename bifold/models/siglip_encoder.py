@@ -116,6 +116,7 @@ class SiglipTowers(nn.Module):
         self._err_flag: Optional[torch.Tensor] = None
         self._saved: Dict[str, Dict] = {}             # per tower: what backward() needs
         self._packed_merged = False
+        self._unmerged_now = False
         # (tower, call index within the step, layer, projection) -> seed of that Linear's dropout mask in the
         # most recent training forward; bf_dropout_mask(seed) replays it
         self.last_dropout_seeds: Dict = {}
@@ -199,8 +200,9 @@ class SiglipTowers(nn.Module):
         return a
 
     def _unmerged(self) -> bool:
-        """PEFT's training-mode forward with an active dropout: the adapters cannot be folded into W."""
-        return (self.lora is not None and self.lora["dropout"] > 0.0 and self.training and torch.is_grad_enabled())
+        """PEFT's training-mode forward with an active dropout: the adapters cannot be folded into W.
+        Decided by _keep() at the top of a tower call (the body runs under no_grad)."""
+        return self._unmerged_now
 
     def begin_step(self) -> None:
         """Called by the model at the top of each forward: resets the per-step call counters that key the
@@ -362,7 +364,9 @@ class SiglipTowers(nn.Module):
         return y, (x, m, r)
 
     def _keep(self) -> bool:
-        return self.lora is not None and torch.is_grad_enabled()
+        keep = self.lora is not None and torch.is_grad_enabled()
+        self._unmerged_now = bool(keep and self.lora["dropout"] > 0.0 and self.training)
+        return keep
 
     def vision_tokens(self, img: torch.Tensor, cdt: torch.dtype) -> torch.Tensor:
         """[N,3,S,S] fp32 -> post_layernorm(tokens) fp32 [N*(S/p)^2, W]."""
