@@ -118,12 +118,42 @@ class PickPlaceConvDecoder(nn.Module):
                 add_param(self, f"{name}_decoder.decoder_net.{i}.weight", init["weight"].view(chans[j + 1], chans[j], 1, 1))
                 add_param(self, f"{name}_decoder.decoder_net.{i}.bias", init["bias"])
         self._U: Optional[torch.Tensor] = None
+        self._collapsed = None
+        self._side_stream = None
 
     def decoder_params(self, name: str):
         net = self._modules[f"{name}_decoder"].decoder_net
         ws = [net._modules[str(i)].weight for i in DEC_IDX]
         bs = [net._modules[str(i)].bias for i in DEC_IDX]
         return ws, bs
+
+    # The collapse of a head's five 1x1 convs into (w_eff, b_eff) and its backward are single-workgroup kernels
+    # (41 / 180 us each, two or four heads): latency, not work.  They run on a side HIP stream -- the forward one
+    # at the top of the model's forward, beside the towers; the backward one beside the fusion layers' backward.
+    def _side(self, device) -> "torch.cuda.Stream":
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=device)
+        return self._side_stream
+
+    def collapse_async(self) -> None:
+        """Start decoder_collapse_fwd for every head on the side stream (after everything already queued on the
+        current stream, i.e. after the optimiser step that produced the weights); decoder_heads_fwd joins it."""
+        ws0, _ = self.decoder_params(self.heads_out[0])
+        dev = ws0[0].device
+        main, side = torch.cuda.current_stream(), self._side(dev)
+        dim, nh = self.dim, len(self.heads_out)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+            b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
+            rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
+            for h, name in enumerate(self.heads_out):
+                ws, bs = self.decoder_params(name)
+                ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
+                                         rows_ws[h])
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._collapsed = (w_eff, b_eff, rows_ws, ev)
 
     def upsample_matrix(self, device) -> torch.Tensor:
         if self._U is None or self._U.device != device:
@@ -231,13 +261,21 @@ def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride
     (models/pickplace.py:71-123 with ConvDecoder collapsed, models/modules.py:58-71)."""
     dim, nh = pp.dim, len(pp.heads_out)
     dev = tok.device
-    w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
-    b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
-    rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
-    for h, name in enumerate(pp.heads_out):
-        ws, bs = pp.decoder_params(name)
-        ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
-                                 rows_ws[h])
+    pending, pp._collapsed = pp._collapsed, None
+    if pending is not None:                                # started by collapse_async on the side stream
+        w_eff, b_eff, rows_ws, ev = pending
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        for t in (w_eff, b_eff, rows_ws):
+            t.record_stream(main)
+    else:
+        w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
+        b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
+        rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
+        for h, name in enumerate(pp.heads_out):
+            ws, bs = pp.decoder_params(name)
+            ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
+                                     rows_ws[h])
     low = ops.decoder_project(tok, tok_bstride, w_eff, b_eff, batch, nh, pp.num_patches, dim)
     heat = ops.decoder_upsample_sigmoid(low, pp.upsample_matrix(dev), nh * batch, pp.grid)
     size = pp.grid * 16
@@ -247,7 +285,8 @@ def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride
 def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstride: int, heat, w_eff, rows_ws,
                       d_heats, d_tok, dtok_bstride: int, batch: int):
     """Backward of decoder_heads_fwd: writes d_tok (fp32 view like tok; token 0 gets zeros) and every
-    decoder parameter gradient into the arena."""
+    decoder parameter gradient into the arena.  Returns the event after which the decoder gradients are
+    complete: the per-head collapse backward runs on the side stream."""
     g = A.grad_view
     dim, nh = pp.dim, len(pp.heads_out)
     dev = tok.device
@@ -262,10 +301,18 @@ def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstrid
     g_b = torch.empty(nh, dtype=torch.float32, device=dev)
     ops.decoder_project_bwd(tok, tok_bstride, w_eff, g_low, d_tok, dtok_bstride, g_w, g_b, batch, nh,
                             pp.num_patches, dim)
-    for h, name in enumerate(pp.heads_out):
-        ws, bs = pp.decoder_params(name)
-        ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], rows_ws[h], g_w[h],
-                                 g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
+    main, side = torch.cuda.current_stream(), pp._side(dev)
+    side.wait_stream(main)                                 # g_w / g_b are ready
+    with torch.cuda.stream(side):
+        for h, name in enumerate(pp.heads_out):
+            ws, bs = pp.decoder_params(name)
+            ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], rows_ws[h], g_w[h],
+                                     g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in (g_w, g_b, rows_ws):
+        t.record_stream(side)
+    return done
 
 
 def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch: int, seq: int,
@@ -294,10 +341,20 @@ def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heat
     first = seq - (pp.num_patches + 1)
     xv = S["x_out"].view(batch, seq, dim)
     dxv = dx.view(batch, seq, dim)
-    decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"], d_heats,
-                      dxv[:, first:], seq * dim, batch)
-    return fusion_stack_bwd(pp.fusion, A, cdt, dx, S["layers"], batch, seq, S["mask_mode"], S["row_mask"],
-                            on_layer_done)
+    dec_done = decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"], d_heats,
+                                 dxv[:, first:], seq * dim, batch)
+    joined = []
+
+    def layer_done(i):             # the decoders' gradients leave with the first bucket: join before it is reported
+        if not joined:
+            torch.cuda.current_stream().wait_event(dec_done)
+            joined.append(True)
+        if on_layer_done is not None:
+            on_layer_done(i)
+    dx = fusion_stack_bwd(pp.fusion, A, cdt, dx, S["layers"], batch, seq, S["mask_mode"], S["row_mask"], layer_done)
+    if not joined:
+        torch.cuda.current_stream().wait_event(dec_done)
+    return dx
 
 
 def component_arena(module: nn.Module) -> ParamArena:
@@ -381,7 +438,8 @@ class _DecoderHeadsFn(torch.autograd.Function):
         A = component_arena(pp)
         d_tok = torch.empty_like(c.tok)
         n, dim = c.tok.shape[1], c.tok.shape[2]
-        decoder_heads_bwd(pp, A, c.tok, n * dim, c.heat, c.w_eff, c.rows_ws, d_heats, d_tok, n * dim, c.batch)
+        done = decoder_heads_bwd(pp, A, c.tok, n * dim, c.heat, c.w_eff, c.rows_ws, d_heats, d_tok, n * dim, c.batch)
+        torch.cuda.current_stream().wait_event(done)
         ctx.c = None
         return (None, d_tok.to(c.dtype)) + tuple(None for _ in range(len(ctx.needs_input_grad) - 2))
 
@@ -442,7 +500,9 @@ class RGBTailFn(torch.autograd.Function):
                                         g(model.rgb_pos_embedding).view(-1, dim),
                                         g(pp.fusion.token_type_embeddings.weight), c.batch, c.n_text, c.n_rgb)
         ops.gemm(d_rgb, c.vis_feat, trans_a=True, b_kn=True, out=g(model.project.weight))
-        ops.colsum(d_rgb, out=g(model.project.bias))
+        # d project.bias = the sum of d rgb_feat over every image token of the batch = the gradient of the image
+        # modality's type embedding, which the assembly backward has just reduced in fp32
+        g(model.project.bias).copy_(g(pp.fusion.token_type_embeddings.weight)[1])
         model._grad_ready(-1)
         ctx.c = None
         # gradients were written into the arena (and attached as .grad) by the kernels

@@ -92,6 +92,7 @@ class RGBOnly(BaseModel):
         cdt = self.compute_dtype
         arena = self.trainable_arena()
         arena.sync_shadow()
+        self.pick_place.collapse_async()                  # decoder collapse beside the towers (side stream)
         # The text tower's GEMMs are small (77 tokens/sample: 0.6-2.4 rounds of tiles) and leave CUs
         # idle; it runs on a side HIP stream concurrently with the vision tower and joins before the
         # fusion tail.  Both towers are frozen (no autograd state crosses the streams).

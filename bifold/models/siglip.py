@@ -87,6 +87,7 @@ class SigLip(BaseModel):
         cdt = self.compute_dtype
         self.trainable_arena().sync_shadow()
         self.siglip_model.begin_step()
+        self.pick_place.collapse_async()                  # decoder collapse beside the towers (side stream)
         img = self._vision(x, cdt)                                            # [B*n, W] fp32
         txt = self.siglip_model.text_tokens(x["instruction"], cdt)            # [B*L, W] fp32
         return img, txt

@@ -389,22 +389,31 @@ extern "C" int bf_colsum(const void* x, int x_dtype, float* out, int rows, int c
 // Column sums of up to four stacked partial arrays [n_arrays][nparts][cols] in ONE launch, written
 // (not accumulated) to separate outputs: LayerNorm backward's dgamma / dbeta / dres-sum / dx-sum
 // partials cost two to four bf_colsum launches plus their memsets otherwise (eight ~5-10 us launches).
-// Block = 64 columns x 16 row groups; rows strided over the groups, LDS tree at the end.
+// Block = 16 columns x 64 row groups (rows strided over the groups, LDS tree at the end): with 64-column blocks a
+// 512-wide problem had 8 x n_arrays workgroups on 256 CUs, each thread adding 64 dependent loads -- 21 us of
+// latency per call, sixteen calls per step.
 __global__ __launch_bounds__(1024) void colsum_multi_kernel(const float* __restrict__ parts, int nparts, int cols,
                                                             float* __restrict__ o0, float* __restrict__ o1,
                                                             float* __restrict__ o2, float* __restrict__ o3) {
-    __shared__ float red[16][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6, a = blockIdx.y;
+    __shared__ float red[64][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, a = blockIdx.y;
+    const int c = blockIdx.x * 16 + cl;
     const float* src = parts + (size_t)a * nparts * cols;
-    float acc = 0.f;
-    if (c < cols)
-        for (int r = rg; r < nparts; r += 16) acc += src[(size_t)r * cols + c];
-    red[rg][threadIdx.x & 63] = acc;
+    float acc0 = 0.f, acc1 = 0.f;
+    if (c < cols) {
+        int r = rg;
+        for (; r + 64 < nparts; r += 128) {
+            acc0 += src[(size_t)r * cols + c];
+            acc1 += src[(size_t)(r + 64) * cols + c];
+        }
+        if (r < nparts) acc0 += src[(size_t)r * cols + c];
+    }
+    red[rg][cl] = acc0 + acc1;
     __syncthreads();
-    if (rg == 0 && c < cols) {
+    if (threadIdx.x < 16 && c < cols) {
         float t = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) t += red[i][threadIdx.x];
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) t += red[i][threadIdx.x];
         float* out = a == 0 ? o0 : a == 1 ? o1 : a == 2 ? o2 : o3;
         out[c] = t;
     }
@@ -416,7 +425,7 @@ extern "C" int bf_colsum_multi(const float* parts, int n_arrays, int nparts, int
                "bf_colsum_multi: bad arguments (n_arrays=%d nparts=%d cols=%d)", n_arrays, nparts, cols);
     float* outs[4] = {out0, out1, out2, out3};
     for (int i = 0; i < n_arrays; ++i) BF_REQUIRE(outs[i] != nullptr, BF_EINVAL, "bf_colsum_multi: out%d is NULL", i);
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(bf_cdiv(cols, 64), n_arrays), dim3(1024), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(bf_cdiv(cols, 16), n_arrays), dim3(1024), 0, (hipStream_t)stream,
                        parts, nparts, cols, out0, out1, out2, out3);
     BF_CHECK_LAUNCH("bf_colsum_multi");
     return BF_OK;
@@ -717,34 +726,50 @@ extern "C" int bf_fusion_assemble(const float* text_feat, const float* rgb_feat,
 template <typename TC>
 __global__ __launch_bounds__(256) void fusion_assemble_bwd_kernel(
     const float* __restrict__ dx, TC* __restrict__ d_rgb_feat, float* __restrict__ d_text_pos,
-    float* __restrict__ d_rgb_pos, int batch, int n_text, int n_rgb, int dim) {
+    float* __restrict__ d_rgb_pos, int batch, int n_text, int n_rgb, int dim, int per_chunk) {
+    // grid.y cuts the batch into chunks: one workgroup column per chunk, partial sums by fp32 atomics into the
+    // zeroed per-token gradients (one thread looping over all 256 samples left 138 workgroups on the chip
+    // streaming 144 MB at 0.9 TB/s)
     const int L = 1 + n_text + n_rgb;
     const int nvec = dim >> 2;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= L * nvec) return;
     const int t = i / nvec, c = i - t * nvec;
+    const int b0 = blockIdx.y * per_chunk, b1 = min(batch, b0 + per_chunk);
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int b = 0; b < batch; ++b) {
+    for (int b = b0; b < b1; ++b) {
         const float4 v = *(const float4*)(dx + ((size_t)b * L + t) * dim + c * 4);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         if (t > n_text)
             Vec4<TC>::store(d_rgb_feat + ((size_t)b * n_rgb + (t - 1 - n_text)) * dim + c * 4, v);
     }
-    if (t <= n_text) *(float4*)(d_text_pos + (size_t)t * dim + c * 4) = acc;
-    else *(float4*)(d_rgb_pos + (size_t)(t - 1 - n_text) * dim + c * 4) = acc;
+    float* o = (t <= n_text) ? d_text_pos + (size_t)t * dim + c * 4
+                             : d_rgb_pos + (size_t)(t - 1 - n_text) * dim + c * 4;
+    atomicAdd(o + 0, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
 }
 // stage 2: type-embedding gradients (sum the per-token sums over each modality) and text_token.
+// Block = 16 columns x 16 row groups.
 __global__ __launch_bounds__(256) void fusion_assemble_bwd2_kernel(
     const float* __restrict__ d_text_pos, const float* __restrict__ d_rgb_pos,
     float* __restrict__ d_text_token, float* __restrict__ d_type, int n_text, int n_rgb, int dim) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= dim) return;
+    __shared__ float r0[16][17], r1[16][17];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f;
-    for (int t = 0; t <= n_text; ++t) s0 += d_text_pos[(size_t)t * dim + c];
-    for (int p = 0; p < n_rgb; ++p) s1 += d_rgb_pos[(size_t)p * dim + c];
-    d_type[c] = s0;
-    d_type[dim + c] = s1;
-    d_text_token[c] = d_text_pos[c];
+    if (c < dim) {
+        for (int t = rg; t <= n_text; t += 16) s0 += d_text_pos[(size_t)t * dim + c];
+        for (int p = rg; p < n_rgb; p += 16) s1 += d_rgb_pos[(size_t)p * dim + c];
+    }
+    r0[rg][cl] = s0; r1[rg][cl] = s1;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < dim) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { a += r0[i][threadIdx.x]; b += r1[i][threadIdx.x]; }
+        d_type[c] = a;
+        d_type[dim + c] = b;
+        d_text_token[c] = d_text_pos[c];
+    }
 }
 
 extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt,
@@ -757,16 +782,22 @@ extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt
                    bf_aligned16(d_rgb_pos), BF_EALIGN, "bf_fusion_assemble_bwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     const int L = 1 + n_text + n_rgb;
-    dim3 grid(bf_cdiv((long)L * (dim / 4), 256)), block(256);
+    BF_REQUIRE(hipMemsetAsync(d_text_pos, 0, (size_t)(1 + n_text) * dim * sizeof(float), s) == hipSuccess &&
+                   hipMemsetAsync(d_rgb_pos, 0, (size_t)n_rgb * dim * sizeof(float), s) == hipSuccess,
+               BF_ELAUNCH, "bf_fusion_assemble_bwd: memset failed");
+    int chunks = batch >= 64 ? 16 : (batch >= 8 ? 4 : 1);
+    const int per_chunk = bf_cdiv(batch, chunks);
+    chunks = bf_cdiv(batch, per_chunk);
+    dim3 grid(bf_cdiv((long)L * (dim / 4), 256), chunks), block(256);
     if (cdt == BF_F32)
         hipLaunchKernelGGL(fusion_assemble_bwd_kernel<float>, grid, block, 0, s, dx, (float*)d_rgb_feat,
-                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim);
+                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
     else if (cdt == BF_BF16)
         hipLaunchKernelGGL(fusion_assemble_bwd_kernel<bf16_t>, grid, block, 0, s, dx, (bf16_t*)d_rgb_feat,
-                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim);
+                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
     else BF_REQUIRE(false, BF_EINVAL, "bf_fusion_assemble_bwd: bad dtype %d", cdt);
     BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/1");
-    hipLaunchKernelGGL(fusion_assemble_bwd2_kernel, dim3(bf_cdiv(dim, 256)), block, 0, s, d_text_pos,
+    hipLaunchKernelGGL(fusion_assemble_bwd2_kernel, dim3(bf_cdiv(dim, 16)), block, 0, s, d_text_pos,
                        d_rgb_pos, d_text_token, d_type, n_text, n_rgb, dim);
     BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/2");
     return BF_OK;
