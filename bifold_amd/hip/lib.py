@@ -112,6 +112,9 @@ PROTOTYPES = {
     "bf_dropout_mask": (c_int, [c_void_p, c_size_t, c_float, C.c_ulonglong, c_void_p]),
     "bf_preprocess_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p]),
+    "bf_resize_normalize_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        POINTER(c_float), POINTER(c_float), c_void_p]),
+    "bf_affine_nearest": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_heatmap_pick": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "bf_gaussian_targets": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int,
                                     c_void_p]),

@@ -581,3 +581,43 @@ def preprocess_rgb(raw: torch.Tensor, mask: Optional[torch.Tensor], mean, std) -
     s3 = (C.c_float * 3)(*[float(v) for v in std])
     check(lib.bf_preprocess_rgb(_ptr(raw), _ptr(mask), _ptr(out), b, s, m3, s3, _stream()), "bf_preprocess_rgb")
     return out
+
+
+def resize_normalize_rgb(raw: torch.Tensor, mask: Optional[torch.Tensor], size: int, mean, std) -> torch.Tensor:
+    """raw uint8 [B, H, W, 3] of any resolution (+ mask [B, H, W] / [B, 1, H, W], 1 = keep) -> fp32 [B, 3, size, size]:
+    mask fill 77, Resize(size, bicubic, antialias), CenterCrop(size), /255, (x - mean) / std -- the rgb_transform of
+    Processor.__call__ (bifold/data/processor.py:87-95) in two launches."""
+    if raw.dtype != torch.uint8 or raw.dim() != 4 or raw.shape[3] != 3:
+        raise RuntimeError(f"raw must be uint8 [B, H, W, 3], got {raw.dtype} {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    _dev(raw, "raw")
+    b, h, w = raw.shape[0], raw.shape[1], raw.shape[2]
+    if mask is not None:
+        if mask.numel() != b * h * w:
+            raise RuntimeError("mask must have one value per pixel")
+        mask = mask.reshape(b, h, w).to(torch.float32).contiguous()
+        _dev(mask, "mask")
+    tmp = torch.empty(b, h, size, 3, dtype=torch.uint8, device=raw.device)
+    out = torch.empty(b, 3, size, size, dtype=torch.float32, device=raw.device)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean])
+    s3 = (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.bf_resize_normalize_rgb(_ptr(raw), _ptr(mask), _ptr(tmp), _ptr(out), b, h, w, int(size), m3, s3,
+                                      _stream()), "bf_resize_normalize_rgb")
+    return out
+
+
+def affine_nearest(x: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
+    """x fp32 [N, C, H, W], params fp32 [N, 3] = (angle degrees, dx, dy) on the device -> the warped copy
+    (v2.functional.affine with its defaults; Processor._spatial_augmentation)."""
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise RuntimeError("affine_nearest needs fp32 [N, C, H, W]")
+    x = x.contiguous()
+    _dev(x, "x")
+    params = params.to(torch.float32).contiguous()
+    _dev(params, "params")
+    if params.shape != (x.shape[0], 3):
+        raise RuntimeError(f"params must be [N, 3] = (angle, dx, dy) per image, got {tuple(params.shape)}")
+    out = torch.empty_like(x)
+    check(lib.bf_affine_nearest(_ptr(x), _ptr(out), _ptr(params), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                                _stream()), "bf_affine_nearest")
+    return out

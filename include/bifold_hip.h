@@ -377,9 +377,28 @@ enum { BF_TARGETS_FIRST = 0, BF_TARGETS_GMM = 1 };
  *   input fp32 [B, 3, S, S]: mask fill with 77 (bifold/data/processor.py:255-258), scale to [0, 1] and
  *   per-channel normalisation (:87-95; mean3 / std3 are HOST pointers to the 3 values of
  *   conf/processor/default.yaml).  Frames must already have the model's resolution (v2.Resize /
- *   CenterCrop are then the identity); resizing is not built. */
+ *   CenterCrop are then the identity); bf_resize_normalize_rgb handles any resolution. */
 int bf_preprocess_rgb(const uint8_t* raw, const float* mask, float* out, int batch, int size,
                       const float* mean3, const float* std3, bf_stream_t stream);
+/* bf_resize_normalize_rgb: the whole rgb_transform of the reference's Processor (bifold/data/processor.py:45-50,
+ *   87-95, 255-258) for frames of ANY resolution: optional mask fill with 77, v2.Resize(size, BICUBIC, antialias) --
+ *   the shorter side becomes `size` -- v2.CenterCrop(size), rounding to uint8 as the reference's uint8 image does,
+ *   v2.ToDtype(float32, scale=True), v2.Normalize(mean, std), HWC -> CHW.  raw uint8 [B, H, W, 3], mask fp32
+ *   [B, H, W] or NULL, tmp_ws >= B * H * size * 3 bytes, out fp32 [B, 3, size, size]; mean3 / std3 are HOST
+ *   pointers.  Antialiased bicubic = Keys' cubic (a = -0.5) stretched by the scale factor, columns first, then
+ *   rows, uint8 rounding after each pass (PIL's two-pass resample, which torch's uint8 interpolate follows).
+ *   torchvision is not in the image: PARITY UNPINNED, checked within 1 LSB against torch's own
+ *   F.interpolate(uint8, bicubic, antialias=True).
+ * bf_affine_nearest: the image half of Processor._spatial_augmentation (processor.py:333-341):
+ *   v2.functional.affine(x, angle, translate=[dx, dy], scale=1, shear=0) with its defaults (nearest neighbour,
+ *   zero fill, rotation about the centre).  in / out fp32 [n_images, channels, H, W] (distinct buffers), params
+ *   fp32 [n_images, 3] = (angle in degrees, dx, dy) on the DEVICE.  PARITY UNPINNED (torchvision absent): checked
+ *   against torch's grid_sample driven by torchvision's documented inverse-matrix construction. */
+int bf_resize_normalize_rgb(const uint8_t* raw, const float* mask, uint8_t* tmp_ws, float* out, int batch,
+                            int height, int width, int size, const float* mean3, const float* std3,
+                            bf_stream_t stream);
+int bf_affine_nearest(const float* in, float* out, const float* params, int n_images, int channels,
+                      int height, int width, bf_stream_t stream);
 int bf_heatmap_pick(const float* heat, const float* mask, int32_t* xy, float* conf, int n_maps,
                     int size, bf_stream_t stream);
 int bf_gaussian_targets(const float* points, const int32_t* counts, float* heat, int n_maps,

@@ -627,3 +627,49 @@ def preprocess_rgb(raw, mask, mean, std):
     mean = np.asarray(mean, dtype=np.float32)[:, None, None]
     std = np.asarray(std, dtype=np.float32)[:, None, None]
     return ((x - mean) / std).astype(np.float32)
+
+
+def resize_normalize_rgb(raw, mask, size: int, mean, std):
+    """The reference's rgb_transform for frames of any resolution (bifold/data/processor.py:45-50, 87-95, 255-258):
+    mask fill 77 -> v2.ToImage -> v2.Resize(size, BICUBIC, antialias) -> v2.CenterCrop(size) ->
+    v2.ToDtype(float32, scale=True) -> v2.Normalize.  raw uint8 [B, H, W, 3].  PARITY UNPINNED: torchvision is
+    absent, so its documented pipeline is restated over torch's own uint8 antialiased bicubic
+    F.interpolate -- the kernel torchvision dispatches to for uint8 CPU images."""
+    x = torch.as_tensor(raw)
+    if mask is not None:
+        m = torch.as_tensor(mask).reshape(x.shape[0], x.shape[1], x.shape[2], 1).float()
+        x = torch.floor(x.float() * m + (1.0 - m) * 77.0).to(torch.uint8)
+    b, h, w, _ = x.shape
+    new_h, new_w = (size, int(size * w / h)) if h <= w else (int(size * h / w), size)
+    img = F.interpolate(x.permute(0, 3, 1, 2).contiguous(), size=(new_h, new_w), mode="bicubic", antialias=True,
+                        align_corners=False)
+    top, left = int(round((new_h - size) / 2.0)), int(round((new_w - size) / 2.0))
+    img = img[:, :, top:top + size, left:left + size].float() / 255.0
+    mean = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    std = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    return (img - mean) / std
+
+
+def affine_nearest(x, angle: float, dx: float, dy: float):
+    """v2.functional.affine(x, angle, translate=[dx, dy], scale=1.0, shear=[0.0]) with its defaults (nearest, zero
+    fill, centre of the image) as Processor._spatial_augmentation calls it (processor.py:333-341).  PARITY UNPINNED
+    (torchvision absent): its tensor path restated -- inverse matrix [cos, sin, tx'; -sin, cos, ty'] about the
+    centre, a base grid of pixel centres, normalisation by half the size, grid_sample(nearest, zeros,
+    align_corners=False)."""
+    import math
+    x = torch.as_tensor(x).float()
+    n, c, h, w = x.shape
+    rot = math.radians(angle)
+    m = [math.cos(rot), math.sin(rot), 0.0, -math.sin(rot), math.cos(rot), 0.0]
+    m[2] += m[0] * (-dx) + m[1] * (-dy)
+    m[5] += m[3] * (-dx) + m[4] * (-dy)
+    theta = torch.tensor(m, dtype=torch.float32).view(1, 2, 3)
+    xs = torch.linspace(-w * 0.5 + 0.5, w * 0.5 + 0.5 - 1, w)
+    ys = torch.linspace(-h * 0.5 + 0.5, h * 0.5 + 0.5 - 1, h)
+    base = torch.empty(1, h, w, 3)
+    base[..., 0] = xs.view(1, 1, w)
+    base[..., 1] = ys.view(1, h, 1)
+    base[..., 2] = 1.0
+    rescaled = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h])
+    grid = (base.view(1, h * w, 3) @ rescaled).view(1, h, w, 2).expand(n, h, w, 2)
+    return F.grid_sample(x, grid, mode="nearest", padding_mode="zeros", align_corners=False)

@@ -1,0 +1,120 @@
+"""The input side of the path: CLIP tokenisation, the Processor's rgb transform for frames
+of any resolution, and its spatial augmentation.
+
+Pinned by the reference itself (oracle/gen_processor_golden.py): `clip.tokenize` ids of instructions built from the
+reference's templates (tests/golden/tokenizer.npz) and `Processor._aug_pixel` (tests/golden/augment.npz).
+PARITY UNPINNED (torchvision is not in the image, so the reference's `v2.Resize` / `v2.functional.affine` cannot
+be run): the device kernels are compared with oracle restatements over torch's own uint8 antialiased-bicubic
+interpolate and grid_sample."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MEAN, STD = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
+
+
+def test_clip_tokenizer_matches_reference_ids():
+    from bifold.models import clip_tokenizer as T
+    try:
+        T.find_bpe_file()
+    except FileNotFoundError:
+        pytest.skip("CLIP's BPE merge table (a data file the reference vendors) is not on this machine")
+    z = np.load(os.path.join(GOLD, "tokenizer.npz"))
+    texts = [str(t) for t in z["texts"]]
+    ids = T.tokenize(texts)
+    assert ids.dtype == torch.int32 and tuple(ids.shape) == (len(texts), 77)
+    assert np.array_equal(ids.numpy(), z["ids"])
+    assert ids[0, 0] == 49406 and (ids == 49407).sum(1).eq(1).all()
+    with pytest.raises(RuntimeError, match="too long"):
+        T.tokenize("fold " * 100)
+    cut = T.tokenize("fold " * 100, truncate=True)
+    assert cut[0, -1] == 49407 and cut[0, 0] == 49406
+
+
+def test_pixel_augmentation_matches_reference():
+    from bifold.augment import aug_pixel, draw_augmentation
+    z = np.load(os.path.join(GOLD, "augment.npz"))
+    size = float(z["size"])
+    for case, ref, ok in zip(z["cases"], z["outs"], z["valid"]):
+        angle, dx, dy, k = case[0], case[1], case[2], int(case[3])
+        px = torch.from_numpy(case[4:4 + 2 * k].reshape(k, 2)).float()
+        got, inside = aug_pixel(px, angle, dx, dy, size)
+        assert inside == bool(ok)
+        if ok:
+            assert torch.equal(got, torch.from_numpy(ref[:2 * k].reshape(k, 2)))
+    # the retry loop: a pixel near the border forces redraws; the accepted draw keeps everything in frame
+    rng = np.random.RandomState(0)
+    pixels = {"pick": torch.tensor([[221.0, 110.0]]), "place": torch.tensor([[10.0, 3.0], [50.0, 60.0]]), "left_pick": None}
+    moved, (angle, dx, dy) = draw_augmentation(pixels, 224, rng=rng)
+    assert set(moved) == {"pick", "place"} and all((v >= 0).all() and (v < 223).all() for v in moved.values())
+    assert -5 <= angle < 6 and -5 <= dx < 6 and -5 <= dy < 6
+    never, p = draw_augmentation({"pick": torch.tensor([[222.9, 222.9]])}, 224, translate=(3, 6), rng=rng)
+    assert never is None and p is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,size", [(480, 640, 224), (300, 300, 224), (224, 224, 224), (720, 540, 384), (100, 160, 224)])
+def test_resize_normalize_rgb_matches_torch_uint8_bicubic(gpu, observed, h, w, size):
+    from oracle import bifold_oracle as O
+    from bifold_amd.hip import ops
+    g = torch.Generator().manual_seed(h * w)
+    base = torch.rand(2, 3, h // 8 + 1, w // 8 + 1, generator=g)
+    raw = (torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear") * 255).round().clamp(0, 255)
+    raw = (raw + torch.randint(-12, 13, raw.shape, generator=g)).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    mask = (torch.rand(2, h, w, generator=g) > 0.2).float()
+    for m in (None, mask):
+        want = O.resize_normalize_rgb(raw, m, size, MEAN, STD)
+        got = ops.resize_normalize_rgb(raw.to(gpu), None if m is None else m.to(gpu), size, MEAN, STD).cpu()
+        assert got.shape == want.shape == (2, 3, size, size)
+        std = torch.tensor(STD).view(1, 3, 1, 1)
+        lsb = ((got - want).abs() * std * 255.0)                 # difference in uint8 steps of the resized image
+        observed(f"resize_{h}x{w}_to_{size}_{'mask' if m is not None else 'nomask'}", max_lsb=float(lsb.max()),
+                 frac_off=float((lsb > 0.5).float().mean()))
+        assert float(lsb.max()) <= 1.01                          # never more than one grey level
+        assert float((lsb > 0.5).float().mean()) < 0.02          # and only where a value sits on a rounding edge
+
+
+@pytest.mark.gpu
+def test_affine_nearest_matches_grid_sample(gpu):
+    from oracle import bifold_oracle as O
+    from bifold_amd.hip import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 64, 64, generator=g)
+    params = torch.tensor([[0.0, 0.0, 0.0], [5.0, -3.5, 2.25], [-4.2, 5.9, -5.9], [1.0, 0.0, 4.0]])
+    got = ops.affine_nearest(x.to(gpu), params.to(gpu)).cpu()
+    for i in range(4):
+        want = O.affine_nearest(x[i:i + 1], *[float(v) for v in params[i]])
+        diff = (got[i:i + 1] != want).float().mean().item()
+        assert diff < 2e-3, (i, diff)                            # only pixels whose source lands on a .5 tie may differ
+    assert torch.equal(got[0], x[0])
+    assert (got[1] == 0).any()                                   # zero fill where the source leaves the frame
+
+
+@pytest.mark.gpu
+def test_augment_batch_moves_images_and_annotations_together(gpu):
+    """A bright dot at the annotated pixel must follow its annotation through the augmentation."""
+    from bifold.augment import augment_batch
+    S, B, T = 96, 6, 2
+    rng = np.random.RandomState(3)
+    pick = torch.tensor(rng.uniform(25, 70, (B, 2)), dtype=torch.float32).round()
+    rgb = torch.zeros(B, 3, S, S)
+    ctx = torch.zeros(B, T, 3, S, S)
+    for b in range(B):
+        x, y = int(pick[b, 0]), int(pick[b, 1])
+        rgb[b, :, y - 1:y + 2, x - 1:x + 2] = 1.0
+        ctx[b, :, :, y - 1:y + 2, x - 1:x + 2] = 1.0
+    sample = {"rgb": rgb.to(gpu), "rgb_context": ctx.to(gpu), "pick": pick.clone(), "pick_heatmap": torch.zeros(B, S, S),
+              "instruction": torch.zeros(B, 77, dtype=torch.int32)}
+    out = augment_batch(sample, S, dict(rotate_augmentation=[-5, 6], translate_augmentation=[-5, 6],
+                                        max_augmentation_trials=5), rng=rng)
+    assert out["pick_heatmap"] is sample["pick_heatmap"] and out["augmentation"].shape == (B, 3)
+    assert not torch.equal(out["pick"], pick)
+    for b in range(B):
+        img = out["rgb"][b, 0].cpu()
+        ys, xs = torch.nonzero(img > 0.5, as_tuple=True)
+        cx, cy = xs.float().mean().item(), ys.float().mean().item()
+        assert abs(cx - out["pick"][b, 0].item()) < 1.0 and abs(cy - out["pick"][b, 1].item()) < 1.0
+        assert torch.equal(out["rgb_context"][b, 0], out["rgb"][b]) and torch.equal(out["rgb_context"][b, 1], out["rgb"][b])
