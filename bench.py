@@ -245,8 +245,9 @@ def main():
     ap.add_argument("--host-fed", action="store_true",
                     help="diagnostic: the batch starts in pinned HOST memory every step (H2D copy on a side stream, "
                          "double-buffered) -- the PCIe-inclusive rate quoted in DESIGN.md, never the headline value")
-    ap.add_argument("--config", default="a", choices=["a", "vitl14", "siglip_seq"],
-                    help="a: BASELINE configs[1] (the metric); vitl14: configs[3], ViT-L/14 @336 (diagnostic line: "
+    ap.add_argument("--config", default="a", choices=["a", "vitl14", "siglip_seq", "fp8"],
+                    help="fp8: BASELINE configs[4] (diagnostic line: config A's shapes with the frozen towers' QKV / "
+                         "fc1 GEMMs in OCP e4m3, run with --batch 512); a: BASELINE configs[1] (the metric); vitl14: configs[3], ViT-L/14 @336 (diagnostic line: "
                          "no roofline, run with --batch 64); siglip_seq: configs[2], siglip_sequential @384 with 4 "
                          "context frames (diagnostic line, run with --batch 128; --lora trains the adapters)")
     ap.add_argument("--lora", action="store_true", help="siglip_seq: LoRA adapters on q/v of both towers (the "
@@ -274,11 +275,14 @@ def main():
     torch.manual_seed(3407)                       # identical replicas on every rank
     big = args.config == "vitl14"
     seq = args.config == "siglip_seq"
+    fp8 = args.config == "fp8"
+    if fp8 and args.dtype != "bf16":
+        raise SystemExit("--config fp8 is the bf16 step with e4m3 towers")
     cfg = dict(name="rgb_clip", image_size=336 if big else 224, is_bimanual=False, requires_graph=False,
                text_encoder="ViT-L/14@336px" if big else "ViT-B/16", patch_size=14 if big else 16, depth=8,
                heads=16, mlp_ratio=4, dropout=0.0,
                text_dropout=0.0, rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
-               fusion_model="concat_transformer", dtype=args.dtype)
+               fusion_model="concat_transformer", dtype="fp8" if fp8 else args.dtype)
     if seq:
         cfg = dict(name="siglip_sequential", image_size=384, is_bimanual=True, requires_graph=False, patch_size=16,
                    automodel_name="google/siglip-base-patch16-384", dim=768, emb_dropout=0.0, lora=args.lora, r=8,
@@ -336,7 +340,7 @@ def main():
             torch.cuda.synchronize()
 
     parity = None
-    if world == 1 and not args.no_parity and not big and not seq and args.dtype == "bf16":
+    if world == 1 and not args.no_parity and not big and not seq and args.dtype == "bf16":    # (fp8: its looser error is reported too)
         parity = parity_vs_oracle(model, sample)       # untimed, before any training step
     for _ in range(args.warmup):
         step()
@@ -377,7 +381,7 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.dtype == "bf16" else "f32",
+            "dtype": "fp8 (e4m3 towers: QKV / fc1) + bf16" if fp8 else ("bf16" if args.dtype == "bf16" else "f32"),
             "data": "synthetic (pinned host memory, H2D copy every step)" if args.host_fed else "synthetic",
             "config": {"workload": ("BASELINE configs[2] (diagnostic): siglip_sequential, SigLIP-base/16 @384 (576 patches), "
                                     "4 context frames with a random valid prefix, fusion 8x768 over 2 950 tokens, 4 "
@@ -386,6 +390,10 @@ def main():
                                     "BASELINE configs[3] (diagnostic): rgb_clip ViT-L/14@336 (577 tokens, 24 layers, "
                                     "width 1024) + CLIP text + fusion 8x768 (16 heads), 384-px heatmaps"
                                     if big else
+                                    "BASELINE configs[4] (diagnostic): config A's shapes, frozen towers' LayerNorm -> QKV / "
+                                    "fc1 GEMMs in OCP e4m3 (v_mfma_scale_f32_16x16x128_f8f6f4, per-token / per-channel "
+                                    "scales), everything else bf16"
+                                    if fp8 else
                                     "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
                                     "fusion 8x512 (16 heads) + 2 conv decoders, BCE, Adam; frozen encoders; "
                                     "random-init weights"), "per_gpu_batch": args.batch,
@@ -440,11 +448,11 @@ def main():
                                for k, v in sorted(summ.items())}
         if big:
             line.pop("step_roofline", None)
-        if big or seq:
+        if big or seq or fp8:
             line.pop("roofline", None)
         if parity is not None:
             line["parity"] = parity
-        if world == 1 and not args.no_cpu_baseline and not big and not seq:
+        if world == 1 and not args.no_cpu_baseline and not big and not seq and not fp8:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
 

@@ -34,7 +34,8 @@ def draw_augmentation(pixels: Mapping[str, Optional[torch.Tensor]], image_size: 
                       max_trials: int = 5, rng=np.random):
     """One sample: ({head: augmented [k, 2] pixels}, (angle, dx, dy)) of the first trial that keeps every
     annotated pixel in frame, or (None, None) when none does (the reference then leaves the sample untouched).
-    The pixels rotate by -angle (processor.py:313-316): image and annotation move together."""
+    The pixels rotate by -angle while the images are warped with +angle (processor.py:313-316, 333-341), exactly
+    as the reference writes it; the translation is common to both."""
     for _ in range(max_trials):
         angle = rng.uniform(*rotate)
         dx = rng.uniform(*translate)

@@ -84,6 +84,20 @@ class CLIPEncoder(nn.Module):
         self.visual.output_width = vw
         self._arena: Optional[ParamArena] = None
         self._err_flag: Optional[torch.Tensor] = None
+        # dtype: fp8 (BASELINE configs[4]): the LayerNorm -> in-projection and LayerNorm -> c_fc pairs of both towers
+        # run in OCP e4m3 with per-token / per-channel scales (csrc/gemm_fp8.hip); everything else stays bf16
+        self.fp8 = False
+        self._w8_cache: Dict[str, tuple] = {}
+
+    def _w8(self, name: str):
+        """(e4m3 bytes [N, K], fp32 per-channel scales [N]) of a frozen weight, quantised once per load."""
+        p = self.get_parameter(name)
+        hit = self._w8_cache.get(name)
+        if hit is None or hit[2] != p._version or hit[0].device != p.device:
+            q, sc = ops.quantize_rows_fp8(p.data.view(p.shape[0], -1))
+            hit = (q, sc, p._version)
+            self._w8_cache[name] = hit
+        return hit[0], hit[1]
 
     def _blocks(self, prefix: str, width: int, layers: int):
         proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
@@ -125,16 +139,27 @@ class CLIPEncoder(nn.Module):
         width = x.shape[1]
         d = width // heads
         mode = L.MASK_CAUSAL if causal else L.MASK_NONE
+        fp8 = self.fp8 and cdt == torch.bfloat16 and width % 128 == 0      # the e4m3 MFMA consumes K in steps of 128
         for i in range(layers):
             b = f"{prefix}.{i}."
-            h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_1.weight"), self._f(b + "ln_1.bias"), cdt)
-            qkv = ops.gemm(h, self._w(b + "attn.in_proj_weight", cdt), bias=self._f(b + "attn.in_proj_bias"))
+            if fp8:
+                h8, hs = ops.layernorm_fwd_fp8(x, self._f(b + "ln_1.weight"), self._f(b + "ln_1.bias"))
+                w8, ws = self._w8(b + "attn.in_proj_weight")
+                qkv = ops.gemm_fp8(h8, hs, w8, ws, bias=self._f(b + "attn.in_proj_bias"))
+            else:
+                h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_1.weight"), self._f(b + "ln_1.bias"), cdt)
+                qkv = ops.gemm(h, self._w(b + "attn.in_proj_weight", cdt), bias=self._f(b + "attn.in_proj_bias"))
             o, _ = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mode)
             ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"),
                      residual=x, out=x)
-            h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
-            a = ops.gemm(h, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
-                         act=L.ACT_QUICK_GELU)
+            if fp8:
+                h8, hs = ops.layernorm_fwd_fp8(x, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"))
+                w8, ws = self._w8(b + "mlp.c_fc.weight")
+                a = ops.gemm_fp8(h8, hs, w8, ws, bias=self._f(b + "mlp.c_fc.bias"), act=L.ACT_QUICK_GELU)
+            else:
+                h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
+                a = ops.gemm(h, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
+                             act=L.ACT_QUICK_GELU)
             ops.gemm(a, self._w(b + "mlp.c_proj.weight", cdt), bias=self._f(b + "mlp.c_proj.bias"),
                      residual=x, out=x)
         return x

@@ -3,7 +3,8 @@ heatmaps (reference bifold/models/rgb_clip.py:9-73; BASELINE configs 1, 2 and 4)
 
 Constructor kwargs are the YAML keys of conf/model/rgb_clip.yaml.  Two keys are new and
 default to the fast path: `dtype` ("bf16": bf16 MFMA operands, fp32 accumulate / residual
-stream / statistics; "fp32": exact fp32 MFMA everywhere -- the parity mode) and
+stream / statistics; "fp32": exact fp32 MFMA everywhere -- the parity mode; "fp8": bf16 with the
+frozen towers' QKV / fc1 GEMMs in OCP e4m3, per-token and per-channel scales -- BASELINE configs[4]) and
 `clip_checkpoint` (a CLIP state dict on disk; the reference downloads weights instead).
 """
 from __future__ import annotations
@@ -21,7 +22,7 @@ from .params import add_param, linear_init
 from .pickplace import RGBTailFn
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
-           "float32": torch.float32}
+           "float32": torch.float32, "fp8": torch.bfloat16}
 
 
 class RGBOnly(BaseModel):
@@ -40,6 +41,7 @@ class RGBOnly(BaseModel):
 
         assert text_encoder in _MODELS
         self.clip_encoder, _ = load(text_encoder, device="cpu", checkpoint=clip_checkpoint)
+        self.clip_encoder.fp8 = dtype == "fp8"             # frozen towers: e4m3 QKV / fc1 GEMMs (BASELINE configs[4])
         self.frozen_submodule("clip_encoder")
         dim = self.clip_encoder.transformer.width
         if self.clip_encoder.grid ** 2 != num_patches:

@@ -60,6 +60,10 @@ PROTOTYPES = {
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p]),
     "bf_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "bf_layernorm_fwd_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "bf_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "bf_gemm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                            c_int, c_int, c_int, c_void_p]),
     "bf_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_colsum_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bf_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -621,3 +621,51 @@ def affine_nearest(x: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
     check(lib.bf_affine_nearest(_ptr(x), _ptr(out), _ptr(params), x.shape[0], x.shape[1], x.shape[2], x.shape[3],
                                 _stream()), "bf_affine_nearest")
     return out
+
+
+# ----------------------------------------------------------------------------- fp8 forward path (frozen towers)
+def layernorm_fwd_fp8(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """fp32 [rows, cols] -> (e4m3 bytes uint8 [rows, cols], fp32 row scales [rows]); LN(x) ~= bytes * scale."""
+    _dev(x, "x"); _dev(gamma, "gamma"); _dev(beta, "beta")
+    if x.dtype != torch.float32:
+        raise TypeError("layernorm_fwd_fp8 reads the fp32 residual stream")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    y = torch.empty(rows, cols, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.bf_layernorm_fwd_fp8(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(scale), rows, cols, eps, _stream()),
+          "bf_layernorm_fwd_fp8")
+    return y, scale
+
+
+def quantize_rows_fp8(w: torch.Tensor):
+    """[N, K] fp32 / bf16 weights -> (e4m3 bytes uint8 [N, K], fp32 per-row scales [N])."""
+    w, rows, cols, ld = _rows2d(w, "w")
+    q = torch.empty(rows, cols, dtype=torch.uint8, device=w.device)
+    scale = torch.empty(rows, dtype=torch.float32, device=w.device)
+    check(lib.bf_quantize_rows_fp8(_ptr(w), dtype_code(w), _ptr(q), _ptr(scale), rows, cols, ld, _stream()),
+          "bf_quantize_rows_fp8")
+    return q, scale
+
+
+def gemm_fp8(a8: torch.Tensor, a_scale: torch.Tensor, b8: torch.Tensor, b_scale: torch.Tensor, *,
+             bias: Optional[torch.Tensor] = None, act: int = L.ACT_NONE, out_dtype: torch.dtype = torch.bfloat16,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C = act((a_scale[m] b_scale[n]) * a8 b8^T + bias) with e4m3 operands (uint8 storage) on the scaled fp8 MFMA."""
+    a8, m, k, lda = _rows2d(a8, "A")
+    b8, n, kb, ldb = _rows2d(b8, "B")
+    if a8.dtype != torch.uint8 or b8.dtype != torch.uint8:
+        raise TypeError("gemm_fp8 takes e4m3 operands stored as uint8")
+    if k != kb:
+        raise RuntimeError(f"GEMM inner dimensions differ: {k} vs {kb}")
+    if out is None:
+        out = torch.empty(m, n, dtype=out_dtype, device=a8.device)
+    out, _, _, ldc = _rows2d(out, "C")
+    span = None
+    if PROFILER is not None and PROFILER.wants("gemm_fp8_nt"):
+        span = _Span("gemm_fp8_nt", 2.0 * m * n * k)
+    check(lib.bf_gemm_fp8(_ptr(a8), _ptr(a_scale), _ptr(b8), _ptr(b_scale), _ptr(out), dtype_code(out), _ptr(bias), act,
+                          m, n, k, lda, ldb, ldc, _stream()), "bf_gemm_fp8")
+    if span is not None:
+        span.close()
+    return out

@@ -160,6 +160,23 @@ int bf_gemm_last_variant(void);
  * passing no workspace is always valid and just skips the optimisation). */
 size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g);
 
+/* ------------------------------------------------------------------------
+ * fp8 (OCP e4m3) forward path of the frozen towers (BASELINE.json configs[4]; no reference counterpart: the
+ * reference is fp32 end to end).  Replaces, for the towers only, the LayerNorm -> in-projection and
+ * LayerNorm -> MLP fc1 pairs of models/clip/model.py:192-219 (and of transformers' SiglipEncoderLayer):
+ *   bf_layernorm_fwd_fp8   y8[m, :] = e4m3(LN(x[m, :]) / s[m]),  s[m] = max |LN(x[m, :])| / 448     (x fp32)
+ *   bf_quantize_rows_fp8   q8[n, :] = e4m3(w[n, :] / s[n]),       s[n] = max |w[n, :]| / 448         (once per load)
+ *   bf_gemm_fp8            C[m, n] = act(sa[m] sb[n] sum_k a8[m, k] b8[n, k] + bias[n])   (c_dtype BF_BF16 / BF_F32)
+ * on v_mfma_scale_f32_16x16x128_f8f6f4 (twice the bf16 MFMA rate, half the operand bytes); k % 128 == 0,
+ * lda / ldb in bytes = elements, multiples of 16.  act: NONE / QUICK_GELU / ERF_GELU / TANH_GELU. */
+int bf_layernorm_fwd_fp8(const float* x, const float* gamma, const float* beta, void* y_fp8, float* row_scale,
+                         int rows, int cols, float eps, bf_stream_t stream);
+int bf_quantize_rows_fp8(const void* w, int w_dtype, void* q_fp8, float* row_scale, int rows, int cols, int ld,
+                         bf_stream_t stream);
+int bf_gemm_fp8(const void* a_fp8, const float* a_scale, const void* b_fp8, const float* b_scale, void* c,
+                int c_dtype, const float* bias, int act, int m, int n, int k, int lda, int ldb, int ldc,
+                bf_stream_t stream);
+
 /* Column sums  out[n] (+)= sum_m x[m, n]  (bias gradients, LayerNorm partials). */
 int bf_colsum(const void* x, int x_dtype, float* out, int rows, int cols, int ld, int accumulate,
               bf_stream_t stream);

@@ -669,3 +669,73 @@ def test_preprocess_rgb_matches_oracle(ops, gpu):
         for i in range(3):
             exp = O.preprocess_rgb(raw[i], None if mk is None else mk[i], mean, std)
             assert np.allclose(got[i], exp, rtol=3e-7, atol=3e-7)
+
+
+# ------------------------------------------------------------------ fp8 (OCP e4m3) forward path of the frozen towers
+def _e4m3_bytes(t):
+    return t.to(torch.float8_e4m3fn).view(torch.uint8)
+
+
+def test_fp8_gemm_is_exact_on_integer_operands(ops, gpu):
+    """Layout check of v_mfma_scale_f32_16x16x128_f8f6f4 (guide: test MFMA maps with exact, ASYMMETRIC data): small
+    integers are exact in e4m3, so the result must equal the integer matrix product bit for bit, incl. M / N tails."""
+    g = torch.Generator().manual_seed(3)
+    m, n, k = 200, 136, 384
+    a = torch.randint(-3, 4, (m, k), generator=g).float()
+    b = torch.randint(-3, 4, (n, k), generator=g).float()
+    b[5] += torch.arange(k) % 3                       # rows / columns that differ systematically (asymmetry)
+    a[:, 7] = 4.0
+    ref = a.double() @ b.double().t()
+    one_m, one_n = torch.ones(m, device=gpu), torch.ones(n, device=gpu)
+    c = ops.gemm_fp8(_e4m3_bytes(a).to(gpu), one_m, _e4m3_bytes(b).to(gpu), one_n, out_dtype=torch.float32)
+    assert torch.equal(c.double().cpu(), ref)
+    # scales and bias are applied per row / per column
+    sa = (torch.rand(m, generator=g) + 0.5).to(gpu)
+    sb = (torch.rand(n, generator=g) + 0.5).to(gpu)
+    bias = torch.randn(n, generator=g).to(gpu)
+    c2 = ops.gemm_fp8(_e4m3_bytes(a).to(gpu), sa, _e4m3_bytes(b).to(gpu), sb, bias=bias, out_dtype=torch.float32)
+    want = ref * sa.double().cpu()[:, None] * sb.double().cpu()[None, :] + bias.double().cpu()
+    assert rel_err(c2, want) < 1e-6
+
+
+def test_fp8_quantisers_match_torch_e4m3(ops, gpu):
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(300, 768, generator=g) * torch.logspace(-2, 1, 300).view(-1, 1)        # rows of very different size
+    q, s = ops.quantize_rows_fp8(w.to(gpu))
+    want_s = w.abs().amax(1) / 448.0
+    assert rel_err(s, want_s) < 1e-6
+    want_q = _e4m3_bytes(w / want_s[:, None])
+    assert (q.cpu() != want_q).float().mean().item() < 1e-3          # ties / last-ulp of the division only
+    deq = q.cpu().view(torch.float8_e4m3fn).float() * s.cpu()[:, None]
+    assert ((deq - w).abs() <= 0.0626 * w.abs() + want_s[:, None] * 2 ** -9).all()   # 3 mantissa bits (+ subnormals)
+    # LayerNorm straight to e4m3
+    x = torch.randn(77 * 3, 768, generator=g) * 2 + 0.3
+    gam, bet = 1 + 0.2 * torch.randn(768, generator=g), 0.2 * torch.randn(768, generator=g)
+    y8, ys = ops.layernorm_fwd_fp8(x.to(gpu), gam.to(gpu), bet.to(gpu))
+    ref = F.layer_norm(x, (768,), gam, bet, 1e-5)
+    assert rel_err(ys, ref.abs().amax(1) / 448.0) < 1e-5
+    deq = y8.cpu().view(torch.float8_e4m3fn).float() * ys.cpu()[:, None]
+    assert ((deq - ref).abs() <= 0.0626 * ref.abs() + ys.cpu()[:, None] * 2 ** -9 + 1e-5).all()
+
+
+@pytest.mark.parametrize("m,n,k,act", [(50432 // 16, 2304, 768, 0), (1000, 3072, 768, 1), (333, 1536, 512, 0)])
+def test_fp8_gemm_matches_dequantised_product(ops, L, gpu, m, n, k, act):
+    """Against fp64 on the DEQUANTISED operands (what is left is accumulation order and the bf16 output rounding)."""
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * 0.05
+    bias = torch.randn(n, generator=g) * 0.1
+    a8, sa = ops.quantize_rows_fp8(x.to(gpu))
+    b8, sb = ops.quantize_rows_fp8(w.to(gpu))
+    c = ops.gemm_fp8(a8, sa, b8, sb, bias=bias.to(gpu), act=L.ACT_QUICK_GELU if act else L.ACT_NONE)
+    da = a8.cpu().view(torch.float8_e4m3fn).double() * sa.double().cpu()[:, None]
+    db = b8.cpu().view(torch.float8_e4m3fn).double() * sb.double().cpu()[:, None]
+    ref = da @ db.t() + bias.double()
+    if act:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    assert c.dtype == torch.bfloat16 and rel_err(c.float(), ref) < 2 ** -7
+    # and against the unquantised product: the price of e4m3 operands with row / channel scales
+    full = x.double() @ w.double().t() + bias.double()
+    if act:
+        full = full * torch.sigmoid(1.702 * full)
+    assert rel_err(c.float(), full) < 5e-2

@@ -73,8 +73,11 @@ def test_resize_normalize_rgb_matches_torch_uint8_bicubic(gpu, observed, h, w, s
         lsb = ((got - want).abs() * std * 255.0)                 # difference in uint8 steps of the resized image
         observed(f"resize_{h}x{w}_to_{size}_{'mask' if m is not None else 'nomask'}", max_lsb=float(lsb.max()),
                  frac_off=float((lsb > 0.5).float().mean()))
-        assert float(lsb.max()) <= 1.01                          # never more than one grey level
-        assert float((lsb > 0.5).float().mean()) < 0.02          # and only where a value sits on a rounding edge
+        # downsampling (camera frames are larger than the model's input): never more than one grey level, and only
+        # where a value sits on a rounding edge (observed 0.35 % of the pixels); upsampling, where torch's uint8
+        # kernel works with 2^-7-quantised integer weights: two levels at most
+        assert float(lsb.max()) <= (1.01 if min(h, w) >= size else 2.01)
+        assert float((lsb > 0.5).float().mean()) < 0.02
 
 
 @pytest.mark.gpu
@@ -95,7 +98,11 @@ def test_affine_nearest_matches_grid_sample(gpu):
 
 @pytest.mark.gpu
 def test_augment_batch_moves_images_and_annotations_together(gpu):
-    """A bright dot at the annotated pixel must follow its annotation through the augmentation."""
+    """A bright dot at the annotated pixel must follow its annotation through the augmentation's TRANSLATION (same
+    (dx, dy) for `_aug_pixel` and `v2.functional.affine`, processor.py:313-341).  For the rotation the reference
+    hands `-angle` to the pixels and `angle` to torchvision's affine; both are reproduced as written (the pixel half
+    pinned by tests/golden/augment.npz, the image half against the oracle's restatement of torchvision)."""
+    from oracle import bifold_oracle as O
     from bifold.augment import augment_batch
     S, B, T = 96, 6, 2
     rng = np.random.RandomState(3)
@@ -108,13 +115,23 @@ def test_augment_batch_moves_images_and_annotations_together(gpu):
         ctx[b, :, :, y - 1:y + 2, x - 1:x + 2] = 1.0
     sample = {"rgb": rgb.to(gpu), "rgb_context": ctx.to(gpu), "pick": pick.clone(), "pick_heatmap": torch.zeros(B, S, S),
               "instruction": torch.zeros(B, 77, dtype=torch.int32)}
-    out = augment_batch(sample, S, dict(rotate_augmentation=[-5, 6], translate_augmentation=[-5, 6],
-                                        max_augmentation_trials=5), rng=rng)
+    shift_only = dict(rotate_augmentation=[0, 0], translate_augmentation=[-5, 6], max_augmentation_trials=5)
+    out = augment_batch(sample, S, shift_only, rng=rng)
     assert out["pick_heatmap"] is sample["pick_heatmap"] and out["augmentation"].shape == (B, 3)
     assert not torch.equal(out["pick"], pick)
     for b in range(B):
         img = out["rgb"][b, 0].cpu()
         ys, xs = torch.nonzero(img > 0.5, as_tuple=True)
         cx, cy = xs.float().mean().item(), ys.float().mean().item()
-        assert abs(cx - out["pick"][b, 0].item()) < 1.0 and abs(cy - out["pick"][b, 1].item()) < 1.0
+        assert abs(cx - out["pick"][b, 0].item()) < 0.51 and abs(cy - out["pick"][b, 1].item()) < 0.51
         assert torch.equal(out["rgb_context"][b, 0], out["rgb"][b]) and torch.equal(out["rgb_context"][b, 1], out["rgb"][b])
+    # with rotation: images follow the oracle's affine for the drawn parameters, pixels follow _aug_pixel(-angle)
+    full = dict(rotate_augmentation=[-5, 6], translate_augmentation=[-5, 6], max_augmentation_trials=5)
+    out = augment_batch(sample, S, full, rng=rng)
+    from bifold.augment import aug_pixel
+    for b in range(B):
+        angle, dx, dy = [float(v) for v in out["augmentation"][b].cpu()]
+        want = O.affine_nearest(rgb[b:b + 1], angle, dx, dy)
+        assert (out["rgb"][b:b + 1].cpu() != want).float().mean().item() < 2e-3
+        moved, inside = aug_pixel(pick[b:b + 1].clone(), -angle, dx, dy, S - 1)
+        assert inside and torch.allclose(out["pick"][b], moved[0], atol=1e-4)
