@@ -66,7 +66,7 @@ def augment_batch(sample: Dict[str, torch.Tensor], image_size: int, cfg=None, rn
     if not images:
         raise ValueError("augment_batch: the sample holds no rgb / depth image")
     batch = sample[images[0]].shape[0]
-    host = {k: sample[k].detach().float().cpu() for k in heads}
+    host = {k: sample[k].detach().float().cpu().clone() for k in heads}     # never write into the caller's tensors
     params = np.zeros((batch, 3), dtype=np.float32)
     for b in range(batch):
         moved, p = draw_augmentation({k: host[k][b] for k in heads}, image_size, rotate, translate, trials, rng)

@@ -39,6 +39,9 @@ struct EpiParams {
     int accumulate;
     float alpha;
     float* colsum;      // fused column sums of the stored result (atomicAdd into a zeroed [n]) or null
+    int store_policy;   // persistent kernel, bf16 epilogue: 0 = plain stores, 1 = sc1 (write-through: the output
+                        // tiles do not stay in the XCD's L2, which the operand panels need), 2 = nt
+    unsigned c_bytes;   // byte extent of c (and of pre) for the buffer descriptor of the policy stores
 };
 
 template <typename TC, typename TD>
@@ -883,7 +886,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                     const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
                     const int m = w.m0 + wm * 128 + H * 64 + lr;
                     const int n = w.n0 + wn * 64 + c16 * 8;
-                    if (m < ep.m && n < ep.n) *(uint4*)(dst + (size_t)m * ep.ldc + n) = q;
+                    if (m < ep.m && n < ep.n) {
+                        if (ep.store_policy == 0) {
+                            *(uint4*)(dst + (size_t)m * ep.ldc + n) = q;
+                        } else {
+                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                            const __amdgpu_buffer_rsrc_t rc =
+                                __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, ep.c_bytes, 0x00020000);
+                            const unsigned voff = (unsigned)(((size_t)m * ep.ldc + n) * 2);
+                            const u32x4 qv = {q.x, q.y, q.z, q.w};
+                            if (ep.store_policy == 1) __builtin_amdgcn_raw_buffer_store_b128(qv, rc, voff, 0, 16);
+                            else __builtin_amdgcn_raw_buffer_store_b128(qv, rc, voff, 0, 2);
+                        }
+                    }
                 }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -1364,6 +1379,14 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     ep.rows_out = g->rows_out; ep.row_off = g->row_off; ep.act = g->act;
     ep.accumulate = g->accumulate; ep.alpha = g->alpha;
     ep.colsum = nullptr;
+    ep.store_policy = 0;
+    ep.c_bytes = 0;
+    {
+        static int pol = -1;
+        if (pol < 0) { const char* e = getenv("BIFOLD_P8_STORE"); pol = e ? atoi(e) : 0; if (pol < 0 || pol > 2) pol = 0; }
+        const size_t cb = ((size_t)(g->m - 1) * g->ldc + g->n) * 2;
+        if (pol && g->c_dtype == BF_BF16 && g->rows_in == 0 && cb < (1ull << 32)) { ep.store_policy = pol; ep.c_bytes = (unsigned)cb; }
+    }
     bool colsum_fused = false;
     BF_REQUIRE(!g->colsum_out || (g->rows_in == 0 && bf_aligned16(g->colsum_out)), BF_EINVAL,
                "bf_gemm: colsum_out needs rows_in == 0 and a 16-byte aligned pointer");
