@@ -39,10 +39,22 @@ struct EpiParams {
     int accumulate;
     float alpha;
     float* colsum;      // fused column sums of the stored result (atomicAdd into a zeroed [n]) or null
-    int store_policy;   // persistent kernel, bf16 epilogue: 0 = plain stores, 1 = sc1 (write-through: the output
-                        // tiles do not stay in the XCD's L2, which the operand panels need), 2 = nt
-    unsigned c_bytes;   // byte extent of c (and of pre) for the buffer descriptor of the policy stores
+    int store_policy;   // persistent kernel: bit 0 / 1 / 2 = non-temporal (`nt`) output stores in the plain-bf16 /
+                        // general / GELU-grad epilogue.  Output tiles are written once and read by a LATER kernel;
+                        // stored plainly they push the operand panels out of the XCD's L2 (fusion QKV: 237 MB of
+                        // operand fetches per launch against 74 MB algorithmic, 186 MB with nt)
 };
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+// 16 bytes to global memory, optionally with the streaming hint
+__device__ __forceinline__ void store16(void* p, uint4 q, bool nt) {
+    if (nt) {
+        const u32x4_t v = {q.x, q.y, q.z, q.w};
+        __builtin_nontemporal_store(v, (u32x4_t*)p);
+    } else {
+        *(uint4*)p = q;
+    }
+}
 
 template <typename TC, typename TD>
 __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int n, float4 v) {
@@ -94,6 +106,11 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
 // instruction wherever the output type allows it.
 template <typename T> struct Vec8;
 template <> struct Vec8<float> {
+    static __device__ __forceinline__ void store_nt(float* p, const float (&v)[8], bool nt) {
+        float4 a = make_float4(v[0], v[1], v[2], v[3]), b = make_float4(v[4], v[5], v[6], v[7]);
+        store16(p, *(const uint4*)&a, nt);
+        store16(p + 4, *(const uint4*)&b, nt);
+    }
     static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
         const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -104,6 +121,12 @@ template <> struct Vec8<float> {
     }
 };
 template <> struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void store_nt(bf16_t* p, const float (&v)[8], bool nt) {
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
+        store16(p, *(const uint4*)&r, nt);
+    }
     static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
         const bf16x8 r = *(const bf16x8*)p;
 #pragma unroll
@@ -128,7 +151,7 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int 
     size_t orow = (size_t)m;
     if (ep.rows_in > 0) orow = (size_t)(m / ep.rows_in) * ep.rows_out + ep.row_off + (m % ep.rows_in);
     if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU || ep.act == BF_ACT_TANH_GELU) {
-        if (ep.pre) Vec8<TD>::store((TD*)ep.pre + orow * ep.ldc + n, v);
+        if (ep.pre) Vec8<TD>::store_nt((TD*)ep.pre + orow * ep.ldc + n, v, ep.store_policy & 2);
         using AM = ActMath<TD>;
         if (ep.act == BF_ACT_QUICK_GELU) {
 #pragma unroll
@@ -167,8 +190,8 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int 
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += o[e];
     }
-    Vec8<TC>::store(cp, v);
-    if (ep.c2) Vec8<bf16_t>::store((bf16_t*)ep.c2 + orow * ep.ldc + n, v);
+    Vec8<TC>::store_nt(cp, v, ep.store_policy & 2);
+    if (ep.c2) Vec8<bf16_t>::store_nt((bf16_t*)ep.c2 + orow * ep.ldc + n, v, ep.store_policy & 2);
 }
 
 #define CT_LD 132   // fp32 staging tile leading dimension (128 + 4 pad)
@@ -886,19 +909,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                     const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
                     const int m = w.m0 + wm * 128 + H * 64 + lr;
                     const int n = w.n0 + wn * 64 + c16 * 8;
-                    if (m < ep.m && n < ep.n) {
-                        if (ep.store_policy == 0) {
-                            *(uint4*)(dst + (size_t)m * ep.ldc + n) = q;
-                        } else {
-                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-                            const __amdgpu_buffer_rsrc_t rc =
-                                __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, ep.c_bytes, 0x00020000);
-                            const unsigned voff = (unsigned)(((size_t)m * ep.ldc + n) * 2);
-                            const u32x4 qv = {q.x, q.y, q.z, q.w};
-                            if (ep.store_policy == 1) __builtin_amdgcn_raw_buffer_store_b128(qv, rc, voff, 0, 16);
-                            else __builtin_amdgcn_raw_buffer_store_b128(qv, rc, voff, 0, 2);
-                        }
-                    }
+                    if (m < ep.m && n < ep.n) store16(dst + (size_t)m * ep.ldc + n, q, ep.store_policy & 1);
                 }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -962,7 +973,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                         o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
                     }
                     if (m < ep.m && n < ep.n) {
-                        *(bf16x8*)((bf16_t*)ep.c + (size_t)m * ep.ldc + n) = o8;
+                        store16((bf16_t*)ep.c + (size_t)m * ep.ldc + n, *(const uint4*)&o8, ep.store_policy & 4);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) cs[e] += (float)o8[e];      // sums of the STORED values
                     }
@@ -1379,13 +1390,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     ep.rows_out = g->rows_out; ep.row_off = g->row_off; ep.act = g->act;
     ep.accumulate = g->accumulate; ep.alpha = g->alpha;
     ep.colsum = nullptr;
-    ep.store_policy = 0;
-    ep.c_bytes = 0;
     {
-        static int pol = -1;
-        if (pol < 0) { const char* e = getenv("BIFOLD_P8_STORE"); pol = e ? atoi(e) : 0; if (pol < 0 || pol > 2) pol = 0; }
-        const size_t cb = ((size_t)(g->m - 1) * g->ldc + g->n) * 2;
-        if (pol && g->c_dtype == BF_BF16 && g->rows_in == 0 && cb < (1ull << 32)) { ep.store_policy = pol; ep.c_bytes = (unsigned)cb; }
+        static int pol = -1;      // bit mask, see EpiParams::store_policy (measured in-step: DESIGN.md §6)
+        if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 1; }
+        ep.store_policy = pol;
     }
     bool colsum_fused = false;
     BF_REQUIRE(!g->colsum_out || (g->rows_in == 0 && bf_aligned16(g->colsum_out)), BF_EINVAL,
