@@ -435,12 +435,23 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 template <int D, int MASK>
 __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
-    const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp) {
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp, int nt_loads) {
     constexpr int mask_mode = MASK;
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;
     constexpr int DB = DP / 32;
     constexpr int KROW = D * 2 + 16;          // bytes
+    // Every byte of the packed QKV buffer is read exactly once by this launch (232 MB at the vision tower's shape,
+    // about the size of the Infinity Cache): streamed with the non-temporal hint it does not push out the
+    // residual stream the next GEMM's epilogue needs.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    auto ld16 = [&](const bf16_t* p) -> uint4 {
+        if (nt_loads) {
+            const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+            return make_uint4(v[0], v[1], v[2], v[3]);
+        }
+        return *(const uint4*)p;
+    };
     constexpr int VROW = DP * 2 + 16;         // bytes (pad columns of D = 48 are zero)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -459,8 +470,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         const int j = idx / (DP / 8), c = idx - j * (DP / 8);
         uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
         if (j < L && c < D / 8) {
-            kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
-            vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+            kv = ld16(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+            vv = ld16(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
         }
         if (c < D / 8) *(uint4*)(k_lds + j * KROW + c * 16) = kv;
         *(uint4*)(v_lds + j * VROW + c * 16) = vv;
@@ -469,8 +480,10 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (q_live) qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
-        else {
+        if (q_live) {
+            const uint4 qq = ld16(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+            qf[ks] = *(const bf16x8*)&qq;
+        } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
         }
@@ -1603,6 +1616,9 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         if (fwd_res_env < 0) { const char* e = getenv("BIFOLD_ATTN_FWD_TILED"); fwd_res_env = (e && atoi(e)) ? 0 : 1; }
         if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024) {
             dim3 rgrid(batch * heads), rblock(nq32 * 64);
+            static int nt_env = -1;
+            if (nt_env < 0) { const char* e = getenv("BIFOLD_ATTN_NT"); nt_env = e ? atoi(e) : 1; }
+            const int nt_loads = nt_env & 1;
 #define FWD_RES2(DD, MM)                                                                           \
     do {                                                                                          \
         static size_t lds_set = 0;                                                                \
@@ -1612,7 +1628,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             lds_set = res_lds;                                                                    \
         }                                                                                         \
         hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
-                           (bf16_t*)out, lse, row_mask, seq, heads, scale, lp);                   \
+                           (bf16_t*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);         \
     } while (0)
 #define FWD_RES(DD)                                                                               \
     do {                                                                                          \
