@@ -10,8 +10,17 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
- *    name ends in _host; the caller owns all memory, the library never allocates,
- *    frees or synchronises, and holds no state besides a thread-local error string;
+ *    name ends in _host; the caller owns all memory: the library never allocates, frees
+ *    or synchronises;
+ *  - process-wide state, all of it internal and none of it data: a thread-local error
+ *    string; tuning knobs read ONCE per process from the environment on first use
+ *    (BIFOLD_GEMM_PIPE, BIFOLD_P8_*, BIFOLD_ATTN_*, BIFOLD_LN_ROWS: kernel selection only,
+ *    results are the same up to summation order) and the matching bf_gemm_set_variant hook
+ *    (not thread-safe: call it before the threads that run GEMMs start); and, for the persistent
+ *    GEMM, a __device__ array of work-ticket counters with a host-side table that hands each
+ *    stream (at most 16 per process, first come first served; further streams fall back to the
+ *    non-persistent kernels) its own ring of counter sets on the device that was current at the
+ *    first bf16 GEMM -- a process drives ONE device (the one-process-per-GPU model of bifold/dist.py);
  *  - every launch goes to the hipStream_t passed as `stream` (void*; NULL = the
  *    legacy default stream);
  *  - tensors are row-major and contiguous unless a leading dimension is given;
