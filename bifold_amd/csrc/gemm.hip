@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
 //     DMA flight, and the stores drain under the next item's main loop.
 #define P8_STAGE 32768
 
-struct P8Item { int m0, n0, kbeg, nk, z; };
+struct P8Item { int m0, n0, kbeg, nk, z, rev; };
 
 #ifdef P8_PROBE
 __device__ unsigned long long p8_probe[16];
@@ -686,6 +686,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     // the end of the main loop and published through LDS at the item boundary.
     const int NX = G < 8 ? G : 8;
     const int xl = bid % NX;
+    const int per_xcd = max(1, G / NX);
+    const int rev_rounds = skew_cycles & 1;            // `skew_cycles` carries mode bits now (the start-skew experiment is retired)
+    const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
     // ranges proportional to the workgroups a lane has (G need not be a multiple of 8): with exactly one
     // item per workgroup no lane may hold more items than workgroups
     auto lane_start = [&](int x) { return (int)((long long)n_items * (x * (G / NX) + min(x, G % NX)) / G); };
@@ -701,6 +704,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         w.m0 = tm * 256; w.n0 = tn * 256;
         w.kbeg = w.z * d.k_per_split;
         w.nk = (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 31) >> 5;
+        // Every other ROUND of an XCD's tickets walks K backwards: the panels two consecutive rounds share (the W
+        // panels of the next row group, the A panels of the next column tiles) are then first touched where the
+        // previous round left them in the L2, instead of at the end that was evicted longest ago.  The direction is
+        // a function of the ticket (not of which workgroup drew it), so a tile's summation order is reproducible.
+        w.rev = rev_rounds ? (int)((ticket / (unsigned)per_xcd) & 1u) : 0;
         return true;
     };
     auto finish = [&]() {              // every workgroup exactly once, after its last draw
@@ -710,10 +718,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         }
     };
     auto issue_a = [&](const P8Item& w, int s) {
-        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + s * 32, wave * 2, 2, lane);
+        const int ks = w.rev ? w.nk - 1 - s : s;
+        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + ks * 32, wave * 2, 2, lane);
     };
     auto issue_b = [&](const P8Item& w, int s) {
-        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, d.ldb, w.n0, w.kbeg + s * 32, wave * 2, 2, lane);
+        const int ks = w.rev ? w.nk - 1 - s : s;
+        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, d.ldb, w.n0, w.kbeg + ks * 32, wave * 2, 2, lane);
     };
 
     P8Item w;
@@ -724,15 +734,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);   // wave-uniform: keeps the item in SGPRs
     unsigned nxt = 0;
     if (!decode(first, w)) { finish(); return; }
-    // Epilogue stores are a burst (128-512 KB per CU) that the memory system takes at ~2.7 TB/s
-    // chip-wide; with every CU in lock step the bursts coincide and the MFMAs idle meanwhile.
-    // Four phase groups per XCD start a fraction of an epilogue apart, so at any time about a
-    // quarter of the CUs write while the others compute.
-    if (skew_cycles > 0) {
-        const long long wait = (long long)((bid >> 3) & 3) * skew_cycles;
-        const long long t0 = clock64();
-        while ((long long)clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
     issue_a(w, 0); issue_b(w, 0);
     if (w.nk > 1) { issue_a(w, 1); issue_b(w, 1); }
 
@@ -770,6 +771,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 #ifdef P8_PROBE
         if (bid == 0 && threadIdx.x == 0 && round == 2) p8_probe[6] = clock64() - pcw;
 #endif
+        // Prefetch distance 3 (`deep`): stage 2 goes out here -- after the barrier, because its slot was an epilogue
+        // staging area of the previous item until every wave passed it -- and stage s + 3 in phase b of stage s: its
+        // slot, (s - 1) & 3, was last read two barrier intervals earlier by the lagging group.  The ring stays 4 slots
+        // (the LDS is full); what changes is that three stages instead of two are in flight, i.e. ~50 % more time for
+        // a load that misses the L2 to arrive before a wave waits for it.
+        if (deep && w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }
         if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind
         const int nk = w.nk;
 #ifdef P8_PROBE
@@ -795,7 +802,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS>(la, wm * 128 + i * 16, lane);
-            if (more) issue_a(w, s + 2);
+            if (more && !deep) issue_a(w, s + 2);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -809,9 +816,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             bf16x8 ag[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) ag[i] = bf16_frag32<A_KS>(la, wm * 128 + 64 + i * 16, lane);
-            if (more) {
-                issue_b(w, s + 2);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage s+1 landed (s+2 in flight)
+            if (!deep) {
+                if (more) {
+                    issue_b(w, s + 2);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage s+1 landed (s+2 in flight)
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            } else if (s + 3 < nk) {
+                issue_a(w, s + 3); issue_b(w, s + 3);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // stage s+1 landed (s+2, s+3 in flight)
+            } else if (more) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // s+2 (the last stage) may still be in flight
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1483,8 +1499,14 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
             unsigned g8 = (unsigned)(n_cu & ~7);      // every CU draws; workgroups that find no ticket exit
             if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
-            const char* skew_e = getenv("BIFOLD_P8_SKEW");
-            const int skew = skew_e ? atoi(skew_e) : 0;
+            // bit 0: alternate the K direction per round of tickets (operand fetches 338 -> 239 MB on the vision QKV
+            // GEMM, no change in time: the re-fetches were Infinity-Cache hits); bit 1: prefetch distance 3, which
+            // pays only where both operands stream from HBM, i.e. the deep dW = dY^T X GEMMs (+5 %; NT / NN -3..5 %)
+            static int rev_env = -1, deep_env = -2;
+            if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
+            if (deep_env == -2) { const char* e = getenv("BIFOLD_P8_DEEP"); deep_env = e ? atoi(e) : -1; }
+            const int deep = deep_env >= 0 ? (deep_env ? 1 : 0) : (g->trans_a && g->b_kn ? 1 : 0);
+            const int skew = rev_env | (deep << 1);
             // which epilogue instantiation (the predicates of the kernel's EPI paths)
             int epi = 0;
             if (!f32out && !slabs && !g->residual && !g->c2 && !g->accumulate && g->rows_in == 0) {
