@@ -15,6 +15,7 @@ epilogues and writes parameter gradients straight into the flat gradient arena.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -28,6 +29,9 @@ from .decoder_math import upsample_operator
 from .params import add_param, layernorm_init, linear_init
 
 DEC_IDX = (0, 2, 4, 6, 8)
+# the fusion MLP saves gelu'(pre) for the backward (one erf evaluation in the forward epilogue, a multiply in the
+# backward's); BIFOLD_GELU_SAVEGRAD=0 keeps `pre` and evaluates gelu' in the backward (the round-1 form, for A/B)
+_SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
 
 
 def head_names(is_bimanual: bool) -> List[str]:
@@ -194,8 +198,10 @@ def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row
     o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mask_mode, row_mask, need_lse=save)
     x2 = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, residual=x, out_dtype=torch.float32)
     h2, m2, r2 = ops.layernorm_fwd(x2, P["g2"].data, P["b2"].data, cdt, save_stats=save)
-    if save:
-        a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data, act=L.ACT_ERF_GELU, want_pre=True)
+    if save:       # the forward saves gelu'(pre), not pre: one erf evaluation serves both outputs of the epilogue,
+        # and the backward GEMM's epilogue is a multiply instead of an erf + exp per element
+        a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data,
+                            act=L.ACT_ERF_GELU_SAVEGRAD if _SAVEGRAD else L.ACT_ERF_GELU, want_pre=True)
     else:
         a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data, act=L.ACT_ERF_GELU), None
     x3 = ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data, residual=x2, out_dtype=torch.float32)
@@ -212,7 +218,8 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
-    da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD, aux=S["a_pre"],
+    da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True,
+                      act=L.ACT_MUL_AUX if _SAVEGRAD else L.ACT_ERF_GELU_GRAD, aux=S["a_pre"],
                       colsum_out=g(P["bb1"]))          # d bias1 = column sums of da_pre, fused into the epilogue
     ops.gemm(op3, S["a"], trans_a=True, b_kn=True, out=g(P["w2"]))
     dh2 = ops.gemm(da_pre, A.operand(P["w1"], cdt), b_kn=True)

@@ -117,6 +117,19 @@ __device__ __forceinline__ float erf_gelu_grad_fast(float x) {
     const float cdf = 0.5f * (1.0f + copysignf(1.0f - ec, z));
     return fmaf(x * 0.39894228040143267794f, e2, cdf);
 }
+// gelu(x) and gelu'(x) from ONE erfc / exp evaluation (the forward epilogue that saves gelu' for the backward)
+__device__ __forceinline__ void erf_gelu_both_fast(float x, float& g, float& gp) {
+    const float z = x * 0.70710678118654752440f;
+    float e2;                                                   // exp(-x^2 / 2)
+    const float ec = fast_erfc_abs(fabsf(z), e2);
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - ec, z));
+    g = x * cdf;
+    gp = fmaf(x * 0.39894228040143267794f, e2, cdf);
+}
+__device__ __forceinline__ void erf_gelu_both_f(float x, float& g, float& gp) {
+    g = erf_gelu_f(x);
+    gp = erf_gelu_grad_f(x);
+}
 __device__ __forceinline__ float quick_gelu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));
 }
@@ -146,6 +159,7 @@ template <> struct ActMath<float> {
     static __device__ __forceinline__ float quick(float x) { return quick_gelu_f(x); }
     static __device__ __forceinline__ float erf(float x) { return erf_gelu_f(x); }
     static __device__ __forceinline__ float erf_grad(float x) { return erf_gelu_grad_f(x); }
+    static __device__ __forceinline__ void erf_both(float x, float& g, float& gp) { erf_gelu_both_f(x, g, gp); }
     static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_f(x); }
     static __device__ __forceinline__ float tanh_grad(float x) { return tanh_gelu_grad_f(x); }
 };
@@ -153,6 +167,7 @@ template <> struct ActMath<bf16_t> {
     static __device__ __forceinline__ float quick(float x) { return quick_gelu_fast(x); }
     static __device__ __forceinline__ float erf(float x) { return erf_gelu_fast(x); }
     static __device__ __forceinline__ float erf_grad(float x) { return erf_gelu_grad_fast(x); }
+    static __device__ __forceinline__ void erf_both(float x, float& g, float& gp) { erf_gelu_both_fast(x, g, gp); }
     static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_fast(x); }
     static __device__ __forceinline__ float tanh_grad(float x) { return tanh_gelu_grad_fast(x); }
 };

@@ -75,6 +75,15 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
         } else {
             v.x = AM::erf(v.x); v.y = AM::erf(v.y); v.z = AM::erf(v.z); v.w = AM::erf(v.w);
         }
+    } else if (ep.act == BF_ACT_ERF_GELU_SAVEGRAD) {
+        using AM = ActMath<TD>;
+        float4 gp;
+        AM::erf_both(v.x, v.x, gp.x); AM::erf_both(v.y, v.y, gp.y);
+        AM::erf_both(v.z, v.z, gp.z); AM::erf_both(v.w, v.w, gp.w);
+        Vec4<TD>::store((TD*)ep.pre + orow * ep.ldc + n, gp);
+    } else if (ep.act == BF_ACT_MUL_AUX) {
+        const float4 a = Vec4<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n);
+        v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
     } else if (ep.act == BF_ACT_ERF_GELU_GRAD) {
         using AM = ActMath<TD>;
         const float4 a = Vec4<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n);
@@ -163,6 +172,17 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = AM::erf(v[e]);
         }
+    } else if (ep.act == BF_ACT_ERF_GELU_SAVEGRAD) {
+        using AM = ActMath<TD>;
+        float gp[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) AM::erf_both(v[e], v[e], gp[e]);
+        Vec8<TD>::store_nt((TD*)ep.pre + orow * ep.ldc + n, gp, ep.store_policy & 2);
+    } else if (ep.act == BF_ACT_MUL_AUX) {
+        float a[8];
+        Vec8<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= a[e];
     } else if (ep.act == BF_ACT_ERF_GELU_GRAD) {
         using AM = ActMath<TD>;
         float a[8];
@@ -877,7 +897,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // Plain bf16 outputs (alpha / bias / activation only): do the math in the MFMA layout, turn
         // the tile around as bf16 (half the LDS bytes: ds_write runs at ~80 B/clk per CU) in two
         // 64-row halves, and store 8 columns per lane.
-        constexpr bool fast16 = EPI == 1;
+        constexpr bool fast16 = EPI == 1 || EPI == 3;
         if constexpr (fast16) {
             float4 bj[4];
 #pragma unroll
@@ -932,12 +952,64 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             };
             const bool want_pre = ep.pre && (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU ||
                                              ep.act == BF_ACT_TANH_GELU);
+            if constexpr (EPI == 3) {
+                // BF_ACT_ERF_GELU_SAVEGRAD: gelu and gelu' of a QUARTER tile (32 rows) from ONE erf evaluation per
+                // element; the two results go to the two halves of the wave's 8 KB staging buffer at once (no
+                // registers held across the turn-around: the half-tile version spilled), then to `c` and `pre`.
+                auto quarter_pair = [&](auto q_) {
+                    constexpr int Q = decltype(q_)::value;          // rows [32 Q, 32 Q + 32) of the wave's 128
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; ++i2) {
+                        const int lr = i2 * 16 + (lane & 15);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 a = acc[j][Q * 2 + i2];
+                            const float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
+                                                fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
+                            bf16x4 pk, gk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float gv, gp;
+                                AM::erf_both(v[e], gv, gp);
+                                pk[e] = (bf16_t)gv;
+                                gk[e] = (bf16_t)gp;
+                            }
+                            const int cc4 = j * 4 + (lane >> 4);
+                            const int off = lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3);
+                            *(bf16x4*)(stg + off) = pk;
+                            *(bf16x4*)(stg + 4096 + off) = gk;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int lr = t * 8 + (lane >> 3), c16 = lane & 7;
+                        const int off = lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4);
+                        const uint4 qa = *(const uint4*)(stg + off);
+                        const uint4 qg = *(const uint4*)(stg + 4096 + off);
+                        const int m = w.m0 + wm * 128 + Q * 32 + lr;
+                        const int n = w.n0 + wn * 64 + c16 * 8;
+                        if (m < ep.m && n < ep.n) {
+                            store16((bf16_t*)ep.c + (size_t)m * ep.ldc + n, qa, ep.store_policy & 1);
+                            store16((bf16_t*)ep.pre + (size_t)m * ep.ldc + n, qg, ep.store_policy & 1);
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                };
+                quarter_pair(std::integral_constant<int, 0>{});
+                quarter_pair(std::integral_constant<int, 1>{});
+                quarter_pair(std::integral_constant<int, 2>{});
+                quarter_pair(std::integral_constant<int, 3>{});
+            } else {
             if (want_pre) {
                 half_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
                 half_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
             }
             half_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
             half_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            }
         } else {
         auto stage_chunk = [&](auto cc_) {
             constexpr int C = decltype(cc_)::value;
@@ -983,10 +1055,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                     const uint4 raw = apre[C * 4 + t];
                     const bf16x8 a8 = *(const bf16x8*)&raw;
                     bf16x8 o8;
+                    if (ep.act == BF_ACT_MUL_AUX) {        // aux already IS gelu'(pre) (forward: ..._SAVEGRAD)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o8[e] = (bf16_t)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
-                        o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
+                        for (int e = 0; e < 4; ++e) {
+                            o8[e] = (bf16_t)(q0[e] * ep.alpha * (float)a8[e]);
+                            o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * (float)a8[4 + e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o8[e] = (bf16_t)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
+                            o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
+                        }
                     }
                     if (m < ep.m && n < ep.n) {
                         store16((bf16_t*)ep.c + (size_t)m * ep.ldc + n, *(const uint4*)&o8, ep.store_policy & 4);
@@ -1358,9 +1438,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                "bf_gemm: fp32 operands produce fp32 output only");
     BF_REQUIRE(!(g->accumulate && g->split_k > 1 && g->c_dtype != BF_F32), BF_EINVAL,
                "bf_gemm: accumulate into a bf16 C cannot be combined with split_k");
-    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_TANH_GELU_GRAD, BF_EINVAL, "bf_gemm: bad act");
-    BF_REQUIRE((g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD) || g->aux, BF_EINVAL,
-               "bf_gemm: the GELU_GRAD activations need aux");
+    BF_REQUIRE(g->act >= BF_ACT_NONE && g->act <= BF_ACT_MUL_AUX, BF_EINVAL, "bf_gemm: bad act");
+    BF_REQUIRE((g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) || g->aux,
+               BF_EINVAL, "bf_gemm: the GELU_GRAD / MUL_AUX activations need aux");
+    BF_REQUIRE(g->act != BF_ACT_ERF_GELU_SAVEGRAD || g->pre, BF_EINVAL, "bf_gemm: BF_ACT_ERF_GELU_SAVEGRAD needs `pre`");
     const int vec = g->cdt == BF_BF16 ? 8 : 4;
     BF_REQUIRE((g->n & 3) == 0 && (g->ldc & 3) == 0 && g->ldc >= g->n, BF_EINVAL,
                "bf_gemm: n and ldc must be multiples of 4 (n=%d ldc=%d)", g->n, g->ldc);
@@ -1481,7 +1562,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             (!g->aux || (g->ld_aux % 8) == 0)) {
             last_variant = 8;
             // column sums fused into the bf16 GELU-grad epilogue (same predicate as the kernel's `fastgrad`)
-            if (g->colsum_out && !slabs && !f32out && g->act == BF_ACT_ERF_GELU_GRAD && !g->bias && !g->residual &&
+            if (g->colsum_out && !slabs && !f32out && (g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->residual &&
                 !g->c2 && !g->pre && !g->accumulate && g->rows_in == 0) {   // == the EPI 2 instantiation below
                 BF_REQUIRE(hipMemsetAsync(g->colsum_out, 0, (size_t)g->n * sizeof(float), s) == hipSuccess, BF_ELAUNCH,
                            "bf_gemm: memset of colsum_out failed");
@@ -1510,8 +1591,9 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             // which epilogue instantiation (the predicates of the kernel's EPI paths)
             int epi = 0;
             if (!f32out && !slabs && !g->residual && !g->c2 && !g->accumulate && g->rows_in == 0) {
-                if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD) epi = 1;
-                else if (g->act == BF_ACT_ERF_GELU_GRAD && !g->bias && !g->pre) epi = 2;
+                if (!g->aux && g->act == BF_ACT_ERF_GELU_SAVEGRAD) epi = 3;
+                else if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) epi = 1;
+                else if ((g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->pre) epi = 2;
             }
 #define LAUNCH_P8E(AKS, BKS, TC, EPI)                                                               \
     do {                                                                                          \
@@ -1528,6 +1610,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         if (f32out) LAUNCH_P8E(AKS, BKS, float, 0);                                               \
         else if (epi == 1) LAUNCH_P8E(AKS, BKS, bf16_t, 1);                                       \
         else if (epi == 2) LAUNCH_P8E(AKS, BKS, bf16_t, 2);                                       \
+        else if (epi == 3) LAUNCH_P8E(AKS, BKS, bf16_t, 3);                                       \
         else LAUNCH_P8E(AKS, BKS, bf16_t, 0);                                                     \
     } while (0)
             if (!g->trans_a && !g->b_kn) LAUNCH_P8(false, false);

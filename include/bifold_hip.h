@@ -116,7 +116,10 @@ int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* 
  * ---------------------------------------------------------------------- */
 enum { BF_ACT_NONE = 0, BF_ACT_QUICK_GELU = 1, BF_ACT_ERF_GELU = 2, BF_ACT_ERF_GELU_GRAD = 3,
        BF_ACT_TANH_GELU = 4 /* gelu_pytorch_tanh: the MLP of transformers' SiglipModel */,
-       BF_ACT_TANH_GELU_GRAD = 5 /* v *= d/dx gelu_pytorch_tanh at aux[m,n] (LoRA: tower backward) */ };
+       BF_ACT_TANH_GELU_GRAD = 5 /* v *= d/dx gelu_pytorch_tanh at aux[m,n] (LoRA: tower backward) */,
+       BF_ACT_ERF_GELU_SAVEGRAD = 6 /* C = gelu(v) and `pre` (required) receives gelu'(v) INSTEAD of v: the erf is
+                                     * evaluated once for both, and the backward GEMM's epilogue becomes ... */,
+       BF_ACT_MUL_AUX = 7 /* ... v *= aux[m,n] (aux = the saved gelu'(v), cdt) */ };
 
 typedef struct bf_gemm_args {
     const void* a;

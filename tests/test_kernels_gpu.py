@@ -739,3 +739,32 @@ def test_fp8_gemm_matches_dequantised_product(ops, L, gpu, m, n, k, act):
     if act:
         full = full * torch.sigmoid(1.702 * full)
     assert rel_err(c.float(), full) < 5e-2
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 256, 128), (16384 + 200, 512, 256)])     # 128x128 kernels / persistent kernel
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_gemm_gelu_savegrad_and_mul_aux(ops, L, gpu, m, n, k, cdt):
+    """BF_ACT_ERF_GELU_SAVEGRAD: C = gelu(v) and pre = gelu'(v) from one erf evaluation; BF_ACT_MUL_AUX: v *= aux --
+    the pair that replaces (ERF_GELU + saved pre, ERF_GELU_GRAD) in the fusion MLP (modules.py:21-27 and its autograd)."""
+    g = torch.Generator().manual_seed(m + k)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) * 0.2
+    b = torch.randn(n, generator=g) * 0.3
+    xc, wc = (x, w) if cdt == torch.float32 else (bf16_round(x), bf16_round(w))
+    v = (xc.double() @ wc.double().t() + b.double()).requires_grad_(True)
+    ref = F.gelu(v)
+    ref.sum().backward()
+    a, gp = ops.gemm(x.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=b.to(gpu), act=L.ACT_ERF_GELU_SAVEGRAD, want_pre=True)
+    tol = 1e-5 if cdt == torch.float32 else 2 ** -7
+    assert rel_err(a.float(), ref) < tol and rel_err(gp.float(), v.grad) < tol
+    # backward half: dX-like product times the saved derivative, against the same product times gelu'(pre) in fp64
+    dy = torch.randn(m, k, generator=g)
+    w2 = torch.randn(k, n, generator=g) * 0.2                  # stored [K, N]: b_kn
+    dyc, w2c = (dy, w2) if cdt == torch.float32 else (bf16_round(dy), bf16_round(w2))
+    want = (dyc.double() @ w2c.double()) * gp.double().cpu()
+    got = ops.gemm(dy.to(gpu).to(cdt), w2.to(gpu).to(cdt), b_kn=True, act=L.ACT_MUL_AUX, aux=gp)
+    assert rel_err(got.float(), want) < tol
+    if cdt == torch.bfloat16 and m >= 16384:                   # the fused bias-gradient sums ride along on this path
+        cs = torch.empty(n, dtype=torch.float32, device=gpu)
+        got2 = ops.gemm(dy.to(gpu).to(cdt), w2.to(gpu).to(cdt), b_kn=True, act=L.ACT_MUL_AUX, aux=gp, colsum_out=cs)
+        assert rel_err(cs, got2.float().double().sum(0)) < 1e-3
