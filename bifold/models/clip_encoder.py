@@ -10,6 +10,7 @@ no pooling, no output projections, no logits.  Both towers are frozen in BiFold
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from typing import Dict, Optional
 
@@ -133,13 +134,22 @@ class CLIPEncoder(nn.Module):
         return self.get_parameter(name).data
 
     def _tower(self, x: torch.Tensor, prefix: str, layers: int, heads: int, batch: int, seq: int,
-               cdt: torch.dtype, causal: bool) -> torch.Tensor:
+               cdt: torch.dtype, causal: bool, final=None) -> torch.Tensor:
         """ResidualAttentionBlock x layers (clip/model.py:192-219) on the fp32 residual stream
-        x [B*L, W]; every GEMM is fused with its bias / QuickGELU / residual epilogue."""
+        x [B*L, W]; every GEMM is fused with its bias / QuickGELU epilogue.  `final` = (name of the LayerNorm
+        that follows the last block, its output dtype): when given, the tower returns that LayerNorm's output."""
         width = x.shape[1]
         d = width // heads
         mode = L.MASK_CAUSAL if causal else L.MASK_NONE
         fp8 = self.fp8 and cdt == torch.bfloat16 and width % 128 == 0      # the e4m3 MFMA consumes K in steps of 128
+        # bf16 mode: the two residual adds of a block move OUT of the GEMM epilogues into the LayerNorm that follows
+        # them (bf_add_layernorm_fwd): out-proj and c_proj then run the plain-bf16 epilogue -- no fp32 residual tile
+        # to fetch before the first MFMA, half the bytes to store -- and the LayerNorm, which streams the residual
+        # anyway, adds the branch's bf16 output on the way (in-step: 139 + 43 -> ~170 us for out-proj + ln_2 at the
+        # vision tower's shape).  `final` = the LayerNorm after the last block (ln_post / ln_final), fused the same way.
+        fuse_add = (cdt == torch.bfloat16 and not fp8 and width in (256, 512, 768, 1024) and final is not None
+                    and os.environ.get("BIFOLD_ADD_LN", "1") != "0")
+        h = None
         for i in range(layers):
             b = f"{prefix}.{i}."
             if fp8:
@@ -147,9 +157,26 @@ class CLIPEncoder(nn.Module):
                 w8, ws = self._w8(b + "attn.in_proj_weight")
                 qkv = ops.gemm_fp8(h8, hs, w8, ws, bias=self._f(b + "attn.in_proj_bias"))
             else:
-                h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_1.weight"), self._f(b + "ln_1.bias"), cdt)
+                if h is None:
+                    h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_1.weight"), self._f(b + "ln_1.bias"), cdt)
                 qkv = ops.gemm(h, self._w(b + "attn.in_proj_weight", cdt), bias=self._f(b + "attn.in_proj_bias"))
+                h = None
             o, _ = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mode)
+            if fuse_add:
+                delta = ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"))
+                h, _, _, _ = ops.add_layernorm_fwd(x, delta, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
+                a = ops.gemm(h, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
+                             act=L.ACT_QUICK_GELU)
+                delta = ops.gemm(a, self._w(b + "mlp.c_proj.weight", cdt), bias=self._f(b + "mlp.c_proj.bias"))
+                if i + 1 < layers:
+                    nb = f"{prefix}.{i + 1}."
+                    h, _, _, _ = ops.add_layernorm_fwd(x, delta, self._f(nb + "ln_1.weight"), self._f(nb + "ln_1.bias"), cdt)
+                else:
+                    gname, out_dtype = final
+                    y, _, _, _ = ops.add_layernorm_fwd(x, delta, self._f(gname + ".weight"), self._f(gname + ".bias"),
+                                                       out_dtype)
+                    return y
+                continue
             ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"),
                      residual=x, out=x)
             if fp8:
@@ -157,11 +184,15 @@ class CLIPEncoder(nn.Module):
                 w8, ws = self._w8(b + "mlp.c_fc.weight")
                 a = ops.gemm_fp8(h8, hs, w8, ws, bias=self._f(b + "mlp.c_fc.bias"), act=L.ACT_QUICK_GELU)
             else:
-                h, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
-                a = ops.gemm(h, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
+                h2, _, _ = ops.layernorm_fwd(x, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
+                a = ops.gemm(h2, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
                              act=L.ACT_QUICK_GELU)
             ops.gemm(a, self._w(b + "mlp.c_proj.weight", cdt), bias=self._f(b + "mlp.c_proj.bias"),
                      residual=x, out=x)
+        if final is not None:
+            gname, out_dtype = final
+            y, _, _ = ops.layernorm_fwd(x, self._f(gname + ".weight"), self._f(gname + ".bias"), out_dtype)
+            return y
         return x
 
     @torch.no_grad()
@@ -186,11 +217,8 @@ class CLIPEncoder(nn.Module):
         x = ops.vision_assemble(patches, self._f("visual.class_embedding"),
                                 self._f("visual.positional_embedding"), self._f("visual.ln_pre.weight"),
                                 self._f("visual.ln_pre.bias"), batch, n)
-        x = self._tower(x, "visual.transformer.resblocks", self.vision_layers, self.vision_heads, batch,
-                        n + 1, cdt, causal=False)
-        y, _, _ = ops.layernorm_fwd(x, self._f("visual.ln_post.weight"), self._f("visual.ln_post.bias"),
-                                    out_dtype or cdt)
-        return y
+        return self._tower(x, "visual.transformer.resblocks", self.vision_layers, self.vision_heads, batch,
+                           n + 1, cdt, causal=False, final=("visual.ln_post", out_dtype or cdt))
 
     @torch.no_grad()
     def encode_text_with_embeddings(self, tokens: torch.Tensor, cdt: torch.dtype):
@@ -206,10 +234,8 @@ class CLIPEncoder(nn.Module):
             self._err_flag = torch.zeros(1, dtype=torch.int32, device=tokens.device)
         x = ops.embed_tokens(tokens, self._f("token_embedding.weight"), self._f("positional_embedding"),
                              self._err_flag)
-        x = self._tower(x, "transformer.resblocks", self.text_layers, self.text_heads, batch, ctx, cdt,
-                        causal=True)
-        y, _, _ = ops.layernorm_fwd(x, self._f("ln_final.weight"), self._f("ln_final.bias"), torch.float32)
-        return y
+        return self._tower(x, "transformer.resblocks", self.text_layers, self.text_heads, batch, ctx, cdt,
+                           causal=True, final=("ln_final", torch.float32))
 
     def check_token_ids(self) -> None:
         """Raise if any forward since the last call saw a token id outside the vocabulary

@@ -178,6 +178,116 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     return BF_OK;
 }
 
+// ------------------------------------------------------------------ residual add + LayerNorm
+// x_out = x + delta ; y = LN(x_out).  `delta` is the bf16 output of the branch's last GEMM (out-proj / MLP fc2, bias
+// included): with the add done HERE the GEMM runs its plain-bf16 epilogue (no 256 KB residual tile to wait for at item
+// start, half the store bytes) and this kernel, which reads the residual stream anyway, adds 2 B/element of traffic.
+// Two rows per wave like ln_fwd_rows_kernel; cols == NC * 256.
+template <typename TY, int NC>
+__global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ x_out, TY* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                          float eps) {
+    constexpr int cols = NC * 256;
+    constexpr int R = 2;
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    float4 v[R][NC];
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int row = min(row0 + r, rows - 1);
+        const float* xr = x + (size_t)row * cols;
+        const bf16_t* dr = delta + (size_t)row * cols;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float4 a = *(const float4*)(xr + (lane + i * 64) * 4);
+            const float4 d = Vec4<bf16_t>::load(dr + (lane + i * 64) * 4);
+            v[r][i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        s[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) s[r] += (v[r][i].x + v[r][i].y) + (v[r][i].z + v[r][i].w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] += __shfl_xor(s[r], o, 64);
+    }
+    float mu[R], q[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        mu[r] = s[r] / (float)cols;
+        q[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const float a = v[r][i].x - mu[r], b = v[r][i].y - mu[r], c = v[r][i].z - mu[r], d = v[r][i].w - mu[r];
+            q[r] += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) q[r] += __shfl_xor(q[r], o, 64);
+    }
+    float4 g[NC], bt[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        g[i] = *(const float4*)(gamma + (lane + i * 64) * 4);
+        bt[i] = *(const float4*)(beta + (lane + i * 64) * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (row0 + r >= rows) break;
+        const float rs = rsqrtf(q[r] / (float)cols + eps);
+        float* xo = x_out + (size_t)(row0 + r) * cols;
+        TY* yr = y + (size_t)(row0 + r) * cols;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            *(float4*)(xo + (lane + i * 64) * 4) = v[r][i];
+            float4 o;
+            o.x = (v[r][i].x - mu[r]) * rs * g[i].x + bt[i].x;
+            o.y = (v[r][i].y - mu[r]) * rs * g[i].y + bt[i].y;
+            o.z = (v[r][i].z - mu[r]) * rs * g[i].z + bt[i].z;
+            o.w = (v[r][i].w - mu[r]) * rs * g[i].w + bt[i].w;
+            Vec4<TY>::store(yr + (lane + i * 64) * 4, o);
+        }
+        if (lane == 0) {
+            if (mean) mean[row0 + r] = mu[r];
+            if (rstd) rstd[row0 + r] = rs;
+        }
+    }
+}
+
+extern "C" int bf_add_layernorm_fwd(const float* x, const void* delta_bf16, const float* gamma, const float* beta,
+                                    float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
+                                    float eps, bf_stream_t stream) {
+    BF_REQUIRE(x && delta_bf16 && gamma && beta && x_out && y, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
+    BF_REQUIRE(rows > 0 && (cols == 256 || cols == 512 || cols == 768 || cols == 1024), BF_EINVAL,
+               "bf_add_layernorm_fwd: cols must be 256, 512, 768 or 1024 (got %d)", cols);
+    BF_REQUIRE(y_dtype == BF_BF16 || y_dtype == BF_F32, BF_EINVAL, "bf_add_layernorm_fwd: bad y dtype");
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(delta_bf16) && bf_aligned16(x_out) && bf_aligned16(y) &&
+                   bf_aligned16(gamma) && bf_aligned16(beta), BF_EALIGN, "bf_add_layernorm_fwd: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(bf_cdiv(rows, 8)), block(256);
+#define ADDLN(TY, NCV) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV>), grid, block, 0, s, x, (const bf16_t*)delta_bf16,                                           gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
+#define ADDLN_NC(TY)                                                                   \
+    do {                                                                               \
+        if (cols == 256) ADDLN(TY, 1); else if (cols == 512) ADDLN(TY, 2);             \
+        else if (cols == 768) ADDLN(TY, 3); else ADDLN(TY, 4);                         \
+    } while (0)
+    if (y_dtype == BF_BF16) ADDLN_NC(bf16_t); else ADDLN_NC(float);
+#undef ADDLN_NC
+#undef ADDLN
+    BF_CHECK_LAUNCH("bf_add_layernorm_fwd");
+    return BF_OK;
+}
+
 // ------------------------------------------------------------------ LayerNorm bwd
 #define LN_BWD_ROWS_PER_WAVE 8
 extern "C" int bf_layernorm_bwd_parts(int rows) {

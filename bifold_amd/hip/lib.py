@@ -56,6 +56,8 @@ PROTOTYPES = {
     "bf_last_hip_error": (c_int, []),
     "bf_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p, c_int, c_int, c_float, c_void_p]),
+    "bf_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_int, c_int, c_float, c_void_p]),
     "bf_layernorm_bwd_parts": (c_int, [c_int]),
     "bf_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -114,6 +114,27 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
     return y, mean, rstd
 
 
+def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                      out_dtype: torch.dtype, x_out: Optional[torch.Tensor] = None, save_stats: bool = False,
+                      eps: float = 1e-5):
+    """x_out = x + delta (fp32 residual stream + the branch's bf16 output), y = LN(x_out).  `x_out=None` updates x in
+    place.  Returns (y, mean, rstd, x_out)."""
+    _dev(x, "x"); _dev(delta, "delta"); _dev(gamma, "gamma"); _dev(beta, "beta")
+    if x.dtype != torch.float32 or delta.dtype != torch.bfloat16 or x.shape != delta.shape:
+        raise TypeError("add_layernorm_fwd: x fp32 and delta bf16 of the same shape")
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    xo = x if x_out is None else x_out
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.bf_add_layernorm_fwd(_ptr(x), _ptr(delta), _ptr(gamma), _ptr(beta), _ptr(xo), _ptr(y), dtype_code(y),
+                                   _ptr(mean), _ptr(rstd), rows, cols, eps, _stream()), "bf_add_layernorm_fwd")
+    return y, mean, rstd, xo
+
+
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
                   rstd: torch.Tensor, dres: Optional[torch.Tensor], cdt: Optional[torch.dtype],
                   dgamma_out: torch.Tensor, dbeta_out: torch.Tensor,

@@ -71,6 +71,15 @@ int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
                      int y_dtype, float* mean, float* rstd, int rows, int cols, float eps,
                      bf_stream_t stream);
 
+/* Residual add fused with the NEXT LayerNorm (models/clip/model.py:217-218 + :178-184; transformer.py:62-63 +
+ * modules.py:11):  x_out = x + delta ;  y = LN(x_out).  delta = the bf16 output (bias included) of the branch's last
+ * GEMM -- out-proj or MLP fc2 -- which can then run its plain-bf16 epilogue instead of loading a fp32 residual tile
+ * and storing a fp32 one.  x_out may alias x (frozen towers update the stream in place).  cols in {256, 512, 768,
+ * 1024}; mean / rstd optional. */
+int bf_add_layernorm_fwd(const float* x, const void* delta_bf16, const float* gamma, const float* beta,
+                         float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
+                         float eps, bf_stream_t stream);
+
 /* Backward of the above fused with the residual branch:
  *   dx = (dres ? dres : 0) + dLN(dy)          fp32 [rows, cols]
  *   dx_cdt (optional, cdt_dtype) = cast(dx)   -- operand for the next dX/dW GEMMs

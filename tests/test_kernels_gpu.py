@@ -768,3 +768,26 @@ def test_gemm_gelu_savegrad_and_mul_aux(ops, L, gpu, m, n, k, cdt):
         cs = torch.empty(n, dtype=torch.float32, device=gpu)
         got2 = ops.gemm(dy.to(gpu).to(cdt), w2.to(gpu).to(cdt), b_kn=True, act=L.ACT_MUL_AUX, aux=gp, colsum_out=cs)
         assert rel_err(cs, got2.float().double().sum(0)) < 1e-3
+
+
+@pytest.mark.parametrize("rows,cols", [(197 * 3 + 1, 768), (77 * 2, 512), (9, 1024), (300, 256)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_add_layernorm_fwd(ops, gpu, rows, cols, out_dtype):
+    """x_out = x + delta (bf16 branch output), y = LN(x_out): the residual add of clip/model.py:217-218 fused into
+    the LayerNorm that follows it; in place and out of place, with statistics."""
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g) * 2 + 0.5
+    delta = (torch.randn(rows, cols, generator=g) * 0.7).bfloat16()
+    w = 1 + 0.2 * torch.randn(cols, generator=g)
+    b = 0.2 * torch.randn(cols, generator=g)
+    xs = x.double() + delta.double()
+    ref = F.layer_norm(xs, (cols,), w.double(), b.double(), 1e-5)
+    xd = x.to(gpu)
+    y, mean, rstd, xo = ops.add_layernorm_fwd(xd, delta.to(gpu), w.to(gpu), b.to(gpu), out_dtype, save_stats=True)
+    assert xo is xd and rel_err(xd, xs) < 1e-6                      # updated in place
+    assert rel_err(y.float(), ref) < (2e-6 if out_dtype == torch.float32 else 2 ** -8)
+    assert rel_err(mean, xs.mean(1)) < 1e-5
+    x2 = x.to(gpu)
+    out = torch.empty_like(x2)
+    y2, _, _, xo2 = ops.add_layernorm_fwd(x2, delta.to(gpu), w.to(gpu), b.to(gpu), out_dtype, x_out=out)
+    assert xo2 is out and torch.equal(x2.cpu(), x) and torch.equal(out, xd) and torch.equal(y2, y)
