@@ -239,3 +239,77 @@ def test_fp8_towers_accuracy_gate_on_config_a(gpu, observed):
     observed("fp8_towers_config_a", **seen)
     assert seen["fp8_heat"] < 5e-3 and seen["fp8_vision"] < 6e-2 and seen["fp8_text"] < 0.2
     assert seen["bf16_heat"] < 1e-3
+
+
+def test_vitl14_336_full_size_matches_oracle(gpu, observed):
+    """BASELINE configs[3] at full size (ViT-L/14 @336: 24 vision layers of width 1024, 577 tokens; text width 768;
+    fusion width 768 over 655 tokens; 384-pixel heatmaps), B = 2, the model's own random init handed to the oracle:
+    heatmaps of both modes against the fp32 CPU restatement.  (The reference's own config would fail on the 384 vs 336
+    target size; targets are not involved here.)"""
+    from oracle import bifold_oracle as O
+    from bifold.models import Models
+    B = 2
+    g = torch.Generator().manual_seed(7)
+    sample = {"rgb": torch.randn(B, 3, 336, 336, generator=g),
+              "instruction": O.synthetic_sample(B, torch.Generator().manual_seed(8))["instruction"]}
+    seen = {}
+    state = None
+    for dtype in ("fp32", "bf16"):
+        cfg = dict(config_a(dtype), image_size=336, text_encoder="ViT-L/14@336px", patch_size=14)
+        torch.manual_seed(11)
+        with pytest.warns(UserWarning):
+            model = Models.get_by_name(cfg, device=gpu)
+        if state is None:
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                ref = O.rgb_clip_forward(state, sample, heads=16)
+        else:
+            model.load_state_dict(state)
+        model = model.to(gpu).eval()
+        with torch.no_grad():
+            out = model({k: v.to(gpu) for k, v in sample.items()})
+        assert out["pick_heatmap"].shape == (B, 384, 384)
+        seen[dtype] = max(rel(out[k], ref[k]) for k in ("pick_heatmap", "place_heatmap"))
+        del model
+        torch.cuda.empty_cache()
+    observed("vitl14_336_full", **seen)
+    assert seen["fp32"] < 1e-3 and seen["bf16"] < 1e-3        # observed 2.1e-7 / 2.2e-4
+
+
+def test_siglip_sequential_full_width_matches_oracle(gpu, observed):
+    """BASELINE configs[2]'s model at full width (SigLIP-base/16 towers: 12 layers of 768, tanh-GELU; fusion 8 x 768
+    with 16 heads of d = 48; bimanual, 4 decoders) at 224 px with T = 2 context frames, one of them masked: a
+    656-token fusion sequence with the query-row mask, i.e. the tiled forward attention at d = 48.  B = 2, frozen
+    towers, the model's own random init handed to the oracle."""
+    from oracle import bifold_oracle as O
+    from bifold.models import Models
+    B, T, S = 2, 2, 224
+    g = torch.Generator().manual_seed(9)
+    sample = {"rgb": torch.randn(B, 3, S, S, generator=g), "rgb_context": torch.randn(B, T, 3, S, S, generator=g),
+              "instruction": torch.randint(0, 32000, (B, 64), generator=g),
+              "context_attention_mask": torch.tensor([[1, 0], [1, 1]])}
+    seen = {}
+    state = None
+    for dtype in ("fp32", "bf16"):
+        cfg = dict(name="siglip_sequential", image_size=S, is_bimanual=True, requires_graph=False, patch_size=16,
+                   automodel_name="google/siglip-base-patch16-224", dim=768, emb_dropout=0.0, lora=False, r=8, lora_alpha=32,
+                   lora_dropout=0.01, target_modules=["q_proj", "v_proj"], threshold=0.5, text_encoder=None,
+                   pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", depth=8, heads=16,
+                   mlp_ratio=4, dropout=0.0, dtype=dtype, context_length=T)
+        torch.manual_seed(13)
+        with pytest.warns(UserWarning):
+            model = Models.get_by_name(cfg, device=gpu)
+        if state is None:
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                ref = O.siglip_sequential_forward(state, sample, 12, 16, True)
+        else:
+            model.load_state_dict(state)
+        model = model.to(gpu).eval()
+        with torch.no_grad():
+            out = model({k: v.to(gpu) for k, v in sample.items()})
+        seen[dtype] = max(rel(out[k], ref[k]) for k in ref if k.endswith("_heatmap"))
+        del model
+        torch.cuda.empty_cache()
+    observed("siglip_sequential_full_width", **seen)
+    assert seen["fp32"] < 1e-3 and seen["bf16"] < 1.5e-3      # observed 2.2e-7 / 4.3e-4
