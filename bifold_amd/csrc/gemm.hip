@@ -1344,12 +1344,20 @@ static int n_cus() {
 // epilogue by splitk_reduce), so the job takes ~2.3 rounds instead of 3.
 struct P8TailPlan { int rows_main; int sub; size_t bytes; };
 static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
+    static int min_k_nt = -1, min_k_nn = -1;
+    if (min_k_nt < 0) {
+        const char* e = getenv("BIFOLD_P8_TAIL_K");        // "nt,nn" thresholds on K
+        min_k_nt = 2048; min_k_nn = 1 << 30;              // in-step A/B (round 2): NN tails at K >= 1536 / 512: +-0.1 %; NT at K >= 768: -2 %
+        if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { min_k_nt = a; min_k_nn = b; } }
+    }
     if (g->cdt != BF_BF16 || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
-        g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 || g->k < 2048 || g->colsum_out)
+        g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 ||
+        g->k < (g->b_kn ? min_k_nn : min_k_nt) || g->colsum_out)
         return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
     if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
     if (pipe_env >= 0 && pipe_env != 8) return false;
-    if (g->b_kn && pipe_env != 8) return false;            // NN stays on the 128x128 kernels by default
+    // dX = dY W (NN) runs on the persistent kernel too; its 512-wide outputs are 2.15-round shapes (550 tiles on
+    // 256 CUs), but splitting their tails measured neutral, so it is opt-in (BIFOLD_P8_TAIL_K="2048,1536")
     if (getenv("BIFOLD_P8_NO_TAIL")) return false;
     const int n_cu = n_cus();
     const long tiles_m = bf_cdiv(g->m, 256), tiles_n = bf_cdiv(g->n, 256);
