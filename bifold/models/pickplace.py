@@ -32,6 +32,48 @@ DEC_IDX = (0, 2, 4, 6, 8)
 # the fusion MLP saves gelu'(pre) for the backward (one erf evaluation in the forward epilogue, a multiply in the
 # backward's); BIFOLD_GELU_SAVEGRAD=0 keeps `pre` and evaluates gelu' in the backward (the round-1 form, for A/B)
 _SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
+# the weight-gradient GEMMs (dW = dY^T X) have no consumer before the optimiser / the gradient all-reduce: they run on a
+# side stream next to the dX chain, so that one persistent GEMM's under-filled last round is filled by the other's
+# workgroups.  0 = everything on one stream; 1 = the main stream joins the side stream at the end of every layer;
+# 2 = it joins one layer late (layer i's dW GEMMs run beside layer i-1's dX chain)
+_DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "0"))
+_dw_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _dw_stream(device) -> "torch.cuda.Stream":
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _dw_streams:
+        _dw_streams[key] = torch.cuda.Stream(device=device)
+    return _dw_streams[key]
+
+
+class _WeightGradSide:
+    """Launches `ops.gemm(dY, X, trans_a=True, b_kn=True, out=dW)` on the side stream once the main stream has produced
+    its operands.  Operands allocated on the main stream are pinned to the side stream (`record_stream`), so that the
+    caching allocator does not hand them out again before the side stream has read them."""
+
+    def __init__(self, device):
+        self.on = _DW_SIDE > 0
+        self.side = _dw_stream(device) if self.on else None
+
+    def gemm(self, dy, x, out):
+        if not self.on:
+            ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
+            return
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
+        dy.record_stream(self.side)
+        x.record_stream(self.side)
+
+    def mark(self):
+        """Event after which everything launched so far on the side stream is complete."""
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        return ev
 
 
 def head_names(is_bimanual: bool) -> List[str]:
@@ -212,29 +254,35 @@ def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row
     return x3, saved
 
 
-def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask):
-    """dx3 fp32 [M, D] (+ its cdt copy or None in fp32 mode) -> (dx, dx_c) for the layer input."""
+def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, wg=None):
+    """dx3 fp32 [M, D] (+ its cdt copy or None in fp32 mode) -> (dx, dx_c) for the layer input.
+    `wg`: the _WeightGradSide that launches the dW GEMMs (default: in line on the current stream)."""
     d = dx3.shape[1] // heads
+    if wg is None:
+        wg = _WeightGradSide.__new__(_WeightGradSide)
+        wg.on, wg.side = False, None
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
+    # (every dW GEMM is issued right after its operands' producer and BEFORE the next dX GEMM, so that on the side
+    # stream it waits for nothing it does not read)
+    wg.gemm(op3, S["a"], g(P["w2"]))
     da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True,
                       act=L.ACT_MUL_AUX if _SAVEGRAD else L.ACT_ERF_GELU_GRAD, aux=S["a_pre"],
                       colsum_out=g(P["bb1"]))          # d bias1 = column sums of da_pre, fused into the epilogue
-    ops.gemm(op3, S["a"], trans_a=True, b_kn=True, out=g(P["w2"]))
+    wg.gemm(da_pre, S["h2"], g(P["w1"]))
     dh2 = ops.gemm(da_pre, A.operand(P["w1"], cdt), b_kn=True)
-    ops.gemm(da_pre, S["h2"], trans_a=True, b_kn=True, out=g(P["w1"]))
     # the LayerNorm backward streams dx3 (in) and dx2 (out): it also emits their column sums,
     # i.e. the bias gradients of net.3 and to_out
     dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]),
                                    dres_sum_out=g(P["bb2"]), dx_sum_out=g(P["bo"]))
     op2 = dx2_c if dx2_c is not None else dx2
     # attention:  x2 = x + attn(h1 Wqkv^T) Wo^T + bo
+    wg.gemm(op2, S["o"], g(P["wo"]))
     do = ops.gemm(op2, A.operand(P["wo"], cdt), b_kn=True)
-    ops.gemm(op2, S["o"], trans_a=True, b_kn=True, out=g(P["wo"]))
     dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask)
+    wg.gemm(dqkv, S["h1"], g(P["wqkv"]))
     dh1 = ops.gemm(dqkv, A.operand(P["wqkv"], cdt), b_kn=True)
-    ops.gemm(dqkv, S["h1"], trans_a=True, b_kn=True, out=g(P["wqkv"]))
     return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
 
 
@@ -253,12 +301,31 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
     """Backward of fusion_stack_fwd: dx fp32 [B*seq, dim] w.r.t. the stack's output -> w.r.t. its input;
     every layer's parameter gradients go straight into the arena."""
     dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
+    wg = _WeightGradSide(dx.device)
+    main = torch.cuda.current_stream() if wg.on else None
+    late = None                                            # (layer, event) whose join is still owed (_DW_SIDE = 2)
     for i in reversed(range(fus.depth)):
         dx, dx_c = fusion_layer_bwd(dx, dx_c, layers[i], fus.layer_params(i), A, cdt, batch, seq, fus.heads,
-                                    mask_mode, row_mask)
+                                    mask_mode, row_mask, wg)
         layers[i] = None                                   # free this layer's activations early
+        done = [i]
+        if wg.on:
+            ev = wg.mark()
+            if _DW_SIDE >= 2:
+                done = []
+                if late is not None:
+                    main.wait_event(late[1])
+                    done = [late[0]]
+                late = (i, ev)
+            else:
+                main.wait_event(ev)
         if on_layer_done is not None:
-            on_layer_done(i)
+            for j in done:
+                on_layer_done(j)
+    if late is not None:
+        main.wait_event(late[1])
+        if on_layer_done is not None:
+            on_layer_done(late[0])
     return dx
 
 

@@ -546,6 +546,23 @@ __device__ __forceinline__ void dma_pieces32(__amdgpu_buffer_rsrc_t rsrc, char* 
     }
 }
 
+// Byte offset (into the operand's buffer) that lane `lane` fetches for 1 KB piece `pc` of a BK = 32 tile whose first
+// row / k is (r0, k0): the per-lane part of dma_pieces32's address, computed ONCE per work item by the persistent kernel.
+// Advancing K by one stage then adds a wave-uniform number of bytes (32 k * 2 B, or 32 k-rows * ld * 2 B).
+template <bool KS>
+__device__ __forceinline__ unsigned dma_piece_offset32(int ld, int r0, int k0, int pc, int lane) {
+    if (!KS) {
+        const int row = pc * 16 + (lane >> 2);
+        const int ch = (lane & 3) ^ kc32_swz(row);
+        return (unsigned)(((size_t)(r0 + row) * ld + k0 + ch * 8) * 2);
+    } else {
+        const int sub = pc >> 3;
+        const int krow = (pc & 7) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ ks_swz(krow);
+        return (unsigned)(((size_t)(k0 + krow) * ld + r0 + sub * 128 + ch * 8) * 2);
+    }
+}
+
 template <bool KS>
 __device__ __forceinline__ bf16x8 bf16_frag32(const char* lds, int rbase, int lane) {
     if (!KS) {
@@ -667,6 +684,12 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
 //     BEFORE the epilogue of the current one, so the epilogue's loads / stores overlap the
 //     DMA flight, and the stores drain under the next item's main loop.
 #define P8_STAGE 32768
+#ifndef P8_RDPIPE
+#define P8_RDPIPE 0
+#endif
+#ifndef P8_ABL_PIECES      // timing ablation only: DMA pieces per wave and operand stage (2 = the real kernel)
+#define P8_ABL_PIECES 2
+#endif
 
 struct P8Item { int m0, n0, kbeg, nk, z, rev; };
 
@@ -708,7 +731,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const int xl = bid % NX;
     const int per_xcd = max(1, G / NX);
     const int rev_rounds = skew_cycles & 1;            // `skew_cycles` carries mode bits now (the start-skew experiment is retired)
-    const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
+    [[maybe_unused]] const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
     // ranges proportional to the workgroups a lane has (G need not be a multiple of 8): with exactly one
     // item per workgroup no lane may hold more items than workgroups
     auto lane_start = [&](int x) { return (int)((long long)n_items * (x * (G / NX) + min(x, G % NX)) / G); };
@@ -737,13 +760,45 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             for (int i = 0; i < 9; ++i) tk[i] = 0u;
         }
     };
+    auto issue_a_any = [&](const P8Item& w, int s) {       // any item: full address computation (item boundaries)
+        const int ks = w.rev ? w.nk - 1 - s : s;
+        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + ks * 32, wave * 2, P8_ABL_PIECES, lane);
+    };
+    auto issue_b_any = [&](const P8Item& w, int s) {
+        const int ks = w.rev ? w.nk - 1 - s : s;
+        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, d.ldb, w.n0, w.kbeg + ks * 32, wave * 2, P8_ABL_PIECES, lane);
+    };
+
+    // In-loop DMA issue.  A piece's address used to be recomputed per piece and stage -- a 32-bit multiply (quarter
+    // rate), two more VALU operations and SGPR-spill reloads in front of every buffer_load -- and VALU work of the
+    // loading wave group comes out of the MFMA issue slots of its SIMD partner: the timing ablation without the DMA
+    // issue ran 1 205 cycles per stage against 1 450 with it.  The per-lane part is now computed once per work item
+    // (4 registers), a stage adds one wave-uniform term: one v_add per piece.  The K advance stays in the VGPR offset
+    // (not the SGPR offset), so the descriptor's range check still zero-fills rows past the end of a matrix.
+    unsigned va[2], vb[2];
+    auto set_bases = [&](const P8Item& it) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            va[p] = dma_piece_offset32<A_KS>(d.lda, it.m0, it.kbeg, wave * 2 + p, lane);
+            vb[p] = dma_piece_offset32<B_KS>(d.ldb, it.n0, it.kbeg, wave * 2 + p, lane);
+        }
+        asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(vb[0]), "+v"(vb[1]));   // live in registers, not rematerialised
+    };
     auto issue_a = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
-        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + ks * 32, wave * 2, 2, lane);
+        const unsigned delta = A_KS ? (unsigned)ks * 64u * (unsigned)d.lda : (unsigned)ks * 64u;
+        char* dst = smem + (s & 3) * P8_STAGE + wave * 2048;
+#pragma unroll
+        for (int p = 0; p < P8_ABL_PIECES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + p * 1024), 16, va[p] + delta, 0, 0, 0);
     };
     auto issue_b = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
-        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, d.ldb, w.n0, w.kbeg + ks * 32, wave * 2, 2, lane);
+        const unsigned delta = B_KS ? (unsigned)ks * 64u * (unsigned)d.ldb : (unsigned)ks * 64u;
+        char* dst = smem + (s & 3) * P8_STAGE + 16384 + wave * 2048;
+#pragma unroll
+        for (int p = 0; p < P8_ABL_PIECES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + p * 1024), 16, vb[p] + delta, 0, 0, 0);
     };
 
     P8Item w;
@@ -754,10 +809,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);   // wave-uniform: keeps the item in SGPRs
     unsigned nxt = 0;
     if (!decode(first, w)) { finish(); return; }
-    issue_a(w, 0); issue_b(w, 0);
-    if (w.nk > 1) { issue_a(w, 1); issue_b(w, 1); }
+    issue_a_any(w, 0); issue_b_any(w, 0);
+    if (w.nk > 1) { issue_a_any(w, 1); issue_b_any(w, 1); }
 
     while (true) {
+        set_bases(w);
         f32x4 acc[4][8];          // acc[j][i]: n tile j (16 cols), m tile i (16 rows); swapped roles
         // A plain residual (C = A B^T + bias + R, the transformer's skip connections) is loaded
         // INTO the accumulators here: 32 loads in flight at once, their latency under the wait for
@@ -796,6 +852,73 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // slot, (s - 1) & 3, was last read two barrier intervals earlier by the lagging group.  The ring stays 4 slots
         // (the LDS is full); what changes is that three stages instead of two are in flight, i.e. ~50 % more time for
         // a load that misses the L2 to arrive before a wave waits for it.
+#if P8_RDPIPE
+        // Read-pipelined main loop, TWO barrier intervals per stage.
+        // Measured on the four-interval loop (two phases of 16 MFMAs per stage, fragment reads + DMA issue in a load
+        // block in front of each): 1 420-1 530 cycles per stage against 1 024 of MFMA issue.  Moving the fragment reads
+        // into the MFMA blocks bought 5 %; doubling the MFMAs per interval (timing ablation) showed why: every barrier
+        // interval costs its MFMAs + ~86 cycles (barrier, priority switch, first-operand wait), whatever else is in it.
+        // So a stage is ONE MFMA block of 32 per wave group and one load block:
+        //   load block   the 4 DMA pieces (A + B) of stage s+3
+        //   MFMA block   32 MFMAs of stage s, i-major (4 per A fragment); A fragment i of stage s+1 is read in place
+        //                as soon as its four MFMAs are issued, the B fragments of stage s+1 go to a second set
+        //                (a ds_read between MFMAs costs the issuing wave ~3 cycles); the block ends with the counted
+        //                wait for this wave's pieces of stage s+2.
+        // The groups run one barrier apart, so one group's MFMA block faces the other's load block.  Stage s+1 is read
+        // during block s by both groups: every wave's pieces of it are retired by the wait at the end of block s-1,
+        // i.e. before the barrier that either group passes in front of block s (the rule: read a staged buffer one
+        // phase after the wait that retires it, one more with staggered groups).  Prefetch distance 3: stage s+3 goes
+        // into slot (s-1)&3, whose fragments were read during block s-2 -- a full interval before the load block.
+        if (w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }     // after the barrier: slots 2-3 were epilogue staging
+        bf16x8 bfr[4], aa[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(smem + 16384, wn * 64 + j * 16, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) aa[i] = bf16_frag32<A_KS>(smem, wm * 128 + i * 16, lane);
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one interval behind
+        const int nk = w.nk;
+#ifdef P8_PROBE
+        const unsigned long long pc0 = clock64(), pw0 = wall_clock64();
+#endif
+        const int draw_stage = nk > 8 ? nk - 8 : 0;
+        unsigned lane_zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+        constexpr int RA = A_KS ? 2 : 1, RB = B_KS ? 2 : 1;   // ds_read instructions per fragment
+        for (int s = 0; s < nk; ++s) {
+            const char* la1 = smem + ((s + 1) & 3) * P8_STAGE;
+            const char* lb1 = la1 + 16384;
+            if (s == draw_stage && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
+            if (s + 3 < nk) { issue_a(w, s + 3); issue_b(w, s + 3); }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+            bf16x8 bn[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], aa[i], acc[j][i], 0, 0, 0);
+                // (past the last stage these read a slot nobody consumes: harmless, and the block stays branch-free)
+                aa[i] = bf16_frag32<A_KS>(la1, wm * 128 + i * 16, lane);
+                if (i < 4) bn[i] = bf16_frag32<B_KS>(lb1, wn * 64 + i * 16, lane);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);           // 4 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, RA + RB, 0);     // the A fragment they freed + a B fragment
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (s + 3 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // stage s+2 landed (s+3 in flight)
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
+        }
+#else
         if (deep && w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }
         if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind
         const int nk = w.nk;
@@ -839,7 +962,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             if (!deep) {
                 if (more) {
                     issue_b(w, s + 2);
+#if P8_ABL_PIECES == 2
                     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // stage s+1 landed (s+2 in flight)
+#elif P8_ABL_PIECES == 1
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#else
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
@@ -861,6 +990,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
         }
+#endif
         if (wm == 0) __builtin_amdgcn_s_barrier();          // realign the groups
 #ifdef P8_PROBE
         const unsigned long long pc1 = clock64(), pw1 = wall_clock64();
@@ -874,8 +1004,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         nxt = __builtin_amdgcn_readfirstlane(bcast[0]);
         const bool has_next = decode(nxt, nx);
         if (has_next) {
-            issue_a(nx, 0); issue_b(nx, 0);
-            if (nx.nk > 1) { issue_a(nx, 1); issue_b(nx, 1); }
+            issue_a_any(nx, 0); issue_b_any(nx, 0);
+            if (nx.nk > 1) { issue_a_any(nx, 1); issue_b_any(nx, 1); }
         }
 #ifdef P8_PROBE
         const unsigned long long pc2 = clock64();
