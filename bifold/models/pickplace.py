@@ -36,7 +36,7 @@ _SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
 # side stream next to the dX chain, so that one persistent GEMM's under-filled last round is filled by the other's
 # workgroups.  0 = everything on one stream; 1 = the main stream joins the side stream at the end of every layer;
 # 2 = it joins one layer late (layer i's dW GEMMs run beside layer i-1's dX chain)
-_DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "0"))
+_DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "1"))
 _dw_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
