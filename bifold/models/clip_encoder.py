@@ -134,7 +134,7 @@ class CLIPEncoder(nn.Module):
         return self.get_parameter(name).data
 
     def _tower(self, x: torch.Tensor, prefix: str, layers: int, heads: int, batch: int, seq: int,
-               cdt: torch.dtype, causal: bool, final=None) -> torch.Tensor:
+               cdt: torch.dtype, causal: bool, final=None, h0: Optional[torch.Tensor] = None) -> torch.Tensor:
         """ResidualAttentionBlock x layers (clip/model.py:192-219) on the fp32 residual stream
         x [B*L, W]; every GEMM is fused with its bias / QuickGELU epilogue.  `final` = (name of the LayerNorm
         that follows the last block, its output dtype): when given, the tower returns that LayerNorm's output."""
@@ -149,7 +149,7 @@ class CLIPEncoder(nn.Module):
         # vision tower's shape).  `final` = the LayerNorm after the last block (ln_post / ln_final), fused the same way.
         fuse_add = (cdt == torch.bfloat16 and not fp8 and width in (256, 512, 768, 1024) and final is not None
                     and os.environ.get("BIFOLD_ADD_LN", "1") != "0")
-        h = None
+        h = None if fp8 else h0           # ln_1 of block 0, when the caller has already computed it (K1)
         for i in range(layers):
             b = f"{prefix}.{i}."
             if fp8:
@@ -213,12 +213,25 @@ class CLIPEncoder(nn.Module):
                 pad[:, :wconv.shape[1]] = wconv
                 self._wconv_pad, self._wconv_pad_key = pad, key
             wconv = self._wconv_pad
-        patches = ops.gemm(cols, wconv, out_dtype=torch.float32)
-        x = ops.vision_assemble(patches, self._f("visual.class_embedding"),
-                                self._f("visual.positional_embedding"), self._f("visual.ln_pre.weight"),
-                                self._f("visual.ln_pre.bias"), batch, n)
+        pos = self._f("visual.positional_embedding")
+        fp8 = self.fp8 and cdt == torch.bfloat16 and vw % 128 == 0
+        h0 = None
+        if not fp8 and os.environ.get("BIFOLD_K1", "1") != "0":
+            # K1: the patch-embed GEMM's epilogue adds pos[1 + p] and writes row b*n + p of the
+            # [B*n] problem to row b*(n+1) + 1 + p of the token stream; one pass then sets the class rows, applies
+            # ln_pre in place and emits block 0's ln_1 -- no [B*n, W] patch buffer, no separate assembly / ln_1 pass
+            x = torch.empty(batch * (n + 1), vw, dtype=torch.float32, device=img.device)
+            ops.gemm(cols, wconv, residual=pos[1:], resid_mod=n, out=x, rows_in=n, rows_out=n + 1, row_off=1)
+            b0 = "visual.transformer.resblocks.0."
+            h0 = ops.vision_lnpre_ln1(x, self._f("visual.class_embedding"), pos[0], self._f("visual.ln_pre.weight"),
+                                      self._f("visual.ln_pre.bias"), self._f(b0 + "ln_1.weight"),
+                                      self._f(b0 + "ln_1.bias"), cdt, batch, n)
+        else:
+            patches = ops.gemm(cols, wconv, out_dtype=torch.float32)
+            x = ops.vision_assemble(patches, self._f("visual.class_embedding"), pos, self._f("visual.ln_pre.weight"),
+                                    self._f("visual.ln_pre.bias"), batch, n)
         return self._tower(x, "visual.transformer.resblocks", self.vision_layers, self.vision_heads, batch,
-                           n + 1, cdt, causal=False, final=("visual.ln_post", out_dtype or cdt))
+                           n + 1, cdt, causal=False, final=("visual.ln_post", out_dtype or cdt), h0=h0)
 
     @torch.no_grad()
     def encode_text_with_embeddings(self, tokens: torch.Tensor, cdt: torch.dtype):

@@ -737,6 +737,117 @@ extern "C" int bf_vision_assemble(const float* patches, const float* cls, const 
     return BF_OK;
 }
 
+// ------------------------------------------------------------------ K1: class token + ln_pre + first ln_1
+// The patch-embed GEMM's epilogue has already written  patches + pos[1 + p]  into rows b*(n+1) + 1 + p of x
+// (row remap + modulo-indexed residual, the machinery of K8).  This pass finishes the token assembly in place:
+// row b*(n+1) becomes cls + pos[0], every row goes through ln_pre (fp32, written back: it is the residual stream),
+// and the SAME registers go through block 0's ln_1, whose output (the first QKV GEMM's operand) is written in the
+// compute dtype -- one read of the stream instead of three (assembly, ln_pre, ln_1; models/clip/model.py:300-309,
+// :206-207).
+template <typename TY>
+__global__ __launch_bounds__(256) void vision_lnpre_ln1_kernel(
+    float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos0,
+    const float* __restrict__ g0, const float* __restrict__ b0, const float* __restrict__ g1,
+    const float* __restrict__ b1, TY* __restrict__ h, int rows, int seq, int width, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bool is_cls = (row % seq) == 0;
+    float* xr = x + (size_t)row * width;
+    const int nvec = width >> 2;
+    float4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            if (is_cls) {
+                const float4 a = *(const float4*)(cls + c * 4);
+                const float4 p = *(const float4*)(pos0 + c * 4);
+                v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+            } else {
+                v[i] = *(const float4*)(xr + c * 4);
+            }
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    // ln_pre
+    float mu = wave_sum(s) / (float)width;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float a = v[i].x - mu, bb = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+    }
+    float rs = rsqrtf(wave_sum(q) / (float)width + eps);
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float4 g = *(const float4*)(g0 + c * 4);
+            const float4 be = *(const float4*)(b0 + c * 4);
+            v[i].x = (v[i].x - mu) * rs * g.x + be.x;
+            v[i].y = (v[i].y - mu) * rs * g.y + be.y;
+            v[i].z = (v[i].z - mu) * rs * g.z + be.z;
+            v[i].w = (v[i].w - mu) * rs * g.w + be.w;
+            *(float4*)(xr + c * 4) = v[i];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    // ln_1 of the first block on the values just written
+    mu = wave_sum(s) / (float)width;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float a = v[i].x - mu, bb = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + bb * bb) + (cc * cc + d * d);
+        }
+    }
+    rs = rsqrtf(wave_sum(q) / (float)width + eps);
+    TY* hr = h + (size_t)row * width;
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nvec) {
+            const float4 g = *(const float4*)(g1 + c * 4);
+            const float4 be = *(const float4*)(b1 + c * 4);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + be.x;
+            o.y = (v[i].y - mu) * rs * g.y + be.y;
+            o.z = (v[i].z - mu) * rs * g.z + be.z;
+            o.w = (v[i].w - mu) * rs * g.w + be.w;
+            Vec4<TY>::store(hr + c * 4, o);
+        }
+    }
+}
+
+extern "C" int bf_vision_lnpre_ln1(float* x, const float* cls, const float* pos0, const float* g0, const float* b0,
+                                   const float* g1, const float* b1, void* h, int h_dtype, int batch, int n_patch,
+                                   int width, float eps, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && n_patch > 0 && (width & 3) == 0 && width <= LN_MAXC * 256, BF_EINVAL,
+               "bf_vision_lnpre_ln1: bad shape (n_patch=%d width=%d)", n_patch, width);
+    BF_REQUIRE(h_dtype == BF_F32 || h_dtype == BF_BF16, BF_EINVAL, "bf_vision_lnpre_ln1: bad output dtype %d", h_dtype);
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(cls) && bf_aligned16(pos0) && bf_aligned16(h) && bf_aligned16(g0) &&
+               bf_aligned16(b0) && bf_aligned16(g1) && bf_aligned16(b1), BF_EALIGN, "bf_vision_lnpre_ln1: unaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = batch * (n_patch + 1);
+    dim3 grid(bf_cdiv((long)rows, 4)), block(256);
+    if (h_dtype == BF_BF16)
+        hipLaunchKernelGGL(vision_lnpre_ln1_kernel<bf16_t>, grid, block, 0, s, x, cls, pos0, g0, b0, g1, b1, (bf16_t*)h,
+                           rows, n_patch + 1, width, eps);
+    else
+        hipLaunchKernelGGL(vision_lnpre_ln1_kernel<float>, grid, block, 0, s, x, cls, pos0, g0, b0, g1, b1, (float*)h,
+                           rows, n_patch + 1, width, eps);
+    BF_CHECK_LAUNCH("bf_vision_lnpre_ln1");
+    return BF_OK;
+}
+
 // ------------------------------------------------------------------ token embedding
 __global__ __launch_bounds__(256) void embed_tokens_kernel(
     const int32_t* __restrict__ tokens, const float* __restrict__ table,

@@ -388,6 +388,18 @@ def vision_assemble(patches, cls, pos, gamma, beta, batch: int, n_patch: int, ep
     return x
 
 
+def vision_lnpre_ln1(x, cls, pos0, g0, b0, g1, b1, out_dtype: torch.dtype, batch: int, n_patch: int, eps: float = 1e-5):
+    """K1: x fp32 [B*(n+1), W] holds patches + pos in its patch rows (written by the patch-embed GEMM's epilogue);
+    finishes it in place (class rows, ln_pre) and returns ln_1(x) in out_dtype."""
+    width = x.shape[-1]
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[0] != batch * (n_patch + 1):
+        raise RuntimeError("vision_lnpre_ln1: x must be a contiguous float32 [B*(n+1), W] tensor")
+    h = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    check(lib.bf_vision_lnpre_ln1(_ptr(x), _ptr(cls), _ptr(pos0), _ptr(g0), _ptr(b0), _ptr(g1), _ptr(b1), _ptr(h),
+                                  dtype_code(h), batch, n_patch, width, eps, _stream()), "bf_vision_lnpre_ln1")
+    return h
+
+
 def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, err_flag: torch.Tensor):
     _dev(tokens, "instruction")
     if tokens.dtype != torch.int32:

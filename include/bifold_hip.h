@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 4
+#define BF_ABI_VERSION 5
 
 enum { BF_F32 = 0, BF_BF16 = 1 };
 
@@ -255,6 +255,14 @@ int bf_patchify_ld(const float* img, void* cols, int cdt, int batch, int size, i
 int bf_vision_assemble(const float* patches, const float* cls, const float* pos,
                        const float* gamma, const float* beta, float* x, int batch, int n_patch,
                        int width, float eps, bf_stream_t stream);
+
+/* K1 of SURVEY.md 2.2 (models/clip/model.py:297-309 + the first block's ln_1, :206-207): the patch-embed GEMM
+ * (bf_gemm with rows_in = n, rows_out = n + 1, row_off = 1, residual = pos[1:], resid_mod = n) has written
+ * patches + pos[1 + p] into rows b*(n+1) + 1 + p of x.  In place: row b*(n+1) = cls + pos0; x = ln_pre(x) (g0, b0);
+ * h = ln_1(x) (g1, b1) in h_dtype.  One pass over the stream instead of assembly, ln_pre and ln_1. */
+int bf_vision_lnpre_ln1(float* x, const float* cls, const float* pos0, const float* g0, const float* b0,
+                        const float* g1, const float* b1, void* h, int h_dtype, int batch, int n_patch,
+                        int width, float eps, bf_stream_t stream);
 
 /* Token-embedding gather + positional add (models/clip/model.py:448-450):
  * x[b,t,:] = table[tokens[b,t],:] + pos[t,:]; ids out of [0, vocab) are an error

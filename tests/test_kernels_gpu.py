@@ -399,6 +399,36 @@ def test_patchify_patch14_padded(ops, gpu, cdt):
     assert rel_err(c[:, :588] @ w.flatten(1).t(), ref) < (1e-5 if cdt == torch.float32 else 1e-2)
 
 
+@pytest.mark.parametrize("cdt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("B,n,W,K", [(3, 16, 128, 192), (300, 196, 768, 768)])
+def test_patch_embed_epilogue_and_lnpre_ln1(ops, gpu, observed, cdt, tol, B, n, W, K):
+    """K1: the patch-embed GEMM writes patches + pos into the token stream through its row-remap epilogue, and
+    bf_vision_lnpre_ln1 finishes it (class rows, ln_pre in place, ln_1 of block 0) -- against the formulas of
+    clip/model.py:297-309 in fp32.  The large case dispatches the persistent GEMM (M = 58 800)."""
+    g = torch.Generator().manual_seed(31)
+    cols, w = torch.randn(B * n, K, generator=g), torch.randn(W, K, generator=g) * K ** -0.5
+    cls, pos = torch.randn(W, generator=g), torch.randn(n + 1, W, generator=g)
+    g0, b0 = 1 + 0.1 * torch.randn(W, generator=g), 0.1 * torch.randn(W, generator=g)
+    g1, b1 = 1 + 0.1 * torch.randn(W, generator=g), 0.1 * torch.randn(W, generator=g)
+    cc, wc = cols.to(cdt), w.to(cdt)
+    patches = cc.double() @ wc.double().t()
+    x_ref = torch.cat([cls.double().expand(B, 1, W), patches.reshape(B, n, W)], 1) + pos.double()
+    x_ref = F.layer_norm(x_ref, (W,), g0.double(), b0.double(), 1e-5)
+    h_ref = F.layer_norm(x_ref, (W,), g1.double(), b1.double(), 1e-5)
+    posg = pos.to(gpu)
+    x = torch.full((B * (n + 1), W), float("nan"), dtype=torch.float32, device=gpu)   # every row must be written
+    ops.gemm(cc.to(gpu), wc.to(gpu), residual=posg[1:], resid_mod=n, out=x, rows_in=n, rows_out=n + 1, row_off=1)
+    h = ops.vision_lnpre_ln1(x, cls.to(gpu), posg[0], g0.to(gpu), b0.to(gpu), g1.to(gpu), b1.to(gpu), cdt, B, n)
+    ex = rel_err(x.reshape(B, n + 1, W), x_ref.float())
+    eh = rel_err(h.float().reshape(B, n + 1, W), h_ref.float())
+    observed(f"k1_patch_embed_lnpre_ln1_{str(cdt).split('.')[-1]}_B{B}", x_rel=ex, h_rel=eh)
+    assert ex < 3e-6 and eh < tol
+    # and the same values as the unfused path (separate GEMM, bf_vision_assemble, LayerNorm)
+    p2 = ops.gemm(cc.to(gpu), wc.to(gpu), out_dtype=torch.float32)
+    x2 = ops.vision_assemble(p2, cls.to(gpu), posg, g0.to(gpu), b0.to(gpu), B, n)
+    assert rel_err(x, x2) < 2e-6
+
+
 def test_vision_assemble_embed_fusion(ops, gpu):
     g = torch.Generator().manual_seed(29)
     B, n, W = 3, 16, 128
