@@ -684,9 +684,6 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
 //     BEFORE the epilogue of the current one, so the epilogue's loads / stores overlap the
 //     DMA flight, and the stores drain under the next item's main loop.
 #define P8_STAGE 32768
-#ifndef P8_RDPIPE
-#define P8_RDPIPE 0
-#endif
 #ifndef P8_ABL_PIECES      // timing ablation only: DMA pieces per wave and operand stage (2 = the real kernel)
 #define P8_ABL_PIECES 2
 #endif
@@ -731,7 +728,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const int xl = bid % NX;
     const int per_xcd = max(1, G / NX);
     const int rev_rounds = skew_cycles & 1;            // `skew_cycles` carries mode bits now (the start-skew experiment is retired)
-    [[maybe_unused]] const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
+    const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
     // ranges proportional to the workgroups a lane has (G need not be a multiple of 8): with exactly one
     // item per workgroup no lane may hold more items than workgroups
     auto lane_start = [&](int x) { return (int)((long long)n_items * (x * (G / NX) + min(x, G % NX)) / G); };
@@ -852,73 +849,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // slot, (s - 1) & 3, was last read two barrier intervals earlier by the lagging group.  The ring stays 4 slots
         // (the LDS is full); what changes is that three stages instead of two are in flight, i.e. ~50 % more time for
         // a load that misses the L2 to arrive before a wave waits for it.
-#if P8_RDPIPE
-        // Read-pipelined main loop, TWO barrier intervals per stage.
-        // Measured on the four-interval loop (two phases of 16 MFMAs per stage, fragment reads + DMA issue in a load
-        // block in front of each): 1 420-1 530 cycles per stage against 1 024 of MFMA issue.  Moving the fragment reads
-        // into the MFMA blocks bought 5 %; doubling the MFMAs per interval (timing ablation) showed why: every barrier
-        // interval costs its MFMAs + ~86 cycles (barrier, priority switch, first-operand wait), whatever else is in it.
-        // So a stage is ONE MFMA block of 32 per wave group and one load block:
-        //   load block   the 4 DMA pieces (A + B) of stage s+3
-        //   MFMA block   32 MFMAs of stage s, i-major (4 per A fragment); A fragment i of stage s+1 is read in place
-        //                as soon as its four MFMAs are issued, the B fragments of stage s+1 go to a second set
-        //                (a ds_read between MFMAs costs the issuing wave ~3 cycles); the block ends with the counted
-        //                wait for this wave's pieces of stage s+2.
-        // The groups run one barrier apart, so one group's MFMA block faces the other's load block.  Stage s+1 is read
-        // during block s by both groups: every wave's pieces of it are retired by the wait at the end of block s-1,
-        // i.e. before the barrier that either group passes in front of block s (the rule: read a staged buffer one
-        // phase after the wait that retires it, one more with staggered groups).  Prefetch distance 3: stage s+3 goes
-        // into slot (s-1)&3, whose fragments were read during block s-2 -- a full interval before the load block.
-        if (w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }     // after the barrier: slots 2-3 were epilogue staging
-        bf16x8 bfr[4], aa[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(smem + 16384, wn * 64 + j * 16, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) aa[i] = bf16_frag32<A_KS>(smem, wm * 128 + i * 16, lane);
-        if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one interval behind
-        const int nk = w.nk;
-#ifdef P8_PROBE
-        const unsigned long long pc0 = clock64(), pw0 = wall_clock64();
-#endif
-        const int draw_stage = nk > 8 ? nk - 8 : 0;
-        unsigned lane_zero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
-        constexpr int RA = A_KS ? 2 : 1, RB = B_KS ? 2 : 1;   // ds_read instructions per fragment
-        for (int s = 0; s < nk; ++s) {
-            const char* la1 = smem + ((s + 1) & 3) * P8_STAGE;
-            const char* lb1 = la1 + 16384;
-            if (s == draw_stage && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
-            if (s + 3 < nk) { issue_a(w, s + 3); issue_b(w, s + 3); }
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_setprio(1);
-            bf16x8 bn[4];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], aa[i], acc[j][i], 0, 0, 0);
-                // (past the last stage these read a slot nobody consumes: harmless, and the block stays branch-free)
-                aa[i] = bf16_frag32<A_KS>(la1, wm * 128 + i * 16, lane);
-                if (i < 4) bn[i] = bf16_frag32<B_KS>(lb1, wn * 64 + i * 16, lane);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);           // 4 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, RA + RB, 0);     // the A fragment they freed + a B fragment
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, RA, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            if (s + 3 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // stage s+2 landed (s+3 in flight)
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bn[j];
-        }
-#else
         if (deep && w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }
         if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind
         const int nk = w.nk;
@@ -990,7 +920,6 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
         }
-#endif
         if (wm == 0) __builtin_amdgcn_s_barrier();          // realign the groups
 #ifdef P8_PROBE
         const unsigned long long pc1 = clock64(), pw1 = wall_clock64();
