@@ -888,8 +888,23 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
 //       no per-step barrier; 46 KB of LDS at L = 275, d = 32 (two to three workgroups per CU).
 // S and dP are computed twice (14 instead of 10 MFMAs per block, exp twice); both kernels read
 // their operands once more from HBM.  Same arithmetic per element as the single kernel.
+#ifdef ATTN_PROBE   // in-kernel phase stamps of the split backward (tools/attn_probe.py); not part of the product build
+#define ATTN_PROBE_WGS 16384
+__device__ unsigned long long attn_probe[ATTN_PROBE_WGS * 8];
+extern "C" int bf_debug_attn_probe(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(attn_probe), sizeof(attn_probe)) == hipSuccess ? 0 : 1;
+}
+#define ATTN_STAMP(slot)                                                                                   \
+    do {                                                                                                   \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                          \
+        if (threadIdx.x == 0 && wg_ < ATTN_PROBE_WGS) attn_probe[wg_ * 8 + (slot)] = wall_clock64();       \
+    } while (0)
+#else
+#define ATTN_STAMP(slot) do {} while (0)
+#endif
+
 template <int D, int MASK>
-__global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
+__global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
     float* __restrict__ delta_ws, int L, int H, float scale, int Lp) {
@@ -909,10 +924,17 @@ __global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
     const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     // blockIdx.y: the 32-query blocks of a (batch, head) are spread over several workgroups of
     // ~5 waves, each with its own K / V image: 9-wave workgroups left 7 of a CU's 16 wave slots idle
-    const int q0 = (blockIdx.y * (blockDim.x >> 6) + wave) * 32;
-    const int qi = q0 + r;
-    const bool q_live = qi < L;
+    // Query blocks of this wave: blockIdx.y spreads the 32-query blocks of a (batch, head) over several workgroups
+    // (each with its own K / V image); inside a workgroup wave slot s walks blocks s, s + waves, s + 2 waves, ...  With
+    // four-wave workgroups every SIMD holds one wave of each workgroup (five-wave workgroups put two waves on the
+    // SIMD the dispatcher starts with: measured 1.5 workgroups alive per CU and that SIMD doing twice the work), and
+    // the slot is rotated by the workgroup id so the wave with the extra block is not always on the same SIMD.
+    const int wpb = blockDim.x >> 6;
+    const int slot = (wave + (int)(blockIdx.x % (unsigned)wpb)) % wpb;
+    const int blk_stride = gridDim.y * wpb;
+    const int nblk = (L + 31) >> 5;
     const int nthreads = blockDim.x;
+    ATTN_STAMP(0);
 
     for (int idx = threadIdx.x; idx < Lp * (DP / 8); idx += nthreads) {
         const int j = idx / (DP / 8), c = idx - j * (DP / 8);
@@ -925,6 +947,13 @@ __global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
         if (c < D / 8) *(uint4*)(v_lds + j * VROW + c * 16) = vv;
     }
 
+    ATTN_STAMP(1);
+    __syncthreads();
+    ATTN_STAMP(2);
+    for (int blk = blockIdx.y * wpb + slot; blk < nblk; blk += blk_stride) {
+    const int q0 = blk * 32;
+    const int qi = q0 + r;
+    const bool q_live = qi < L;
     bf16x8 qf[KS], dof[KS];
     float delta = 0.f, lse_q = 1e30f;
     bool row_masked = false;
@@ -961,8 +990,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqacc[db][e] = 0.f;
     const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
-    __syncthreads();
-    if (q0 >= L) return;                          // spare wave of the last workgroup
 
     for (int j0 = 0; j0 < key_end; j0 += 32) {
         f32x16 sacc, pacc;
@@ -1027,10 +1054,16 @@ __global__ __launch_bounds__(1024) void attn_bwd_q_kernel(
                 }
             }
     }
+    }   // blocks of this wave
+    ATTN_STAMP(3);
+#ifdef ATTN_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ATTN_STAMP(4);
+#endif
 }
 
 template <int D, int MASK>
-__global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
+__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
     int L, int H, float scale) {
@@ -1047,7 +1080,9 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
     int* msk_s = (int*)(del_s + Lp);
 
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6);   // this wave's 32-key block
+    const int wpb = blockDim.x >> 6;                   // key blocks of this wave: see attn_bwd_q_kernel
+    const int slot = ((int)(threadIdx.x >> 6) + (int)(blockIdx.x % (unsigned)wpb)) % wpb;
+    const int blk_stride = gridDim.y * wpb;
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
@@ -1075,6 +1110,8 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
         }
         lse_s[i] = ls; del_s[i] = dl; msk_s[i] = mk;
     }
+    __syncthreads();
+    for (int w = blockIdx.y * wpb + slot; w < nw; w += blk_stride) {
     const int key = w * 32 + r;
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -1094,8 +1131,6 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
         for (int e = 0; e < 16; ++e) { dkacc[db][e] = 0.f; dvacc[db][e] = 0.f; }
     const float inv_len = 1.0f / (float)L;
     const float lane_on = key < L ? 1.0f : 0.0f;
-    __syncthreads();
-    if (w >= nw) return;                          // spare wave of the last workgroup
 
     for (int t = 0; t < nw; ++t) {
         int qb = w + t;                           // start at the diagonal: spreads the LDS rows touched per step
@@ -1171,6 +1206,7 @@ __global__ __launch_bounds__(1024) void attn_bwd_kv_kernel(
                 }
             }
     }
+    }   // key blocks of this wave
 }
 
 // =====================================================================================
@@ -1751,9 +1787,15 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
             // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);
             // with larger images (d = 64: two workgroups per CU either way) one workgroup per (batch, head)
-            const size_t lds_max = lds_q > lds_kv ? lds_q : lds_kv;
-            const int n_split = (lds_max * 3 <= 160 * 1024 && nq32 > 5) ? bf_cdiv(nq32, 5) : 1;
-            const int wpb = bf_cdiv(nq32, n_split);
+            // Workgroup shape of the split pair: `wpb` waves, `n_split` workgroups per (batch, head); a wave walks the
+            // 32-row blocks slot, slot + n_split * wpb, ...  Default: ONE four-wave workgroup per (batch, head) -- one wave
+            // per SIMD, three workgroups per CU by LDS, one K / V (Q / dO) image load per (batch, head).  (Five-wave
+            // workgroups, one block per wave, measured 1.5 workgroups alive per CU: tools/attn_probe.py.)
+            static int wpb_env = -1, split_env2 = -1;
+            if (wpb_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_WPB"); wpb_env = e ? atoi(e) : 4; if (wpb_env < 1) wpb_env = 1; }
+            if (split_env2 < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SPLIT"); split_env2 = e ? atoi(e) : 1; if (split_env2 < 1) split_env2 = 1; }
+            const int wpb = (wpb_env < nq32 ? wpb_env : nq32) < 8 ? (wpb_env < nq32 ? wpb_env : nq32) : 8;   // launch bound: 512 threads
+            const int n_split = bf_cdiv(nq32, wpb) < split_env2 ? bf_cdiv(nq32, wpb) : split_env2;
             dim3 grid(batch * heads, n_split), block(wpb * 64);
 #define BWD_SPLIT2(DD, MM)                                                                          \
     do {                                                                                            \
