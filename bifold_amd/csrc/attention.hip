@@ -1776,13 +1776,16 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         static int split_env = -1;
         if (split_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SINGLE"); split_env = (e && atoi(e)) ? 0 : 1; }
         // (short causal sequences stay on the single kernel: 72 vs 116 us at L = 77)
-        static int res_wide_env = -1;     // d = 48 / 64 resident kernels spill at their 128-register cap: A/B switch
-        if (res_wide_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_RESIDENT_WIDE"); res_wide_env = e ? atoi(e) : 0; }
+        static int res_wide_env = -2;     // which head widths take the resident pair: A/B switch
+        if (res_wide_env == -2) { const char* e = getenv("BIFOLD_ATTN_BWD_RESIDENT_WIDE"); res_wide_env = e ? atoi(e) : 0; }   // 1: also d = 64; -1: d = 32 only
         static int stream_min_env = -1;
         if (stream_min_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_MIN_Q32"); stream_min_env = e ? atoi(e) : 1; }
         static int stream_d32_env = -1;
         if (stream_d32_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_D32"); stream_d32_env = e ? atoi(e) : 0; }
-        const bool wide_ok = (head_dim == 32 && !stream_d32_env) || res_wide_env || nq32 < stream_min_env;
+        // d = 48 joins d = 32 on the resident pair since its kernels are bounded at 512 threads (148-174 registers, no
+        // scratch: 80.8 vs 92.9 us at 262 x 48); d = 64 stays on the streamed pair (300 x 64: 99 vs 134 us resident)
+        const bool wide_ok = (head_dim == 32 && !stream_d32_env) || (head_dim == 48 && res_wide_env != -1) || res_wide_env > 0 ||
+                             nq32 < stream_min_env;
         if (cdt == BF_BF16 && split_env && wide_ok && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
             !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
             // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);
