@@ -432,7 +432,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 // are loaded ONCE, row-major, and every wave then walks all key tiles without a barrier;
 // V^T fragments come from the row-major image by ds_read_b64_tr_b16 (the recipe of the
 // backward kernel's dO^T / Q^T operands).  Same arithmetic, same order as the tiled kernel.
-template <int D, int MASK>
+template <int D, int MASK, int NKB>
 __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
     const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp, int nt_loads) {
@@ -500,10 +500,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
     __syncthreads();
 
-    for (int j0 = 0; j0 < key_end; j0 += KT) {
-        f32x16 sacc[2];
+    // NKB 32-key halves per step: 2 (a 64-key tile) or 1 -- a sequence whose last 64-key tile would be more than half
+    // empty (197 = 6 x 32 + 5, 275 = 8 x 32 + 19) walks 32-key steps: 12 % / 10 % fewer exponentials, the kernel's bound
+    for (int j0 = 0; j0 < key_end; j0 += NKB * 32) {
+        f32x16 sacc[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
@@ -512,16 +514,16 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
             }
         }
-        const bool edge = (j0 + KT > L) || (mask_mode == BF_MASK_CAUSAL && j0 + KT - 1 > q0);
+        const bool edge = (j0 + NKB * 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + NKB * 32 - 1 > q0);
         if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sacc[kb][e] = -100000.0f / scale;
         }
         if (edge) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         }
         float tmax = -INFINITY;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         f32x2 psum2 = {0.f, 0.f};
         const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
                 f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
@@ -562,7 +564,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
             for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
 
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 bf16x8 pf;
@@ -1655,16 +1657,25 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             static int nt_env = -1;
             if (nt_env < 0) { const char* e = getenv("BIFOLD_ATTN_NT"); nt_env = e ? atoi(e) : 1; }
             const int nt_loads = nt_env & 1;
+            static int kt_env = -1;      // 0: 64-key tiles always; 1: 32-key steps always; default: by the last tile's fill
+            if (kt_env < 0) { const char* e = getenv("BIFOLD_ATTN_FWD_KT32"); kt_env = e ? atoi(e) : 2; }
+            const bool half_steps = kt_env == 1 || (kt_env == 2 && mask_mode != BF_MASK_CAUSAL && (seq % 64) != 0 && (seq % 64) <= 32);
 #define FWD_RES2(DD, MM)                                                                           \
     do {                                                                                          \
         static size_t lds_set = 0;                                                                \
         if (res_lds > lds_set) {                                                                  \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM>,                   \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 2>,                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 1>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
             lds_set = res_lds;                                                                    \
         }                                                                                         \
-        hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
-                           (bf16_t*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);         \
+        if (half_steps)                                                                           \
+            hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 1>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
+                               (bf16_t*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
+        else                                                                                      \
+            hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 2>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
+                               (bf16_t*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
     } while (0)
 #define FWD_RES(DD)                                                                               \
     do {                                                                                          \
