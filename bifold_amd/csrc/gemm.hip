@@ -1209,6 +1209,286 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
 }
 
 // =====================================================================================
+//   e4m3 sibling of the persistent kernel (frozen towers, BASELINE configs[4]): "p8f"
+// =====================================================================================
+// Same workgroup geometry, ticket draw, LDS byte images and staggered wave groups as gemm_bf16_p8_kernel, with one-byte
+// operands: a 32 KB stage (256 rows x 64 B of A | B) holds K = 64, and v_mfma_scale_f32_16x16x128_f8f6f4 (twice the
+// bf16 rate, block scales fixed at 2^0) consumes K = 128, i.e. a PAIR of stages: lanes 0-31 of a fragment read the even
+// stage's slot, lanes 32-63 the odd stage's.  The four ring slots therefore hold two stage pairs: pair d is consumed
+// from slots {2d, 2d+1} & 3 while pair d+1 lands in the other two.
+//   load block a : B fragments (4) + A fragments of rows 0-63 (4) of pair d, then ALL 8 DMA pieces of pair d+1
+//                  (their slots were last read in load block b of pair d-1, whose reads are retired -- lgkmcnt(0) --
+//                  before that block's barrier: the one-phase restaging rule);
+//   MFMA block a : 16 MFMAs of K = 128 (32 cycles each);
+//   load block b : A fragments of rows 64-127, lgkmcnt(0), then vmcnt(0): every wave's pieces of pair d+1 have landed
+//                  before the barrier both wave groups pass in front of pair d+1's first read;
+//   MFMA block b : 16 MFMAs.
+// Per K the loop moves half the bytes of the bf16 kernel through HBM / L2 / LDS and issues a quarter of its MFMA
+// cycles, which is what counts at the socket's power cap.  Epilogue: the plain-bf16 one (scales
+// sa[m] * sb[n] on the fp32 accumulator, bias, activation, LDS turn-around, 16-byte row-segment stores).
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+struct Fp8P8Epi {
+    bf16_t* c; const float* sa; const float* sb; const float* bias;
+    int m, n, ldc, act, store_policy;
+};
+
+__device__ __forceinline__ unsigned dma_piece_offset_fp8(int ld, int r0, int k0, int pc, int lane) {
+    const int row = pc * 16 + (lane >> 2);                 // 16 rows x 64 B per 1 KB piece, as dma_pieces32<false>
+    const int ch = (lane & 3) ^ kc32_swz(row);
+    return (unsigned)((size_t)(r0 + row) * ld + k0 + ch * 16);
+}
+
+// 16 rows x K = 128: lane l holds row (l & 15) and the 32 bytes of k-block (l >> 4): k-blocks 0-1 live in the even
+// stage's 64-byte row, 2-3 in the odd stage's
+__device__ __forceinline__ i32x8_t fp8_frag_pair(const char* even, const char* odd, int rbase, int lane) {
+    const int row = rbase + (lane & 15);
+    const int kb = lane >> 4;
+    const char* base = ((kb & 2) ? odd : even) + row * 64;
+    const int c0 = (kb & 1) * 2;
+    const uint4 lo = *(const uint4*)(base + (((c0) ^ kc32_swz(row)) << 4));
+    const uint4 hi = *(const uint4*)(base + (((c0 + 1) ^ kc32_swz(row)) << 4));
+    i32x8_t r;
+    r[0] = (int)lo.x; r[1] = (int)lo.y; r[2] = (int)lo.z; r[3] = (int)lo.w;
+    r[4] = (int)hi.x; r[5] = (int)hi.y; r[6] = (int)hi.z; r[7] = (int)hi.w;
+    return r;
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_fp8_p8_kernel(
+    const uint8_t* __restrict__ A, const uint8_t* __restrict__ B, GemmDims d, Fp8P8Epi ep,
+    unsigned a_bytes, unsigned b_bytes, int n_items, int rev_rounds, unsigned* __restrict__ tk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB) + 16 B
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int G = gridDim.x, bid = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    const int NX = G < 8 ? G : 8;
+    const int xl = bid % NX;
+    const int per_xcd = max(1, G / NX);
+    auto lane_start = [&](int x) { return (int)((long long)n_items * (x * (G / NX) + min(x, G % NX)) / G); };
+    const int x_base = lane_start(xl);
+    const int x_cnt = lane_start(xl + 1) - x_base;
+    volatile unsigned* bcast = (volatile unsigned*)(smem + 4 * P8_STAGE);
+    const int npairs = d.k >> 7;                          // K = 128 per stage pair
+    auto decode = [&](unsigned ticket, P8Item& w) -> bool {
+        if (ticket >= (unsigned)x_cnt) return false;
+        int tm, tn;
+        tile_coords(x_base + (int)ticket, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+        w.m0 = tm * 256; w.n0 = tn * 256; w.kbeg = 0; w.nk = npairs; w.z = 0;
+        w.rev = rev_rounds ? (int)((ticket / (unsigned)per_xcd) & 1u) : 0;
+        return true;
+    };
+    auto finish = [&]() {
+        if (threadIdx.x == 0 && atomicAdd(tk + 8, 1u) == (unsigned)G - 1u) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) tk[i] = 0u;
+        }
+    };
+    unsigned va[2], vb[2];
+    auto set_bases = [&](const P8Item& it) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            va[p] = dma_piece_offset_fp8(d.lda, it.m0, 0, wave * 2 + p, lane);
+            vb[p] = dma_piece_offset_fp8(d.ldb, it.n0, 0, wave * 2 + p, lane);
+        }
+        asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(vb[0]), "+v"(vb[1]));
+    };
+    // pair `pr` of item `w`: its even / odd stages go to slots (2 pr) & 3 and (2 pr + 1) & 3
+    auto issue_pair = [&](const P8Item& w, int pr, const unsigned* pa, const unsigned* pb) {
+        const int kp = w.rev ? w.nk - 1 - pr : pr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const unsigned delta = (unsigned)(kp * 128 + h * 64);
+            char* dst = smem + ((2 * pr + h) & 3) * P8_STAGE + wave * 2048;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + p * 1024), 16, pa[p] + delta, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + 16384 + p * 1024), 16, pb[p] + delta, 0, 0, 0);
+            }
+        }
+    };
+
+    P8Item w;
+    [[maybe_unused]] int round = 0;
+    unsigned pend = 0;
+    if (threadIdx.x == 0) bcast[0] = atomicAdd(tk + xl, 1u);
+    __syncthreads();
+    const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);
+    if (!decode(first, w)) { finish(); return; }
+    set_bases(w);
+    issue_pair(w, 0, va, vb);
+    const int unit = 0x7F7F7F7F;                          // e8m0 2^0 in every byte: no block scaling
+
+    while (true) {
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef P8_PROBE
+        const unsigned long long pcw = clock64();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pair 0 (and the previous item's stores)
+        __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+        if (bid == 0 && threadIdx.x == 0 && round == 2) p8_probe[6] = clock64() - pcw;
+#endif
+        if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one barrier behind
+        const int nk = w.nk;
+#ifdef P8_PROBE
+        const unsigned long long pc0 = clock64(), pw0 = wall_clock64();
+#endif
+        const int draw_pair = nk > 3 ? nk - 3 : 0;
+        unsigned lane_zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+        for (int pr = 0; pr < nk; ++pr) {
+            const char* ev = smem + ((2 * pr) & 3) * P8_STAGE;
+            const char* od = smem + ((2 * pr + 1) & 3) * P8_STAGE;
+            // ---------------- load block a
+            i32x8_t bfr[4], af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = fp8_frag_pair(ev + 16384, od + 16384, wn * 64 + j * 16, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = fp8_frag_pair(ev, od, wm * 128 + i * 16, lane);
+            if (pr + 1 < nk) issue_pair(w, pr + 1, va, vb);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[j][i], 0, 0, 0, unit, 0, unit);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---------------- load block b
+            i32x8_t ag[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ag[i] = fp8_frag_pair(ev, od, wm * 128 + 64 + i * 16, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this pair's slots are free once the barrier is passed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // pair pr + 1 has landed
+            // the next item is drawn here, right behind the wait: the atomic has a whole pair to return before the next one
+            if (pr == draw_pair && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][4 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], ag[i], acc[j][4 + i], 0, 0, 0, unit, 0, unit);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (wm == 0) __builtin_amdgcn_s_barrier();          // realign the groups
+#ifdef P8_PROBE
+        const unsigned long long pc1 = clock64(), pw1 = wall_clock64();
+        ++round;
+#endif
+
+        // next item's first pair goes out before this item's epilogue -- into slots 0-1; the epilogue stages through
+        // slots 2-3 (an odd number of pairs ends in slots 0-1... so the LAST pair's slots are never the staging area's:
+        // with nk even the last pair sat in slots 2-3 and every wave has passed the barrier behind its last read)
+        P8Item nx;
+        if (threadIdx.x == 0) bcast[0] = pend;
+        __builtin_amdgcn_s_barrier();
+        const unsigned nxt = __builtin_amdgcn_readfirstlane(bcast[0]);
+        const bool has_next = decode(nxt, nx);
+        unsigned na[2], nb[2];
+        if (has_next) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                na[p] = dma_piece_offset_fp8(d.lda, nx.m0, 0, wave * 2 + p, lane);
+                nb[p] = dma_piece_offset_fp8(d.ldb, nx.n0, 0, wave * 2 + p, lane);
+            }
+            issue_pair(nx, 0, na, nb);
+        }
+
+        // epilogue: scales, bias, activation in the MFMA layout; bf16 turn-around through this wave's 8 KB of slots 2-3
+        char* stg = smem + 2 * P8_STAGE + wave * 8192;
+        // this wave's 8 x 16 token scales: requested in one batch, ahead of everything that uses them (one dependent
+        // global load per 16 rows inside the store loop cost 2 k cycles each; holding them through the main loop
+        // instead made the loop itself 50 % slower)
+        float sa8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int mrow = w.m0 + wm * 128 + i * 16 + (lane & 15);
+            sa8[i] = mrow < ep.m ? ep.sa[mrow] : 0.f;
+        }
+        // channel scales first, in place (their registers are dead before the bias ones are live: the epilogue with both
+        // sets held next to the 128 accumulators spilled 35 registers and took 29 k cycles per tile instead of 9 k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = w.n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            const float4 sj = n < ep.n ? *(const float4*)(ep.sb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[j][i][0] *= sj.x; acc[j][i][1] *= sj.y; acc[j][i][2] *= sj.z; acc[j][i][3] *= sj.w;
+            }
+        }
+        float4 bj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = w.n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        using AM = ActMath<bf16_t>;
+        auto half_tile = [&](auto h_) {
+            constexpr int H = decltype(h_)::value;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int lr = ii * 16 + (lane & 15);
+                const float sa = sa8[H * 4 + ii];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 a = acc[j][H * 4 + ii];
+                    float v[4] = {fmaf(a[0], sa, bj[j].x), fmaf(a[1], sa, bj[j].y), fmaf(a[2], sa, bj[j].z),
+                                  fmaf(a[3], sa, bj[j].w)};
+                    if (ep.act == BF_ACT_QUICK_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = AM::quick(v[e]);
+                    } else if (ep.act == BF_ACT_TANH_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = AM::tanh_gelu(v[e]);
+                    } else if (ep.act == BF_ACT_ERF_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
+                    }
+                    bf16x4 pk;
+                    pk[0] = (bf16_t)v[0]; pk[1] = (bf16_t)v[1]; pk[2] = (bf16_t)v[2]; pk[3] = (bf16_t)v[3];
+                    const int cc4 = j * 4 + (lane >> 4);
+                    *(bf16x4*)(stg + lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3)) = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int lr = t * 8 + (lane >> 3), c16 = lane & 7;
+                const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
+                const int m = w.m0 + wm * 128 + H * 64 + lr;
+                const int n = w.n0 + wn * 64 + c16 * 8;
+                if (m < ep.m && n < ep.n) store16(ep.c + (size_t)m * ep.ldc + n, q, ep.store_policy & 1);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        half_tile(std::integral_constant<int, 0>{});
+        half_tile(std::integral_constant<int, 1>{});
+#ifdef P8_PROBE
+        if (bid == 0 && threadIdx.x == 0 && round == 1) {
+            p8_probe[0] = pc1 - pc0; p8_probe[1] = pw1 - pw0; p8_probe[2] = nk;
+            p8_probe[3] = clock64() - pc1; p8_probe[4] = wall_clock64() - pw1; p8_probe[5] = 0;
+        }
+#endif
+        if (!has_next) break;
+        w = nx;
+        va[0] = na[0]; va[1] = na[1]; vb[0] = nb[0]; vb[1] = nb[1];
+    }
+    finish();
+}
+
+// =====================================================================================
 //                                   exact fp32 MFMA kernel
 // =====================================================================================
 #define F32_LD 132  // [16][128+4] k-major operand tiles
@@ -1469,6 +1749,39 @@ static unsigned* p8_ticket_set(hipStream_t s) {
     }
     const unsigned set = next[slot]++ % P8_TK_RING;
     return base + ((size_t)slot * P8_TK_RING + set) * 16;
+}
+
+// Launcher of the persistent e4m3 kernel for bf_gemm_fp8 (gemm_fp8.hip): returns BF_OK when it took the call,
+// 1 when the shape is not its (the caller then runs its 128 x 128 kernel).
+int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const float* sb, void* c, int c_dtype,
+                       const float* bias, int act, int m, int n, int k, int lda, int ldb, int ldc, bf_stream_t stream) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("BIFOLD_FP8_P8"); on = e ? atoi(e) : 1; }
+    const int n_cu = n_cus();
+    const long tiles = (long)bf_cdiv(m, 256) * bf_cdiv(n, 256);
+    if (!on || c_dtype != BF_BF16 || m < 16384 || tiles < n_cu / 2 || (k % 128) != 0 || (n % 8) != 0 || (ldc % 8) != 0 ||
+        tiles >= (1L << 30))
+        return 1;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* tk8 = p8_ticket_set(s);
+    if (!tk8) return 1;
+    static int p8_group = -1, rev_env = -1, pol = -1;
+    if (p8_group < 0) { const char* e = getenv("BIFOLD_P8_GROUP_M"); p8_group = e ? atoi(e) : 4; if (p8_group < 1) p8_group = 1; }
+    if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
+    if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 1; }
+    GemmDims d{m, n, k, lda, ldb, bf_cdiv(m, 256), bf_cdiv(n, 256), k, p8_group};
+    Fp8P8Epi ep{(bf16_t*)c, sa, sb, bias, m, n, ldc, act, pol};
+    const size_t a_ext = (size_t)(m - 1) * lda + k, b_ext = (size_t)(n - 1) * ldb + k;
+    static bool lds_ok = false;
+    if (!lds_ok) {
+        (void)hipFuncSetAttribute((const void*)gemm_fp8_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE + 16);
+        lds_ok = true;
+    }
+    const unsigned g8 = (unsigned)(n_cu & ~7);
+    hipLaunchKernelGGL(gemm_fp8_p8_kernel, dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, (const uint8_t*)a8, (const uint8_t*)b8, d,
+                       ep, (unsigned)a_ext, (unsigned)b_ext, (int)tiles, rev_env, tk8);
+    BF_CHECK_LAUNCH("bf_gemm_fp8");
+    return BF_OK;
 }
 
 extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {

@@ -19,6 +19,9 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr8;
 
 #define FP8_MAX 448.0f
 
+int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const float* sb, void* c, int c_dtype,
+                       const float* bias, int act, int m, int n, int k, int lda, int ldb, int ldc, bf_stream_t stream);
+
 namespace {
 
 __device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d) {
@@ -275,6 +278,10 @@ extern "C" int bf_gemm_fp8(const void* a_fp8, const float* a_scale, const void* 
                    (!bias || bf_aligned16(bias)), BF_EALIGN, "bf_gemm_fp8: unaligned pointer");
     const size_t a_ext = (size_t)(m - 1) * lda + k, b_ext = (size_t)(n - 1) * ldb + k;
     BF_REQUIRE(a_ext < (1ull << 32) && b_ext < (1ull << 32), BF_EINVAL, "bf_gemm_fp8: operand larger than 4 GiB");
+    {   // large-M problems: the persistent 256 x 256 kernel (gemm.hip)
+        const int rc = bf_gemm_fp8_p8_try(a_fp8, a_scale, b_fp8, b_scale, c, c_dtype, bias, act, m, n, k, lda, ldb, ldc, stream);
+        if (rc <= 0) return rc;
+    }
     Fp8Dims d{m, n, k, lda, ldb, bf_cdiv(m, 128), bf_cdiv(n, 128)};
     Fp8Epi ep{c, a_scale, b_scale, bias, ldc, act, c_dtype == BF_F32};
     const long nblk = (long)d.tiles_m * d.tiles_n;

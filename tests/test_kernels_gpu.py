@@ -728,6 +728,34 @@ def test_fp8_gemm_is_exact_on_integer_operands(ops, gpu):
     assert rel_err(c2, want) < 1e-6
 
 
+@pytest.mark.parametrize("k", [128, 384, 768, 1024])
+def test_fp8_persistent_gemm_is_exact_on_integer_operands(ops, L, gpu, k):
+    """The persistent 256 x 256 e4m3 kernel (M >= 16 384 and at least one tile per two CUs): integer operands are exact in
+    e4m3 and in the fp32 accumulator, the bf16 output holds integers up to 256 -- so every element must equal the integer
+    product bit for bit: fragment layout across the stage PAIR a K = 128 MFMA reads, ring hand-over between pairs (1, 3, 6,
+    8 pairs), ticket order, ragged M / N tails.  Then scales, bias and activation against fp64."""
+    g = torch.Generator().manual_seed(11 + k)
+    m, n = 256 * 70 - 56, 1024 - 24                    # 70 x 4 tiles, ragged last row / column tile
+    a = torch.randint(-1, 2, (m, k), generator=g).float()
+    b = torch.randint(-1, 2, (n, k), generator=g).float()
+    a[:, 5] = 0.0                                      # keep |sums| small: bf16 holds integers up to 256 exactly
+    a[3::7, 9] = 2.0
+    b[2::5, 9] = 2.0                                   # asymmetric structure along m, n and k
+    ref = a.double() @ b.double().t()
+    assert ref.abs().max() < 256
+    one_m, one_n = torch.ones(m, device=gpu), torch.ones(n, device=gpu)
+    a8, b8 = _e4m3_bytes(a).to(gpu), _e4m3_bytes(b).to(gpu)
+    c = ops.gemm_fp8(a8, one_m, b8, one_n)
+    assert c.dtype == torch.bfloat16 and torch.equal(c.double().cpu(), ref)
+    L.lib.bf_gemm_set_variant(-1)
+    sa = (torch.rand(m, generator=g) + 0.5).to(gpu)
+    sb = (torch.rand(n, generator=g) + 0.5).to(gpu)
+    bias = torch.randn(n, generator=g).to(gpu)
+    c2 = ops.gemm_fp8(a8, sa, b8, sb, bias=bias, act=L.ACT_QUICK_GELU)
+    z = ref * sa.double().cpu()[:, None] * sb.double().cpu()[None, :] + bias.double().cpu()
+    assert rel_err(c2.float(), z * torch.sigmoid(1.702 * z)) < 2 ** -7
+
+
 def test_fp8_quantisers_match_torch_e4m3(ops, gpu):
     g = torch.Generator().manual_seed(4)
     w = torch.randn(300, 768, generator=g) * torch.logspace(-2, 1, 300).view(-1, 1)        # rows of very different size
@@ -748,7 +776,8 @@ def test_fp8_quantisers_match_torch_e4m3(ops, gpu):
     assert ((deq - ref).abs() <= 0.0626 * ref.abs() + ys.cpu()[:, None] * 2 ** -9 + 1e-5).all()
 
 
-@pytest.mark.parametrize("m,n,k,act", [(50432 // 16, 2304, 768, 0), (1000, 3072, 768, 1), (333, 1536, 512, 0)])
+@pytest.mark.parametrize("m,n,k,act", [(50432 // 16, 2304, 768, 0), (1000, 3072, 768, 1), (333, 1536, 512, 0),
+                                       (197 * 96, 2304, 768, 0), (77 * 256, 2048, 512, 1)])      # the last two: persistent kernel
 def test_fp8_gemm_matches_dequantised_product(ops, L, gpu, m, n, k, act):
     """Against fp64 on the DEQUANTISED operands (what is left is accumulation order and the bf16 output rounding)."""
     g = torch.Generator().manual_seed(m + n)
