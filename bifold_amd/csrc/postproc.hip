@@ -134,6 +134,40 @@ __global__ __launch_bounds__(PP_THREADS) void gaussian_targets_kernel(const floa
         s_cy[tid] = rint((double)points[((size_t)map * max_points + tid) * 2 + 1]);
     }
     __syncthreads();
+    if (n > 1 && strategy == BF_TARGETS_FIT) {
+        // scipy.stats.multivariate_normal(mean(points), cov(points, ddof = 1)).pdf on the pixel grid (processor.py:427-436):
+        // the UNROUNDED points, an unnormalised density (no division by the maximum).  exp(-1/2 d^T S^-1 d) / (2 pi sqrt|S|)
+        // in fp64; scipy's eigen-decomposition form differs from the closed 2 x 2 inverse in the last fp64 ulp only.
+        // numpy semantics of the reference's two calls: the density's centre is np.mean of the fp32 points -- an fp32
+        // sequential sum / n -- while np.cov promotes to fp64 and centres with its own fp64 mean
+        float fx = 0.0f, fy = 0.0f;
+        double ax = 0.0, ay = 0.0;
+        for (int p = 0; p < n; ++p) {
+            const float px = points[((size_t)map * max_points + p) * 2 + 0], py = points[((size_t)map * max_points + p) * 2 + 1];
+            fx = __fadd_rn(fx, px); fy = __fadd_rn(fy, py);
+            ax += (double)px; ay += (double)py;
+        }
+        const double mx = (double)__fdiv_rn(fx, (float)n), my = (double)__fdiv_rn(fy, (float)n);
+        ax /= (double)n; ay /= (double)n;
+        double sxx = 0.0, sxy = 0.0, syy = 0.0;
+        for (int p = 0; p < n; ++p) {
+            const double dx = (double)points[((size_t)map * max_points + p) * 2 + 0] - ax;
+            const double dy = (double)points[((size_t)map * max_points + p) * 2 + 1] - ay;
+            sxx += dx * dx; sxy += dx * dy; syy += dy * dy;
+        }
+        sxx /= (double)(n - 1); sxy /= (double)(n - 1); syy /= (double)(n - 1);
+        const double det = sxx * syy - sxy * sxy;
+        // a singular covariance (two points, collinear points) makes scipy raise: NaN here, so it is seen
+        const double inv_det = det > 0.0 ? 1.0 / det : nan("");
+        const double ixx = syy * inv_det, ixy = -sxy * inv_det, iyy = sxx * inv_det;
+        const double norm = 1.0 / (2.0 * M_PI * sqrt(det));
+        for (int i = tid; i < pixels; i += PP_THREADS) {
+            const int r = i / size, c = i - r * size;
+            const double dx = (double)c - mx, dy = (double)r - my;
+            out[i] = (float)(exp(-0.5 * (dx * dx * ixx + 2.0 * dx * dy * ixy + dy * dy * iyy)) * norm);
+        }
+        return;
+    }
     if (n == 1 || strategy == BF_TARGETS_FIRST) {
         const double cx = s_cx[0], cy = s_cy[0];
         for (int i = tid; i < pixels; i += PP_THREADS) {
@@ -232,8 +266,8 @@ extern "C" int bf_gaussian_targets(const float* points, const int32_t* counts, f
     BF_REQUIRE(max_points >= 1 && max_points <= BF_MAX_TARGET_POINTS, BF_EINVAL,
                "bf_gaussian_targets: max_points must be in [1, %d] (got %d)", BF_MAX_TARGET_POINTS, max_points);
     BF_REQUIRE(sigma > 0.0, BF_EINVAL, "bf_gaussian_targets: sigma must be positive");
-    BF_REQUIRE(strategy == BF_TARGETS_FIRST || strategy == BF_TARGETS_GMM, BF_EINVAL,
-               "bf_gaussian_targets: strategy %d is not built (first=0, gmm=1; `fit` is not)", strategy);
+    BF_REQUIRE(strategy == BF_TARGETS_FIRST || strategy == BF_TARGETS_GMM || strategy == BF_TARGETS_FIT, BF_EINVAL,
+               "bf_gaussian_targets: unknown strategy %d (first=0, gmm=1, fit=2)", strategy);
     if (n_maps == 0) return BF_OK;
     hipLaunchKernelGGL(gaussian_targets_kernel, dim3(n_maps), dim3(PP_THREADS), 0, (hipStream_t)stream, points,
                        (const int*)counts, heat, max_points, size, sigma, strategy);

@@ -18,7 +18,7 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TANH_GELU_GRAD = 0, 1, 2, 3, 4, 5
 ACT_ERF_GELU_SAVEGRAD, ACT_MUL_AUX = 6, 7
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
-TARGETS_FIRST, TARGETS_GMM, MAX_TARGET_POINTS = 0, 1, 16
+TARGETS_FIRST, TARGETS_GMM, TARGETS_FIT, MAX_TARGET_POINTS = 0, 1, 2, 16
 ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -579,10 +579,9 @@ def gaussian_targets(points: torch.Tensor, counts: Optional[torch.Tensor], size:
     """points fp32 [n, P, 2] (x, y) pixels, counts int32 [n] (None = all P valid) -> fp32 [n, S, S]."""
     if points.dim() != 3 or points.shape[2] != 2 or points.dtype != torch.float32:
         raise RuntimeError("points must be fp32 [n_maps, max_points, 2]")
-    codes = {"first": L.TARGETS_FIRST, "gmm": L.TARGETS_GMM}
+    codes = {"first": L.TARGETS_FIRST, "gmm": L.TARGETS_GMM, "fit": L.TARGETS_FIT}
     if strategy not in codes:
-        raise ValueError(f"Strategy {strategy} not recognized" if strategy != "fit"
-                         else "Strategy fit (scipy multivariate_normal) is not built on the HIP path")
+        raise ValueError(f"Strategy {strategy} not recognized")
     if counts is not None and (counts.dtype != torch.int32 or counts.numel() != points.shape[0]):
         raise RuntimeError("counts must be int32 [n_maps]")
     points = points.contiguous()

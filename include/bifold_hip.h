@@ -414,11 +414,12 @@ int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t cou
  *   pixels, counts int32 [n_maps] valid points per map (NULL = all max_points); count 0
  *   gives the all-zero map (:409-410), count 1 or strategy FIRST the peak-1 Gaussian at
  *   the rounded first point (:413-417), strategy GMM the max-normalised sum (:418-426).
- *   fp64 arithmetic like the reference's numpy, stored as fp32.  The `fit` strategy
- *   (scipy multivariate_normal) is not built.
+ *   strategy FIT the density of the bivariate normal fitted to the UNROUNDED points (mean, ddof = 1 covariance;
+ *   scipy.stats.multivariate_normal.pdf, :427-436; not normalised; a singular covariance -- fewer than three
+ *   non-collinear points -- gives NaN where scipy raises).  fp64 arithmetic like the reference's numpy, stored as fp32.
  * ---------------------------------------------------------------------- */
 #define BF_MAX_TARGET_POINTS 16
-enum { BF_TARGETS_FIRST = 0, BF_TARGETS_GMM = 1 };
+enum { BF_TARGETS_FIRST = 0, BF_TARGETS_GMM = 1, BF_TARGETS_FIT = 2 };
 /* bf_preprocess_rgb: camera frames raw uint8 [B, S, S, 3] (+ optional 0/1 mask fp32 [B, S, S]) -> network
  *   input fp32 [B, 3, S, S]: mask fill with 77 (bifold/data/processor.py:255-258), scale to [0, 1] and
  *   per-channel normalisation (:87-95; mean3 / std3 are HOST pointers to the 3 values of

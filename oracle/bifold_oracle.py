@@ -593,7 +593,8 @@ def select_action(output, mask, is_bimanual, threshold=0.01, constrain_pick_mask
 def make_gaussmap(points, size: int, sigma: float = 5.0, strategy: str = "gmm"):
     """Target heatmap of one head (bifold/data/processor.py:405-439).  points: None (all-zero
     map) or fp32 [P,2] (x, y) pixels; one point, or strategy `first`: peak-1 Gaussian at the
-    rounded (half-to-even) first point; `gmm`: sum of normalised Gaussians / its maximum.
+    rounded (half-to-even) first point; `gmm`: sum of normalised Gaussians / its maximum; `fit`: the
+    density of a bivariate normal fitted to the (unrounded) points.
     fp64 arithmetic, fp32 result."""
     grid = np.arange(size)
     x, y = np.meshgrid(grid, grid)
@@ -609,8 +610,22 @@ def make_gaussmap(points, size: int, sigma: float = 5.0, strategy: str = "gmm"):
             d = (x - np.float64(cx)) ** 2 + (y - np.float64(cy)) ** 2
             g += np.exp(-d / (2 * sigma ** 2)) / ((2 * np.pi) * sigma ** 2)
         g /= g.max()
+    elif strategy == "fit":
+        # scipy.stats.multivariate_normal(mean, cov).pdf restated in closed form (processor.py:427-436): mean and the
+        # ddof = 1 covariance of the UNROUNDED points, density not normalised; a singular covariance raises in scipy
+        # numpy semantics of the reference's two calls: np.mean of the fp32 points is an fp32 (sequential) sum / n,
+        # np.cov promotes to fp64 and centres with ITS OWN fp64 mean
+        mean = np.mean(points, axis=0).astype(np.float64)
+        cov = np.cov(points, rowvar=False)
+        det = cov[0, 0] * cov[1, 1] - cov[0, 1] * cov[1, 0]
+        if not det > 0:
+            raise np.linalg.LinAlgError("singular covariance: the `fit` strategy needs three non-collinear points")
+        inv = np.array([[cov[1, 1], -cov[0, 1]], [-cov[1, 0], cov[0, 0]]]) / det
+        dx, dy = x - mean[0], y - mean[1]
+        maha = dx * dx * inv[0, 0] + 2 * dx * dy * inv[0, 1] + dy * dy * inv[1, 1]
+        g = np.exp(-0.5 * maha) / (2 * np.pi * np.sqrt(det))
     else:
-        raise ValueError(f"Strategy {strategy} is not restated (only first / gmm)")
+        raise ValueError(f"Strategy {strategy} not recognized")
     return g.astype(np.float32)
 
 

@@ -548,9 +548,20 @@ def postproc_fixture(seed: int):
             assert np.array_equal(ref, mine), (strategy, name, np.abs(ref - mine).max())
             out[f"gauss.{strategy}.{name}.points"] = pts
             out[f"gauss.{strategy}.{name}.expect"] = ref
+    # `fit` (scipy multivariate_normal on the unrounded points): needs a non-singular covariance, i.e. >= 3 non-collinear
+    # points; one point falls back to `first` like every strategy.  The closed-form restatement may differ from scipy's
+    # eigen-decomposition in the last fp64 ulp, i.e. by at most one fp32 ulp after the cast.
+    proc = types.SimpleNamespace(image_size=gsize, cfg=types.SimpleNamespace(strategy="fit", sigma=5))
+    for name in ("single", "multi", "edge"):
+        pts = cases[name]
+        ref = RefProcessor._make_gaussmap(proc, torch.from_numpy(pts)).numpy()
+        mine = O.make_gaussmap(pts, gsize, 5, "fit")
+        assert np.allclose(ref, mine, rtol=2.4e-7, atol=1e-37), ("fit", name, np.abs(ref - mine).max())
+        out[f"gauss.fit.{name}.points"] = pts
+        out[f"gauss.fit.{name}.expect"] = ref
     ref = RefProcessor._make_gaussmap(proc).numpy()
     assert np.array_equal(ref, O.make_gaussmap(None, gsize)) and not ref.any()
-    print("  [ok] _make_gaussmap first/gmm/None: oracle == reference (exact)")
+    print("  [ok] _make_gaussmap first/gmm/None: oracle == reference (exact); fit: within 1 fp32 ulp")
     np.savez_compressed(os.path.join(GOLD, "postproc.npz"), **out)
 
 

@@ -652,8 +652,9 @@ def test_gaussian_targets_match_reference_fixture(ops):
     1 fp32 ulp (1.2e-7 relative), stated here."""
     import numpy as np
     z = _postproc()
-    for strategy in ("first", "gmm"):
+    for strategy in ("first", "gmm", "fit"):
         names = [k.split(".")[2] for k in z.files if k.startswith(f"gauss.{strategy}.") and k.endswith(".points")]
+        assert names, strategy
         pmax = max(z[f"gauss.{strategy}.{n}.points"].shape[0] for n in names)
         pts = torch.zeros(len(names) + 1, pmax, 2)
         cnt = torch.zeros(len(names) + 1, dtype=torch.int32)
@@ -680,8 +681,14 @@ def test_gaussian_targets_full_size_properties(ops):
         for i in (0, 17, 63):
             exp = torch.from_numpy(O.make_gaussmap(pts[i, :cnt[i]].numpy(), 224, 5.0, strategy))
             assert torch.allclose(maps[i], exp, rtol=2.4e-7, atol=1e-37)
+    # fit: three points per map (non-singular covariance), the unnormalised density of the fitted normal
+    cnt3 = torch.full((64,), 3, dtype=torch.int32)
+    maps = ops.gaussian_targets(pts.cuda(), cnt3.cuda(), 224, 5.0, "fit").cpu()
+    for i in (0, 17, 63):
+        exp = torch.from_numpy(O.make_gaussmap(pts[i].numpy(), 224, 5.0, "fit"))
+        assert torch.allclose(maps[i], exp, rtol=4.8e-7, atol=1e-37)
     with pytest.raises(ValueError):
-        ops.gaussian_targets(pts.cuda(), cnt.cuda(), 224, 5.0, "fit")
+        ops.gaussian_targets(pts.cuda(), cnt.cuda(), 224, 5.0, "bogus")
 
 
 def test_preprocess_rgb_matches_oracle(ops, gpu):

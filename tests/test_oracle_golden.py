@@ -166,7 +166,10 @@ def test_postprocessing_and_targets_match_reference(golden_dir):
         if k.startswith("gauss.") and k.endswith(".points"):
             _, strategy, name, _ = k.split(".")
             got = O.make_gaussmap(z[k], 40, 5, strategy)
-            assert np.array_equal(got, z[f"gauss.{strategy}.{name}.expect"]), k
+            if strategy == "fit":       # closed form vs scipy's eigen-decomposition: the last fp64 ulp -> at most 1 fp32 ulp
+                assert np.allclose(got, z[f"gauss.{strategy}.{name}.expect"], rtol=2.4e-7, atol=1e-37), k
+            else:
+                assert np.array_equal(got, z[f"gauss.{strategy}.{name}.expect"]), k
             n += 1
-    assert n == 10
+    assert n == 13
     assert not O.make_gaussmap(None, 40).any()
