@@ -25,6 +25,7 @@ from bifold_amd.hip import lib as L
 from bifold_amd.hip import ops
 from . import Components
 from .arena import ParamArena
+from .streams import side_stream
 from .decoder_math import upsample_operator
 from .params import add_param, layernorm_init, linear_init
 
@@ -37,14 +38,8 @@ _SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
 # workgroups.  0 = everything on one stream; 1 = the main stream joins the side stream at the end of every layer;
 # 2 = it joins one layer late (layer i's dW GEMMs run beside layer i-1's dX chain)
 _DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "1"))
-_dw_streams: Dict[int, "torch.cuda.Stream"] = {}
-
-
 def _dw_stream(device) -> "torch.cuda.Stream":
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _dw_streams:
-        _dw_streams[key] = torch.cuda.Stream(device=device)
-    return _dw_streams[key]
+    return side_stream(device, "dw")
 
 
 class _WeightGradSide:
@@ -165,7 +160,6 @@ class PickPlaceConvDecoder(nn.Module):
                 add_param(self, f"{name}_decoder.decoder_net.{i}.bias", init["bias"])
         self._U: Optional[torch.Tensor] = None
         self._collapsed = None
-        self._side_stream = None
 
     def decoder_params(self, name: str):
         net = self._modules[f"{name}_decoder"].decoder_net
@@ -177,9 +171,7 @@ class PickPlaceConvDecoder(nn.Module):
     # (41 / 180 us each, two or four heads): latency, not work.  They run on a side HIP stream -- the forward one
     # at the top of the model's forward, beside the towers; the backward one beside the fusion layers' backward.
     def _side(self, device) -> "torch.cuda.Stream":
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=device)
-        return self._side_stream
+        return side_stream(device, "decoder")
 
     def collapse_async(self) -> None:
         """Start decoder_collapse_fwd for every head on the side stream (after everything already queued on the

@@ -16,6 +16,7 @@ import torch
 from torch import nn
 
 from . import BaseModel, Components
+from .streams import side_stream
 from .arena import ParamArena, arena_of
 from .clip_encoder import _MODELS, load
 from .params import add_param, linear_init
@@ -57,7 +58,6 @@ class RGBOnly(BaseModel):
         self.pick_place.fusion.compute_dtype = self.compute_dtype
         self._train_arena: Optional[ParamArena] = None
         self._grad_hooks: List[Callable[[int], None]] = []
-        self._side_stream = None
 
     # ------------------------------------------------------------------ runtime plumbing
     def trainable_params(self):
@@ -99,9 +99,7 @@ class RGBOnly(BaseModel):
         # idle; it runs on a side HIP stream concurrently with the vision tower and joins before the
         # fusion tail.  Both towers are frozen (no autograd state crosses the streams).
         main = torch.cuda.current_stream()
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=rgb.device)
-        side = self._side_stream
+        side = side_stream(rgb.device, "text")
         self.clip_encoder._runtime(cdt)                   # arenas / bf16 copies ready before the fork
         if os.environ.get("BIFOLD_TEXT_STREAM", "1") == "0":     # both towers on the main stream
             text_feat = self.clip_encoder.encode_text_with_embeddings(instr, cdt)
