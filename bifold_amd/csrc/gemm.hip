@@ -1310,6 +1310,25 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_p8_kernel(
         }
     };
 
+    // Fragment addressing: a fragment is 16 rows x K = 128; lane l holds row (l & 15) and k-block (l >> 4) = two 16-byte
+    // chunks of that row in the even (k-blocks 0-1) or odd (2-3) stage's slot.  A fragment's first row is a multiple of
+    // 16, so the row swizzle kc32_swz depends on (l & 15) only: FOUR per-lane offsets (A / B x low / high chunk) serve
+    // every fragment, which differ by compile-time constants (the per-fragment address arithmetic cost 35 spilled
+    // registers and VALU work in the load blocks).
+    const int frow = lane & 15, fkb = lane >> 4;
+    const int fz = kc32_swz(frow), fc0 = (fkb & 1) * 2;
+    const unsigned f_lo = (unsigned)(frow * 64 + (((fc0) ^ fz) << 4)), f_hi = (unsigned)(frow * 64 + (((fc0 + 1) ^ fz) << 4));
+    const unsigned a_lo = f_lo + (unsigned)(wm * 128 * 64), a_hi = f_hi + (unsigned)(wm * 128 * 64);
+    const unsigned b_lo = f_lo + 16384u + (unsigned)(wn * 64 * 64), b_hi = f_hi + 16384u + (unsigned)(wn * 64 * 64);
+    auto frag = [&](const char* sel, unsigned lo_off, unsigned hi_off, int row16) -> i32x8_t {
+        const uint4 lo = *(const uint4*)(sel + lo_off + row16 * 1024);
+        const uint4 hi = *(const uint4*)(sel + hi_off + row16 * 1024);
+        i32x8_t r;
+        r[0] = (int)lo.x; r[1] = (int)lo.y; r[2] = (int)lo.z; r[3] = (int)lo.w;
+        r[4] = (int)hi.x; r[5] = (int)hi.y; r[6] = (int)hi.z; r[7] = (int)hi.w;
+        return r;
+    };
+
     P8Item w;
     [[maybe_unused]] int round = 0;
     unsigned pend = 0;
@@ -1347,11 +1366,12 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_p8_kernel(
             const char* ev = smem + ((2 * pr) & 3) * P8_STAGE;
             const char* od = smem + ((2 * pr + 1) & 3) * P8_STAGE;
             // ---------------- load block a
+            const char* sel = (fkb & 2) ? od : ev;              // this lane's k-blocks live in the even or the odd stage
             i32x8_t bfr[4], af[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = fp8_frag_pair(ev + 16384, od + 16384, wn * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = frag(sel, b_lo, b_hi, j);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = fp8_frag_pair(ev, od, wm * 128 + i * 16, lane);
+            for (int i = 0; i < 4; ++i) af[i] = frag(sel, a_lo, a_hi, i);
             if (pr + 1 < nk) issue_pair(w, pr + 1, va, vb);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
@@ -1365,7 +1385,7 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_p8_kernel(
             // ---------------- load block b
             i32x8_t ag[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ag[i] = fp8_frag_pair(ev, od, wm * 128 + 64 + i * 16, lane);
+            for (int i = 0; i < 4; ++i) ag[i] = frag(sel, a_lo, a_hi, 4 + i);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this pair's slots are free once the barrier is passed
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // pair pr + 1 has landed
             // the next item is drawn here, right behind the wait: the atomic has a whole pair to return before the next one
@@ -1379,6 +1399,15 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_p8_kernel(
                     acc[j][4 + i] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], ag[i], acc[j][4 + i], 0, 0, 0, unit, 0, unit);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
+        }
+        // this wave's 8 x 16 token scales for the epilogue: requested here, behind the last MFMA block, so that they
+        // travel under the realign / publish barriers and the next item's prologue issue (one dependent global load per
+        // 16 rows inside the store loop cost 2 k cycles each; held through the whole main loop they slowed the loop)
+        float sa8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int mrow = w.m0 + wm * 128 + i * 16 + (lane & 15);
+            sa8[i] = mrow < ep.m ? ep.sa[mrow] : 0.f;
         }
         if (wm == 0) __builtin_amdgcn_s_barrier();          // realign the groups
 #ifdef P8_PROBE
@@ -1406,15 +1435,6 @@ __global__ __launch_bounds__(512, 1) void gemm_fp8_p8_kernel(
 
         // epilogue: scales, bias, activation in the MFMA layout; bf16 turn-around through this wave's 8 KB of slots 2-3
         char* stg = smem + 2 * P8_STAGE + wave * 8192;
-        // this wave's 8 x 16 token scales: requested in one batch, ahead of everything that uses them (one dependent
-        // global load per 16 rows inside the store loop cost 2 k cycles each; holding them through the main loop
-        // instead made the loop itself 50 % slower)
-        float sa8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int mrow = w.m0 + wm * 128 + i * 16 + (lane & 15);
-            sa8[i] = mrow < ep.m ? ep.sa[mrow] : 0.f;
-        }
         // channel scales first, in place (their registers are dead before the bias ones are live: the epilogue with both
         // sets held next to the 128 accumulators spilled 35 registers and took 29 k cycles per tile instead of 9 k)
 #pragma unroll
