@@ -208,6 +208,7 @@ def parity_vs_oracle(model, sample, n: int = 4):
     model.train()
     return {"heatmap_max_rel": float(f"{worst_rel:.3e}"), "logit_max_rel": float(f"{logit_rel:.3e}"),
             "heatmap_max_abs": float(f"{worst_abs:.3e}"), "heatmap_mse": float(f"{mse:.3e}"), "gate_rel": 1e-3,
+            "heatmap_within_gate": bool(worst_rel <= 1e-3), "logit_within_gate": bool(logit_rel <= 1e-3),
             "within_gate": bool(worst_rel <= 1e-3 and logit_rel <= 1e-3), "samples_checked": n,
             "against": "oracle/bifold_oracle.py (fp32 CPU restatement pinned to the reference), same random-init "
                        "weights and inputs, checked before the first optimisation step; rel = max|diff| / max|ref| "
