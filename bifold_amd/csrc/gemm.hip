@@ -1788,7 +1788,7 @@ int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const fl
     static int p8_group = -1, rev_env = -1, pol = -1;
     if (p8_group < 0) { const char* e = getenv("BIFOLD_P8_GROUP_M"); p8_group = e ? atoi(e) : 4; if (p8_group < 1) p8_group = 1; }
     if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
-    if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 1; }
+    if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 5; }   // plain-bf16 and GELU-grad outputs non-temporal (in-step A/B, round 2: 1 -> 5 +0.3 %)
     GemmDims d{m, n, k, lda, ldb, bf_cdiv(m, 256), bf_cdiv(n, 256), k, p8_group};
     Fp8P8Epi ep{(bf16_t*)c, sa, sb, bias, m, n, ldc, act, pol};
     const size_t a_ext = (size_t)(m - 1) * lda + k, b_ext = (size_t)(n - 1) * ldb + k;
@@ -1889,7 +1889,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     ep.colsum = nullptr;
     {
         static int pol = -1;      // bit mask, see EpiParams::store_policy (measured in-step: DESIGN.md §6)
-        if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 1; }
+        if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 5; }   // plain-bf16 and GELU-grad outputs non-temporal (in-step A/B, round 2: 1 -> 5 +0.3 %)
         ep.store_policy = pol;
     }
     bool colsum_fused = false;
