@@ -38,6 +38,7 @@ _SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
 # workgroups.  0 = everything on one stream; 1 = the main stream joins the side stream at the end of every layer;
 # 2 = it joins one layer late (layer i's dW GEMMs run beside layer i-1's dX chain)
 _DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "1"))
+_DW_ORDER = int(os.environ.get("BIFOLD_DW_ORDER", "1"))
 def _dw_stream(device) -> "torch.cuda.Stream":
     return side_stream(device, "dw")
 
@@ -51,12 +52,22 @@ class _WeightGradSide:
         self.on = _DW_SIDE > 0
         self.side = _dw_stream(device) if self.on else None
 
-    def gemm(self, dy, x, out):
+    def ready(self):
+        """Event on the main stream: everything queued so far (the operands of the next dW GEMM) is produced."""
+        if not self.on:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def gemm(self, dy, x, out, after=None):
         if not self.on:
             ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
             return
-        main = torch.cuda.current_stream()
-        self.side.wait_stream(main)
+        if after is not None:
+            self.side.wait_event(after)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
         dy.record_stream(self.side)
@@ -256,25 +267,42 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
-    # (every dW GEMM is issued right after its operands' producer and BEFORE the next dX GEMM, so that on the side
-    # stream it waits for nothing it does not read)
-    wg.gemm(op3, S["a"], g(P["w2"]))
+    # Every dW GEMM waits only for the producer of its operands (an event recorded right behind it) but is ISSUED after the
+    # next dX GEMM of the chain (_DW_ORDER = 1): both become runnable at the same moment, and the one the hardware sees
+    # first takes the CUs -- it should be the one the rest of the backward waits for.  (_DW_ORDER = 0: dW first.)
+    e3 = wg.ready()
+    if not _DW_ORDER:
+        wg.gemm(op3, S["a"], g(P["w2"]), e3)
     da_pre = ops.gemm(op3, A.operand(P["w2"], cdt), b_kn=True,
                       act=L.ACT_MUL_AUX if _SAVEGRAD else L.ACT_ERF_GELU_GRAD, aux=S["a_pre"],
                       colsum_out=g(P["bb1"]))          # d bias1 = column sums of da_pre, fused into the epilogue
-    wg.gemm(da_pre, S["h2"], g(P["w1"]))
+    if _DW_ORDER:
+        wg.gemm(op3, S["a"], g(P["w2"]), e3)
+    e_pre = wg.ready()
+    if not _DW_ORDER:
+        wg.gemm(da_pre, S["h2"], g(P["w1"]), e_pre)
     dh2 = ops.gemm(da_pre, A.operand(P["w1"], cdt), b_kn=True)
+    if _DW_ORDER:
+        wg.gemm(da_pre, S["h2"], g(P["w1"]), e_pre)
     # the LayerNorm backward streams dx3 (in) and dx2 (out): it also emits their column sums,
     # i.e. the bias gradients of net.3 and to_out
     dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]),
                                    dres_sum_out=g(P["bb2"]), dx_sum_out=g(P["bo"]))
     op2 = dx2_c if dx2_c is not None else dx2
     # attention:  x2 = x + attn(h1 Wqkv^T) Wo^T + bo
-    wg.gemm(op2, S["o"], g(P["wo"]))
+    e2 = wg.ready()
+    if not _DW_ORDER:
+        wg.gemm(op2, S["o"], g(P["wo"]), e2)
     do = ops.gemm(op2, A.operand(P["wo"], cdt), b_kn=True)
+    if _DW_ORDER:
+        wg.gemm(op2, S["o"], g(P["wo"]), e2)
     dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask)
-    wg.gemm(dqkv, S["h1"], g(P["wqkv"]))
+    e_qkv = wg.ready()
+    if not _DW_ORDER:
+        wg.gemm(dqkv, S["h1"], g(P["wqkv"]), e_qkv)
     dh1 = ops.gemm(dqkv, A.operand(P["wqkv"], cdt), b_kn=True)
+    if _DW_ORDER:
+        wg.gemm(dqkv, S["h1"], g(P["wqkv"]), e_qkv)
     return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
 
 
