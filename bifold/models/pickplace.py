@@ -38,7 +38,10 @@ _SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
 # workgroups.  0 = everything on one stream; 1 = the main stream joins the side stream at the end of every layer;
 # 2 = it joins one layer late (layer i's dW GEMMs run beside layer i-1's dX chain)
 _DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "1"))
+# 1 = a dW GEMM is issued AFTER the dX GEMM that becomes runnable at the same moment (see fusion_layer_bwd); 0 = before
 _DW_ORDER = int(os.environ.get("BIFOLD_DW_ORDER", "1"))
+
+
 def _dw_stream(device) -> "torch.cuda.Stream":
     return side_stream(device, "dw")
 
