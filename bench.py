@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--timer-stride", type=int, default=4,
+                    help="HIP-event pairs around the dominant kernel in every Nth timed step (1 = every step)")
     ap.add_argument("--per-shape", action="store_true", help="diagnostic: time every GEMM shape separately")
     ap.add_argument("--all-kernels", action="store_true", help="time every matrix kernel, not just the dominant one")
     ap.add_argument("--host-fed", action="store_true",
@@ -353,9 +355,17 @@ def main():
         # kernel cost ~3 % of the step); --per-shape / --all-kernels time everything
         timer = ops.KernelTimer(per_shape=args.per_shape,
                                 only_prefix=None if (args.per_shape or args.all_kernels) else dom_label)
-        ops.PROFILER = timer
+    # The event pairs are not free (each record is a barrier packet between two kernels: timing the dominant kernel in
+    # EVERY step costs 1.5 % of the step, tools/ab_timer.sh), so the default samples every 4th timed step -- whole
+    # steps, so that the mix of shapes is the step's -- and scales the share of the step accordingly.
+    stride = 1 if (args.per_shape or args.all_kernels or timer is None) else max(1, args.timer_stride)
+    timed_steps = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if timer is not None:
+            on = i % stride == 0
+            ops.PROFILER = timer if on else None
+            timed_steps += int(on)
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -438,14 +448,16 @@ def main():
                                     "traffic": traffic[0] if traffic else None,
                                     "traffic_note": traffic[1] if traffic else "no PMC summary under profiles/",
                                     "launches": d["launches"], "avg_us": round(d["avg_us"], 2),
-                                    "share_of_step": round(d["ms"] / (1e3 * elapsed), 4),
+                                    "share_of_step": round(d["ms"] / (1e3 * elapsed * timed_steps / args.steps), 4),
+                                    "timed_steps": timed_steps,
                                     "timing": "HIP events on the launching stream around each bf_gemm host call "
                                               "(one host call = 1 device launch, or 2 when the last round of tiles "
-                                              "runs as a split-K tail)",
+                                              f"runs as a split-K tail), in {timed_steps} of the {args.steps} timed steps "
+                                              "(--timer-stride; every step costs 1.5 % of the step)",
                                     "rocprof": rocprof_nt_average_us()}
             line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
                                    "tflops": round(v["tflops"], 1),
-                                   "share_of_step": round(v["ms"] / (1e3 * elapsed), 4)}
+                                   "share_of_step": round(v["ms"] / (1e3 * elapsed * timed_steps / args.steps), 4)}
                                for k, v in sorted(summ.items())}
         if big:
             line.pop("step_roofline", None)
