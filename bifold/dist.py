@@ -162,6 +162,9 @@ class GradSync:
         if self.world == 1 and os.environ.get("BIFOLD_FORCE_PG") != "1":
             return
         if os.environ.get("BIFOLD_DDP_DRYRUN") == "1":      # diagnosis: process group alive, no collective issued
+            if self.world > 1:                              # replicas would silently train on un-averaged gradients
+                raise RuntimeError("BIFOLD_DDP_DRYRUN=1 is a single-rank rehearsal knob (BIFOLD_FORCE_PG=1); "
+                                   f"refusing to skip the gradient all-reduce with world size {self.world}")
             return
         for a, b in spans:
             view = self.grad[a:b]

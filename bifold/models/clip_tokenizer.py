@@ -5,8 +5,8 @@ ids for instructions built from its templates).
 
 Host-side string processing, outside the GPU hot path; it exists so that a user of this build can feed text.
 The merge table is OpenAI's published `bpe_simple_vocab_16e6.txt.gz` -- a data file the reference vendors and
-this repository does not: pass its path, or set BIFOLD_CLIP_BPE, or keep a checkout of the reference where
-`find_bpe_file` looks.  Unicode repair (`ftfy.fix_text` in the reference) is applied when ftfy is installed and
+this repository does not: pass its path, or set BIFOLD_CLIP_BPE to it, or BIFOLD_REFERENCE to a checkout of the
+reference.  Unicode repair (`ftfy.fix_text` in the reference) is applied when ftfy is installed and
 skipped otherwise (identity on well-formed text).
 """
 from __future__ import annotations
@@ -30,8 +30,7 @@ _PATTERN = re.compile(r"<\|startoftext\|>|<\|endoftext\|>|'s|'t|'re|'ve|'m|'ll|'
 
 def find_bpe_file(path: Optional[str] = None) -> str:
     cands = [path, os.environ.get("BIFOLD_CLIP_BPE"),
-             os.path.join(os.environ.get("BIFOLD_REFERENCE", ""), "bifold", "models", "clip", "bpe_simple_vocab_16e6.txt.gz"),
-             "/root/reference/bifold/models/clip/bpe_simple_vocab_16e6.txt.gz"]
+             os.path.join(os.environ.get("BIFOLD_REFERENCE", ""), "bifold", "models", "clip", "bpe_simple_vocab_16e6.txt.gz")]
     for c in cands:
         if c and os.path.isfile(c):
             return c

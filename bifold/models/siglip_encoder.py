@@ -255,6 +255,10 @@ class SiglipTowers(nn.Module):
             self._calls[tower] = call + 1
             # one host-side draw per tower call from torch's CPU generator (seeded by cfg.seed): no device sync
             base_seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            # the Trainer seeds (and on resume restores) that generator identically on every data-parallel rank:
+            # fold the rank in, so replicas drop different elements like one process over the whole batch would
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                base_seed ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
             p_drop, scale = self.lora["dropout"], self.lora["alpha"] / self.lora["r"]
         for i in range(cfg["num_hidden_layers"]):
             b = f"{tower}.encoder.layers.{i}."

@@ -1751,24 +1751,41 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
 #define P8_TK_STREAMS 16
 #define P8_TK_RING 64
 __device__ unsigned p8_ticket_sets[P8_TK_STREAMS * P8_TK_RING * 16];
+// One owner table per device (a `__device__` array has one copy per device); a 17th distinct stream on a device takes
+// the least recently used slot after a device synchronise (the old owner's launches may still read their sets).
+#define P8_TK_DEVICES 16
+struct P8TicketDev {
+    unsigned* base;
+    hipStream_t owners[P8_TK_STREAMS];
+    unsigned next[P8_TK_STREAMS];
+    unsigned long long last_use[P8_TK_STREAMS];
+    int n_owner;
+};
 static unsigned* p8_ticket_set(hipStream_t s) {
-    static unsigned* base = nullptr;
-    static hipStream_t owners[P8_TK_STREAMS];
-    static unsigned next[P8_TK_STREAMS];
-    static int n_owner = 0;
+    static P8TicketDev devs[P8_TK_DEVICES];
+    static unsigned long long clock = 0;
     static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= P8_TK_DEVICES) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(p8_ticket_sets)) != hipSuccess) return nullptr;
+    P8TicketDev& t = devs[dev];
+    if (!t.base && hipGetSymbolAddress((void**)&t.base, HIP_SYMBOL(p8_ticket_sets)) != hipSuccess) return nullptr;
     int slot = -1;
-    for (int i = 0; i < n_owner; ++i) if (owners[i] == s) { slot = i; break; }
+    for (int i = 0; i < t.n_owner; ++i) if (t.owners[i] == s) { slot = i; break; }
     if (slot < 0) {
-        if (n_owner == P8_TK_STREAMS) return nullptr;          // more streams than rings: caller falls back
-        slot = n_owner++;
-        owners[slot] = s;
-        next[slot] = 0;
+        if (t.n_owner < P8_TK_STREAMS) {
+            slot = t.n_owner++;
+        } else {
+            slot = 0;
+            for (int i = 1; i < P8_TK_STREAMS; ++i) if (t.last_use[i] < t.last_use[slot]) slot = i;
+            if (hipDeviceSynchronize() != hipSuccess) return nullptr;     // rare: only when a slot changes hands
+        }
+        t.owners[slot] = s;
+        t.next[slot] = 0;
     }
-    const unsigned set = next[slot]++ % P8_TK_RING;
-    return base + ((size_t)slot * P8_TK_RING + set) * 16;
+    t.last_use[slot] = ++clock;
+    const unsigned set = t.next[slot]++ % P8_TK_RING;
+    return t.base + ((size_t)slot * P8_TK_RING + set) * 16;
 }
 
 // Launcher of the persistent e4m3 kernel for bf_gemm_fp8 (gemm_fp8.hip): returns BF_OK when it took the call,

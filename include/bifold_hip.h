@@ -17,10 +17,10 @@
  *    (BIFOLD_GEMM_PIPE, BIFOLD_P8_*, BIFOLD_ATTN_*, BIFOLD_LN_ROWS: kernel selection only,
  *    results are the same up to summation order) and the matching bf_gemm_set_variant hook
  *    (not thread-safe: call it before the threads that run GEMMs start); and, for the persistent
- *    GEMM, a __device__ array of work-ticket counters with a host-side table that hands each
- *    stream (at most 16 per process, first come first served; further streams fall back to the
- *    non-persistent kernels) its own ring of counter sets on the device that was current at the
- *    first bf16 GEMM -- a process drives ONE device (the one-process-per-GPU model of bifold/dist.py);
+ *    GEMM, a __device__ array of work-ticket counters (one copy per device) with a host-side table per
+ *    device that hands each stream its own ring of counter sets: 16 streams per device hold rings at a
+ *    time, a further stream takes over the least recently used ring after one hipDeviceSynchronize();
+ *    the table is keyed by the device current at the call, so one process may drive several devices;
  *  - every launch goes to the hipStream_t passed as `stream` (void*; NULL = the
  *    legacy default stream);
  *  - tensors are row-major and contiguous unless a leading dimension is given;

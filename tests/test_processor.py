@@ -16,8 +16,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MEAN, STD = [0.48145466, 0.4578275, 0.40821073], [0.26862954, 0.26130258, 0.27577711]
 
 
-def test_clip_tokenizer_matches_reference_ids():
+def test_clip_tokenizer_matches_reference_ids(monkeypatch):
     from bifold.models import clip_tokenizer as T
+    if not os.environ.get("BIFOLD_CLIP_BPE") and not os.environ.get("BIFOLD_REFERENCE"):
+        monkeypatch.setenv("BIFOLD_REFERENCE", "/root/reference")      # the build container's read-only checkout
     try:
         T.find_bpe_file()
     except FileNotFoundError:
