@@ -471,6 +471,136 @@ def siglip_fixture(sequential: bool, fname: str, seed: int):
     print(f"  wrote {fname}")
 
 
+def siglip_lora_fixture(sequential: bool, fname: str, seed: int, r: int = 8, lora_alpha: float = 32.0):
+    """A reference-run pin for `lora: true` (models/siglip.py:33-40) without `peft`.
+
+    `peft` is absent and is neither imported nor stood in for.  What is assumed about it is ONLY the defining
+    formula of a LoRA-wrapped Linear at dropout 0, W' = W + (alpha / r) B A (peft.tuners.lora: `merge`), and PEFT's key
+    naming.  Everything else is the reference itself: its SigLip / SiglipSequential with `lora=False` is built around
+    towers whose q_proj / v_proj weights ARE W', those weights get `requires_grad` back, and the reference's own
+    forward, loss and autograd give heatmaps, loss, every tail gradient and G = dL/dW'.  By the chain rule on the
+    formula the adapter gradients are dA = (alpha / r) B^T G and dB = (alpha / r) G A^T: the tests derive them from
+    the recorded G.  The same run pins oracle/lora_oracle.py at dropout 0 (asserted here)."""
+    from transformers import SiglipConfig, SiglipModel
+    from oracle import lora_oracle as LO
+    print(f"== tiny siglip with merged LoRA weights, sequential={sequential}")
+    torch.manual_seed(seed)
+    scale = lora_alpha / r
+    adapters = {}
+
+    class FakeAuto:
+        @staticmethod
+        def from_pretrained(name):
+            m = SiglipModel(SiglipConfig(**TINY_SIGLIP)).float().eval()
+            g = torch.Generator().manual_seed(seed + 5)
+            with torch.no_grad():
+                for k, p in m.named_parameters():
+                    if "layer_norm" in k or "layernorm" in k or k.endswith("bias"):
+                        p.add_(0.1 * torch.randn(p.shape, generator=g))
+                for k, p in m.named_parameters():
+                    if k.endswith(("self_attn.q_proj.weight", "self_attn.v_proj.weight")) and ".head." not in k:
+                        a = torch.randn(r, p.shape[1], generator=g) * p.shape[1] ** -0.5
+                        b = torch.randn(p.shape[0], r, generator=g) * 0.05
+                        adapters[k] = (p.detach().clone(), a, b)
+                        p.add_(scale * (b @ a))
+            return m
+
+    ref_siglip.AutoModel = FakeAuto
+    is_bimanual = sequential
+    kw = dict(device=torch.device("cpu"), image_size=32, is_bimanual=is_bimanual, requires_graph=False,
+              patch_size=16, dim=64, lora=False, r=r, lora_alpha=lora_alpha, lora_dropout=0.0, automodel_name="tiny",
+              target_modules=["q_proj", "v_proj"], pick_place_model="pick_place_convdecoder",
+              fusion_model="concat_transformer", depth=2, heads=2, mlp_ratio=4, dropout=0.0, emb_dropout=0.0,
+              threshold=0.5, text_encoder=None)
+    T = 2
+    model = (ref_siglip.SiglipSequential(context_length=T, **kw) if sequential else ref_siglip.SigLip(**kw))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if ".norm." in k:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    assert len(adapters) == 2 * 2 * 2                     # towers x layers x {q, v}
+    named = dict(model.named_parameters())
+    for k in adapters:
+        named["siglip_model." + k].requires_grad_(True)   # the only tower tensors LoRA lets a gradient reach
+    B = 3
+    gen = torch.Generator().manual_seed(seed + 7)
+    sample = {"rgb": torch.randn(B, 3, 32, 32, generator=gen),
+              "instruction": torch.randint(0, 100, (B, 8), generator=gen)}
+    if sequential:
+        sample["rgb_context"] = torch.randn(B, T, 3, 32, 32, generator=gen)
+        sample["context_attention_mask"] = torch.tensor([[1, 0], [1, 1], [0, 0]], dtype=torch.int64)
+    for n in O.decoder_heads(is_bimanual):
+        c = torch.randint(0, 32, (B, 2), generator=gen)
+        sample[f"{n}_heatmap"] = O.gaussian_heatmaps(c, 32, sigma=3.0)
+    loss_fn = RefLosses.get_by_name(cfg=Cfg(name="bce_gaussmap", is_bimanual=is_bimanual, mask_pick_heatmap=False))
+    model.train()
+    out = model({k: v.clone() for k, v in sample.items()})
+    loss, _ = loss_fn(out, sample)
+    loss.backward()
+    out = {k: v.detach() for k, v in out.items() if v is not None}
+
+    # the state a `lora: true` model carries, in PEFT's key layout
+    state = {}
+    for k, v in model.state_dict().items():
+        if not k.startswith("siglip_model."):
+            state[k] = v.detach().clone()
+            continue
+        hf = k[len("siglip_model."):]
+        stem = hf.rsplit(".", 1)[0]
+        if stem + ".weight" in adapters:
+            state[LO.PEFT_PREFIX + stem + ".base_layer." + hf.rsplit(".", 1)[1]] = (
+                adapters[stem + ".weight"][0] if hf.endswith(".weight") else v.detach().clone())
+        else:
+            state[LO.PEFT_PREFIX + hf] = v.detach().clone()
+    for k, (_, a, b) in adapters.items():
+        stem = k.rsplit(".", 1)[0]
+        state[f"{LO.PEFT_PREFIX}{stem}.lora_A.siglip_adapter.weight"] = a
+        state[f"{LO.PEFT_PREFIX}{stem}.lora_B.siglip_adapter.weight"] = b
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()
+             if p.requires_grad and not k.startswith("siglip_model.")}
+    grad_w = {k: named["siglip_model." + k].grad.detach().clone() for k in adapters}
+
+    # pin oracle/lora_oracle.py (adapters applied unmerged, torch autograd) at dropout 0 against this run
+    lo_state = {k: v.clone() for k, v in state.items()}
+    keys = list(LO.trainable_keys(lo_state))
+    for k in keys:
+        lo_state[k].requires_grad_(True)
+    fwd = LO.siglip_sequential_forward if sequential else LO.siglip_forward
+    oo = fwd(lo_state, sample, 2, 2, is_bimanual, r=r, lora_alpha=lora_alpha)
+    lo_loss, _ = O.bce_gaussmap(oo, sample, is_bimanual)
+    lo_grads = dict(zip(keys, torch.autograd.grad(lo_loss, [lo_state[k] for k in keys])))
+    for k, t in out.items():
+        check(f"lora_oracle out[{k}]", oo[k].detach(), t)
+    check("lora_oracle loss", lo_loss.detach(), loss.detach(), rtol=1e-6)
+    for k, gr in grads.items():
+        check(f"lora_oracle grad[{k}]", lo_grads[k], gr, rtol=1e-4, atol=1e-7)
+    for k, (_, a, b) in adapters.items():
+        stem = k.rsplit(".", 1)[0]
+        check(f"lora_oracle dA[{stem}]", lo_grads[f"{LO.PEFT_PREFIX}{stem}.lora_A.siglip_adapter.weight"],
+              scale * b.t() @ grad_w[k], rtol=1e-4, atol=1e-8)
+        check(f"lora_oracle dB[{stem}]", lo_grads[f"{LO.PEFT_PREFIX}{stem}.lora_B.siglip_adapter.weight"],
+              scale * grad_w[k] @ a.t(), rtol=1e-4, atol=1e-8)
+
+    blob = {}
+    for k, t in np_state(state).items():
+        blob["state/" + k] = t
+    for k, t in sample.items():
+        blob["sample/" + k] = t.numpy()
+    for k, t in out.items():
+        blob["out/" + k] = t.numpy()
+    blob["loss"] = loss.detach().numpy()
+    for k, t in grads.items():
+        blob["grad/" + k] = t.numpy()
+    for k, t in grad_w.items():
+        blob["gradw/" + k] = t.numpy()
+    blob["meta/is_bimanual"] = np.array(int(is_bimanual))
+    blob["meta/context_length"] = np.array(T if sequential else 0)
+    blob["meta/r"], blob["meta/lora_alpha"] = np.array(r), np.array(lora_alpha)
+    np.savez_compressed(os.path.join(GOLD, fname), **blob)
+    print(f"  wrote {fname}")
+
+
 def postproc_fixture(seed: int):
     """Heatmap -> action and pixel -> target-map vectors from the reference's own functions
     (models/utils.py:60-83, models/__init__.py:79-173, data/processor.py:405-439)."""
@@ -607,6 +737,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
     ap.add_argument("--only-siglip", action="store_true")
+    ap.add_argument("--only-lora", action="store_true")
     ap.add_argument("--only-postproc", action="store_true")
     ap.add_argument("--only-patch14", action="store_true")
     args = ap.parse_args()
@@ -615,12 +746,18 @@ def main():
     if args.only_patch14:
         tiny_end_to_end(False, "tiny_patch14.npz", seed=3414, patch=14)
         return
+    if args.only_lora:
+        siglip_lora_fixture(False, "tiny_siglip_lora.npz", seed=3415)
+        siglip_lora_fixture(True, "tiny_siglip_sequential_lora.npz", seed=3416)
+        return
     postproc_fixture(seed=3413)
     if args.only_postproc:
         return
     tiny_end_to_end(False, "tiny_patch14.npz", seed=3414, patch=14)
     siglip_fixture(False, "tiny_siglip.npz", seed=3411)
     siglip_fixture(True, "tiny_siglip_sequential.npz", seed=3412)
+    siglip_lora_fixture(False, "tiny_siglip_lora.npz", seed=3415)
+    siglip_lora_fixture(True, "tiny_siglip_sequential_lora.npz", seed=3416)
     if args.only_siglip:
         return
     tiny_end_to_end(False, "tiny_unimanual.npz", seed=3407)

@@ -4,9 +4,16 @@ target_modules, lora_dropout), "siglip_adapter")`).
 
 TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``): the product package never imports this.
 
-PARITY UNPINNED.  The adapter arithmetic lives in the third-party package `peft` (unpinned in the
-reference's pyproject.toml:28), which is not installed in this image, so neither the reference's
-LoRA path nor PEFT itself can be run here and the reference holds no test or fixture for it.  This
+PINNED AT DROPOUT 0, UNPINNED FOR THE DROPOUT MASK.  The adapter arithmetic lives in the third-party package `peft`
+(unpinned in the reference's pyproject.toml:28), which is not installed in this image and is neither imported nor
+stood in for.  Since round 3 the file is pinned by a run of the reference itself wherever dropout is the identity
+(p = 0, eval mode): oracle/gen_golden.py::siglip_lora_fixture runs the reference's `lora=False` model around towers
+whose q_proj / v_proj weights are W' = W + (alpha / r) B A, records heatmaps, loss, tail gradients and dL/dW', and
+asserts this file's unmerged forward and autograd gradients against them (adapter gradients through the chain rule
+dA = (alpha / r) B^T G, dB = (alpha / r) G A^T); tests/test_host_logic.py repeats it from the committed fixtures
+(tests/golden/tiny_siglip*_lora.npz).  The one thing assumed about PEFT is that defining formula.  What stays
+unpinned is training-mode `lora_dropout` > 0: nn.Dropout on the adapter branch's input, replayed here from the
+masks the implementation under test drew.  This
 file restates PEFT's published definition of a LoRA-wrapped nn.Linear
 
         y = base_layer(x) + lora_B(lora_A(lora_dropout(x))) * (lora_alpha / r)

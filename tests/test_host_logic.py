@@ -316,3 +316,45 @@ def test_bench_contract_helpers():
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"ms_per_step"', '"higher_is_better"', '"scaling"',
                 '"vs_baseline"', '"dtype"', '"data"', '"config"', '"roofline"', '"cpu_baseline"'):
         assert key in src, key
+
+
+@pytest.mark.parametrize("fixture", ["tiny_siglip_lora.npz", "tiny_siglip_sequential_lora.npz"])
+def test_lora_oracle_is_pinned_by_the_reference_at_dropout_0(golden_dir, fixture):
+    """oracle/lora_oracle.py (adapters applied UNMERGED, gradients from torch autograd) against what the reference
+    itself computed with the merged weights W' = W + (alpha / r) B A in its `lora=False` towers
+    (oracle/gen_golden.py::siglip_lora_fixture): heatmaps, loss, every tail gradient, and the adapter gradients that
+    the chain rule gives from the reference's dL/dW' -- dA = (alpha / r) B^T G, dB = (alpha / r) G A^T."""
+    from oracle import bifold_oracle as O
+    from oracle import lora_oracle as LO
+    z = np.load(os.path.join(golden_dir, fixture))
+    state = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("state/")}
+    sample = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sample/")}
+    bim, T = bool(int(z["meta/is_bimanual"])), int(z["meta/context_length"])
+    r, alpha = int(z["meta/r"]), float(z["meta/lora_alpha"])
+    keys = list(LO.trainable_keys(state))
+    for k in keys:
+        state[k].requires_grad_(True)
+    fwd = LO.siglip_sequential_forward if T else LO.siglip_forward
+    out = fwd(state, sample, 2, 2, bim, r=r, lora_alpha=alpha)
+    loss, _ = O.bce_gaussmap(out, sample, bim)
+    grads = dict(zip(keys, torch.autograd.grad(loss, [state[k] for k in keys])))
+
+    def close(a, b, tol=2e-5):
+        a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+        return (a - b).abs().max().item() <= tol * b.abs().max().item() + 1e-9
+    for k in z.files:
+        if k.startswith("out/"):
+            assert close(out[k[4:]].detach(), z[k]), k
+        elif k.startswith("grad/"):
+            assert close(grads[k[5:]], z[k], 1e-4), k
+    assert abs(loss.item() - float(z["loss"])) < 1e-6 * abs(float(z["loss"]))
+    n = 0
+    for k in z.files:
+        if not k.startswith("gradw/"):
+            continue
+        stem, g = LO.PEFT_PREFIX + k[6:].rsplit(".", 1)[0], torch.from_numpy(z[k])
+        a, b = state[stem + ".lora_A.siglip_adapter.weight"].detach(), state[stem + ".lora_B.siglip_adapter.weight"].detach()
+        assert close(grads[stem + ".lora_A.siglip_adapter.weight"], (alpha / r) * b.t() @ g, 1e-4), k
+        assert close(grads[stem + ".lora_B.siglip_adapter.weight"], (alpha / r) * g @ a.t(), 1e-4), k
+        n += 1
+    assert n == 8
