@@ -73,22 +73,47 @@ def test_config_a_batch_256_bf16_matches_oracle_and_exact_mode(gpu, observed):
     sub = {k: v[:N_CHECK] for k, v in sample.items()}
     with torch.no_grad():
         ref = O.rgb_clip_forward(state, sub, heads=16)
-    err = {}
+    # ---- the same restatement under torch autograd on ALL 256 samples, evaluated by torch's own fp32 kernels on the
+    # GPU (rocBLAS / ATen: nothing of libbifold_hip): loss and every trainable gradient at the bench's shapes, i.e. what
+    # the persistent dgrad / wgrad GEMMs at M = 70 400 produce is compared with something outside the library
+    trainable = sorted(got["fp32"]["grad"])
+    gstate = {k: (v.to(gpu).requires_grad_(True) if k in trainable else v.to(gpu)) for k, v in state.items()}
+    gout = O.rgb_clip_forward(gstate, dev_sample, heads=16)
+    gloss, _ = O.bce_gaussmap(gout, dev_sample, False)
+    ggrads = {k: g.float().cpu() for k, g in zip(trainable, torch.autograd.grad(gloss, [gstate[k] for k in trainable]))}
+    torch_heat = max(rel(gout[k][:N_CHECK], ref[k]) for k in ("pick_heatmap", "place_heatmap"))
+    gloss = gloss.item()
+    del gout, gstate
+    torch.cuda.empty_cache()
+    assert torch_heat < 1e-4                        # torch-on-GPU fp32 == torch-on-CPU fp32 up to summation order
+
+    def logit(t):
+        return torch.logit(t.double().clamp(1e-300, 1 - 1e-16))
+    err, lerr = {}, {}
     for dtype in ("bf16", "fp32"):
         err[dtype] = max(rel(got[dtype]["heat"][k], ref[k]) for k in ("pick_heatmap", "place_heatmap"))
+        lerr[dtype] = max(rel(logit(got[dtype]["heat"][k]), logit(ref[k])) for k in ("pick_heatmap", "place_heatmap"))
     mse = max(((got["bf16"]["heat"][k].double() - ref[k].double()) ** 2).mean().item()
               for k in ("pick_heatmap", "place_heatmap"))
-    loss_rel = abs(got["bf16"]["loss"] - got["fp32"]["loss"]) / abs(got["fp32"]["loss"])
-    grad_err = {n: rel(got["bf16"]["grad"][n], g32) for n, g32 in got["fp32"]["grad"].items()}
-    worst = max(grad_err, key=grad_err.get)
+    loss_rel = {d: abs(got[d]["loss"] - gloss) / abs(gloss) for d in got}
+    grad_err = {d: {n: rel(got[d]["grad"][n], g) for n, g in ggrads.items()} for d in got}
+    worst = {d: max(grad_err[d], key=grad_err[d].get) for d in got}
     observed("config_a_b256", heat_rel_bf16=err["bf16"], heat_rel_fp32=err["fp32"], heat_mse_bf16=mse,
-             loss_rel_bf16_vs_fp32=loss_rel, worst_grad_rel=grad_err[worst], worst_grad=worst,
-             median_grad_rel=float(np.median(list(grad_err.values()))))
-    assert err["fp32"] < 1e-3                       # the exact mode meets north_star's gate at the bench shapes
-    # observed on MI355X: heatmaps 2.4e-4, loss 2.2e-5, worst gradient tensor 6.8e-3 (median 2.8e-3)
-    assert err["bf16"] < 1e-3                       # the bf16 mode meets north_star's 1e-3 gate at the bench shapes
-    assert loss_rel < 1e-4
-    assert grad_err[worst] < 2e-2, (worst, grad_err[worst])
+             logit_rel_bf16=lerr["bf16"], logit_rel_fp32=lerr["fp32"],
+             loss_rel_bf16=loss_rel["bf16"], loss_rel_fp32=loss_rel["fp32"],
+             worst_grad_rel_bf16=grad_err["bf16"][worst["bf16"]], worst_grad_bf16=worst["bf16"],
+             worst_grad_rel_fp32=grad_err["fp32"][worst["fp32"]], worst_grad_fp32=worst["fp32"],
+             median_grad_rel_bf16=float(np.median(list(grad_err["bf16"].values()))))
+    # the exact mode meets north_star's gate at the bench shapes on heatmaps, LOGITS, loss and every gradient
+    assert err["fp32"] < 1e-3 and lerr["fp32"] < 1e-3 and loss_rel["fp32"] < 1e-4
+    assert grad_err["fp32"][worst["fp32"]] < 1e-3, (worst["fp32"], grad_err["fp32"][worst["fp32"]])
+    # bf16, observed on MI355X: heatmaps 2.4e-4, loss 2.2e-5, worst gradient tensor 6.8e-3 (median 2.8e-3);
+    # LOGITS at random initialisation 2.6e-3 .. 3.1e-3 of max |logit| = 0.17 -- above north_star's 1e-3: the bound
+    # asserted here is ~3x the observed value so that it cannot drift silently (the fp16 mode is the one that meets it)
+    assert err["bf16"] < 1e-3                       # the bf16 mode meets north_star's 1e-3 gate on HEATMAPS at the bench shapes
+    assert lerr["bf16"] < 8e-3, lerr["bf16"]
+    assert loss_rel["bf16"] < 1e-4
+    assert grad_err["bf16"][worst["bf16"]] < 2e-2, (worst["bf16"], grad_err["bf16"][worst["bf16"]])
 
 
 def test_reference_per_op_fixtures_through_the_hip_kernels(gpu, golden_dir, observed):
@@ -211,15 +236,18 @@ def test_fp8_towers_accuracy_gate_on_config_a(gpu, observed):
     error, which is why bf16 stays the headline dtype."""
     from oracle import bifold_oracle as O
     from bifold.models import Models
-    B = 4
+    # B = 96: the vision tower's GEMMs have M = 96 x 197 = 18 912 >= 16 384 rows, i.e. they dispatch the PERSISTENT e4m3
+    # kernel (gemm_fp8_p8_kernel, csrc/gemm.hip) end to end; 8 of the 96 samples are checked against the CPU oracle
+    B, N_CHECK = 96, 8
     gen = torch.Generator().manual_seed(3407)
     state = {**O.make_clip_state(gen), **O.make_tail_state(gen)}
     sample = O.synthetic_sample(B, torch.Generator().manual_seed(3419))
     dev_sample = {k: v.to(gpu) for k, v in sample.items()}
+    sub = {k: v[:N_CHECK] for k, v in sample.items()}
     with torch.no_grad():
-        ref = O.rgb_clip_forward(state, sample, heads=16)
-        ref_vis = O.clip_vision_tokens(state, sample["rgb"])
-        ref_txt = O.clip_text_tokens(state, sample["instruction"])
+        ref = O.rgb_clip_forward(state, sub, heads=16)
+        ref_vis = O.clip_vision_tokens(state, sub["rgb"])
+        ref_txt = O.clip_text_tokens(state, sub["instruction"])
     seen = {}
     for dtype in ("fp8", "bf16"):
         with pytest.warns(UserWarning):
@@ -231,9 +259,9 @@ def test_fp8_towers_accuracy_gate_on_config_a(gpu, observed):
             out = model(dev_sample)
             vis = model.clip_encoder.encode_image_with_embeddings(dev_sample["rgb"], torch.bfloat16).float().view(B, 197, 768)
             txt = model.clip_encoder.encode_text_with_embeddings(dev_sample["instruction"], torch.bfloat16).view(B, 77, 512)
-        seen[f"{dtype}_heat"] = max(rel(out[k], ref[k]) for k in ("pick_heatmap", "place_heatmap"))
-        seen[f"{dtype}_vision"] = rel(vis, ref_vis)
-        seen[f"{dtype}_text"] = rel(txt, ref_txt)
+        seen[f"{dtype}_heat"] = max(rel(out[k][:N_CHECK], ref[k]) for k in ("pick_heatmap", "place_heatmap"))
+        seen[f"{dtype}_vision"] = rel(vis[:N_CHECK], ref_vis)
+        seen[f"{dtype}_text"] = rel(txt[:N_CHECK], ref_txt)
         del model
         torch.cuda.empty_cache()
     observed("fp8_towers_config_a", **seen)
@@ -313,3 +341,99 @@ def test_siglip_sequential_full_width_matches_oracle(gpu, observed):
         torch.cuda.empty_cache()
     observed("siglip_sequential_full_width", **seen)
     assert seen["fp32"] < 1e-3 and seen["bf16"] < 1.5e-3      # observed 2.2e-7 / 4.3e-4
+
+
+def _training_step_vs_oracle(gpu, cfg_of, sample, ref_forward, bim, dtypes, seed):
+    """fwd + loss + bwd of the build (one model per dtype, same init) against the fp32 CPU oracle under torch
+    autograd on the identical weights and batch: heatmaps, loss, every trainable gradient."""
+    from oracle import bifold_oracle as O
+    from bifold.losses import Losses
+    from bifold.models import Models
+    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=bim, mask_pick_heatmap=False))
+    dev_sample = {k: v.to(gpu) for k, v in sample.items()}
+    state, ref, seen = None, None, {}
+    for dtype in dtypes:
+        torch.manual_seed(seed)
+        with pytest.warns(UserWarning):
+            model = Models.get_by_name(cfg_of(dtype), device=gpu)
+        if state is None:
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            trainable = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+            rstate = {k: (v.clone().requires_grad_(True) if k in trainable else v) for k, v in state.items()}
+            rout = ref_forward(rstate, sample)
+            rloss, _ = O.bce_gaussmap(rout, sample, bim)
+            rgrads = dict(zip(trainable, torch.autograd.grad(rloss, [rstate[k] for k in trainable])))
+            ref = dict(out={k: v.detach() for k, v in rout.items() if k.endswith("_heatmap")}, loss=rloss.item())
+            del rout, rloss, rstate
+        else:
+            model.load_state_dict(state)
+        model = model.to(gpu).train()
+        out = model(dev_sample)
+        loss, _ = loss_fn(out, dev_sample)
+        model.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        named = dict(model.named_parameters())
+        gerr = {k: rel(named[k].grad, rgrads[k]) for k in trainable}
+        worst = max(gerr, key=gerr.get)
+        lg = {k: (torch.logit(out[k].detach().double().cpu().clamp(1e-300, 1 - 1e-16)),
+                  torch.logit(ref["out"][k].double().clamp(1e-300, 1 - 1e-16))) for k in ref["out"]}
+        seen[dtype] = dict(heat=max(rel(out[k], ref["out"][k]) for k in ref["out"]),
+                           logit=max(rel(a, b) for a, b in lg.values()),
+                           loss=abs(loss.item() - ref["loss"]) / abs(ref["loss"]),
+                           grad=gerr[worst], worst_grad=worst, median_grad=float(np.median(list(gerr.values()))))
+        del model, out, loss, named
+        torch.cuda.empty_cache()
+    return seen
+
+
+# gates of the full-width training-step tests: north_star's 1e-3 on heatmaps and loss for every mode; the 16-bit modes'
+# gradients carry their operand rounding (bf16 2^-9, fp16 2^-11) through 8 layers of backward -- ~3x observed
+STEP_GATES = {"fp32": dict(heat=1e-3, loss=1e-3, grad=1e-3), "bf16": dict(heat=1e-3, loss=1e-3, grad=3e-2)}
+
+
+def test_siglip_sequential_384_t4_training_step_matches_oracle(gpu, observed):
+    """BASELINE configs[2]'s model at its FULL size (reference conf/dataset/bimanual_sequential.yaml at 384 px, T = 4 as
+    BASELINE names it): SigLIP-base/16 @384 towers (576 patches), T = 4 context frames two of them masked, a
+    2 950-token fusion sequence with the query-row mask (models/siglip.py:85-137, models/pickplace.py:73-106) -- the
+    streamed d = 48 attention backward, the tanh-GELU towers, the 4-decoder collapse backward at width 768 -- one
+    training step (forward, BCE, backward) at B = 1 against the oracle under torch autograd."""
+    from oracle import bifold_oracle as O
+    B, T, S = 1, 4, 384
+    g = torch.Generator().manual_seed(21)
+    sample = {"rgb": torch.randn(B, 3, S, S, generator=g), "rgb_context": torch.randn(B, T, 3, S, S, generator=g),
+              "instruction": torch.randint(0, 32000, (B, 64), generator=g),
+              "context_attention_mask": torch.tensor([[1, 1, 0, 0]])}
+    for hn in O.decoder_heads(True):
+        sample[f"{hn}_heatmap"] = O.gaussian_heatmaps(torch.randint(0, S, (B, 2), generator=g), S)
+
+    def cfg_of(dtype):
+        return dict(name="siglip_sequential", image_size=S, is_bimanual=True, requires_graph=False, patch_size=16,
+                    automodel_name="google/siglip-base-patch16-384", dim=768, emb_dropout=0.0, lora=False, r=8,
+                    lora_alpha=32, lora_dropout=0.01, target_modules=["q_proj", "v_proj"], threshold=0.5,
+                    text_encoder=None, pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer",
+                    depth=8, heads=16, mlp_ratio=4, dropout=0.0, dtype=dtype, context_length=T)
+    seen = _training_step_vs_oracle(gpu, cfg_of, sample, lambda st, sm: O.siglip_sequential_forward(st, sm, 12, 16, True),
+                                    True, list(STEP_GATES), seed=23)
+    for dtype, v in seen.items():
+        observed(f"siglip_sequential_384_t4_step_{dtype}", **v)
+    for dtype, gate in STEP_GATES.items():
+        assert all(seen[dtype][k] < gate[k] for k in gate), (dtype, seen[dtype])
+
+
+def test_vitl14_336_training_step_matches_oracle(gpu, observed):
+    """BASELINE configs[3]'s model at full size (ViT-L/14 @336: 24 x 1024 vision tower, 577 tokens; width-768 text tower
+    and fusion over 655 tokens; the decoder upsamples the 24 x 24 patch grid x16 -> 384-pixel heatmaps and targets) --
+    one training step at B = 2 against the oracle under torch autograd."""
+    from oracle import bifold_oracle as O
+    B = 2
+    sample = O.synthetic_sample(B, torch.Generator().manual_seed(32), size=336, heat_size=384)
+
+    def cfg_of(dtype):
+        return dict(config_a(dtype), image_size=336, text_encoder="ViT-L/14@336px", patch_size=14)
+    seen = _training_step_vs_oracle(gpu, cfg_of, sample, lambda st, sm: O.rgb_clip_forward(st, sm, heads=16), False,
+                                    list(STEP_GATES), seed=33)
+    for dtype, v in seen.items():
+        observed(f"vitl14_336_step_{dtype}", **v)
+    for dtype, gate in STEP_GATES.items():
+        assert all(seen[dtype][k] < gate[k] for k in gate), (dtype, seen[dtype])
