@@ -238,11 +238,17 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["fp16", "bf16", "fp32"],
+                    help="16-bit MFMA operand type of the step (fp32 = the exact parity mode); fp16 = CLIP's native "
+                         "dtype with a loss-scaled backward, the mode that meets the 1e-3 gate on logits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--timer-stride", type=int, default=4,
-                    help="HIP-event pairs around the dominant kernel in every Nth timed step (1 = every step)")
+    ap.add_argument("--timer-stride", type=int, default=0,
+                    help="0 (default): the dominant kernel is timed in --roofline-steps extra steps AFTER the timed region, "
+                         "with the step's side streams folded into the main stream, so that a HIP-event pair brackets "
+                         "the kernel alone; N > 0: event pairs inside every Nth TIMED step instead (intervals then include "
+                         "the time the kernel shares the CUs with the side streams' kernels)")
+    ap.add_argument("--roofline-steps", type=int, default=4)
     ap.add_argument("--per-shape", action="store_true", help="diagnostic: time every GEMM shape separately")
     ap.add_argument("--all-kernels", action="store_true", help="time every matrix kernel, not just the dominant one")
     ap.add_argument("--host-fed", action="store_true",
@@ -279,6 +285,7 @@ def main():
     big = args.config == "vitl14"
     seq = args.config == "siglip_seq"
     fp8 = args.config == "fp8"
+    tag = {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[args.dtype]
     if fp8 and args.dtype != "bf16":
         raise SystemExit("--config fp8 is the bf16 step with e4m3 towers")
     cfg = dict(name="rgb_clip", image_size=336 if big else 224, is_bimanual=False, requires_graph=False,
@@ -343,14 +350,15 @@ def main():
             torch.cuda.synchronize()
 
     parity = None
-    if world == 1 and not args.no_parity and not big and not seq and args.dtype == "bf16":    # (fp8: its looser error is reported too)
+    check_parity = world == 1 and not args.no_parity and not big and not seq     # (fp8: its looser error is reported too)
+    if check_parity:
         parity = parity_vs_oracle(model, sample)       # untimed, before any training step
     for _ in range(args.warmup):
         step()
     fence()
     timer = None
+    dom_label = f"gemm_{tag}_nt"
     if not args.no_kernel_timer:
-        dom_label = "gemm_bf16_nt" if args.dtype == "bf16" else "gemm_f32_nt"
         # default: HIP events around the dominant kernel only (event pairs around EVERY matrix
         # kernel cost ~3 % of the step); --per-shape / --all-kernels time everything
         timer = ops.KernelTimer(per_shape=args.per_shape,
@@ -358,11 +366,12 @@ def main():
     # The event pairs are not free (each record is a barrier packet between two kernels: timing the dominant kernel in
     # EVERY step costs 1.5 % of the step, tools/ab_timer.sh), so the default samples every 4th timed step -- whole
     # steps, so that the mix of shapes is the step's -- and scales the share of the step accordingly.
-    stride = 1 if (args.per_shape or args.all_kernels or timer is None) else max(1, args.timer_stride)
+    in_step = timer is not None and (args.per_shape or args.all_kernels or args.timer_stride > 0)
+    stride = 1 if (args.per_shape or args.all_kernels) else max(1, args.timer_stride)
     timed_steps = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if timer is not None:
+        if in_step:
             on = i % stride == 0
             ops.PROFILER = timer if on else None
             timed_steps += int(on)
@@ -373,6 +382,39 @@ def main():
     final_loss = float(loss.item())
     if not (final_loss == final_loss and abs(final_loss) < 1e6):
         raise SystemExit(f"training diverged in the bench: loss = {final_loss}")
+    serial_ms = None
+    if timer is not None and not in_step and args.roofline_steps > 0:
+        # Roofline sample, OUTSIDE the timed region: the same step with its side streams folded into the main stream
+        # (text tower, weight-gradient GEMMs), so that a HIP-event pair on the launching stream brackets the dominant
+        # kernel ALONE -- in the concurrent step the same pair also spans the time the kernel shares the CUs with the
+        # side streams' kernels (157 us in-step against 86 - 130 us in the rocprof summary of round 2).
+        from bifold.models import pickplace as _pp
+        saved = (_pp._DW_SIDE, os.environ.get("BIFOLD_TEXT_STREAM"))
+        _pp._DW_SIDE = 0
+        os.environ["BIFOLD_TEXT_STREAM"] = "0"
+        try:
+            step()
+            fence()
+            ts = time.perf_counter()
+            for _ in range(args.roofline_steps):
+                ops.PROFILER = timer
+                step()
+                timed_steps += 1
+            fence()
+            serial_ms = 1e3 * (time.perf_counter() - ts) / args.roofline_steps
+        finally:
+            ops.PROFILER = None
+            _pp._DW_SIDE = saved[0]
+            if saved[1] is None:
+                os.environ.pop("BIFOLD_TEXT_STREAM", None)
+            else:
+                os.environ["BIFOLD_TEXT_STREAM"] = saved[1]
+    parity_trained = None
+    if check_parity:
+        # the same check on the weights AFTER the optimisation steps above: logits of a trained model are an order of
+        # magnitude larger than at random initialisation (max |logit| 0.17 there), which is what "relative" divides by
+        parity_trained = parity_vs_oracle(model, sample)
+        parity_trained["after_steps"] = opt.step_count
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -392,7 +434,7 @@ def main():
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8 (e4m3 towers: QKV / fc1) + bf16" if fp8 else ("bf16" if args.dtype == "bf16" else "f32"),
+            "dtype": "fp8 (e4m3 towers: QKV / fc1) + bf16" if fp8 else tag,
             "data": "synthetic (pinned host memory, H2D copy every step)" if args.host_fed else "synthetic",
             "config": {"workload": ("BASELINE configs[2] (diagnostic): siglip_sequential, SigLIP-base/16 @384 (576 patches), "
                                     "4 context frames with a random valid prefix, fusion 8x768 over 2 950 tokens, 4 "
@@ -418,7 +460,7 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
-            dom = "gemm_bf16_nt" if args.dtype == "bf16" else "gemm_f32_nt"
+            dom = dom_label
             if args.per_shape:
                 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
                     print(f"{v['ms'] / args.steps:8.3f} ms/step {v['launches'] / args.steps:5.1f}x {v['avg_us']:8.1f} us "
@@ -441,23 +483,29 @@ def main():
                 d["avg_us"] = 1e3 * d["ms"] / d["launches"]
                 d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12
             if d:
-                peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+                peak = PEAK_BF16_TFLOPS if args.dtype != "fp32" else 157.3     # fp16 and bf16 MFMA run at the same rate
                 traffic = profiled_traffic(dom)
                 line["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 2),
                                     "peak": peak, "unit": "TFLOP/s", "frac": round(d["tflops"] / peak, 4),
                                     "traffic": traffic[0] if traffic else None,
                                     "traffic_note": traffic[1] if traffic else "no PMC summary under profiles/",
                                     "launches": d["launches"], "avg_us": round(d["avg_us"], 2),
-                                    "share_of_step": round(d["ms"] / (1e3 * elapsed * timed_steps / args.steps), 4),
+                                    "share_of_step": round(d["ms"] / timed_steps / ms, 4),
                                     "timed_steps": timed_steps,
-                                    "timing": "HIP events on the launching stream around each bf_gemm host call "
-                                              "(one host call = 1 device launch, or 2 when the last round of tiles "
-                                              f"runs as a split-K tail), in {timed_steps} of the {args.steps} timed steps "
-                                              "(--timer-stride; every step costs 1.5 % of the step)",
+                                    "timing": ("HIP events on the launching stream around each bf_gemm host call (one host "
+                                               "call = 1 device launch, or 2 when the last round of tiles runs as a split-K "
+                                               "tail), " +
+                                               (f"in {timed_steps} of the {args.steps} timed steps (--timer-stride): the "
+                                                "intervals include the time the kernel shares the CUs with the side streams"
+                                                if in_step else
+                                                f"in {timed_steps} extra steps after the timed region with the side streams "
+                                                f"folded into the main stream ({serial_ms:.2f} ms/step that way): kernel "
+                                                "durations as the profiler sees them; share_of_step = this kernel's ms per "
+                                                "step / the timed ms_per_step")),
                                     "rocprof": rocprof_nt_average_us()}
             line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
                                    "tflops": round(v["tflops"], 1),
-                                   "share_of_step": round(v["ms"] / (1e3 * elapsed * timed_steps / args.steps), 4)}
+                                   "share_of_step": round(v["ms"] / timed_steps / ms, 4)}
                                for k, v in sorted(summ.items())}
         if big:
             line.pop("step_roofline", None)
@@ -465,6 +513,8 @@ def main():
             line.pop("roofline", None)
         if parity is not None:
             line["parity"] = parity
+        if parity_trained is not None:
+            line["parity_trained"] = parity_trained
         if world == 1 and not args.no_cpu_baseline and not big and not seq and not fp8:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

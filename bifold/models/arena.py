@@ -1,7 +1,7 @@
 """Flat parameter arenas.
 
 All trainable parameters of a model live in ONE contiguous fp32 buffer (and their
-gradients in a second one, their bf16 GEMM-operand copies in a third).  nn.Parameters
+gradients in a second one, their 16-bit (bf16 / fp16) GEMM-operand copies in a third).  nn.Parameters
 stay ordinary Parameters -- `state_dict()`, `named_parameters()`, checkpoints keep the
 reference's key names -- but their `.data` / `.grad` are views into the arenas, so that
 
@@ -23,7 +23,7 @@ ALIGN = 64  # elements; keeps every parameter 256-byte aligned (GEMM operands ne
 
 class ParamArena:
     def __init__(self, named_params: Iterable[Tuple[str, nn.Parameter]], *, with_grad: bool,
-                 with_shadow: bool):
+                 with_shadow: bool, shadow_dtype: torch.dtype = torch.bfloat16):
         items = [(n, p) for n, p in named_params]
         if not items:
             raise ValueError("ParamArena needs at least one parameter")
@@ -44,7 +44,7 @@ class ParamArena:
         self.count = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(off, dtype=torch.float32, device=dev) if with_grad else None
-        self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=dev) if with_shadow else None
+        self.shadow = torch.zeros(off, dtype=shadow_dtype, device=dev) if with_shadow else None
         for n, p in items:
             o, cnt = self.offsets[n]
             view = self.flat[o:o + cnt].view(p.shape)
@@ -77,11 +77,22 @@ class ParamArena:
         return g
 
     def operand(self, p: nn.Parameter, cdt: torch.dtype) -> torch.Tensor:
-        """The parameter in the compute dtype (bf16 shadow view, or the fp32 master)."""
+        """The parameter in the compute dtype (16-bit shadow view, or the fp32 master).  The shadow follows the
+        compute dtype that asks for it: an arena created with bf16 copies (the optimiser may build it before the model
+        runs) is re-cast once when an fp16 model takes its first operand."""
         if cdt == torch.float32:
             return p.data
+        if self.shadow is None or self.shadow.dtype != cdt:
+            self.set_shadow_dtype(cdt)
         o, cnt = self.offsets[self._by_id[id(p)]]
         return self.shadow[o:o + cnt].view(p.shape)
+
+    def set_shadow_dtype(self, dtype: torch.dtype) -> None:
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise TypeError(f"operand copies are bfloat16 or float16, got {dtype}")
+        if self.shadow is None or self.shadow.dtype != dtype:
+            self.shadow = torch.zeros(self.count, dtype=dtype, device=self.flat.device)
+            self.sync_shadow(force=True)
 
     def begin_backward(self) -> None:
         """The fused backward OVERWRITES the gradient arena; a second backward before the optimiser
@@ -109,7 +120,7 @@ class ParamArena:
         ver = sum(p._version for p in self.params)
         if force or ver != self._versions:
             from bifold_amd.hip import ops
-            ops.cast(self.flat, torch.bfloat16, out=self.shadow)
+            ops.cast(self.flat, self.shadow.dtype, out=self.shadow)
             self._versions = ver
 
     def mark_synced(self) -> None:

@@ -122,8 +122,11 @@ class CLIPEncoder(nn.Module):
     def _runtime(self, cdt: torch.dtype) -> ParamArena:
         a = self._arena
         if a is None or not a.still_bound() or (cdt != torch.float32 and a.shadow is None):
-            a = ParamArena(self.named_parameters(), with_grad=False, with_shadow=(cdt != torch.float32))
+            a = ParamArena(self.named_parameters(), with_grad=False, with_shadow=(cdt != torch.float32),
+                           shadow_dtype=cdt if cdt != torch.float32 else torch.bfloat16)
             self._arena = a
+        if cdt != torch.float32:
+            a.set_shadow_dtype(cdt)
         a.sync_shadow()
         return a
 
@@ -147,7 +150,7 @@ class CLIPEncoder(nn.Module):
         # to fetch before the first MFMA, half the bytes to store -- and the LayerNorm, which streams the residual
         # anyway, adds the branch's bf16 output on the way (in-step: 139 + 43 -> ~170 us for out-proj + ln_2 at the
         # vision tower's shape).  `final` = the LayerNorm after the last block (ln_post / ln_final), fused the same way.
-        fuse_add = (cdt == torch.bfloat16 and not fp8 and width in (256, 512, 768, 1024) and final is not None
+        fuse_add = (cdt in ops.HALF and not fp8 and width in (256, 512, 768, 1024) and final is not None
                     and os.environ.get("BIFOLD_ADD_LN", "1") != "0")
         h = None if fp8 else h0           # ln_1 of block 0, when the caller has already computed it (K1)
         for i in range(layers):

@@ -25,6 +25,7 @@ from bifold_amd.hip import lib as L
 from bifold_amd.hip import ops
 from . import Components
 from .arena import ParamArena
+from .gradscale import scaler_of
 from .streams import side_stream
 from .decoder_math import upsample_operator
 from .params import add_param, layernorm_init, linear_init
@@ -380,10 +381,11 @@ def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride
 
 
 def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstride: int, heat, w_eff, rows_ws,
-                      d_heats, d_tok, dtok_bstride: int, batch: int):
+                      d_heats, d_tok, dtok_bstride: int, batch: int, grad_scale: float = 1.0):
     """Backward of decoder_heads_fwd: writes d_tok (fp32 view like tok; token 0 gets zeros) and every
     decoder parameter gradient into the arena.  Returns the event after which the decoder gradients are
-    complete: the per-head collapse backward runs on the side stream."""
+    complete: the per-head collapse backward runs on the side stream.  `grad_scale` (fp16 mode, models/gradscale.py)
+    multiplies the low-resolution logit gradients, i.e. everything this function and its callers produce."""
     g = A.grad_view
     dim, nh = pp.dim, len(pp.heads_out)
     dev = tok.device
@@ -394,6 +396,8 @@ def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstrid
             g_low[h].zero_()
         else:
             ops.decoder_upsample_sigmoid_bwd(heat[h], d_heats[h].contiguous(), U, batch, pp.grid, out=g_low[h])
+    if grad_scale != 1.0:
+        ops.scale_check_(g_low, grad_scale)
     g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
     g_b = torch.empty(nh, dtype=torch.float32, device=dev)
     ops.decoder_project_bwd(tok, tok_bstride, w_eff, g_low, d_tok, dtok_bstride, g_w, g_b, batch, nh,
@@ -429,9 +433,10 @@ def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch:
     return heat, saved
 
 
-def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heats, on_layer_done=None):
+def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heats, on_layer_done=None,
+                       grad_scale: float = 1.0):
     """Backward of fusion_decoder_fwd: writes every fusion / decoder parameter gradient into the
-    arena and returns d(fusion input) fp32 [B*seq, dim]."""
+    arena and returns d(fusion input) fp32 [B*seq, dim] (all of it times `grad_scale`)."""
     dim = pp.dim
     batch, seq = S["batch"], S["seq"]
     dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=S["x_out"].device)
@@ -439,7 +444,7 @@ def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heat
     xv = S["x_out"].view(batch, seq, dim)
     dxv = dx.view(batch, seq, dim)
     dec_done = decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"], d_heats,
-                                 dxv[:, first:], seq * dim, batch)
+                                 dxv[:, first:], seq * dim, batch, grad_scale)
     joined = []
 
     def layer_done(i):             # the decoders' gradients leave with the first bucket: join before it is reported
@@ -591,7 +596,9 @@ class RGBTailFn(torch.autograd.Function):
         cdt = model.compute_dtype
         g = A.grad_view
         dim = pp.dim
-        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, model._grad_ready)
+        gs = scaler_of(model)                                  # fp16: static loss scale (models/gradscale.py)
+        ready = gs.ready if gs is not None else model._grad_ready
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else 1.0)
         d_rgb = ops.fusion_assemble_bwd(dx, cdt, g(model.text_token).view(-1),
                                         g(model.text_pos_embedding).view(-1, dim),
                                         g(model.rgb_pos_embedding).view(-1, dim),
@@ -600,7 +607,7 @@ class RGBTailFn(torch.autograd.Function):
         # d project.bias = the sum of d rgb_feat over every image token of the batch = the gradient of the image
         # modality's type embedding, which the assembly backward has just reduced in fp32
         g(model.project.bias).copy_(g(pp.fusion.token_type_embeddings.weight)[1])
-        model._grad_ready(-1)
+        ready(-1)
         ctx.c = None
         # gradients were written into the arena (and attached as .grad) by the kernels
         return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))
@@ -655,7 +662,9 @@ class SegmentTailFn(torch.autograd.Function):
         cdt = model.compute_dtype
         g = A.grad_view
         dim = pp.dim
-        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, model._grad_ready)
+        gs = scaler_of(model)                                  # fp16: static loss scale (models/gradscale.py)
+        ready = gs.ready if gs is not None else model._grad_ready
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else 1.0)
         d_type = g(pp.fusion.token_type_embeddings.weight)
         d_type.zero_()
         leads = {id(sg["lead"]): sg["lead"] for sg in c.segments}
@@ -669,6 +678,6 @@ class SegmentTailFn(torch.autograd.Function):
             ops.segment_assemble_bwd(dx, g(sg["lead"]).view(-1), d_pos, d_type[sg["modality"]], c.batch, sg["n"],
                                      c.seq, sg["row_off"])
         model.tower_backward(dx, c.segments, c.batch, c.seq)    # LoRA adapters of the towers (no-op when frozen)
-        model._grad_ready(-1)
+        ready(-1)
         ctx.c = None
         return (None, None, None) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))

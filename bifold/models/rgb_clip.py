@@ -23,18 +23,20 @@ from .params import add_param, linear_init
 from .pickplace import RGBTailFn
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
-           "float32": torch.float32, "fp8": torch.bfloat16}
+           "float32": torch.float32, "fp8": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16,
+           "float16": torch.float16}
 
 
 class RGBOnly(BaseModel):
     def __init__(self, patch_size, text_dropout, rgb_dropout, text_encoder, pick_place_model,
-                 dtype="bf16", clip_checkpoint=None, **kwargs):
+                 dtype="bf16", clip_checkpoint=None, loss_scale="auto", **kwargs):
         super().__init__(**kwargs)
         if text_dropout != 0.0 or rgb_dropout != 0.0:
             raise NotImplementedError("dropout > 0 is not implemented on the HIP path")
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
         self.compute_dtype = _DTYPES[dtype]
+        self.loss_scale = loss_scale                           # fp16 mode only (models/gradscale.py)
         self.patch_size = patch_size
         self.rgb_size = self.image_size
         assert self.rgb_size % self.patch_size == 0, "Image dimensions must be divisible by the patch size."

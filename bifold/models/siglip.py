@@ -26,16 +26,18 @@ from .arena import ParamArena, arena_of
 from .pickplace import SegmentTailFn
 from .siglip_encoder import from_pretrained
 
-_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
+           "fp16": torch.float16, "f16": torch.float16, "float16": torch.float16}
 
 
 class SigLip(BaseModel):
     def __init__(self, patch_size, dim, lora, r, lora_alpha, lora_dropout, automodel_name, target_modules,
-                 pick_place_model, dtype="bf16", siglip_checkpoint=None, **kwargs):
+                 pick_place_model, dtype="bf16", siglip_checkpoint=None, loss_scale="auto", **kwargs):
         super().__init__(**kwargs)
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
         self.compute_dtype = _DTYPES[dtype]
+        self.loss_scale = loss_scale                           # fp16 mode only (models/gradscale.py)
         self.patch_size = patch_size
         self.lora = bool(lora)
         adapters = (dict(r=r, alpha=lora_alpha, targets=list(target_modules), adapter="siglip_adapter",

@@ -173,9 +173,12 @@ class SiglipTowers(nn.Module):
         if a is None or not a.still_bound() or (cdt != torch.float32 and a.shadow is None):
             # the adapters live in the MODEL's trainable arena (gradients, Adam state), not here
             a = ParamArena([(n, p) for n, p in self.named_parameters() if ".lora_" not in n],
-                           with_grad=False, with_shadow=(cdt != torch.float32))
+                           with_grad=False, with_shadow=(cdt != torch.float32),
+                           shadow_dtype=cdt if cdt != torch.float32 else torch.bfloat16)
             self._arena = a
             self._packed_version = -1
+        if cdt != torch.float32:
+            a.set_shadow_dtype(cdt)
         a.sync_shadow()
         ver = sum(p._version for p in a.params)
         if ver != self._packed_version or self._packed.get("dtype") != cdt:

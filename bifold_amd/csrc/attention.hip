@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
 //      V^T tile [DP][KT keys'] bf16, row stride KT*2+16 bytes; DP = D rounded up to 32;
 //      within every 16-key group the key index has bits 2 and 3 swapped, which is the k
 //      order of an accumulator tile reused as an MFMA operand (guide §3).
-template <int D, int MASK>
+template <int D, int MASK, typename HT>
 __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+    const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse,
     const int32_t* __restrict__ row_mask, int L, int H, float scale, int waves_per_block) {
     constexpr int mask_mode = MASK;
     constexpr int DP = (D + 31) / 32 * 32;
@@ -264,13 +264,13 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
     const bool q_live = qi < L;
 
     // Q fragments (B operand): B[k = 8hh + j][col r] = Q[qi][16 ks + 8 hh + j]
-    bf16x8 qf[KS];
+    typename H16<HT>::x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (q_live) qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+        if (q_live) qf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
         else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (HT)0.f;
         }
     }
     const bool row_masked = q_live && mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
             for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(k_lds + (kb * 32 + r) * KROW + ks * 32 + hh * 16);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (kb * 32 + r) * KROW + ks * 32 + hh * 16);
+                sacc[kb] = mfma_32x32x16(kf, qf[ks], sacc[kb]);
             }
         }
         // ---- masks + online softmax (log2 domain; raw scores stay in sacc) --------------
@@ -381,42 +381,42 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 pf;
+                typename H16<HT>::x8 pf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[kb][8 * s + e];
+                for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[kb][8 * s + e];
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const bf16x8 vf =
-                        *(const bf16x8*)(v_lds + (db * 32 + r) * VROW + (kb * 32 + s * 16 + hh * 8) * 2);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                    const typename H16<HT>::x8 vf =
+                        *(const typename H16<HT>::x8*)(v_lds + (db * 32 + r) * VROW + (kb * 32 + s * 16 + hh * 8) * 2);
+                    oacc[db] = mfma_32x32x16(vf, pf, oacc[db]);
                 }
             }
     }
 
     if (q_live) {
         const float inv = 1.0f / l;
-        bf16_t* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
+        HT* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 o4;
+                    typename H16<HT>::x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)(oacc[db][4 * g + e] * inv);
-                    *(bf16x4*)(op + d0) = o4;
+                    for (int e = 0; e < 4; ++e) o4[e] = (HT)(oacc[db][4 * g + e] * inv);
+                    *(typename H16<HT>::x4*)(op + d0) = o4;
                 }
             }
         if (lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
     }
 }
 
-typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
-__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p0);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)p1);
-    bf16x8 r;
+template <typename HT>
+__device__ __forceinline__ typename H16<HT>::x8 tr_pair(const char* p0, const char* p1) {
+    const typename H16<HT>::x4 lo = lds_read_tr16<HT>(p0);
+    const typename H16<HT>::x4 hi = lds_read_tr16<HT>(p1);
+    typename H16<HT>::x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -432,9 +432,9 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 // are loaded ONCE, row-major, and every wave then walks all key tiles without a barrier;
 // V^T fragments come from the row-major image by ds_read_b64_tr_b16 (the recipe of the
 // backward kernel's dO^T / Q^T operands).  Same arithmetic, same order as the tiled kernel.
-template <int D, int MASK, int NKB>
+template <int D, int MASK, int NKB, typename HT>
 __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+    const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse,
     const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp, int nt_loads) {
     constexpr int mask_mode = MASK;
     constexpr int DP = (D + 31) / 32 * 32;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     // about the size of the Infinity Cache): streamed with the non-temporal hint it does not push out the
     // residual stream the next GEMM's epilogue needs.
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    auto ld16 = [&](const bf16_t* p) -> uint4 {
+    auto ld16 = [&](const HT* p) -> uint4 {
         if (nt_loads) {
             const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
             return make_uint4(v[0], v[1], v[2], v[3]);
@@ -477,15 +477,15 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         *(uint4*)(v_lds + j * VROW + c * 16) = vv;
     }
 
-    bf16x8 qf[KS];
+    typename H16<HT>::x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (q_live) {
             const uint4 qq = ld16(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
-            qf[ks] = *(const bf16x8*)&qq;
+            qf[ks] = *(const typename H16<HT>::x8*)&qq;
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (HT)0.f;
         }
     }
     const bool row_masked = q_live && mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
@@ -510,8 +510,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
             for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(k_lds + (j0 + kb * 32 + r) * KROW + ks * 32 + hh * 16);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (j0 + kb * 32 + r) * KROW + ks * 32 + hh * 16);
+                sacc[kb] = mfma_32x32x16(kf, qf[ks], sacc[kb]);
             }
         }
         const bool edge = (j0 + NKB * 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + NKB * 32 - 1 > q0);
@@ -567,15 +567,15 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 pf;
+                typename H16<HT>::x8 pf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[kb][8 * s + e];
+                for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[kb][8 * s + e];
                 const int row0 = j0 + kb * 32 + 16 * s + 4 * hh + q4;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                    const bf16x8 vf = tr_pair(v_lds + row0 * VROW + cb, v_lds + (row0 + 8) * VROW + cb);
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[db], 0, 0, 0);
+                    const typename H16<HT>::x8 vf = tr_pair<HT>(v_lds + row0 * VROW + cb, v_lds + (row0 + 8) * VROW + cb);
+                    oacc[db] = mfma_32x32x16(vf, pf, oacc[db]);
                 }
             }
     }
@@ -594,10 +594,10 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 o4;
+                    typename H16<HT>::x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)(oacc[db][4 * g + e] * inv);
-                    *(bf16x4*)(ot + r * KROW + d0 * 2) = o4;
+                    for (int e = 0; e < 4; ++e) o4[e] = (HT)(oacc[db][4 * g + e] * inv);
+                    *(typename H16<HT>::x4*)(ot + r * KROW + d0 * 2) = o4;
                 }
             }
     }
@@ -646,10 +646,10 @@ struct BwdCfg {
 // rows.  dK/dV stay in registers across all query tiles.  Each tile's dQ is accumulated in LDS
 // and flushed when the tile is done: straight to dqkv when there is a single key chunk,
 // otherwise by fp32 atomics into dq_ws [B, L, H*D] (cast to bf16 by attn_dq_cast_kernel).
-template <int D, int MASK>
+template <int D, int MASK, typename HT>
 __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
     float* __restrict__ dq_ws, int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
@@ -685,15 +685,15 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
         *(uint4*)(k_lds + i * ROW + c * 16) = kv;
     }
     const int key = key0 + w * 32 + r;
-    bf16x8 kf[KS], vf[KS];
+    typename H16<HT>::x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (key < L) {
-            kf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
-            vf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+            kf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
+            vf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[ks][e] = (bf16_t)0.f; vf[ks][e] = (bf16_t)0.f; }
+            for (int e = 0; e < 8; ++e) { kf[ks][e] = (HT)0.f; vf[ks][e] = (HT)0.f; }
         }
     }
     f32x16 dkacc[DB], dvacc[DB];
@@ -730,8 +730,8 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
                 const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
 #pragma unroll
                 for (int c = 0; c < D / 8; ++c) {
-                    const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
-                    const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
+                    const typename H16<HT>::x8 ov = *(const typename H16<HT>::x8*)(out + oo + c * 8);
+                    const typename H16<HT>::x8 gv = *(const typename H16<HT>::x8*)(dout + oo + c * 8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
                 }
@@ -763,10 +763,10 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 qa = *(const bf16x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-                    const bf16x8 da = *(const bf16x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
-                    pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+                    const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+                    const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+                    sacc = mfma_32x32x16(qa, kf[ks], sacc);
+                    pacc = mfma_32x32x16(da, vf[ks], pacc);
                 }
                 // ---- P and dS (lane = key column, register = query row) -----------------------
 #pragma unroll
@@ -781,18 +781,18 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
                     sacc[e] = p;
                     pacc[e] = ds;
                 }
-                bf16x8 pb[2], dsb[2];
+                typename H16<HT>::x8 pb[2], dsb[2];
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+                    for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
                 // dS image for dQ: [key column][query row], 64-byte rows
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    bf16x4 v4;
+                    typename H16<HT>::x4 v4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)pacc[4 * g + e];
-                    *(bf16x4*)(my_img + r * 64 + (8 * g + 4 * hh) * 2) = v4;
+                    for (int e = 0; e < 4; ++e) v4[e] = (HT)pacc[4 * g + e];
+                    *(typename H16<HT>::x4*)(my_img + r * 64 + (8 * g + 4 * hh) * 2) = v4;
                 }
                 // ---- dV^T += dO^T P ;  dK^T += Q^T dS   (A operands by transposed LDS reads) ----
 #pragma unroll
@@ -801,10 +801,10 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
 #pragma unroll
                     for (int db = 0; db < DB; ++db) {
                         const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                        const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
-                        const bf16x8 qtt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
-                        dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
-                        dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtt, dsb[s], dkacc[db], 0, 0, 0);
+                        const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                        const typename H16<HT>::x8 qtt = tr_pair<HT>(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                        dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
+                        dkacc[db] = mfma_32x32x16(qtt, dsb[s], dkacc[db]);
                     }
                 }
                 // ---- dQ_qb += dS K_w : A = dS^T image (transposed read), B = K rows (transposed read)
@@ -820,11 +820,11 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
                     for (int s = 0; s < 2; ++s) {
                         const int krow = 16 * s + 8 * hh + q4;          // key within the block (natural k order)
                         const int cq = (16 * (g16 & 1) + 4 * p4) * 2;   // query column in the image
-                        const bf16x8 a = tr_pair(my_img + krow * 64 + cq, my_img + (krow + 4) * 64 + cq);
+                        const typename H16<HT>::x8 a = tr_pair<HT>(my_img + krow * 64 + cq, my_img + (krow + 4) * 64 + cq);
                         const int cd = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
                         const char* kr = k_lds + (w * 32 + krow) * ROW + cd;
-                        const bf16x8 kb2 = tr_pair(kr, kr + 4 * ROW);
-                        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kb2, dq, 0, 0, 0);
+                        const typename H16<HT>::x8 kb2 = tr_pair<HT>(kr, kr + 4 * ROW);
+                        dq = mfma_32x32x16(a, kb2, dq);
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -840,10 +840,10 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
         if (n_chunks == 1) {
             for (int idx = threadIdx.x; idx < rows * (D / 8); idx += nthreads) {
                 const int i = idx / (D / 8), c = idx - i * (D / 8);
-                bf16x8 o8;
+                typename H16<HT>::x8 o8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] = (bf16_t)dq_lds[i * DP + c * 8 + e];
-                *(bf16x8*)(dqkv + qkv_off(b, qbase + i, 0, h, L, H, D) + c * 8) = o8;
+                for (int e = 0; e < 8; ++e) o8[e] = (HT)dq_lds[i * DP + c * 8 + e];
+                *(typename H16<HT>::x8*)(dqkv + qkv_off(b, qbase + i, 0, h, L, H, D) + c * 8) = o8;
             }
         } else {
             for (int idx = threadIdx.x; idx < rows * D; idx += nthreads) {
@@ -855,19 +855,19 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
 
     // ---- epilogue: dK, dV from the accumulators (lane = key, 4 consecutive d per store) -------
     if (key < L) {
-        bf16_t* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
-        bf16_t* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+        HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+        HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 k4, v4;
+                    typename H16<HT>::x4 k4, v4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { k4[e] = (bf16_t)dkacc[db][4 * g + e]; v4[e] = (bf16_t)dvacc[db][4 * g + e]; }
-                    *(bf16x4*)(dkp + d0) = k4;
-                    *(bf16x4*)(dvp + d0) = v4;
+                    for (int e = 0; e < 4; ++e) { k4[e] = (HT)dkacc[db][4 * g + e]; v4[e] = (HT)dvacc[db][4 * g + e]; }
+                    *(typename H16<HT>::x4*)(dkp + d0) = k4;
+                    *(typename H16<HT>::x4*)(dvp + d0) = v4;
                 }
             }
     }
@@ -905,10 +905,10 @@ extern "C" int bf_debug_attn_probe(unsigned long long* out) {
 #define ATTN_STAMP(slot) do {} while (0)
 #endif
 
-template <int D, int MASK>
+template <int D, int MASK, typename HT>
 __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
     float* __restrict__ delta_ws, int L, int H, float scale, int Lp) {
     constexpr int mask_mode = MASK;
     constexpr int DP = (D + 31) / 32 * 32;
@@ -956,20 +956,20 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     const int q0 = blk * 32;
     const int qi = q0 + r;
     const bool q_live = qi < L;
-    bf16x8 qf[KS], dof[KS];
+    typename H16<HT>::x8 qf[KS], dof[KS];
     float delta = 0.f, lse_q = 1e30f;
     bool row_masked = false;
     if (q_live) {
         const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
-            dof[ks] = *(const bf16x8*)(dout + oo + ks * 16 + hh * 8);
+            qf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+            dof[ks] = *(const typename H16<HT>::x8*)(dout + oo + ks * 16 + hh * 8);
         }
 #pragma unroll
         for (int c = 0; c < D / 8; ++c) {
-            const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
-            const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
+            const typename H16<HT>::x8 ov = *(const typename H16<HT>::x8*)(out + oo + c * 8);
+            const typename H16<HT>::x8 gv = *(const typename H16<HT>::x8*)(dout + oo + c * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) delta = fmaf((float)ov[e], (float)gv[e], delta);
         }
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { qf[ks][e] = (bf16_t)0.f; dof[ks][e] = (bf16_t)0.f; }
+            for (int e = 0; e < 8; ++e) { qf[ks][e] = (HT)0.f; dof[ks][e] = (HT)0.f; }
     }
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
@@ -999,10 +999,10 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
         for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf = *(const bf16x8*)(k_lds + (j0 + r) * KROW + ks * 32 + hh * 16);
-            const bf16x8 vf = *(const bf16x8*)(v_lds + (j0 + r) * VROW + ks * 32 + hh * 16);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+            const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (j0 + r) * KROW + ks * 32 + hh * 16);
+            const typename H16<HT>::x8 vf = *(const typename H16<HT>::x8*)(v_lds + (j0 + r) * VROW + ks * 32 + hh * 16);
+            sacc = mfma_32x32x16(kf, qf[ks], sacc);
+            pacc = mfma_32x32x16(vf, dof[ks], pacc);
         }
         // dS^T (rows = keys, lane = query); masked scores carry no gradient
         const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
@@ -1028,31 +1028,31 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 pf;
+            typename H16<HT>::x8 pf;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[8 * s + e];
+            for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[8 * s + e];
             const int row0 = j0 + 16 * s + 4 * hh + q4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                const bf16x8 kt = tr_pair(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
-                dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, pf, dqacc[db], 0, 0, 0);
+                const typename H16<HT>::x8 kt = tr_pair<HT>(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
+                dqacc[db] = mfma_32x32x16(kt, pf, dqacc[db]);
             }
         }
     }
 
     if (q_live) {
-        bf16_t* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
+        HT* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 o4;
+                    typename H16<HT>::x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)dqacc[db][4 * g + e];
-                    *(bf16x4*)(dq + d0) = o4;
+                    for (int e = 0; e < 4; ++e) o4[e] = (HT)dqacc[db][4 * g + e];
+                    *(typename H16<HT>::x4*)(dq + d0) = o4;
                 }
             }
     }
@@ -1064,10 +1064,10 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #endif
 }
 
-template <int D, int MASK>
+template <int D, int MASK, typename HT>
 __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    const HT* __restrict__ qkv, const HT* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
     int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
@@ -1115,15 +1115,15 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
     __syncthreads();
     for (int w = blockIdx.y * wpb + slot; w < nw; w += blk_stride) {
     const int key = w * 32 + r;
-    bf16x8 kf[KS], vf[KS];
+    typename H16<HT>::x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (key < L) {
-            kf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
-            vf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+            kf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
+            vf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[ks][e] = (bf16_t)0.f; vf[ks][e] = (bf16_t)0.f; }
+            for (int e = 0; e < 8; ++e) { kf[ks][e] = (HT)0.f; vf[ks][e] = (HT)0.f; }
         }
     }
     f32x16 dkacc[DB], dvacc[DB];
@@ -1150,10 +1150,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qa = *(const bf16x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-            const bf16x8 da = *(const bf16x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+            const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+            const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+            sacc = mfma_32x32x16(qa, kf[ks], sacc);
+            pacc = mfma_32x32x16(da, vf[ks], pacc);
         }
         const f32x2 sl2v = {sl2, sl2}, onv = {lane_on, lane_on}, scalev = {scale, scale};
 #pragma unroll
@@ -1172,39 +1172,39 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
             sacc[e] = p2[0]; sacc[e + 1] = p2[1];
             pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
         }
-        bf16x8 pb[2], dsb[2];
+        typename H16<HT>::x8 pb[2], dsb[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+            for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int row0 = qrow0 + 16 * s + 4 * hh + q4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
-                const bf16x8 qtt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
-                dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
-                dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtt, dsb[s], dkacc[db], 0, 0, 0);
+                const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                const typename H16<HT>::x8 qtt = tr_pair<HT>(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
+                dkacc[db] = mfma_32x32x16(qtt, dsb[s], dkacc[db]);
             }
         }
     }
 
     if (key < L) {
-        bf16_t* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
-        bf16_t* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+        HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+        HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 k4, v4;
+                    typename H16<HT>::x4 k4, v4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { k4[e] = (bf16_t)dkacc[db][4 * g + e]; v4[e] = (bf16_t)dvacc[db][4 * g + e]; }
-                    *(bf16x4*)(dkp + d0) = k4;
-                    *(bf16x4*)(dvp + d0) = v4;
+                    for (int e = 0; e < 4; ++e) { k4[e] = (HT)dkacc[db][4 * g + e]; v4[e] = (HT)dvacc[db][4 * g + e]; }
+                    *(typename H16<HT>::x4*)(dkp + d0) = k4;
+                    *(typename H16<HT>::x4*)(dvp + d0) = v4;
                 }
             }
     }
@@ -1235,10 +1235,10 @@ struct StreamCfg {
     static constexpr int NPF_KV = (CH * (D / 8) + NT - 1) / NT;   // (kv kernel: Q, dO)
 };
 
-template <int D, int MASK>
+template <int D, int MASK, typename HT>
 __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
-    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout,
+    const float* __restrict__ lse, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
     float* __restrict__ delta_ws, int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using SC = StreamCfg<D>;
@@ -1289,20 +1289,20 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
         }
     };
 
-    bf16x8 qf[KS], dof[KS];
+    typename H16<HT>::x8 qf[KS], dof[KS];
     float delta = 0.f, lse_q = 1e30f;
     bool row_masked = false;
     if (q_live) {
         const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *(const bf16x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
-            dof[ks] = *(const bf16x8*)(dout + oo + ks * 16 + hh * 8);
+            qf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+            dof[ks] = *(const typename H16<HT>::x8*)(dout + oo + ks * 16 + hh * 8);
         }
 #pragma unroll
         for (int c = 0; c < D / 8; ++c) {
-            const bf16x8 ov = *(const bf16x8*)(out + oo + c * 8);
-            const bf16x8 gv = *(const bf16x8*)(dout + oo + c * 8);
+            const typename H16<HT>::x8 ov = *(const typename H16<HT>::x8*)(out + oo + c * 8);
+            const typename H16<HT>::x8 gv = *(const typename H16<HT>::x8*)(dout + oo + c * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) delta = fmaf((float)ov[e], (float)gv[e], delta);
         }
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { qf[ks][e] = (bf16_t)0.f; dof[ks][e] = (bf16_t)0.f; }
+            for (int e = 0; e < 8; ++e) { qf[ks][e] = (HT)0.f; dof[ks][e] = (HT)0.f; }
     }
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
@@ -1349,10 +1349,10 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
             for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(k_lds + (jl + r) * KROW + ks * 32 + hh * 16);
-                const bf16x8 vf = *(const bf16x8*)(v_lds + (jl + r) * VROW + ks * 32 + hh * 16);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], pacc, 0, 0, 0);
+                const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (jl + r) * KROW + ks * 32 + hh * 16);
+                const typename H16<HT>::x8 vf = *(const typename H16<HT>::x8*)(v_lds + (jl + r) * VROW + ks * 32 + hh * 16);
+                sacc = mfma_32x32x16(kf, qf[ks], sacc);
+                pacc = mfma_32x32x16(vf, dof[ks], pacc);
             }
             const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
             const f32x2 sl2v = {sl2, sl2}, scalev = {scale, scale};
@@ -1377,41 +1377,41 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8 pf;
+                typename H16<HT>::x8 pf;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sacc[8 * s + e];
+                for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[8 * s + e];
                 const int row0 = jl + 16 * s + 4 * hh + q4;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                    const bf16x8 kt = tr_pair(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
-                    dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, pf, dqacc[db], 0, 0, 0);
+                    const typename H16<HT>::x8 kt = tr_pair<HT>(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
+                    dqacc[db] = mfma_32x32x16(kt, pf, dqacc[db]);
                 }
             }
         }
     }
 
     if (q_live) {
-        bf16_t* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
+        HT* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 o4;
+                    typename H16<HT>::x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (bf16_t)dqacc[db][4 * g + e];
-                    *(bf16x4*)(dq + d0) = o4;
+                    for (int e = 0; e < 4; ++e) o4[e] = (HT)dqacc[db][4 * g + e];
+                    *(typename H16<HT>::x4*)(dq + d0) = o4;
                 }
             }
     }
 }
 
-template <int D, int MASK>
+template <int D, int MASK, typename HT>
 __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel(
-    const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, bf16_t* __restrict__ dqkv,
+    const HT* __restrict__ qkv, const HT* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
     int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
@@ -1478,15 +1478,15 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
     };
 
     const int key = w * 32 + r;
-    bf16x8 kf[KS], vf[KS];
+    typename H16<HT>::x8 kf[KS], vf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (key < L) {
-            kf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
-            vf[ks] = *(const bf16x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+            kf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
+            vf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[ks][e] = (bf16_t)0.f; vf[ks][e] = (bf16_t)0.f; }
+            for (int e = 0; e < 8; ++e) { kf[ks][e] = (HT)0.f; vf[ks][e] = (HT)0.f; }
         }
     }
     f32x16 dkacc[DB], dvacc[DB];
@@ -1520,17 +1520,17 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
                 // every (query, key), dS = 0 -> only dV^T += dO^T P is left, no scores, no exp, no dK
                 const int qrow = qrow0 + r;
                 if (__all(msk_s[lq0 + r] != 0 || qrow >= L)) {
-                    bf16x8 pconst;
+                    typename H16<HT>::x8 pconst;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) pconst[e] = (bf16_t)(inv_len * lane_on);
+                    for (int e = 0; e < 8; ++e) pconst[e] = (HT)(inv_len * lane_on);
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         const int row0 = lq0 + 16 * s + 4 * hh + q4;
 #pragma unroll
                         for (int db = 0; db < DB; ++db) {
                             const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                            const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
-                            dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pconst, dvacc[db], 0, 0, 0);
+                            const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                            dvacc[db] = mfma_32x32x16(dot, pconst, dvacc[db]);
                         }
                     }
                     continue;
@@ -1547,10 +1547,10 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
             }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 qa = *(const bf16x8*)(q_lds + (lq0 + r) * ROW + ks * 32 + hh * 16);
-                const bf16x8 da = *(const bf16x8*)(do_lds + (lq0 + r) * ROW + ks * 32 + hh * 16);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], pacc, 0, 0, 0);
+                const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)(q_lds + (lq0 + r) * ROW + ks * 32 + hh * 16);
+                const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(do_lds + (lq0 + r) * ROW + ks * 32 + hh * 16);
+                sacc = mfma_32x32x16(qa, kf[ks], sacc);
+                pacc = mfma_32x32x16(da, vf[ks], pacc);
             }
             const f32x2 sl2v = {sl2, sl2}, onv = {lane_on, lane_on}, scalev = {scale, scale};
 #pragma unroll
@@ -1569,54 +1569,55 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
                 sacc[e] = p2[0]; sacc[e + 1] = p2[1];
                 pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
             }
-            bf16x8 pb[2], dsb[2];
+            typename H16<HT>::x8 pb[2], dsb[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { pb[s][e] = (bf16_t)sacc[8 * s + e]; dsb[s][e] = (bf16_t)pacc[8 * s + e]; }
+                for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int row0 = lq0 + 16 * s + 4 * hh + q4;
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                    const bf16x8 dot = tr_pair(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
-                    const bf16x8 qtt = tr_pair(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
-                    dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pb[s], dvacc[db], 0, 0, 0);
-                    dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtt, dsb[s], dkacc[db], 0, 0, 0);
+                    const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
+                    const typename H16<HT>::x8 qtt = tr_pair<HT>(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                    dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
+                    dkacc[db] = mfma_32x32x16(qtt, dsb[s], dkacc[db]);
                 }
             }
         }
     }
 
     if (key < L) {
-        bf16_t* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
-        bf16_t* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+        HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+        HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = db * 32 + 8 * g + 4 * hh;
                 if (d0 < D) {
-                    bf16x4 k4, v4;
+                    typename H16<HT>::x4 k4, v4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { k4[e] = (bf16_t)dkacc[db][4 * g + e]; v4[e] = (bf16_t)dvacc[db][4 * g + e]; }
-                    *(bf16x4*)(dkp + d0) = k4;
-                    *(bf16x4*)(dvp + d0) = v4;
+                    for (int e = 0; e < 4; ++e) { k4[e] = (HT)dkacc[db][4 * g + e]; v4[e] = (HT)dvacc[db][4 * g + e]; }
+                    *(typename H16<HT>::x4*)(dkp + d0) = k4;
+                    *(typename H16<HT>::x4*)(dvp + d0) = v4;
                 }
             }
     }
 }
 
 // dq_ws fp32 [B, L, H*D] -> the Q slot of dqkv [B, L, 3, H, D] (bf16)
-__global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, bf16_t* __restrict__ dqkv,
+template <typename HT>
+__global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, HT* __restrict__ dqkv,
                                                            size_t rows, int hd) {
     const int c4n = hd >> 2;
     const size_t total = rows * c4n;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t row = i / c4n;
         const int c = (int)(i - row * c4n) * 4;
-        Vec4<bf16_t>::store(dqkv + row * 3 * hd + c, *(const float4*)(dq_ws + row * hd + c));
+        Vec4<HT>::store(dqkv + row * 3 * hd + c, *(const float4*)(dq_ws + row * hd + c));
     }
 }
 
@@ -1630,7 +1631,7 @@ static int attn_check(const char* who, const void* qkv, int batch, int seq, int 
                "%s: head_dim must be 32, 48 or 64 (got %d)", who, head_dim);
     BF_REQUIRE(mask_mode >= BF_MASK_NONE && mask_mode <= BF_MASK_QUERY_ROW, BF_EINVAL, "%s: bad mask_mode", who);
     BF_REQUIRE(mask_mode != BF_MASK_QUERY_ROW || row_mask, BF_EINVAL, "%s: row_mask is NULL", who);
-    BF_REQUIRE(cdt == BF_F32 || cdt == BF_BF16, BF_EINVAL, "%s: bad cdt", who);
+    BF_REQUIRE(cdt == BF_F32 || bf_is_half(cdt), BF_EINVAL, "%s: bad cdt", who);
     BF_REQUIRE(bf_aligned16(qkv), BF_EALIGN, "%s: unaligned qkv", who);
     BF_REQUIRE((long)batch * heads < 65536L * 32768L, BF_EINVAL, "%s: batch*heads too large", who);
     return BF_OK;
@@ -1643,7 +1644,9 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
     if (rc) return rc;
     BF_REQUIRE(bf_aligned16(out), BF_EALIGN, "bf_attention_fwd: unaligned out");
     hipStream_t s = (hipStream_t)stream;
-    if (cdt == BF_BF16) {
+    const bool f16 = cdt == BF_F16;
+#define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
+    if (bf_is_half(cdt)) {
         const int nq32 = bf_cdiv(seq, 32);
         // whole-sequence K / V resident in LDS when they fit and one workgroup can hold every
         // 32-query wave (the sequences of this model family); otherwise the tiled kernel
@@ -1660,22 +1663,23 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             static int kt_env = -1;      // 0: 64-key tiles always; 1: 32-key steps always; default: by the last tile's fill
             if (kt_env < 0) { const char* e = getenv("BIFOLD_ATTN_FWD_KT32"); kt_env = e ? atoi(e) : 2; }
             const bool half_steps = kt_env == 1 || (kt_env == 2 && mask_mode != BF_MASK_CAUSAL && (seq % 64) != 0 && (seq % 64) <= 32);
-#define FWD_RES2(DD, MM)                                                                           \
+#define FWD_RES2(DD, MM) BY_HALF(FWD_RES3, DD, MM)
+#define FWD_RES3(DD, MM, HT)                                                                       \
     do {                                                                                          \
         static size_t lds_set = 0;                                                                \
         if (res_lds > lds_set) {                                                                  \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 2>,                \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 2, HT>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 1>,                \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 1, HT>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
             lds_set = res_lds;                                                                    \
         }                                                                                         \
         if (half_steps)                                                                           \
-            hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 1>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
-                               (bf16_t*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
+            hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 1, HT>), rgrid, rblock, res_lds, s, (const HT*)qkv, \
+                               (HT*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
         else                                                                                      \
-            hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 2>), rgrid, rblock, res_lds, s, (const bf16_t*)qkv, \
-                               (bf16_t*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
+            hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 2, HT>), rgrid, rblock, res_lds, s, (const HT*)qkv, \
+                               (HT*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
     } while (0)
 #define FWD_RES(DD)                                                                               \
     do {                                                                                          \
@@ -1688,15 +1692,17 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             else FWD_RES(64);
 #undef FWD_RES
 #undef FWD_RES2
+#undef FWD_RES3
             BF_CHECK_LAUNCH("bf_attention_fwd");
             return BF_OK;
         }
         const int chunks = bf_cdiv(nq32, 8);
         const int wpb = bf_cdiv(nq32, chunks);
         dim3 grid(batch * heads, chunks), block(wpb * 64);
-#define FWD_MFMA2(DD, MM)                                                                         \
-    hipLaunchKernelGGL((attn_fwd_mfma_kernel<DD, MM>), grid, block, 0, s, (const bf16_t*)qkv,     \
-                       (bf16_t*)out, lse, row_mask, seq, heads, scale, wpb)
+#define FWD_MFMA2(DD, MM) BY_HALF(FWD_MFMA3, DD, MM)
+#define FWD_MFMA3(DD, MM, HT)                                                                     \
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<DD, MM, HT>), grid, block, 0, s, (const HT*)qkv,     \
+                       (HT*)out, lse, row_mask, seq, heads, scale, wpb)
 #define FWD_MFMA(DD)                                                                              \
     do {                                                                                          \
         if (mask_mode == BF_MASK_NONE) FWD_MFMA2(DD, BF_MASK_NONE);                               \
@@ -1708,6 +1714,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         else FWD_MFMA(64);
 #undef FWD_MFMA
 #undef FWD_MFMA2
+#undef FWD_MFMA3
     } else {
         dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
 #define FWD_SIMPLE(DD)                                                                            \
@@ -1718,6 +1725,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         else FWD_SIMPLE(64);
 #undef FWD_SIMPLE
     }
+#undef BY_HALF
     BF_CHECK_LAUNCH("bf_attention_fwd");
     return BF_OK;
 }
@@ -1774,6 +1782,8 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     BF_REQUIRE(bf_aligned16(out) && bf_aligned16(dout) && bf_aligned16(dqkv), BF_EALIGN,
                "bf_attention_bwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
+    const bool f16 = cdt == BF_F16, half = bf_is_half(cdt);
+#define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
     // MFMA kernel geometry: one chunk of 32*nw keys per workgroup.  Short sequences run as ONE chunk
     // (whole sequence in LDS, dQ stored directly); longer ones use the largest nw whose LDS image
     // fits 160 KB and accumulate dQ across key chunks through dq_ws.
@@ -1797,7 +1807,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         // scratch: 80.8 vs 92.9 us at 262 x 48); d = 64 stays on the streamed pair (300 x 64: 99 vs 134 us resident)
         const bool wide_ok = (head_dim == 32 && !stream_d32_env) || (head_dim == 48 && res_wide_env != -1) || res_wide_env > 0 ||
                              nq32 < stream_min_env;
-        if (cdt == BF_BF16 && split_env && wide_ok && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
+        if (half && split_env && wide_ok && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
             !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
             // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);
             // with larger images (d = 64: two workgroups per CU either way) one workgroup per (batch, head)
@@ -1811,25 +1821,26 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             const int wpb = (wpb_env < nq32 ? wpb_env : nq32) < 8 ? (wpb_env < nq32 ? wpb_env : nq32) : 8;   // launch bound: 512 threads
             const int n_split = bf_cdiv(nq32, wpb) < split_env2 ? bf_cdiv(nq32, wpb) : split_env2;
             dim3 grid(batch * heads, n_split), block(wpb * 64);
-#define BWD_SPLIT2(DD, MM)                                                                          \
+#define BWD_SPLIT2(DD, MM) BY_HALF(BWD_SPLIT3, DD, MM)
+#define BWD_SPLIT3(DD, MM, HT)                                                                      \
     do {                                                                                            \
         static size_t set_q = 0, set_kv = 0;                                                        \
         if (lds_q > set_q) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DD, MM>,                       \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DD, MM, HT>,                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
             set_q = lds_q;                                                                          \
         }                                                                                           \
         if (lds_kv > set_kv) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM>,                      \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM, HT>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
             set_kv = lds_kv;                                                                        \
         }                                                                                           \
-        hipLaunchKernelGGL((attn_bwd_q_kernel<DD, MM>), grid, block, lds_q, s, (const bf16_t*)qkv,  \
-                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,   \
+        hipLaunchKernelGGL((attn_bwd_q_kernel<DD, MM, HT>), grid, block, lds_q, s, (const HT*)qkv,  \
+                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,   \
                            delta_ws, seq, heads, scale, lp);                                        \
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM>), grid, block, lds_kv, s, (const bf16_t*)qkv, \
-                           (const bf16_t*)dout, lse, (const float*)delta_ws, row_mask,              \
-                           (bf16_t*)dqkv, seq, heads, scale);                                       \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT>), grid, block, lds_kv, s, (const HT*)qkv, \
+                           (const HT*)dout, lse, (const float*)delta_ws, row_mask,              \
+                           (HT*)dqkv, seq, heads, scale);                                       \
     } while (0)
 #define BWD_SPLIT(DD)                                                                               \
     do {                                                                                            \
@@ -1842,6 +1853,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             else BWD_SPLIT(64);
 #undef BWD_SPLIT
 #undef BWD_SPLIT2
+#undef BWD_SPLIT3
             BF_CHECK_LAUNCH("bf_attention_bwd");
             return BF_OK;
         }
@@ -1854,7 +1866,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         if (stream_min_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_MIN_Q32"); stream_min_env = e ? atoi(e) : 1; }
         static int stream_d32_env = -1;
         if (stream_d32_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_D32"); stream_d32_env = e ? atoi(e) : 0; }
-        if (cdt == BF_BF16 && stream_env && nq32 >= ((head_dim == 32 && !stream_d32_env) ? 9 : stream_min_env)) {
+        if (half && stream_env && nq32 >= ((head_dim == 32 && !stream_d32_env) ? 9 : stream_min_env)) {
             // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
             // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)
             const int CH = head_dim == 32 ? StreamCfg<32>::CH : StreamCfg<64>::CH;       // see StreamCfg
@@ -1863,25 +1875,26 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             const size_t lds_q = (size_t)CH * ((dp * 2 + 16) + row);
             const size_t lds_kv = 2 * ((size_t)CH * row + 64) + 3 * (size_t)CH * 4;
             dim3 grid(batch * heads, bf_cdiv(nq32, wpb)), block(wpb * 64);
-#define BWD_STREAM2(DD, MM)                                                                         \
+#define BWD_STREAM2(DD, MM) BY_HALF(BWD_STREAM3, DD, MM)
+#define BWD_STREAM3(DD, MM, HT)                                                                         \
     do {                                                                                            \
         static size_t set_q = 0, set_kv = 0;                                                        \
         if (lds_q > set_q) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_q_stream_kernel<DD, MM>,                \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_stream_kernel<DD, MM, HT>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
             set_q = lds_q;                                                                          \
         }                                                                                           \
         if (lds_kv > set_kv) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_stream_kernel<DD, MM>,               \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_stream_kernel<DD, MM, HT>,               \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
             set_kv = lds_kv;                                                                        \
         }                                                                                           \
-        hipLaunchKernelGGL((attn_bwd_q_stream_kernel<DD, MM>), grid, block, lds_q, s, (const bf16_t*)qkv, \
-                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,   \
+        hipLaunchKernelGGL((attn_bwd_q_stream_kernel<DD, MM, HT>), grid, block, lds_q, s, (const HT*)qkv, \
+                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,   \
                            delta_ws, seq, heads, scale);                                            \
-        hipLaunchKernelGGL((attn_bwd_kv_stream_kernel<DD, MM>), grid, block, lds_kv, s, (const bf16_t*)qkv, \
-                           (const bf16_t*)dout, lse, (const float*)delta_ws, row_mask,              \
-                           (bf16_t*)dqkv, seq, heads, scale);                                       \
+        hipLaunchKernelGGL((attn_bwd_kv_stream_kernel<DD, MM, HT>), grid, block, lds_kv, s, (const HT*)qkv, \
+                           (const HT*)dout, lse, (const float*)delta_ws, row_mask,              \
+                           (HT*)dqkv, seq, heads, scale);                                       \
     } while (0)
 #define BWD_STREAM(DD)                                                                              \
     do {                                                                                            \
@@ -1894,13 +1907,14 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             else BWD_STREAM(64);
 #undef BWD_STREAM
 #undef BWD_STREAM2
+#undef BWD_STREAM3
             BF_CHECK_LAUNCH("bf_attention_bwd");
             return BF_OK;
         }
     }
     const int nw = bwd_pick_nw(seq, head_dim, dq_ws != nullptr);
     auto lds_of = [&](int n) { return bwd_lds_of(head_dim, n); };
-    if (cdt == BF_BF16 && nw > 0) {
+    if (half && nw > 0) {
         const int chunks = bf_cdiv(seq, nw * 32);
         BF_REQUIRE(chunks == 1 || (dq_ws && bf_aligned16(dq_ws)), BF_EINVAL,
                    "bf_attention_bwd: dq_ws is required for sequences longer than one key chunk");
@@ -1910,16 +1924,17 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         }
         dim3 grid(batch * heads, chunks), block(nw * 64);
         const size_t lds = lds_of(nw);
-#define BWD_MFMA2(DD, MM)                                                                           \
+#define BWD_MFMA2(DD, MM) BY_HALF(BWD_MFMA3, DD, MM)
+#define BWD_MFMA3(DD, MM, HT)                                                                           \
     do {                                                                                            \
         static size_t lds_set = 0;                                                                  \
         if (lds > lds_set) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM>,                    \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM, HT>,                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
             lds_set = lds;                                                                          \
         }                                                                                           \
-        hipLaunchKernelGGL((attn_bwd_mfma_kernel<DD, MM>), grid, block, lds, s, (const bf16_t*)qkv, \
-                           (const bf16_t*)out, (const bf16_t*)dout, lse, row_mask, (bf16_t*)dqkv,  \
+        hipLaunchKernelGGL((attn_bwd_mfma_kernel<DD, MM, HT>), grid, block, lds, s, (const HT*)qkv, \
+                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,  \
                            dq_ws, seq, heads, scale);                                               \
     } while (0)
 #define BWD_MFMA(DD)                                                                                \
@@ -1933,20 +1948,29 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         else BWD_MFMA(64);
 #undef BWD_MFMA
 #undef BWD_MFMA2
+#undef BWD_MFMA3
         if (chunks > 1) {
             BF_CHECK_LAUNCH("bf_attention_bwd");
             const size_t rows = (size_t)batch * seq;
             size_t blocks = (rows * (heads * head_dim / 4) + 255) / 256;
             if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(attn_dq_cast_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dq_ws, (bf16_t*)dqkv,
-                               rows, heads * head_dim);
+            if (f16)
+                hipLaunchKernelGGL(attn_dq_cast_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, s, dq_ws, (f16_t*)dqkv,
+                                   rows, heads * head_dim);
+            else
+                hipLaunchKernelGGL(attn_dq_cast_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, dq_ws, (bf16_t*)dqkv,
+                                   rows, heads * head_dim);
         }
-    } else if (cdt == BF_BF16)
+    } else if (cdt == BF_F16)
+        attn_bwd_launch<f16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
+                               head_dim, scale, mask_mode, s);
+    else if (cdt == BF_BF16)
         attn_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
                                 head_dim, scale, mask_mode, s);
     else
         attn_bwd_launch<float>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
                                head_dim, scale, mask_mode, s);
+#undef BY_HALF
     BF_CHECK_LAUNCH("bf_attention_bwd");
     return BF_OK;
 }

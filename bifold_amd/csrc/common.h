@@ -10,6 +10,9 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;                                            // IEEE binary16: CLIP's native dtype, BF_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -38,7 +41,8 @@ void bf_set_error(int hip_code, const char* fmt, ...);
 
 static inline bool bf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int bf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-static inline size_t bf_dtype_size(int dt) { return dt == BF_BF16 ? 2 : 4; }
+static inline size_t bf_dtype_size(int dt) { return (dt == BF_BF16 || dt == BF_F16) ? 2 : 4; }
+static inline bool bf_is_half(int dt) { return dt == BF_BF16 || dt == BF_F16; }       // a 16-bit MFMA operand type
 
 // ---- device helpers -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -55,9 +59,40 @@ __device__ __forceinline__ float wave_max(float v) {
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <> __device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
+
+// The two 16-bit operand types share every byte image (LDS tiles, fragments, stores); what differs is the MFMA
+// opcode, the transposing LDS read's builtin and the fp32 <-> 16-bit conversion.  H16<H> names the vector types.
+template <typename H> struct H16;
+template <> struct H16<bf16_t> { typedef bf16x4 x4; typedef bf16x8 x8; };
+template <> struct H16<f16_t> { typedef f16x4 x4; typedef f16x8 x8; };
+
+__device__ __forceinline__ f32x4 mfma_16x16x32(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// ds_read_b64_tr_b16: the hardware-transposed LDS read (the instruction does not look at the element type)
+template <typename H> __device__ __forceinline__ typename H16<H>::x4 lds_read_tr16(const void* lds_addr);
+template <> __device__ __forceinline__ bf16x4 lds_read_tr16<bf16_t>(const void* lds_addr) {
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)lds_addr);
+}
+template <> __device__ __forceinline__ f16x4 lds_read_tr16<f16_t>(const void* lds_addr) {
+    typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
+    return __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)lds_addr));
+}
 
 // 4 consecutive elements <-> float4, for fp32 and bf16 storage
 template <typename T> struct Vec4;
@@ -77,6 +112,18 @@ template <> struct Vec4<bf16_t> {
     }
 };
 
+template <> struct Vec4<f16_t> {
+    static __device__ __forceinline__ float4 load(const f16_t* p) {
+        f16x4 r = *(const f16x4*)p;
+        return make_float4((float)r[0], (float)r[1], (float)r[2], (float)r[3]);
+    }
+    static __device__ __forceinline__ void store(f16_t* p, float4 v) {
+        f16x4 r;
+        r[0] = (f16_t)v.x; r[1] = (f16_t)v.y; r[2] = (f16_t)v.z; r[3] = (f16_t)v.w;
+        *(f16x4*)p = r;
+    }
+};
+
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + expf(-1.702f * x)); }
 __device__ __forceinline__ float erf_gelu_f(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -88,9 +135,9 @@ __device__ __forceinline__ float erf_gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-// ---- fast variants for the bf16 path -----------------------------------------------------
+// ---- fast variants for the 16-bit paths (bf16 and fp16) -----------------------------------------------------
 // The accurate erff/expf above cost ~40 VALU instructions per element; in a GEMM epilogue
-// over 1.4e8 elements that is >150 us with the MFMA pipe idle.  bf16 outputs carry 2^-9
+// over 1.4e8 elements that is >150 us with the MFMA pipe idle.  16-bit outputs carry 2^-9 (bf16) / 2^-11 (fp16)
 // relative rounding, so the Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7: one v_exp, one
 // v_rcp, six FMAs) is three orders of magnitude below what the output can resolve.  The fp32
 // ("exact") mode keeps the accurate functions.
@@ -171,3 +218,4 @@ template <> struct ActMath<bf16_t> {
     static __device__ __forceinline__ float tanh_gelu(float x) { return tanh_gelu_fast(x); }
     static __device__ __forceinline__ float tanh_grad(float x) { return tanh_gelu_grad_fast(x); }
 };
+template <> struct ActMath<f16_t> : ActMath<bf16_t> {};          // same fast forms: 1.5e-7 absolute is below 2^-11 too

@@ -56,6 +56,9 @@ __device__ __forceinline__ void store16(void* p, uint4 q, bool nt) {
     }
 }
 
+// type of the optional 16-bit copy of an fp32 result (`c2`): the call's 16-bit operand type (exact mode: unused)
+template <typename TD> using Half2Of = std::conditional_t<std::is_same<TD, float>::value, bf16_t, TD>;
+
 template <typename TC, typename TD>
 __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int n, float4 v) {
     v.x *= ep.alpha; v.y *= ep.alpha; v.z *= ep.alpha; v.w *= ep.alpha;
@@ -106,7 +109,7 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
     Vec4<TC>::store(cp, v);
-    if (ep.c2) Vec4<bf16_t>::store((bf16_t*)ep.c2 + orow * ep.ldc + n, v);
+    if (ep.c2) Vec4<Half2Of<TD>>::store((Half2Of<TD>*)ep.c2 + orow * ep.ldc + n, v);
 }
 
 // 8 consecutive columns of one output row.  A store instruction costs the issuing wave the
@@ -146,6 +149,26 @@ template <> struct Vec8<bf16_t> {
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = (bf16_t)v[e];
         *(bf16x8*)p = r;
+    }
+};
+
+template <> struct Vec8<f16_t> {
+    static __device__ __forceinline__ void store_nt(f16_t* p, const float (&v)[8], bool nt) {
+        f16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (f16_t)v[e];
+        store16(p, *(const uint4*)&r, nt);
+    }
+    static __device__ __forceinline__ void load(const f16_t* p, float (&v)[8]) {
+        const f16x8 r = *(const f16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)r[e];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float (&v)[8]) {
+        f16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (f16_t)v[e];
+        *(f16x8*)p = r;
     }
 };
 
@@ -211,7 +234,7 @@ __device__ __forceinline__ void epilogue_store8(const EpiParams& ep, int m, int 
         for (int e = 0; e < 8; ++e) v[e] += o[e];
     }
     Vec8<TC>::store_nt(cp, v, ep.store_policy & 2);
-    if (ep.c2) Vec8<bf16_t>::store_nt((bf16_t*)ep.c2 + orow * ep.ldc + n, v, ep.store_policy & 2);
+    if (ep.c2) Vec8<Half2Of<TD>>::store_nt((Half2Of<TD>*)ep.c2 + orow * ep.ldc + n, v, ep.store_policy & 2);
 }
 
 #define CT_LD 132   // fp32 staging tile leading dimension (128 + 4 pad)
@@ -265,8 +288,8 @@ struct GemmDims {
 
 // ---- global -> register tile loads (4 x 16 B per thread per operand) -------------------
 // KC: element (r,k) at p[r*ld + k];  KS: element (r,k) at p[k*ld + r].
-template <bool KS>
-__device__ __forceinline__ void bf16_tile_load(uint4 (&reg)[4], const bf16_t* __restrict__ p, int ld,
+template <bool KS, typename H>
+__device__ __forceinline__ void bf16_tile_load(uint4 (&reg)[4], const H* __restrict__ p, int ld,
                                                int r0, int rtot, int k0, int kend) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -304,31 +327,32 @@ __device__ __forceinline__ void bf16_tile_store(const uint4 (&reg)[4], char* lds
 }
 
 // ---- LDS -> MFMA fragment (16 rows x 32 k), rows [rbase, rbase+16), k-substep s -------
-template <bool KS>
-__device__ __forceinline__ bf16x8 bf16_frag(const char* lds, int rbase, int s, int lane) {
+template <bool KS, typename H>
+__device__ __forceinline__ typename H16<H>::x8 bf16_frag(const char* lds, int rbase, int s, int lane) {
+    typedef typename H16<H>::x4 H4;
+    typedef typename H16<H>::x8 H8;
     if (!KS) {
         const int row = rbase + (lane & 15);
         const int ch = s * 4 + (lane >> 4);
-        return *(const bf16x8*)(lds + row * 128 + ((ch ^ (row & 7)) << 4));
+        return *(const H8*)(lds + row * 128 + ((ch ^ (row & 7)) << 4));
     } else {
         const int gl = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const int kk = s * 32 + gl * 8 + q;
         const int rc = (rbase >> 3) + (p >> 1);
         const int sw = ks_swz(kk);                       // identical for kk and kk+4
         const int o0 = kk * 256 + ((rc ^ sw) << 4) + ((p & 1) << 3);
-        typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lds + o0));
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(lds + o0 + 4 * 256));
-        bf16x8 r;
+        const H4 lo = lds_read_tr16<H>(lds + o0);
+        const H4 hi = lds_read_tr16<H>(lds + o0 + 4 * 256);
+        H8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
         return r;
     }
 }
 
-template <bool A_KS, bool B_KS, typename TC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
-                                                           const bf16_t* __restrict__ B,
+template <bool A_KS, bool B_KS, typename TC, typename H>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const H* __restrict__ A,
+                                                           const H* __restrict__ B,
                                                            GemmDims d, EpiParams ep,
                                                            float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -368,16 +392,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
+            typename H16<H>::x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = bf16_frag<A_KS>(la, wm * 64 + i * 16, s, lane);
+            for (int i = 0; i < 4; ++i) af[i] = bf16_frag<A_KS, H>(la, wm * 64 + i * 16, s, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag<B_KS>(lb, wn * 64 + j * 16, s, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag<B_KS, H>(lb, wn * 64 + j * 16, s, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_16x16x32(af[i], bfr[j], acc[i][j]);
         }
         if (more) {
             char* na = smem + ((kt + 1) & 1) * 32768;
@@ -399,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                     acc[i][j][r];
     __syncthreads();
     float* slab = slabs ? slabs + (size_t)z * ep.m * ep.n : nullptr;
-    tile_epilogue<TC, bf16_t>(ct, ep, m0, n0, slab);
+    tile_epilogue<TC, H>(ct, ep, m0, n0, slab);
 }
 
 // =====================================================================================
@@ -437,9 +461,9 @@ __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_
     }
 }
 
-template <bool A_KS, bool B_KS, typename TC>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const bf16_t* __restrict__ A,
-                                                               const bf16_t* __restrict__ B,
+template <bool A_KS, bool B_KS, typename TC, typename H>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const H* __restrict__ A,
+                                                               const H* __restrict__ B,
                                                                GemmDims d, EpiParams ep,
                                                                float* __restrict__ slabs,
                                                                unsigned a_bytes, unsigned b_bytes) {
@@ -482,16 +506,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const bf16_t* __r
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[4], bfr[4];
+            typename H16<H>::x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = bf16_frag<A_KS>(la, wm * 64 + i * 16, s, lane);
+            for (int i = 0; i < 4; ++i) af[i] = bf16_frag<A_KS, H>(la, wm * 64 + i * 16, s, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag<B_KS>(lb, wn * 64 + j * 16, s, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag<B_KS, H>(lb, wn * 64 + j * 16, s, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma_16x16x32(bfr[j], af[i], acc[j][i]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -508,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_dma_kernel(const bf16_t* __r
             if (m < ep.m && n < ep.n) {
                 const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
                 if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
-                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
+                else epilogue_store4<TC, H>(ep, m, n, v);
             }
         }
     }
@@ -563,21 +587,22 @@ __device__ __forceinline__ unsigned dma_piece_offset32(int ld, int r0, int k0, i
     }
 }
 
-template <bool KS>
-__device__ __forceinline__ bf16x8 bf16_frag32(const char* lds, int rbase, int lane) {
+template <bool KS, typename H>
+__device__ __forceinline__ typename H16<H>::x8 bf16_frag32(const char* lds, int rbase, int lane) {
+    typedef typename H16<H>::x4 H4;
+    typedef typename H16<H>::x8 H8;
     if (!KS) {
         const int row = rbase + (lane & 15);
         const int ch = lane >> 4;
-        return *(const bf16x8*)(lds + row * 64 + ((ch ^ kc32_swz(row)) << 4));
+        return *(const H8*)(lds + row * 64 + ((ch ^ kc32_swz(row)) << 4));
     } else {
         const int gl = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
         const int kk = gl * 8 + q;
         const int rc = ((rbase & 127) >> 3) + (p >> 1);
         const char* base = lds + (rbase >> 7) * 8192 + kk * 256 + ((rc ^ ks_swz(kk)) << 4) + ((p & 1) << 3);
-        typedef __attribute__((address_space(3))) bf16x4* lds_ptr;
-        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)base);
-        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + 4 * 256));
-        bf16x8 r;
+        const H4 lo = lds_read_tr16<H>(base);
+        const H4 hi = lds_read_tr16<H>(base + 4 * 256);
+        H8 r;
         r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
         return r;
@@ -594,9 +619,9 @@ __device__ __forceinline__ bf16x8 bf16_frag32(const char* lds, int rbase, int la
 // WT = 16-row MFMA tiles per wave along M: 4 -> 128x128 block (4 blocks/CU), 2 -> 64x128 block
 // (24 KB LDS, 6 blocks/CU).  The small tile is for narrow-N GEMMs whose 128x128 tiling fills the
 // chip's workgroup slots only ~70 % in its last round (e.g. 70400x512: 2200 tiles on 1024 slots).
-template <bool A_KS, bool B_KS, typename TC, int WT>
+template <bool A_KS, bool B_KS, typename TC, int WT, typename H>
 __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmDims d, EpiParams ep,
+    const H* __restrict__ A, const H* __restrict__ B, GemmDims d, EpiParams ep,
     float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes) {
     constexpr int BM = WT * 32;                    // 2 waves along M
     constexpr int A_BYTES = BM * 64;               // one BK=32 stage of A
@@ -635,16 +660,16 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
         const char* la = smem + (kt & 1) * STAGE;
         const char* lb = la + A_BYTES;
         if (kt + 1 < nk) stage_tile(kt + 1);
-        bf16x8 af[WT], bfr[4];
+        typename H16<H>::x8 af[WT], bfr[4];
 #pragma unroll
-        for (int i = 0; i < WT; ++i) af[i] = bf16_frag32<A_KS>(la, wm * (WT * 16) + i * 16, lane);
+        for (int i = 0; i < WT; ++i) af[i] = bf16_frag32<A_KS, H>(la, wm * (WT * 16) + i * 16, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
+        for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS, H>(lb, wn * 64 + j * 16, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < WT; ++i)
-                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+                acc[j][i] = mfma_16x16x32(bfr[j], af[i], acc[j][i]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -658,7 +683,7 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
             if (m < ep.m && n < ep.n) {
                 const float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
                 if (slab) *(float4*)(slab + (size_t)m * ep.n + n) = v;
-                else epilogue_store4<TC, bf16_t>(ep, m, n, v);
+                else epilogue_store4<TC, H>(ep, m, n, v);
             }
         }
     }
@@ -701,9 +726,9 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 // (any output type, residual / aux / copies / row remap / split-K slabs), 1 = plain bf16 (alpha, bias,
 // activation, optional pre-activation copy), 2 = bf16 GELU-grad.  One kernel with all three paths sat at
 // the 256-register limit and spilled differently with every edit.
-template <bool A_KS, bool B_KS, typename TC, int EPI>
+template <bool A_KS, bool B_KS, typename TC, int EPI, typename H>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, GemmDims d, EpiParams ep,
+    const H* __restrict__ A, const H* __restrict__ B, GemmDims d, EpiParams ep,
     float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
     unsigned* __restrict__ tk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB) + 16 B
@@ -870,11 +895,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             const bool more = s + 2 < nk;
             if (s == draw_stage && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
             // ---------------- phase a
-            bf16x8 bfr[4], af[4];
+            typename H16<H>::x8 bfr[4], af[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS>(lb, wn * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS, H>(lb, wn * 64 + j * 16, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS>(la, wm * 128 + i * 16, lane);
+            for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS, H>(la, wm * 128 + i * 16, lane);
             if (more && !deep) issue_a(w, s + 2);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
@@ -882,13 +907,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = mfma_16x16x32(bfr[j], af[i], acc[j][i]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
             // ---------------- phase b
-            bf16x8 ag[4];
+            typename H16<H>::x8 ag[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ag[i] = bf16_frag32<A_KS>(la, wm * 128 + 64 + i * 16, lane);
+            for (int i = 0; i < 4; ++i) ag[i] = bf16_frag32<A_KS, H>(la, wm * 128 + 64 + i * 16, lane);
             if (!deep) {
                 if (more) {
                     issue_b(w, s + 2);
@@ -916,7 +941,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], ag[i], acc[j][4 + i], 0, 0, 0);
+                    acc[j][4 + i] = mfma_16x16x32(bfr[j], ag[i], acc[j][4 + i]);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_s_barrier();
         }
@@ -964,18 +989,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 const int n = w.n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
                 bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            using AM = ActMath<bf16_t>;
+            using AM = ActMath<H>;
             // pass 0 writes the pre-activation copy the backward pass needs (ep.pre), pass 1 the result
             auto half_tile = [&](auto h_, auto pass_) {
-                constexpr int H = decltype(h_)::value;
+                constexpr int HALF = decltype(h_)::value;
                 constexpr int PASS = decltype(pass_)::value;
-                bf16_t* dst = PASS == 0 ? (bf16_t*)ep.pre : (bf16_t*)ep.c;
+                H* dst = PASS == 0 ? (H*)ep.pre : (H*)ep.c;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int lr = ii * 16 + (lane & 15);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const f32x4 a = acc[j][H * 4 + ii];
+                        const f32x4 a = acc[j][HALF * 4 + ii];
                         float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
                                       fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
                         if (PASS == 1) {
@@ -990,10 +1015,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                                 for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
                             }
                         }
-                        bf16x4 pk;
-                        pk[0] = (bf16_t)v[0]; pk[1] = (bf16_t)v[1]; pk[2] = (bf16_t)v[2]; pk[3] = (bf16_t)v[3];
+                        typename H16<H>::x4 pk;
+                        pk[0] = (H)v[0]; pk[1] = (H)v[1]; pk[2] = (H)v[2]; pk[3] = (H)v[3];
                         const int cc4 = j * 4 + (lane >> 4);
-                        *(bf16x4*)(stg + lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3)) = pk;
+                        *(typename H16<H>::x4*)(stg + lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3)) = pk;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1002,7 +1027,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 for (int t = 0; t < 8; ++t) {
                     const int lr = t * 8 + (lane >> 3), c16 = lane & 7;
                     const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
-                    const int m = w.m0 + wm * 128 + H * 64 + lr;
+                    const int m = w.m0 + wm * 128 + HALF * 64 + lr;
                     const int n = w.n0 + wn * 64 + c16 * 8;
                     if (m < ep.m && n < ep.n) store16(dst + (size_t)m * ep.ldc + n, q, ep.store_policy & 1);
                 }
@@ -1025,18 +1050,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                             const f32x4 a = acc[j][Q * 2 + i2];
                             const float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
                                                 fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
-                            bf16x4 pk, gk;
+                            typename H16<H>::x4 pk, gk;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float gv, gp;
                                 AM::erf_both(v[e], gv, gp);
-                                pk[e] = (bf16_t)gv;
-                                gk[e] = (bf16_t)gp;
+                                pk[e] = (H)gv;
+                                gk[e] = (H)gp;
                             }
                             const int cc4 = j * 4 + (lane >> 4);
                             const int off = lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3);
-                            *(bf16x4*)(stg + off) = pk;
-                            *(bf16x4*)(stg + 4096 + off) = gk;
+                            *(typename H16<H>::x4*)(stg + off) = pk;
+                            *(typename H16<H>::x4*)(stg + 4096 + off) = gk;
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1050,8 +1075,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                         const int m = w.m0 + wm * 128 + Q * 32 + lr;
                         const int n = w.n0 + wn * 64 + c16 * 8;
                         if (m < ep.m && n < ep.n) {
-                            store16((bf16_t*)ep.c + (size_t)m * ep.ldc + n, qa, ep.store_policy & 1);
-                            store16((bf16_t*)ep.pre + (size_t)m * ep.ldc + n, qg, ep.store_policy & 1);
+                            store16((H*)ep.c + (size_t)m * ep.ldc + n, qa, ep.store_policy & 1);
+                            store16((H*)ep.pre + (size_t)m * ep.ldc + n, qg, ep.store_policy & 1);
                         }
                     }
                     asm volatile("" ::: "memory");
@@ -1087,13 +1112,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // one load latency instead of sixteen; lean body, fully unrolled.
         constexpr bool fastgrad = EPI == 2;
         if constexpr (fastgrad) {
-            using AM = ActMath<bf16_t>;
+            using AM = ActMath<H>;
             uint4 apre[16];
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) {
                 const int m = w.m0 + wm * 128 + ct * 8 + (lane >> 3);
                 const int n = w.n0 + wn * 64 + (lane & 7) * 8;
-                apre[ct] = (m < ep.m && n < ep.n) ? *(const uint4*)((const bf16_t*)ep.aux + (size_t)m * ep.ld_aux + n)
+                apre[ct] = (m < ep.m && n < ep.n) ? *(const uint4*)((const H*)ep.aux + (size_t)m * ep.ld_aux + n)
                                                   : make_uint4(0, 0, 0, 0);
             }
             float cs[8];
@@ -1112,23 +1137,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                     const int m = w.m0 + wm * 128 + C * 32 + lr;
                     const int n = w.n0 + wn * 64 + c2 * 4;
                     const uint4 raw = apre[C * 4 + t];
-                    const bf16x8 a8 = *(const bf16x8*)&raw;
-                    bf16x8 o8;
+                    const typename H16<H>::x8 a8 = *(const typename H16<H>::x8*)&raw;
+                    typename H16<H>::x8 o8;
                     if (ep.act == BF_ACT_MUL_AUX) {        // aux already IS gelu'(pre) (forward: ..._SAVEGRAD)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            o8[e] = (bf16_t)(q0[e] * ep.alpha * (float)a8[e]);
-                            o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * (float)a8[4 + e]);
+                            o8[e] = (H)(q0[e] * ep.alpha * (float)a8[e]);
+                            o8[4 + e] = (H)(q1[e] * ep.alpha * (float)a8[4 + e]);
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            o8[e] = (bf16_t)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
-                            o8[4 + e] = (bf16_t)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
+                            o8[e] = (H)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
+                            o8[4 + e] = (H)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
                         }
                     }
                     if (m < ep.m && n < ep.n) {
-                        store16((bf16_t*)ep.c + (size_t)m * ep.ldc + n, *(const uint4*)&o8, ep.store_policy & 4);
+                        store16((H*)ep.c + (size_t)m * ep.ldc + n, *(const uint4*)&o8, ep.store_policy & 4);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) cs[e] += (float)o8[e];      // sums of the STORED values
                     }
@@ -1187,7 +1212,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                         *(f32x4*)(sp + 4) = q1;
                     } else {
                         float v[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-                        epilogue_store8<TC, bf16_t>(epi, m, n, v, b8);
+                        epilogue_store8<TC, H>(epi, m, n, v, b8);
                     }
                 }
             }
@@ -1709,7 +1734,7 @@ static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
         min_k_nt = 2048; min_k_nn = 1 << 30;              // in-step A/B (round 2): NN tails at K >= 1536 / 512: +-0.1 %; NT at K >= 768: -2 %
         if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { min_k_nt = a; min_k_nn = b; } }
     }
-    if (g->cdt != BF_BF16 || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
+    if (!bf_is_half(g->cdt) || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
         g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 ||
         g->k < (g->b_kn ? min_k_nn : min_k_nt) || g->colsum_out)
         return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
@@ -1849,8 +1874,9 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
     BF_REQUIRE(g->m > 0 && g->n > 0 && g->k > 0, BF_EINVAL, "bf_gemm: m, n, k must be > 0 (%d %d %d)",
                g->m, g->n, g->k);
-    BF_REQUIRE(g->cdt == BF_F32 || g->cdt == BF_BF16, BF_EINVAL, "bf_gemm: bad cdt %d", g->cdt);
-    BF_REQUIRE(g->c_dtype == BF_F32 || g->c_dtype == BF_BF16, BF_EINVAL, "bf_gemm: bad c_dtype");
+    BF_REQUIRE(g->cdt == BF_F32 || bf_is_half(g->cdt), BF_EINVAL, "bf_gemm: bad cdt %d", g->cdt);
+    BF_REQUIRE(g->c_dtype == BF_F32 || g->c_dtype == g->cdt, BF_EINVAL,
+               "bf_gemm: c_dtype must be BF_F32 or the compute dtype (cdt %d, c_dtype %d)", g->cdt, g->c_dtype);
     BF_REQUIRE(!(g->cdt == BF_F32 && g->c_dtype != BF_F32), BF_EINVAL,
                "bf_gemm: fp32 operands produce fp32 output only");
     BF_REQUIRE(!(g->accumulate && g->split_k > 1 && g->c_dtype != BF_F32), BF_EINVAL,
@@ -1859,12 +1885,13 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     BF_REQUIRE((g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) || g->aux,
                BF_EINVAL, "bf_gemm: the GELU_GRAD / MUL_AUX activations need aux");
     BF_REQUIRE(g->act != BF_ACT_ERF_GELU_SAVEGRAD || g->pre, BF_EINVAL, "bf_gemm: BF_ACT_ERF_GELU_SAVEGRAD needs `pre`");
-    const int vec = g->cdt == BF_BF16 ? 8 : 4;
+    const bool half = bf_is_half(g->cdt);
+    const int vec = half ? 8 : 4;
     BF_REQUIRE((g->n & 3) == 0 && (g->ldc & 3) == 0 && g->ldc >= g->n, BF_EINVAL,
                "bf_gemm: n and ldc must be multiples of 4 (n=%d ldc=%d)", g->n, g->ldc);
     BF_REQUIRE(g->lda % vec == 0 && g->ldb % vec == 0, BF_EALIGN,
                "bf_gemm: lda/ldb must be multiples of %d elements (lda=%d ldb=%d)", vec, g->lda, g->ldb);
-    if (g->cdt == BF_BF16) {
+    if (half) {
         // 16-byte chunks along the contiguous dimension must not straddle the extent
         BF_REQUIRE(g->trans_a ? (g->m & 7) == 0 : (g->k & 7) == 0, BF_EINVAL,
                    "bf_gemm(bf16): contiguous extent of A must be a multiple of 8");
@@ -1884,7 +1911,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     BF_REQUIRE(g->rows_in >= 0 && (g->rows_in == 0 || (g->rows_out >= g->rows_in + g->row_off && g->row_off >= 0)),
                BF_EINVAL, "bf_gemm: bad row remap (%d -> %d + %d)", g->rows_in, g->rows_out, g->row_off);
 
-    const int ktile = g->cdt == BF_BF16 ? 64 : 16;
+    const int ktile = half ? 64 : 16;
     int split = g->split_k > 1 ? g->split_k : 1;
     int kps = ((bf_cdiv(g->k, split) + ktile - 1) / ktile) * ktile;
     split = bf_cdiv(g->k, kps);
@@ -1920,22 +1947,26 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     dim3 grid((unsigned)nblk), block(256);
     const size_t lds = (size_t)128 * CT_LD * sizeof(float);   // 67,584 B >= operand buffers
 
-    if (g->cdt == BF_BF16) {
+    if (half) {
+        const bool f16 = g->cdt == BF_F16;
         static int group_m_env = -1;
         if (group_m_env < 0) { const char* e = getenv("BIFOLD_GEMM_GROUP_M"); group_m_env = e ? atoi(e) : 16; if (group_m_env < 1) group_m_env = 1; }
         GemmDims d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps, group_m_env};
-        const bf16_t* A = (const bf16_t*)g->a;
-        const bf16_t* B = (const bf16_t*)g->b;
-#define LAUNCH_BF16(AKS, BKS, TC)                                                                  \
+        // every launch macro below ends in ..._H(..., H): H = the 16-bit operand type of the call; the output type is
+        // float (f32out) or H
+#define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
+#define LAUNCH_BF16_T(AKS, BKS, TC, H)                                                             \
     do {                                                                                          \
         static bool lds_ok = false;  /* > 64 KB of dynamic LDS must be opted into, once */        \
         if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKS, BKS, TC>,                      \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKS, BKS, TC, H>,             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
             lds_ok = true;                                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_kernel<AKS, BKS, TC>), grid, block, lds, s, A, B, d, ep, slabs); \
+        hipLaunchKernelGGL((gemm_bf16_kernel<AKS, BKS, TC, H>), grid, block, lds, s, (const H*)g->a, (const H*)g->b, d, ep, slabs); \
     } while (0)
+#define LAUNCH_BF16_H(AKS, BKS, H) do { if (f32out) LAUNCH_BF16_T(AKS, BKS, float, H); else LAUNCH_BF16_T(AKS, BKS, H, H); } while (0)
+#define LAUNCH_BF16(AKS, BKS) BY_HALF(LAUNCH_BF16_H, AKS, BKS)
         const bool f32out = (g->c_dtype == BF_F32) || slabs;   // slabs path ignores TC
         // LDS-DMA kernel: K-contiguous operands need whole 64-wide K slabs (no in-row tail),
         // and the byte extents must fit the 32-bit buffer descriptor.
@@ -2012,29 +2043,31 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                 else if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) epi = 1;
                 else if ((g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->pre) epi = 2;
             }
-#define LAUNCH_P8E(AKS, BKS, TC, EPI)                                                               \
+#define LAUNCH_P8E(AKS, BKS, TC, EPI, H)                                                            \
     do {                                                                                          \
         static bool lds_ok = false;                                                               \
         if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC, EPI>,        \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC, EPI, H>,     \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE + 16);  \
             lds_ok = true;                                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC, EPI>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, A, B, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC, EPI, H>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, (const H*)g->a, (const H*)g->b, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
     } while (0)
-#define LAUNCH_P8(AKS, BKS)                                                                         \
+#define LAUNCH_P8_H(AKS, BKS, H)                                                                    \
     do {                                                                                          \
-        if (f32out) LAUNCH_P8E(AKS, BKS, float, 0);                                               \
-        else if (epi == 1) LAUNCH_P8E(AKS, BKS, bf16_t, 1);                                       \
-        else if (epi == 2) LAUNCH_P8E(AKS, BKS, bf16_t, 2);                                       \
-        else if (epi == 3) LAUNCH_P8E(AKS, BKS, bf16_t, 3);                                       \
-        else LAUNCH_P8E(AKS, BKS, bf16_t, 0);                                                     \
+        if (f32out) LAUNCH_P8E(AKS, BKS, float, 0, H);                                            \
+        else if (epi == 1) LAUNCH_P8E(AKS, BKS, H, 1, H);                                         \
+        else if (epi == 2) LAUNCH_P8E(AKS, BKS, H, 2, H);                                         \
+        else if (epi == 3) LAUNCH_P8E(AKS, BKS, H, 3, H);                                         \
+        else LAUNCH_P8E(AKS, BKS, H, 0, H);                                                       \
     } while (0)
+#define LAUNCH_P8(AKS, BKS) BY_HALF(LAUNCH_P8_H, AKS, BKS)
             if (!g->trans_a && !g->b_kn) LAUNCH_P8(false, false);
             else if (!g->trans_a && g->b_kn) LAUNCH_P8(false, true);
             else if (g->trans_a && g->b_kn) LAUNCH_P8(true, true);
             else LAUNCH_P8(true, false);
 #undef LAUNCH_P8E
+#undef LAUNCH_P8_H
 #undef LAUNCH_P8
         } else if (dma_ok && (variant == 4 || (variant == 8 && !long_nt))) {
             last_variant = 4;
@@ -2050,45 +2083,56 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             // L2 -> LDS bytes per FLOP), so it is opt-in (BIFOLD_GEMM_BM=64), K-contiguous A only
             (void)e128; (void)e64;
             const bool small = bm_env == 64 && !g->trans_a;
-#define LAUNCH_K32(AKS, BKS, TC)                                                                    \
+#define LAUNCH_K32_T(AKS, BKS, TC, H)                                                                \
     do {                                                                                          \
         if (small) {                                                                              \
             GemmDims d64 = d; d64.tiles_m = bf_cdiv(g->m, 64);                                    \
-            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 2>), dim3((unsigned)t64), block, 24576, s, A, B, d64, ep, slabs, ab, bb); \
+            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 2, H>), dim3((unsigned)t64), block, 24576, s, (const H*)g->a, (const H*)g->b, d64, ep, slabs, ab, bb); \
         } else {                                                                                  \
-            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 4>), grid, block, 32768, s, A, B, d, ep, slabs, ab, bb); \
+            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 4, H>), grid, block, 32768, s, (const H*)g->a, (const H*)g->b, d, ep, slabs, ab, bb); \
         }                                                                                         \
     } while (0)
-            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_K32(false, false, float); else LAUNCH_K32(false, false, bf16_t); }
-            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(false, true, float); else LAUNCH_K32(false, true, bf16_t); }
-            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_K32(true, true, float); else LAUNCH_K32(true, true, bf16_t); }
-            else { if (f32out) LAUNCH_K32(true, false, float); else LAUNCH_K32(true, false, bf16_t); }
+#define LAUNCH_K32_H(AKS, BKS, H) do { if (f32out) LAUNCH_K32_T(AKS, BKS, float, H); else LAUNCH_K32_T(AKS, BKS, H, H); } while (0)
+#define LAUNCH_K32(AKS, BKS) BY_HALF(LAUNCH_K32_H, AKS, BKS)
+            if (!g->trans_a && !g->b_kn) LAUNCH_K32(false, false);
+            else if (!g->trans_a && g->b_kn) LAUNCH_K32(false, true);
+            else if (g->trans_a && g->b_kn) LAUNCH_K32(true, true);
+            else LAUNCH_K32(true, false);
+#undef LAUNCH_K32_T
+#undef LAUNCH_K32_H
 #undef LAUNCH_K32
         } else if (dma_ok) {
             last_variant = 0;
             const size_t lds2 = 65536;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-#define LAUNCH_DMA(AKS, BKS, TC)                                                                    \
+#define LAUNCH_DMA_T(AKS, BKS, TC, H)                                                                \
     do {                                                                                          \
         static bool lds_ok = false;                                                               \
         if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AKS, BKS, TC>,            \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AKS, BKS, TC, H>,         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);     \
             lds_ok = true;                                                                        \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_dma_kernel<AKS, BKS, TC>), grid, block, lds2, s, A, B, d, ep, slabs, ab, bb); \
+        hipLaunchKernelGGL((gemm_bf16_dma_kernel<AKS, BKS, TC, H>), grid, block, lds2, s, (const H*)g->a, (const H*)g->b, d, ep, slabs, ab, bb); \
     } while (0)
-            if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_DMA(false, false, float); else LAUNCH_DMA(false, false, bf16_t); }
-            else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_DMA(false, true, float); else LAUNCH_DMA(false, true, bf16_t); }
-            else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_DMA(true, true, float); else LAUNCH_DMA(true, true, bf16_t); }
-            else { if (f32out) LAUNCH_DMA(true, false, float); else LAUNCH_DMA(true, false, bf16_t); }
+#define LAUNCH_DMA_H(AKS, BKS, H) do { if (f32out) LAUNCH_DMA_T(AKS, BKS, float, H); else LAUNCH_DMA_T(AKS, BKS, H, H); } while (0)
+#define LAUNCH_DMA(AKS, BKS) BY_HALF(LAUNCH_DMA_H, AKS, BKS)
+            if (!g->trans_a && !g->b_kn) LAUNCH_DMA(false, false);
+            else if (!g->trans_a && g->b_kn) LAUNCH_DMA(false, true);
+            else if (g->trans_a && g->b_kn) LAUNCH_DMA(true, true);
+            else LAUNCH_DMA(true, false);
+#undef LAUNCH_DMA_T
+#undef LAUNCH_DMA_H
 #undef LAUNCH_DMA
         } else
-        if (!g->trans_a && !g->b_kn) { if (f32out) LAUNCH_BF16(false, false, float); else LAUNCH_BF16(false, false, bf16_t); }
-        else if (!g->trans_a && g->b_kn) { if (f32out) LAUNCH_BF16(false, true, float); else LAUNCH_BF16(false, true, bf16_t); }
-        else if (g->trans_a && g->b_kn) { if (f32out) LAUNCH_BF16(true, true, float); else LAUNCH_BF16(true, true, bf16_t); }
-        else { if (f32out) LAUNCH_BF16(true, false, float); else LAUNCH_BF16(true, false, bf16_t); }
+        if (!g->trans_a && !g->b_kn) LAUNCH_BF16(false, false);
+        else if (!g->trans_a && g->b_kn) LAUNCH_BF16(false, true);
+        else if (g->trans_a && g->b_kn) LAUNCH_BF16(true, true);
+        else LAUNCH_BF16(true, false);
+#undef LAUNCH_BF16_T
+#undef LAUNCH_BF16_H
 #undef LAUNCH_BF16
+#undef BY_HALF
     } else {
         last_variant = -1;
         GemmDimsF d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps};
@@ -2122,6 +2166,11 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                 hipLaunchKernelGGL((splitk_reduce_kernel<float, bf16_t>), rgrid, block, 0, s, slabs, split, ep);
             else
                 hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, bf16_t>), rgrid, block, 0, s, slabs, split, ep);
+        } else if (g->cdt == BF_F16) {
+            if (g->c_dtype == BF_F32)
+                hipLaunchKernelGGL((splitk_reduce_kernel<float, f16_t>), rgrid, block, 0, s, slabs, split, ep);
+            else
+                hipLaunchKernelGGL((splitk_reduce_kernel<f16_t, f16_t>), rgrid, block, 0, s, slabs, split, ep);
         } else {
             hipLaunchKernelGGL((splitk_reduce_kernel<float, float>), rgrid, block, 0, s, slabs, split, ep);
         }

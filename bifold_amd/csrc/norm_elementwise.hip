@@ -3,6 +3,8 @@
 // wave-shuffle reductions, fp32 math.
 #include "common.h"
 
+#include <type_traits>
+
 #define LN_MAXC 8   // float4 chunks per lane kept in registers -> cols <= 2048
 
 // ------------------------------------------------------------------ LayerNorm fwd
@@ -149,7 +151,7 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     dim3 grid(bf_cdiv(rows, 4)), block(256);
     static const int ln_rows = []() { const char* e = getenv("BIFOLD_LN_ROWS"); return e ? atoi(e) : 2; }();
     if (x_dtype == BF_F32 && (cols == 512 || cols == 768 || cols == 1024) && ln_rows > 1 &&
-        (y_dtype == BF_BF16 || y_dtype == BF_F32)) {
+        (bf_is_half(y_dtype) || y_dtype == BF_F32)) {
 #define LN_ROWS(TY, NC, R)                                                                       \
     hipLaunchKernelGGL((ln_fwd_rows_kernel<float, TY, NC, R>), dim3(bf_cdiv(rows, 4 * R)), block, 0, \
                        s, (const float*)x, gamma, beta, (TY*)y, mean, rstd, rows, eps)
@@ -159,6 +161,7 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
         else LN_ROWS(TY, 4, R);                                                                 \
     } while (0)
         if (y_dtype == BF_BF16) { if (ln_rows >= 4) LN_ROWS_NC(bf16_t, 4); else LN_ROWS_NC(bf16_t, 2); }
+        else if (y_dtype == BF_F16) { if (ln_rows >= 4) LN_ROWS_NC(f16_t, 4); else LN_ROWS_NC(f16_t, 2); }
         else { if (ln_rows >= 4) LN_ROWS_NC(float, 4); else LN_ROWS_NC(float, 2); }
 #undef LN_ROWS_NC
 #undef LN_ROWS
@@ -172,6 +175,9 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
     else if (x_dtype == BF_F32 && y_dtype == BF_BF16) LN_LAUNCH(float, bf16_t);
     else if (x_dtype == BF_BF16 && y_dtype == BF_BF16) LN_LAUNCH(bf16_t, bf16_t);
     else if (x_dtype == BF_BF16 && y_dtype == BF_F32) LN_LAUNCH(bf16_t, float);
+    else if (x_dtype == BF_F32 && y_dtype == BF_F16) LN_LAUNCH(float, f16_t);
+    else if (x_dtype == BF_F16 && y_dtype == BF_F16) LN_LAUNCH(f16_t, f16_t);
+    else if (x_dtype == BF_F16 && y_dtype == BF_F32) LN_LAUNCH(f16_t, float);
     else BF_REQUIRE(false, BF_EINVAL, "bf_layernorm_fwd: bad dtype codes %d/%d", x_dtype, y_dtype);
 #undef LN_LAUNCH
     BF_CHECK_LAUNCH("bf_layernorm_fwd");
@@ -183,8 +189,8 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 // included): with the add done HERE the GEMM runs its plain-bf16 epilogue (no 256 KB residual tile to wait for at item
 // start, half the store bytes) and this kernel, which reads the residual stream anyway, adds 2 B/element of traffic.
 // Two rows per wave like ln_fwd_rows_kernel; cols == NC * 256.
-template <typename TY, int NC>
-__global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+template <typename TY, int NC, typename TDL = bf16_t>
+__global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restrict__ x, const TDL* __restrict__ delta,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ x_out, TY* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int rows,
@@ -200,11 +206,11 @@ __global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restric
     for (int r = 0; r < R; ++r) {
         const int row = min(row0 + r, rows - 1);
         const float* xr = x + (size_t)row * cols;
-        const bf16_t* dr = delta + (size_t)row * cols;
+        const TDL* dr = delta + (size_t)row * cols;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const float4 a = *(const float4*)(xr + (lane + i * 64) * 4);
-            const float4 d = Vec4<bf16_t>::load(dr + (lane + i * 64) * 4);
+            const float4 d = Vec4<TDL>::load(dr + (lane + i * 64) * 4);
             v[r][i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
         }
     }
@@ -270,18 +276,21 @@ extern "C" int bf_add_layernorm_fwd(const float* x, const void* delta_bf16, cons
     BF_REQUIRE(x && delta_bf16 && gamma && beta && x_out && y, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
     BF_REQUIRE(rows > 0 && (cols == 256 || cols == 512 || cols == 768 || cols == 1024), BF_EINVAL,
                "bf_add_layernorm_fwd: cols must be 256, 512, 768 or 1024 (got %d)", cols);
-    BF_REQUIRE(y_dtype == BF_BF16 || y_dtype == BF_F32, BF_EINVAL, "bf_add_layernorm_fwd: bad y dtype");
+    BF_REQUIRE(bf_is_half(y_dtype) || y_dtype == BF_F32, BF_EINVAL, "bf_add_layernorm_fwd: bad y dtype");
     BF_REQUIRE(bf_aligned16(x) && bf_aligned16(delta_bf16) && bf_aligned16(x_out) && bf_aligned16(y) &&
                    bf_aligned16(gamma) && bf_aligned16(beta), BF_EALIGN, "bf_add_layernorm_fwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bf_cdiv(rows, 8)), block(256);
-#define ADDLN(TY, NCV) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV>), grid, block, 0, s, x, (const bf16_t*)delta_bf16,                                           gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
+    // `delta` has y's type when y is a 16-bit tensor (the branch output of that compute dtype), bf16 next to an fp32 y
+#define ADDLN(TY, NCV) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV, std::conditional_t<std::is_same<TY, float>::value, bf16_t, TY>>), \
+                                          grid, block, 0, s, x, (const std::conditional_t<std::is_same<TY, float>::value, bf16_t, TY>*)delta_bf16, \
+                                          gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
 #define ADDLN_NC(TY)                                                                   \
     do {                                                                               \
         if (cols == 256) ADDLN(TY, 1); else if (cols == 512) ADDLN(TY, 2);             \
         else if (cols == 768) ADDLN(TY, 3); else ADDLN(TY, 4);                         \
     } while (0)
-    if (y_dtype == BF_BF16) ADDLN_NC(bf16_t); else ADDLN_NC(float);
+    if (y_dtype == BF_BF16) ADDLN_NC(bf16_t); else if (y_dtype == BF_F16) ADDLN_NC(f16_t); else ADDLN_NC(float);
 #undef ADDLN_NC
 #undef ADDLN
     BF_CHECK_LAUNCH("bf_add_layernorm_fwd");
@@ -433,6 +442,9 @@ extern "C" int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, co
     else if (dy_dtype == BF_F32 && cd == BF_BF16) LNB_LAUNCH(float, bf16_t);
     else if (dy_dtype == BF_BF16 && cd == BF_BF16) LNB_LAUNCH(bf16_t, bf16_t);
     else if (dy_dtype == BF_BF16 && cd == BF_F32) LNB_LAUNCH(bf16_t, float);
+    else if (dy_dtype == BF_F32 && cd == BF_F16) LNB_LAUNCH(float, f16_t);
+    else if (dy_dtype == BF_F16 && cd == BF_F16) LNB_LAUNCH(f16_t, f16_t);
+    else if (dy_dtype == BF_F16 && cd == BF_F32) LNB_LAUNCH(f16_t, float);
     else BF_REQUIRE(false, BF_EINVAL, "bf_layernorm_bwd: bad dtype codes");
 #undef LNB_LAUNCH
 #undef LNB_LAUNCH_NC
@@ -491,6 +503,8 @@ extern "C" int bf_colsum(const void* x, int x_dtype, float* out, int rows, int c
         hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)x, out, rows, cols, ld, rpb);
     else if (x_dtype == BF_BF16)
         hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, out, rows, cols, ld, rpb);
+    else if (x_dtype == BF_F16)
+        hipLaunchKernelGGL(colsum_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, out, rows, cols, ld, rpb);
     else BF_REQUIRE(false, BF_EINVAL, "bf_colsum: bad dtype %d", x_dtype);
     BF_CHECK_LAUNCH("bf_colsum");
     return BF_OK;
@@ -569,6 +583,16 @@ extern "C" int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype,
         hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, s, (const float*)src, (float*)dst, n4, count);
     else if (src_dtype == BF_BF16 && dst_dtype == BF_BF16)
         hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, n4, count);
+    else if (src_dtype == BF_F32 && dst_dtype == BF_F16)
+        hipLaunchKernelGGL((cast_kernel<float, f16_t>), grid, block, 0, s, (const float*)src, (f16_t*)dst, n4, count);
+    else if (src_dtype == BF_F16 && dst_dtype == BF_F32)
+        hipLaunchKernelGGL((cast_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)src, (float*)dst, n4, count);
+    else if (src_dtype == BF_F16 && dst_dtype == BF_F16)
+        hipLaunchKernelGGL((cast_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)src, (f16_t*)dst, n4, count);
+    else if (src_dtype == BF_BF16 && dst_dtype == BF_F16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, f16_t>), grid, block, 0, s, (const bf16_t*)src, (f16_t*)dst, n4, count);
+    else if (src_dtype == BF_F16 && dst_dtype == BF_BF16)
+        hipLaunchKernelGGL((cast_kernel<f16_t, bf16_t>), grid, block, 0, s, (const f16_t*)src, (bf16_t*)dst, n4, count);
     else BF_REQUIRE(false, BF_EINVAL, "bf_cast: bad dtype codes");
     BF_CHECK_LAUNCH("bf_cast");
     return BF_OK;
@@ -645,6 +669,8 @@ extern "C" int bf_patchify_ld(const float* img, void* cols, int cdt, int batch, 
         hipLaunchKernelGGL(patchify_ld_kernel<float>, grid, block, 0, s, img, (float*)cols, batch, size, patch, ld);
     else if (cdt == BF_BF16)
         hipLaunchKernelGGL(patchify_ld_kernel<bf16_t>, grid, block, 0, s, img, (bf16_t*)cols, batch, size, patch, ld);
+    else if (cdt == BF_F16)
+        hipLaunchKernelGGL(patchify_ld_kernel<f16_t>, grid, block, 0, s, img, (f16_t*)cols, batch, size, patch, ld);
     else BF_REQUIRE(false, BF_EINVAL, "bf_patchify_ld: bad dtype %d", cdt);
     BF_CHECK_LAUNCH("bf_patchify_ld");
     return BF_OK;
@@ -664,6 +690,8 @@ extern "C" int bf_patchify(const float* img, void* cols, int cdt, int batch, int
         hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, s, img, (float*)cols, batch, size, patch);
     else if (cdt == BF_BF16)
         hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, s, img, (bf16_t*)cols, batch, size, patch);
+    else if (cdt == BF_F16)
+        hipLaunchKernelGGL(patchify_kernel<f16_t>, grid, block, 0, s, img, (f16_t*)cols, batch, size, patch);
     else BF_REQUIRE(false, BF_EINVAL, "bf_patchify: bad dtype %d", cdt);
     BF_CHECK_LAUNCH("bf_patchify");
     return BF_OK;
@@ -832,7 +860,7 @@ extern "C" int bf_vision_lnpre_ln1(float* x, const float* cls, const float* pos0
                                    int width, float eps, bf_stream_t stream) {
     BF_REQUIRE(batch > 0 && n_patch > 0 && (width & 3) == 0 && width <= LN_MAXC * 256, BF_EINVAL,
                "bf_vision_lnpre_ln1: bad shape (n_patch=%d width=%d)", n_patch, width);
-    BF_REQUIRE(h_dtype == BF_F32 || h_dtype == BF_BF16, BF_EINVAL, "bf_vision_lnpre_ln1: bad output dtype %d", h_dtype);
+    BF_REQUIRE(h_dtype == BF_F32 || bf_is_half(h_dtype), BF_EINVAL, "bf_vision_lnpre_ln1: bad output dtype %d", h_dtype);
     BF_REQUIRE(bf_aligned16(x) && bf_aligned16(cls) && bf_aligned16(pos0) && bf_aligned16(h) && bf_aligned16(g0) &&
                bf_aligned16(b0) && bf_aligned16(g1) && bf_aligned16(b1), BF_EALIGN, "bf_vision_lnpre_ln1: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -840,6 +868,9 @@ extern "C" int bf_vision_lnpre_ln1(float* x, const float* cls, const float* pos0
     dim3 grid(bf_cdiv((long)rows, 4)), block(256);
     if (h_dtype == BF_BF16)
         hipLaunchKernelGGL(vision_lnpre_ln1_kernel<bf16_t>, grid, block, 0, s, x, cls, pos0, g0, b0, g1, b1, (bf16_t*)h,
+                           rows, n_patch + 1, width, eps);
+    else if (h_dtype == BF_F16)
+        hipLaunchKernelGGL(vision_lnpre_ln1_kernel<f16_t>, grid, block, 0, s, x, cls, pos0, g0, b0, g1, b1, (f16_t*)h,
                            rows, n_patch + 1, width, eps);
     else
         hipLaunchKernelGGL(vision_lnpre_ln1_kernel<float>, grid, block, 0, s, x, cls, pos0, g0, b0, g1, b1, (float*)h,
@@ -1016,6 +1047,9 @@ extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt
     else if (cdt == BF_BF16)
         hipLaunchKernelGGL(fusion_assemble_bwd_kernel<bf16_t>, grid, block, 0, s, dx, (bf16_t*)d_rgb_feat,
                            d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
+    else if (cdt == BF_F16)
+        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<f16_t>, grid, block, 0, s, dx, (f16_t*)d_rgb_feat,
+                           d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
     else BF_REQUIRE(false, BF_EINVAL, "bf_fusion_assemble_bwd: bad dtype %d", cdt);
     BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/1");
     hipLaunchKernelGGL(fusion_assemble_bwd2_kernel, dim3(bf_cdiv(dim, 16)), block, 0, s, d_text_pos,
@@ -1145,7 +1179,7 @@ extern "C" int bf_dropout(const void* x, void* y, int dtype, size_t count, float
                           int accumulate, bf_stream_t stream) {
     BF_REQUIRE(x && y && count > 0 && (count & 3) == 0, BF_EINVAL, "bf_dropout: count must be a positive multiple of 4");
     BF_REQUIRE(p >= 0.f && p < 1.f, BF_EINVAL, "bf_dropout: p must be in [0, 1) (got %f)", (double)p);
-    BF_REQUIRE(dtype == BF_F32 || dtype == BF_BF16, BF_EINVAL, "bf_dropout: bad dtype");
+    BF_REQUIRE(dtype == BF_F32 || bf_is_half(dtype), BF_EINVAL, "bf_dropout: bad dtype");
     BF_REQUIRE(bf_aligned16(x) && bf_aligned16(y), BF_EALIGN, "bf_dropout: unaligned pointer");
     const size_t n4 = count / 4;
     size_t blocks = (n4 + 255) / 256;
@@ -1156,6 +1190,7 @@ extern "C" int bf_dropout(const void* x, void* y, int dtype, size_t count, float
 #define BF_DROP(T, ACC) hipLaunchKernelGGL((dropout_kernel<T, ACC>), dim3((unsigned)blocks), dim3(256), 0, s, \
                                            (const T*)x, (T*)y, n4, thr, inv_keep, seed)
     if (dtype == BF_F32) { if (accumulate) BF_DROP(float, true); else BF_DROP(float, false); }
+    else if (dtype == BF_F16) { if (accumulate) BF_DROP(f16_t, true); else BF_DROP(f16_t, false); }
     else { if (accumulate) BF_DROP(bf16_t, true); else BF_DROP(bf16_t, false); }
 #undef BF_DROP
     BF_CHECK_LAUNCH("bf_dropout");

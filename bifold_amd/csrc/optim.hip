@@ -4,10 +4,10 @@
 
 #include <math.h>
 
-template <bool SHADOW>
+template <bool SHADOW, typename TS>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   bf16_t* __restrict__ shadow, size_t n4, float lr,
+                                                   TS* __restrict__ shadow, size_t n4, float lr,
                                                    float beta1, float beta2, float eps, float wd,
                                                    int decoupled, float step_size, float sqrt_bc2,
                                                    const float* __restrict__ gscale) {
@@ -36,17 +36,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         ((float4*)p)[i] = pv;
         ((float4*)m)[i] = mv;
         ((float4*)v)[i] = vv;
-        if (SHADOW) Vec4<bf16_t>::store(shadow + i * 4, pv);
+        if (SHADOW) Vec4<TS>::store(shadow + i * 4, pv);
     }
 }
 
 extern "C" int bf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
-                            size_t count, int step, float lr, float beta1, float beta2, float eps,
+                            int shadow_dtype, size_t count, int step, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int decoupled, const float* grad_scale_dev,
                             bf_stream_t stream) {
     BF_REQUIRE(count > 0 && (count & 3) == 0, BF_EINVAL,
                "bf_adam_step: the arena length must be a multiple of 4 (got %zu)", count);
     BF_REQUIRE(step >= 1, BF_EINVAL, "bf_adam_step: step is 1-based (got %d)", step);
+    BF_REQUIRE(!shadow || bf_is_half(shadow_dtype), BF_EINVAL, "bf_adam_step: the shadow copy is BF_BF16 or BF_F16 (got %d)",
+               shadow_dtype);
     BF_REQUIRE(bf_aligned16(param) && bf_aligned16(grad) && bf_aligned16(exp_avg) && bf_aligned16(exp_avg_sq) &&
                    (!shadow || bf_aligned16(shadow)), BF_EALIGN, "bf_adam_step: unaligned pointer");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -58,11 +60,14 @@ extern "C" int bf_adam_step(float* param, const float* grad, float* exp_avg, flo
     if (blocks > 8192) blocks = 8192;
     dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (shadow)
-        hipLaunchKernelGGL(adam_kernel<true>, grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow,
+    if (shadow && shadow_dtype == BF_F16)
+        hipLaunchKernelGGL((adam_kernel<true, f16_t>), grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (f16_t*)shadow,
+                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
+    else if (shadow)
+        hipLaunchKernelGGL((adam_kernel<true, bf16_t>), grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow,
                            n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
     else
-        hipLaunchKernelGGL(adam_kernel<false>, grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)nullptr,
+        hipLaunchKernelGGL((adam_kernel<false, bf16_t>), grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)nullptr,
                            n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
     BF_CHECK_LAUNCH("bf_adam_step");
     return BF_OK;
@@ -171,5 +176,40 @@ extern "C" int bf_clip_grad_norm(float* grad, size_t count, float max_norm, floa
     hipLaunchKernelGGL(scale_inplace_kernel, dim3((unsigned)sblocks), dim3(256), 0, s, grad, n4, count,
                        ws + SUMSQ_BLOCKS + 1);
     BF_CHECK_LAUNCH("bf_clip_grad_norm/3");
+    return BF_OK;
+}
+
+// x *= scale in place, counting the non-finite results: the two ends of the fp16 mode's loss scaling (the gradient
+// entering the tail's backward is multiplied by S, every slice of the gradient arena by 1 / S when it completes).
+__global__ __launch_bounds__(256) void scale_check_kernel(float* __restrict__ x, size_t n4, size_t count, float c,
+                                                          unsigned* __restrict__ nonfinite) {
+    unsigned bad = 0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = ((float4*)x)[i];
+        v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+        ((float4*)x)[i] = v;
+        bad += !isfinite(v.x) + !isfinite(v.y) + !isfinite(v.z) + !isfinite(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const float t = x[n4 * 4 + threadIdx.x] * c;
+        x[n4 * 4 + threadIdx.x] = t;
+        bad += !isfinite(t);
+    }
+    if (nonfinite && __any(bad != 0)) {
+        bad = (unsigned)wave_sum((float)bad);
+        if ((threadIdx.x & 63) == 0 && bad) atomicAdd(nonfinite, bad);
+    }
+}
+
+extern "C" int bf_scale_check(float* x, size_t count, float scale, unsigned* nonfinite_count, bf_stream_t stream) {
+    BF_REQUIRE(x && count > 0, BF_EINVAL, "bf_scale_check: bad args");
+    BF_REQUIRE(bf_aligned16(x), BF_EALIGN, "bf_scale_check: unaligned pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, count, scale,
+                       nonfinite_count);
+    BF_CHECK_LAUNCH("bf_scale_check");
     return BF_OK;
 }

@@ -14,12 +14,12 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_long, c_size_t
 # that both resolve to ONE HIP runtime (device pointers and streams cross this boundary).
 import torch  # noqa: F401
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TANH_GELU_GRAD = 0, 1, 2, 3, 4, 5
 ACT_ERF_GELU_SAVEGRAD, ACT_MUL_AUX = 6, 7
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, TARGETS_FIT, MAX_TARGET_POINTS = 0, 1, 2, 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
@@ -107,7 +107,8 @@ PROTOTYPES = {
     "bf_decoder_project_bwd_ws": (c_size_t, [c_int, c_int, c_int]),
     "bf_decoder_project_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "bf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float,
+    "bf_scale_check": (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
+    "bf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_float,
                              c_float, c_float, c_float, c_float, c_int, c_void_p, c_void_p]),
     "bf_sumsq": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bf_clip_coef": (c_int, [c_void_p, c_float, c_void_p, c_void_p]),

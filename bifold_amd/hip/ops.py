@@ -14,8 +14,10 @@ import torch
 from . import lib as L
 from .lib import check, lib
 
-_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
-_TORCH = {L.F32: torch.float32, L.BF16: torch.bfloat16}
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}
+_TORCH = {L.F32: torch.float32, L.BF16: torch.bfloat16, L.F16: torch.float16}
+HALF = (torch.bfloat16, torch.float16)        # the 16-bit MFMA operand types (one per call)
+_TAG = {L.F32: "f32", L.BF16: "bf16", L.F16: "f16"}
 
 
 class KernelTimer:
@@ -71,7 +73,7 @@ def dtype_code(t) -> int:
     try:
         return _DT[dt]
     except KeyError:
-        raise TypeError(f"bifold_hip supports float32 / bfloat16 tensors, got {dt}") from None
+        raise TypeError(f"bifold_hip supports float32 / bfloat16 / float16 tensors, got {dt}") from None
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -117,11 +119,12 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
 def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                       out_dtype: torch.dtype, x_out: Optional[torch.Tensor] = None, save_stats: bool = False,
                       eps: float = 1e-5):
-    """x_out = x + delta (fp32 residual stream + the branch's bf16 output), y = LN(x_out).  `x_out=None` updates x in
+    """x_out = x + delta (fp32 residual stream + the branch's 16-bit output), y = LN(x_out).  `x_out=None` updates x in
     place.  Returns (y, mean, rstd, x_out)."""
     _dev(x, "x"); _dev(delta, "delta"); _dev(gamma, "gamma"); _dev(beta, "beta")
-    if x.dtype != torch.float32 or delta.dtype != torch.bfloat16 or x.shape != delta.shape:
-        raise TypeError("add_layernorm_fwd: x fp32 and delta bf16 of the same shape")
+    want_delta = out_dtype if out_dtype in HALF else torch.bfloat16
+    if x.dtype != torch.float32 or delta.dtype != want_delta or x.shape != delta.shape:
+        raise TypeError(f"add_layernorm_fwd: x fp32 and delta {want_delta} of the same shape")
     cols = x.shape[-1]
     rows = x.numel() // cols
     xo = x if x_out is None else x_out
@@ -150,7 +153,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: 
     want = dres_sum_out is not None
     parts = torch.empty(4 if want else 2, nparts, cols, dtype=torch.float32, device=x.device)
     check(lib.bf_layernorm_bwd(_ptr(dy), dtype_code(dy), _ptr(x), _ptr(gamma), _ptr(mean), _ptr(rstd),
-                               _ptr(dres), _ptr(dx), _ptr(dx_c), L.BF16 if dx_c is not None else L.F32,
+                               _ptr(dres), _ptr(dx), _ptr(dx_c), dtype_code(dx_c) if dx_c is not None else L.F32,
                                _ptr(parts[0]), _ptr(parts[1]), _ptr(parts[2]) if want else None,
                                _ptr(parts[3]) if want else None, rows, cols, _stream()), "bf_layernorm_bwd")
     check(lib.bf_colsum_multi(_ptr(parts), 4 if want else 2, nparts, cols, _ptr(dgamma_out), _ptr(dbeta_out),
@@ -231,26 +234,26 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
     g.accumulate = int(accumulate)
     copy = None
     if want_bf16_copy:
-        copy = torch.empty(out.shape, dtype=torch.bfloat16, device=a.device)
+        copy = torch.empty(out.shape, dtype=a.dtype if a.dtype in HALF else torch.bfloat16, device=a.device)
         g.c2 = copy.data_ptr()
     if colsum_out is not None:
         if colsum_out.dtype != torch.float32 or colsum_out.numel() != n or not colsum_out.is_contiguous():
             raise RuntimeError("colsum_out must be a contiguous float32 [n] tensor")
         g.colsum_out = colsum_out.data_ptr()
-    sk = (pick_split_k(m, n, k, deep_tn=(trans_a and b_kn and a.dtype == torch.bfloat16))
+    sk = (pick_split_k(m, n, k, deep_tn=(trans_a and b_kn and a.dtype in HALF))
           if split_k is None else split_k)
     ws = None
     if sk > 1:
         ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.split_k = sk
-    if sk <= 1 and cdt == L.BF16 and m >= 16384:
+    if sk <= 1 and cdt != L.F32 and m >= 16384:
         tail = lib.bf_gemm_tail_workspace_bytes(C.byref(g))
         if tail:
             ws = torch.empty(tail // 4, dtype=torch.float32, device=a.device)
             g.workspace, g.workspace_bytes = ws.data_ptr(), tail
     span = None
-    label = f"gemm_{'bf16' if cdt == L.BF16 else 'f32'}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}"
+    label = f"gemm_{_TAG[cdt]}_{'t' if trans_a else 'n'}{'n' if b_kn else 't'}"
     if PROFILER is not None and PROFILER.wants(label):
         if PROFILER.per_shape:
             extras = "".join(t for t, on in (("+bias", bias is not None), (f"+act{act}", act != 0),
@@ -260,7 +263,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         span = _Span(label, 2.0 * m * n * k)
     check(lib.bf_gemm(C.byref(g), _stream()), "bf_gemm")
     if span is not None:
-        if cdt == L.BF16:          # name the device kernel that ran: gemm_bf16_nt[p8] / [k32] / [bk64] / [reg]
+        if cdt != L.F32:           # name the device kernel that ran: gemm_bf16_nt[p8] / [k32] / [bk64] / [reg]
             span.label = span.label.replace(" ", f"[{_VARIANT_TAG.get(lib.bf_gemm_last_variant(), '?')}] ", 1) \
                 if " " in span.label else span.label + f"[{_VARIANT_TAG.get(lib.bf_gemm_last_variant(), '?')}]"
         span.close()
@@ -324,7 +327,7 @@ def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim:
     span = None
     if PROFILER is not None and PROFILER.wants("attn_fwd"):
         causal = 0.5 if mask_mode == L.MASK_CAUSAL else 1.0
-        span = _Span(f"attn_fwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
+        span = _Span(f"attn_fwd_{_TAG[dtype_code(qkv)]}_d{head_dim}",
                      4.0 * batch * heads * seq * seq * head_dim * causal)
     check(lib.bf_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(row_mask), batch, seq, heads,
                                head_dim, scale, mask_mode, dtype_code(qkv), _stream()), "bf_attention_fwd")
@@ -340,10 +343,10 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_
     delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
     # long sequences (bf16): dQ is accumulated across key chunks in an fp32 scratch
     dq_ws = (torch.empty(batch * seq, heads * head_dim, dtype=torch.float32, device=qkv.device)
-             if (qkv.dtype == torch.bfloat16 and lib.bf_attention_bwd_needs_dq_ws(seq, head_dim)) else None)
+             if (qkv.dtype in HALF and lib.bf_attention_bwd_needs_dq_ws(seq, head_dim)) else None)
     span = None
     if PROFILER is not None and PROFILER.wants("attn_bwd"):
-        span = _Span(f"attn_bwd_{'bf16' if qkv.dtype == torch.bfloat16 else 'f32'}_d{head_dim}",
+        span = _Span(f"attn_bwd_{_TAG[dtype_code(qkv)]}_d{head_dim}",
                      10.0 * batch * heads * seq * seq * head_dim)
     check(lib.bf_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
                                _ptr(delta), _ptr(dq_ws), batch, seq, heads, head_dim, scale, mask_mode,
@@ -525,8 +528,16 @@ def bce_mean_bwd(heat, target, gscale: torch.Tensor):
 def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, step, lr, beta1, beta2, eps, weight_decay,
               decoupled, grad_scale=None):
     check(lib.bf_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(shadow),
-                           param.numel(), step, lr, beta1, beta2, eps, weight_decay, int(decoupled),
+                           dtype_code(shadow) if shadow is not None else L.BF16, param.numel(), step, lr, beta1, beta2, eps, weight_decay, int(decoupled),
                            _ptr(grad_scale), _stream()), "bf_adam_step")
+
+
+def scale_check_(x: torch.Tensor, scale: float, nonfinite: Optional[torch.Tensor] = None) -> None:
+    """x *= scale in place (fp32, contiguous); `nonfinite` (int32 [1], optional) counts inf / nan results."""
+    _dev(x, "x")
+    if x.dtype != torch.float32 or (nonfinite is not None and nonfinite.dtype != torch.int32):
+        raise TypeError("scale_check_: x float32, nonfinite int32")
+    check(lib.bf_scale_check(_ptr(x), x.numel(), float(scale), _ptr(nonfinite), _stream()), "bf_scale_check")
 
 
 def sumsq(x: torch.Tensor) -> torch.Tensor:

@@ -25,7 +25,10 @@
  *    legacy default stream);
  *  - tensors are row-major and contiguous unless a leading dimension is given;
  *    pointers must be 16-byte aligned;
- *  - dtype codes: BF_F32 = 0 (IEEE fp32), BF_BF16 = 1 (bfloat16).  "cdt" below is
+ *  - dtype codes: BF_F32 = 0 (IEEE fp32), BF_BF16 = 1 (bfloat16), BF_F16 = 2 (IEEE binary16, CLIP's native
+ *    dtype, models/clip/model.py:480-506 `convert_weights`; same MFMA rate as bf16 on gfx950, 2^-11 instead of
+ *    2^-9 operand rounding; wherever a comment below says "bf16" for a 16-bit tensor, BF_F16 is accepted too and
+ *    all 16-bit tensors of one call share one type).  "cdt" below is
  *    the compute dtype of a call: operands of matrix products; accumulation,
  *    LayerNorm statistics, softmax, the residual stream, losses and optimiser
  *    state are always fp32;
@@ -42,9 +45,9 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 5
+#define BF_ABI_VERSION 6
 
-enum { BF_F32 = 0, BF_BF16 = 1 };
+enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
 enum {
     BF_OK = 0,
@@ -363,13 +366,13 @@ int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_ef
  * arena: all trainable parameters, gradients and both moments live in four
  * contiguous fp32 buffers of `count` elements, so one launch updates the model.
  *   step is 1-based; decoupled != 0 selects AdamW's decay.
- *   shadow (optional, bf16 [count]) receives the bf16 copy of the new parameters
- *   (the cdt operands of next step's GEMMs).
+ *   shadow (optional, [count] of shadow_dtype = BF_BF16 / BF_F16) receives the 16-bit copy of the new
+ *   parameters (the cdt operands of next step's GEMMs).
  *   grad_scale_dev (optional device fp32 scalar) multiplies the gradient first
  *   (gradient clipping, __main__.py:148-149; DDP averaging).
  * ---------------------------------------------------------------------- */
 int bf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
-                 size_t count, int step, float lr, float beta1, float beta2, float eps,
+                 int shadow_dtype, size_t count, int step, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int decoupled, const float* grad_scale_dev,
                  bf_stream_t stream);
 
@@ -384,6 +387,14 @@ int bf_clip_coef(const float* sumsq, float max_norm, float* out, bf_stream_t str
  * ws: fp32 scratch >= 1026 floats. */
 int bf_clip_grad_norm(float* grad, size_t count, float max_norm, float* ws, float* norm_out,
                       bf_stream_t stream);
+
+/* x[i] *= scale in place (fp32 [count]); *nonfinite_count (optional device counter, never reset here) += the number
+ * of results that are inf / nan.  The two ends of the BF_F16 mode's loss scaling: the gradient that enters the
+ * trainable tail's backward is multiplied by S so that the 16-bit gradient tensors stay inside binary16's range
+ * (BCE's mean puts 1 / (B S^2) in front of every logit gradient -- 8e-8 at B = 256, below binary16's smallest
+ * subnormal), and each slice of the gradient arena by 1 / S as the backward completes it.  The reference trains in
+ * fp32 (__main__.py:135-150) and has no counterpart. */
+int bf_scale_check(float* x, size_t count, float scale, unsigned* nonfinite_count, bf_stream_t stream);
 
 /* Inverted dropout with a replayable mask: y[i] (+)= keep(seed, i) ? x[i] / (1 - p) : 0, keep = a pure function
  * of (seed, element index) (splitmix64, 24 bits against p * 2^24), so the backward pass regenerates the mask from

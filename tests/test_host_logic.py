@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
     for name in declared:
         assert hasattr(L.lib, name)
-    assert L.lib.bf_abi_version() == L.ABI_VERSION == 5
+    assert L.lib.bf_abi_version() == L.ABI_VERSION == 6
 
 
 def test_c_abi_rejects_bad_arguments_before_launching():
@@ -45,7 +45,10 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert L.lib.bf_layernorm_fwd(None, 0, None, None, None, 0, None, None, 4, 30, 1e-5, None) == -1
     assert L.lib.bf_attention_fwd(None, None, None, None, 1, 8, 1, 40, 1.0, 0, 1, None) == -1   # head_dim 40
     assert b"head_dim" in L.lib.bf_last_error()
-    assert L.lib.bf_adam_step(None, None, None, None, None, 6, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1
+    assert L.lib.bf_adam_step(None, None, None, None, None, 1, 6, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1
+    assert L.lib.bf_scale_check(None, 0, 1.0, None, None) == -1
+    g.m = g.n = g.k = 64; g.lda = g.ldb = g.ldc = 64; g.cdt, g.c_dtype = L.F16, L.BF16      # 16-bit output of another type
+    assert L.lib.bf_gemm(C.byref(g), None) == -1 and b"c_dtype" in L.lib.bf_last_error()
     assert L.lib.bf_bce_parts(256) == 1024 and L.lib.bf_layernorm_bwd_parts(70400) > 0
     assert L.lib.bf_attention_bwd_needs_dq_ws(275, 32) == 0 and L.lib.bf_attention_bwd_needs_dq_ws(2950, 48) == 1
 

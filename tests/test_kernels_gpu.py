@@ -25,6 +25,13 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+HALF = (torch.bfloat16, torch.float16)      # the two 16-bit compute dtypes: same kernels, other MFMA opcode / rounding
+
+
+def round_to(t, cdt):
+    return t.to(cdt).to(torch.float32)
+
+
 @pytest.fixture(scope="module")
 def ops(gpu):
     from bifold_amd.hip import ops as _ops
@@ -39,7 +46,7 @@ def L(gpu):
 
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("rows,cols", [(7, 512), (197 * 3, 768), (5, 96), (33, 2048)])
-@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_layernorm_fwd(ops, gpu, rows, cols, out_dtype):
     g = torch.Generator().manual_seed(rows * cols)
     x = torch.randn(rows, cols, generator=g) * 3 + 0.7
@@ -54,7 +61,7 @@ def test_layernorm_fwd(ops, gpu, rows, cols, out_dtype):
 
 
 @pytest.mark.parametrize("rows,cols", [(9, 512), (275 * 2, 768), (40, 96)])
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_layernorm_bwd(ops, gpu, rows, cols, cdt):
     g = torch.Generator().manual_seed(1 + rows)
     x = (torch.randn(rows, cols, generator=g) * 2 + 0.3).requires_grad_(True)
@@ -62,7 +69,7 @@ def test_layernorm_bwd(ops, gpu, rows, cols, cdt):
     b = (0.2 * torch.randn(cols, generator=g)).requires_grad_(True)
     dy = torch.randn(rows, cols, generator=g)
     dres = torch.randn(rows, cols, generator=g)
-    dy_used = bf16_round(dy) if cdt == torch.bfloat16 else dy
+    dy_used = round_to(dy, cdt) if cdt in HALF else dy
     y = F.layer_norm(x, (cols,), w, b, 1e-5)
     y.backward(dy_used)
     ref_dx = x.grad + dres
@@ -80,7 +87,7 @@ def test_layernorm_bwd(ops, gpu, rows, cols, cdt):
     assert torch.equal(dx_b, dx)
     assert rel_err(dgam, w.grad) < 1e-5
     assert rel_err(dbet, b.grad) < 1e-5
-    if cdt == torch.bfloat16:
+    if cdt in HALF:
         assert dxc is not None and rel_err(dxc.float(), ref_dx) < 2 ** -8
     else:
         assert dxc is None
@@ -116,7 +123,7 @@ GEMM_SHAPES = [  # m, n, k
 
 @pytest.mark.parametrize("m,n,k", GEMM_SHAPES)
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn", "tt"])
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt, gemm_variant):
     _skip_f32_dup(cdt, gemm_variant)
     trans_a = layout[0] == "t"
@@ -126,8 +133,8 @@ def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt, gemm_variant):
     g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
     a = torch.randn((k, m) if trans_a else (m, k), generator=g)
     b = torch.randn((k, n) if b_kn else (n, k), generator=g)
-    if cdt == torch.bfloat16:
-        a, b = bf16_round(a), bf16_round(b)
+    if cdt in HALF:
+        a, b = round_to(a, cdt), round_to(b, cdt)
     ref = ref_gemm(a, b, trans_a, b_kn)
     out = ops.gemm(a.to(gpu).to(cdt), b.to(gpu).to(cdt), trans_a=trans_a, b_kn=b_kn,
                    out_dtype=torch.float32, split_k=1)
@@ -135,7 +142,7 @@ def test_gemm_layouts(ops, gpu, m, n, k, layout, cdt, gemm_variant):
     assert rel_err(out, ref) < 2e-6 * math.sqrt(k) + 1e-6
 
 
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("split", [1, 3, 8])
 def test_gemm_splitk_tn(ops, gpu, cdt, split, gemm_variant):
     """dW = dY^T X with the token dimension (not a multiple of the K tile) split."""
@@ -144,15 +151,15 @@ def test_gemm_splitk_tn(ops, gpu, cdt, split, gemm_variant):
     tokens, n_out, k_in = 275 * 3 + 1, 256, 136
     dy = torch.randn(tokens, n_out, generator=g)
     x = torch.randn(tokens, k_in, generator=g)
-    if cdt == torch.bfloat16:
-        dy, x = bf16_round(dy), bf16_round(x)
+    if cdt in HALF:
+        dy, x = round_to(dy, cdt), round_to(x, cdt)
     ref = dy.double().t() @ x.double()
     out = ops.gemm(dy.to(gpu).to(cdt), x.to(gpu).to(cdt), trans_a=True, b_kn=True, out_dtype=torch.float32,
                    split_k=split)
     assert rel_err(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("act", ["none", "quick", "erf", "tanh"])
 def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act, gemm_variant):
     _skip_f32_dup(cdt, gemm_variant)
@@ -161,8 +168,8 @@ def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act, gemm_variant):
     a, w = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) * k ** -0.5
     bias = torch.randn(n, generator=g)
     res = torch.randn(m, n, generator=g)
-    if cdt == torch.bfloat16:
-        a, w = bf16_round(a), bf16_round(w)
+    if cdt in HALF:
+        a, w = round_to(a, cdt), round_to(w, cdt)
     pre = a.double() @ w.double().t() + bias.double()
     if act == "quick":
         v = pre * torch.sigmoid(1.702 * pre)
@@ -181,36 +188,36 @@ def test_gemm_epilogue_bias_act_residual(ops, L, gpu, cdt, act, gemm_variant):
         assert rel_err(got_pre.float(), pre) < (2e-6 if cdt == torch.float32 else 2 ** -8)
     assert rel_err(got, ref) < 5e-6
     # bf16 output + in-place residual (C aliases the residual)
-    if cdt == torch.bfloat16:
+    if cdt in HALF:
         o16 = ops.gemm(a.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=bias.to(gpu), act=code,
-                       out_dtype=torch.bfloat16)
+                       out_dtype=cdt)
         assert rel_err(o16.float(), v) < 2 ** -8
     xres = res.to(gpu).clone()
     ops.gemm(a.to(gpu).to(cdt), w.to(gpu).to(cdt), bias=bias.to(gpu), residual=xres, out=xres)
     assert rel_err(xres, pre + res.double()) < 5e-6
 
 
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt, gemm_variant):
     _skip_f32_dup(cdt, gemm_variant)
     g = torch.Generator().manual_seed(13)
     m, n, k = 3 * 17, 256, 64
     dy, w = torch.randn(m, k, generator=g), torch.randn(k, n, generator=g)     # dX = dY W, W stored [K,N]
     pre = torch.randn(m, n, generator=g)
-    if cdt == torch.bfloat16:
-        dy, w, pre = bf16_round(dy), bf16_round(w), bf16_round(pre)
+    if cdt in HALF:
+        dy, w, pre = round_to(dy, cdt), round_to(w, cdt), round_to(pre, cdt)
     p = pre.double().requires_grad_(True)
     F.gelu(p).backward(dy.double() @ w.double())
     got = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
                    aux=pre.to(gpu).to(cdt), out_dtype=torch.float32)
     assert rel_err(got, p.grad) < 1e-5
-    if cdt == torch.bfloat16:      # bf16 result (the fused MLP backward): fast erf' + final rounding
+    if cdt in HALF:      # bf16 result (the fused MLP backward): fast erf' + final rounding
         got16 = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
-                         aux=pre.to(gpu).to(cdt), out_dtype=torch.bfloat16)
+                         aux=pre.to(gpu).to(cdt), out_dtype=cdt)
         assert rel_err(got16.float(), p.grad) < 2 ** -7
     # fused bias gradient: column sums of the STORED result, whatever kernel ran (fused in the persistent
     # kernel's GELU-grad epilogue, a bf_colsum launch otherwise)
-    for odt in ((torch.float32, torch.bfloat16) if cdt == torch.bfloat16 else (torch.float32,)):
+    for odt in ((torch.float32, cdt) if cdt in HALF else (torch.float32,)):
         cs = torch.full((n,), 123.0, device=gpu)
         o = ops.gemm(dy.to(gpu).to(cdt), w.to(gpu).to(cdt), b_kn=True, act=L.ACT_ERF_GELU_GRAD,
                      aux=pre.to(gpu).to(cdt), out_dtype=odt, colsum_out=cs)
@@ -226,21 +233,22 @@ def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt, gemm_variant):
     assert (o[:, :2] == -7).all() and (o[:, 19:] == -7).all()
 
 
+@pytest.mark.parametrize("half", HALF)
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-def test_gemm_persistent_rounds(ops, L, gpu, layout):
+def test_gemm_persistent_rounds(ops, L, gpu, layout, half):
     """More 256x256 work items than CUs (the persistent kernel loops, the next item's first
     stages are in flight during the epilogue), ragged M / N tails, 3 K stages, bf16 and fp32 out."""
     trans_a, b_kn = layout[0] == "t", layout[1] == "n"
     m, n, k = 5000, 3592, 96
     g = torch.Generator().manual_seed(77)
-    a = bf16_round(torch.randn((k, m) if trans_a else (m, k), generator=g))
-    b = bf16_round(torch.randn((k, n) if b_kn else (n, k), generator=g))
+    a = round_to(torch.randn((k, m) if trans_a else (m, k), generator=g), half)
+    b = round_to(torch.randn((k, n) if b_kn else (n, k), generator=g), half)
     bias = torch.randn(n, generator=g)
     ref = ref_gemm(a, b, trans_a, b_kn) + bias.double()
     L.lib.bf_gemm_set_variant(8)
     try:
-        for odt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2 ** -8)):
-            out = ops.gemm(a.to(gpu).bfloat16(), b.to(gpu).bfloat16(), trans_a=trans_a, b_kn=b_kn,
+        for odt, tol in ((torch.float32, 1e-5), (half, 2 ** -8 if half == torch.bfloat16 else 2 ** -11)):
+            out = ops.gemm(a.to(gpu).to(half), b.to(gpu).to(half), trans_a=trans_a, b_kn=b_kn,
                            bias=bias.to(gpu), out_dtype=odt, split_k=1)
             assert rel_err(out.float(), ref) < tol
     finally:
@@ -298,12 +306,12 @@ ATTN_CASES = [  # B, L, H, D, mode
 
 
 @pytest.mark.parametrize("B,Lq,H,D,mode", ATTN_CASES)
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_attention_fwd(ops, gpu, B, Lq, H, D, mode, cdt):
     g = torch.Generator().manual_seed(B * Lq + D)
     qkv = torch.randn(B * Lq, 3 * H * D, generator=g)
-    if cdt == torch.bfloat16:
-        qkv = bf16_round(qkv)
+    if cdt in HALF:
+        qkv = round_to(qkv, cdt)
     row_mask = None
     if mode == 2:
         row_mask = (torch.rand(B, Lq, generator=g) > 0.3).int()
@@ -325,13 +333,13 @@ def test_attention_fwd(ops, gpu, B, Lq, H, D, mode, cdt):
                                             # ragged last chunk, every head width
                                             (1, 700, 2, 64, 1), (1, 577, 2, 48, 1), (1, 900, 1, 32, 0),
                                             (2, 576, 2, 64, 0), (1, 1290, 1, 48, 2)])
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_attention_bwd(ops, gpu, B, Lq, H, D, mode, cdt):
     g = torch.Generator().manual_seed(Lq + D)
     qkv = torch.randn(B * Lq, 3 * H * D, generator=g)
     dout = torch.randn(B * Lq, H * D, generator=g)
-    if cdt == torch.bfloat16:
-        qkv, dout = bf16_round(qkv), bf16_round(dout)
+    if cdt in HALF:
+        qkv, dout = round_to(qkv, cdt), round_to(dout, cdt)
     row_mask = None
     if mode == 2:
         row_mask = (torch.rand(B, Lq, generator=g) > 0.3).int()
@@ -372,7 +380,7 @@ def test_attention_bwd_with_whole_masked_segments(ops, gpu, B, Lq, H, D, spans):
 
 
 # ------------------------------------------------------------------ token plumbing
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_patchify_matches_conv(ops, gpu, cdt):
     g = torch.Generator().manual_seed(23)
     img = torch.randn(2, 3, 64, 64, generator=g)
@@ -381,11 +389,11 @@ def test_patchify_matches_conv(ops, gpu, cdt):
     ref = F.conv2d(img, w, stride=16).flatten(2).transpose(1, 2).reshape(-1, 40)
     got = cols.float().cpu() @ w.flatten(1).t()
     assert rel_err(got, ref) < (1e-5 if cdt == torch.float32 else 1e-2)
-    assert torch.equal(cols.float().cpu(), (bf16_round(cols.float().cpu()) if cdt == torch.bfloat16
+    assert torch.equal(cols.float().cpu(), (round_to(cols.float().cpu(), cdt) if cdt in HALF
                                             else cols.cpu()))
 
 
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_patchify_patch14_padded(ops, gpu, cdt):
     """ViT-L/14: 14-pixel patches, im2col rows padded with zeros from 588 to 640 columns."""
     g = torch.Generator().manual_seed(24)
@@ -399,7 +407,7 @@ def test_patchify_patch14_padded(ops, gpu, cdt):
     assert rel_err(c[:, :588] @ w.flatten(1).t(), ref) < (1e-5 if cdt == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("cdt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("cdt,tol", [(torch.float32, 3e-6), (torch.bfloat16, 1.2e-2), (torch.float16, 3e-3)])
 @pytest.mark.parametrize("B,n,W,K", [(3, 16, 128, 192), (300, 196, 768, 768)])
 def test_patch_embed_epilogue_and_lnpre_ln1(ops, gpu, observed, cdt, tol, B, n, W, K):
     """K1: the patch-embed GEMM writes patches + pos into the token stream through its row-remap epilogue, and
@@ -584,26 +592,46 @@ def test_bce_forward_backward(ops, gpu):
 
 
 # ------------------------------------------------------------------ optimiser
+@pytest.mark.parametrize("half", HALF)
 @pytest.mark.parametrize("decoupled,wd", [(False, 0.0), (True, 0.01), (False, 0.01)])
-def test_adam_matches_torch(ops, gpu, decoupled, wd):
+def test_adam_matches_torch(ops, gpu, decoupled, wd, half):
     g = torch.Generator().manual_seed(37)
     n = 4096 + 4
     p0 = torch.randn(n, generator=g)
     ref_p = torch.nn.Parameter(p0.clone())
     opt = (torch.optim.AdamW if decoupled else torch.optim.Adam)([ref_p], lr=1e-3, weight_decay=wd)
     p, m, v = p0.to(gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
-    shadow = torch.empty(n, dtype=torch.bfloat16, device=gpu)
+    shadow = torch.empty(n, dtype=half, device=gpu)
     for step in range(1, 5):
         gr = torch.randn(n, generator=g)
         ref_p.grad = gr.clone()
         opt.step()
         ops.adam_step(p, gr.to(gpu), m, v, shadow, step, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled)
     assert rel_err(p, ref_p.detach()) < 1e-6
-    assert torch.equal(shadow.cpu(), p.cpu().to(torch.bfloat16))
+    assert torch.equal(shadow.cpu(), p.cpu().to(half))
     ss = ops.sumsq(p)
     assert abs(ss.item() - (p.double() ** 2).sum().item()) < 1e-4 * ss.item()
     c = ops.clip_coef(ss, 1.0)
     assert abs(c.item() - min(1.0, 1.0 / (math.sqrt(ss.item()) + 1e-6))) < 1e-6
+
+
+def test_scale_check_scales_in_place_and_counts_nonfinite(ops, gpu):
+    """bf_scale_check: the two ends of the fp16 mode's loss scaling (x *= S exactly for a power of two; inf / nan counted)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4099, generator=g)
+    xd = x.to(gpu)
+    flag = torch.zeros(1, dtype=torch.int32, device=gpu)
+    ops.scale_check_(xd[:4096], 2.0 ** 20, flag)
+    assert torch.equal(xd[:4096].cpu(), x[:4096] * 2.0 ** 20) and torch.equal(xd[4096:].cpu(), x[4096:]) and flag.item() == 0
+    ops.scale_check_(xd[:4096], 2.0 ** -20, flag)
+    assert torch.equal(xd.cpu(), x) and flag.item() == 0
+    xd[7], xd[100], xd[4000] = float("inf"), float("nan"), 3e38
+    ops.scale_check_(xd[:4096], 4.0, flag)                      # 3e38 * 4 overflows to inf as well
+    assert flag.item() == 3
+    y = torch.randn(6, device=gpu)                               # count % 4 != 0: the tail elements are scaled too
+    y0 = y.clone()
+    ops.scale_check_(y, 0.5)
+    assert torch.equal(y, y0 * 0.5)
 
 
 # ------------------------------------------------------------------ either side of the step
@@ -808,7 +836,7 @@ def test_fp8_gemm_matches_dequantised_product(ops, L, gpu, m, n, k, act):
 
 
 @pytest.mark.parametrize("m,n,k", [(300, 256, 128), (16384 + 200, 512, 256)])     # 128x128 kernels / persistent kernel
-@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_gelu_savegrad_and_mul_aux(ops, L, gpu, m, n, k, cdt):
     """BF_ACT_ERF_GELU_SAVEGRAD: C = gelu(v) and pre = gelu'(v) from one erf evaluation; BF_ACT_MUL_AUX: v *= aux --
     the pair that replaces (ERF_GELU + saved pre, ERF_GELU_GRAD) in the fusion MLP (modules.py:21-27 and its autograd)."""
@@ -816,7 +844,7 @@ def test_gemm_gelu_savegrad_and_mul_aux(ops, L, gpu, m, n, k, cdt):
     x = torch.randn(m, k, generator=g)
     w = torch.randn(n, k, generator=g) * 0.2
     b = torch.randn(n, generator=g) * 0.3
-    xc, wc = (x, w) if cdt == torch.float32 else (bf16_round(x), bf16_round(w))
+    xc, wc = (x, w) if cdt == torch.float32 else (round_to(x, cdt), round_to(w, cdt))
     v = (xc.double() @ wc.double().t() + b.double()).requires_grad_(True)
     ref = F.gelu(v)
     ref.sum().backward()
@@ -826,24 +854,24 @@ def test_gemm_gelu_savegrad_and_mul_aux(ops, L, gpu, m, n, k, cdt):
     # backward half: dX-like product times the saved derivative, against the same product times gelu'(pre) in fp64
     dy = torch.randn(m, k, generator=g)
     w2 = torch.randn(k, n, generator=g) * 0.2                  # stored [K, N]: b_kn
-    dyc, w2c = (dy, w2) if cdt == torch.float32 else (bf16_round(dy), bf16_round(w2))
+    dyc, w2c = (dy, w2) if cdt == torch.float32 else (round_to(dy, cdt), round_to(w2, cdt))
     want = (dyc.double() @ w2c.double()) * gp.double().cpu()
     got = ops.gemm(dy.to(gpu).to(cdt), w2.to(gpu).to(cdt), b_kn=True, act=L.ACT_MUL_AUX, aux=gp)
     assert rel_err(got.float(), want) < tol
-    if cdt == torch.bfloat16 and m >= 16384:                   # the fused bias-gradient sums ride along on this path
+    if cdt in HALF and m >= 16384:                   # the fused bias-gradient sums ride along on this path
         cs = torch.empty(n, dtype=torch.float32, device=gpu)
         got2 = ops.gemm(dy.to(gpu).to(cdt), w2.to(gpu).to(cdt), b_kn=True, act=L.ACT_MUL_AUX, aux=gp, colsum_out=cs)
         assert rel_err(cs, got2.float().double().sum(0)) < 1e-3
 
 
 @pytest.mark.parametrize("rows,cols", [(197 * 3 + 1, 768), (77 * 2, 512), (9, 1024), (300, 256)])
-@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_add_layernorm_fwd(ops, gpu, rows, cols, out_dtype):
     """x_out = x + delta (bf16 branch output), y = LN(x_out): the residual add of clip/model.py:217-218 fused into
     the LayerNorm that follows it; in place and out of place, with statistics."""
     g = torch.Generator().manual_seed(rows + cols)
     x = torch.randn(rows, cols, generator=g) * 2 + 0.5
-    delta = (torch.randn(rows, cols, generator=g) * 0.7).bfloat16()
+    delta = (torch.randn(rows, cols, generator=g) * 0.7).to(out_dtype if out_dtype in HALF else torch.bfloat16)
     w = 1 + 0.2 * torch.randn(cols, generator=g)
     b = 0.2 * torch.randn(cols, generator=g)
     xs = x.double() + delta.double()
