@@ -41,6 +41,11 @@ _SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
 _DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "1"))
 # 1 = a dW GEMM is issued AFTER the dX GEMM that becomes runnable at the same moment (see fusion_layer_bwd); 0 = before
 _DW_ORDER = int(os.environ.get("BIFOLD_DW_ORDER", "1"))
+# 1 = the four dW GEMMs of a layer are collected and issued as ONE grouped launch of the persistent kernel once the last
+# of their operands (dQKV) exists (bf_gemm_tn_grouped: 48 tiles x 5 K-splits for the 8 x 512 layer instead of four GEMMs
+# split 16 / 16 / 64 / 21 ways, a quarter of the fp32 partial slabs, 2 launches instead of 8); groups that do not
+# qualify (fp32 mode, short or ragged token counts) and 0 run the GEMMs one by one as before
+_DW_GROUPED = int(os.environ.get("BIFOLD_DW_GROUPED", "1"))
 
 
 def _dw_stream(device) -> "torch.cuda.Stream":
@@ -55,6 +60,28 @@ class _WeightGradSide:
     def __init__(self, device):
         self.on = _DW_SIDE > 0
         self.side = _dw_stream(device) if self.on else None
+        self.group = [] if _DW_GROUPED else None       # (dy, x, out) of the layer being walked
+        self.group_after = None                         # event behind the producer of the LAST collected operand
+
+    def flush(self):
+        """Issue what `gemm` collected (end of a layer: every operand has been produced on the main stream)."""
+        if not self.group:
+            return
+        todo, self.group = self.group, []
+        after, self.group_after = self.group_after, None
+        if self.on:
+            if after is not None:
+                self.side.wait_event(after)             # not for what the main stream queued since (the next dX GEMM)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side) if self.on else _NullCtx():
+            if not ops.gemm_tn_grouped(todo):
+                for dy, x, out in todo:
+                    ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
+        if self.on:
+            for dy, x, _ in todo:
+                dy.record_stream(self.side)
+                x.record_stream(self.side)
 
     def ready(self):
         """Event on the main stream: everything queued so far (the operands of the next dW GEMM) is produced."""
@@ -65,6 +92,10 @@ class _WeightGradSide:
         return ev
 
     def gemm(self, dy, x, out, after=None):
+        if self.group is not None and dy.dtype in ops.HALF:
+            self.group.append((dy, x, out))
+            self.group_after = after
+            return
         if not self.on:
             ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
             return
@@ -84,6 +115,14 @@ class _WeightGradSide:
         ev = torch.cuda.Event()
         ev.record(self.side)
         return ev
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def head_names(is_bimanual: bool) -> List[str]:
@@ -267,7 +306,7 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     d = dx3.shape[1] // heads
     if wg is None:
         wg = _WeightGradSide.__new__(_WeightGradSide)
-        wg.on, wg.side = False, None
+        wg.on, wg.side, wg.group, wg.group_after = False, None, None, None
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
@@ -307,6 +346,7 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     dh1 = ops.gemm(dqkv, A.operand(P["wqkv"], cdt), b_kn=True)
     if _DW_ORDER:
         wg.gemm(dqkv, S["h1"], g(P["wqkv"]), e_qkv)
+    wg.flush()
     return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
 
 

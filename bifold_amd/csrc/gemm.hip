@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <type_traits>
@@ -713,7 +714,23 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
 #define P8_ABL_PIECES 2
 #endif
 
-struct P8Item { int m0, n0, kbeg, nk, z, rev; };
+struct P8Item { int m0, n0, kbeg, nk, z, rev, p; };
+
+// A GROUP of deep dW = dY^T X problems that share K (the four weight gradients of one transformer layer) handed to ONE
+// launch of the persistent kernel: their output tiles are numbered consecutively, an item is (split, tile) over the union,
+// and a single K split of the union fills the CUs -- 48 tiles x 5 splits for the 8 x 512 fusion layer, where the four
+// GEMMs on their own need 16 / 16 / 64 / 21 splits (and as many fp32 partial slabs each) to fill 256 CUs.
+#define P8_MAX_GROUP 8
+struct P8Group {
+    const void* a[P8_MAX_GROUP];
+    const void* b[P8_MAX_GROUP];
+    float* slab[P8_MAX_GROUP];        // [split][m][n] fp32 partials of problem p
+    int m[P8_MAX_GROUP], n[P8_MAX_GROUP], lda[P8_MAX_GROUP], ldb[P8_MAX_GROUP];
+    int tiles_n[P8_MAX_GROUP];
+    int tile_base[P8_MAX_GROUP + 1];  // first tile of problem p in the union; [count] = all tiles
+    unsigned a_bytes[P8_MAX_GROUP], b_bytes[P8_MAX_GROUP];
+    int count;
+};
 
 #ifdef P8_PROBE
 __device__ unsigned long long p8_probe[16];
@@ -726,19 +743,29 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 // (any output type, residual / aux / copies / row remap / split-K slabs), 1 = plain bf16 (alpha, bias,
 // activation, optional pre-activation copy), 2 = bf16 GELU-grad.  One kernel with all three paths sat at
 // the 256-register limit and spilled differently with every edit.
-template <bool A_KS, bool B_KS, typename TC, int EPI, typename H>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
-    const H* __restrict__ A, const H* __restrict__ B, GemmDims d, EpiParams ep,
+template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, bool GROUPED = false>
+__device__ __forceinline__ void p8_body(
+    const H* __restrict__ A, const H* __restrict__ B, const GemmDims& d, const EpiParams& ep,
     float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
-    unsigned* __restrict__ tk) {
+    unsigned* __restrict__ tk, const P8Group* __restrict__ grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB) + 16 B
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int tiles = d.tiles_m * d.tiles_n;
+    const int tiles = GROUPED ? grp->tile_base[grp->count] : d.tiles_m * d.tiles_n;
     const int G = gridDim.x, bid = blockIdx.x;
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    // operand descriptors and leading dimensions: fixed for a plain launch, re-bound per work item in a grouped one
+    __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, a_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, b_bytes, 0x00020000);
+    int lda = d.lda, ldb = d.ldb;
+    auto bind = [&](const P8Item& it) {
+        if constexpr (GROUPED) {
+            ra = __builtin_amdgcn_make_buffer_rsrc((void*)grp->a[it.p], 0, grp->a_bytes[it.p], 0x00020000);
+            rb = __builtin_amdgcn_make_buffer_rsrc((void*)grp->b[it.p], 0, grp->b_bytes[it.p], 0x00020000);
+            lda = grp->lda[it.p];
+            ldb = grp->ldb[it.p];
+        }
+    };
 
     // Work distribution.  Items (split, tile) are cut into one contiguous range per XCD (blocks with
     // equal bid % 8 share an XCD and therefore an L2: neighbouring tiles, the same A / W panels).  Inside
@@ -765,7 +792,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         const int item = x_base + (int)ticket;
         w.z = item / tiles;
         int tm, tn;
-        tile_coords(item - w.z * tiles, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+        w.p = 0;
+        if constexpr (GROUPED) {
+            const int t = item - w.z * tiles;
+            int p = 0;
+            while (p + 1 < grp->count && t >= grp->tile_base[p + 1]) ++p;
+            const int loc = t - grp->tile_base[p];
+            w.p = p;
+            tm = loc / grp->tiles_n[p];
+            tn = loc - tm * grp->tiles_n[p];
+        } else {
+            tile_coords(item - w.z * tiles, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+        }
         w.m0 = tm * 256; w.n0 = tn * 256;
         w.kbeg = w.z * d.k_per_split;
         w.nk = (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 31) >> 5;
@@ -784,11 +822,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     };
     auto issue_a_any = [&](const P8Item& w, int s) {       // any item: full address computation (item boundaries)
         const int ks = w.rev ? w.nk - 1 - s : s;
-        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, d.lda, w.m0, w.kbeg + ks * 32, wave * 2, P8_ABL_PIECES, lane);
+        dma_pieces32<A_KS>(ra, smem + (s & 3) * P8_STAGE, lda, w.m0, w.kbeg + ks * 32, wave * 2, P8_ABL_PIECES, lane);
     };
     auto issue_b_any = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
-        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, d.ldb, w.n0, w.kbeg + ks * 32, wave * 2, P8_ABL_PIECES, lane);
+        dma_pieces32<B_KS>(rb, smem + (s & 3) * P8_STAGE + 16384, ldb, w.n0, w.kbeg + ks * 32, wave * 2, P8_ABL_PIECES, lane);
     };
 
     // In-loop DMA issue.  A piece's address used to be recomputed per piece and stage -- a 32-bit multiply (quarter
@@ -801,14 +839,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     auto set_bases = [&](const P8Item& it) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            va[p] = dma_piece_offset32<A_KS>(d.lda, it.m0, it.kbeg, wave * 2 + p, lane);
-            vb[p] = dma_piece_offset32<B_KS>(d.ldb, it.n0, it.kbeg, wave * 2 + p, lane);
+            va[p] = dma_piece_offset32<A_KS>(lda, it.m0, it.kbeg, wave * 2 + p, lane);
+            vb[p] = dma_piece_offset32<B_KS>(ldb, it.n0, it.kbeg, wave * 2 + p, lane);
         }
         asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(vb[0]), "+v"(vb[1]));   // live in registers, not rematerialised
     };
     auto issue_a = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
-        const unsigned delta = A_KS ? (unsigned)ks * 64u * (unsigned)d.lda : (unsigned)ks * 64u;
+        const unsigned delta = A_KS ? (unsigned)ks * 64u * (unsigned)lda : (unsigned)ks * 64u;
         char* dst = smem + (s & 3) * P8_STAGE + wave * 2048;
 #pragma unroll
         for (int p = 0; p < P8_ABL_PIECES; ++p)
@@ -816,7 +854,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     };
     auto issue_b = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
-        const unsigned delta = B_KS ? (unsigned)ks * 64u * (unsigned)d.ldb : (unsigned)ks * 64u;
+        const unsigned delta = B_KS ? (unsigned)ks * 64u * (unsigned)ldb : (unsigned)ks * 64u;
         char* dst = smem + (s & 3) * P8_STAGE + 16384 + wave * 2048;
 #pragma unroll
         for (int p = 0; p < P8_ABL_PIECES; ++p)
@@ -831,6 +869,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);   // wave-uniform: keeps the item in SGPRs
     unsigned nxt = 0;
     if (!decode(first, w)) { finish(); return; }
+    bind(w);
     issue_a_any(w, 0); issue_b_any(w, 0);
     if (w.nk > 1) { issue_a_any(w, 1); issue_b_any(w, 1); }
 
@@ -958,6 +997,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         nxt = __builtin_amdgcn_readfirstlane(bcast[0]);
         const bool has_next = decode(nxt, nx);
         if (has_next) {
+            bind(nx);
             issue_a_any(nx, 0); issue_b_any(nx, 0);
             if (nx.nk > 1) { issue_a_any(nx, 1); issue_b_any(nx, 1); }
         }
@@ -971,7 +1011,10 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         // turns its 128x64 tile around in 32-row chunks through a private 8 KB of ring slots 2-3
         // (slots 0-1 are receiving the next item), so that 16 adjacent lanes cover 64 consecutive
         // columns of one row: 4 whole 128/256-byte row segments per store instruction.
-        float* slab = slabs ? slabs + (size_t)w.z * ep.m * ep.n : nullptr;
+        // output extent of this item: the launch's (plain) or its problem's (grouped: fp32 partial slabs only)
+        const int epm = GROUPED ? grp->m[w.p] : ep.m, epn = GROUPED ? grp->n[w.p] : ep.n;
+        float* slab = GROUPED ? grp->slab[w.p] + (size_t)w.z * epm * epn
+                              : (slabs ? slabs + (size_t)w.z * ep.m * ep.n : nullptr);
         char* stg = smem + 2 * P8_STAGE + wave * 8192;
         EpiParams epi = ep;
         if (res_init) epi.residual = nullptr;              // already in the accumulators
@@ -1182,7 +1225,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         float b8[8];                   // the lane's 8 columns are the same for every row of the tile
         {
             const int n = w.n0 + wn * 64 + (lane & 7) * 8;
-            if (ep.bias && !slab && n < ep.n) Vec8<float>::load(ep.bias + n, b8);
+            if (ep.bias && !slab && n < epn) Vec8<float>::load(ep.bias + n, b8);
             else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) b8[e] = 0.f;
@@ -1205,9 +1248,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
                 const f32x4 q1 = *(const f32x4*)(stg + lr * 256 + (((c2 + 1) ^ (lr & 15)) << 4));
                 const int m = w.m0 + wm * 128 + c * 32 + lr;
                 const int n = w.n0 + wn * 64 + c2 * 4;
-                if (m < ep.m && n < ep.n) {
+                if (m < epm && n < epn) {
                     if (slab) {
-                        float* sp = slab + (size_t)m * ep.n + n;
+                        float* sp = slab + (size_t)m * epn + n;
                         *(f32x4*)sp = q0;
                         *(f32x4*)(sp + 4) = q1;
                     } else {
@@ -1231,6 +1274,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
         w = nx;
     }
     finish();
+}
+
+template <bool A_KS, bool B_KS, typename TC, int EPI, typename H>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
+    const H* __restrict__ A, const H* __restrict__ B, GemmDims d, EpiParams ep,
+    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
+    unsigned* __restrict__ tk) {
+    p8_body<A_KS, B_KS, TC, EPI, H, false>(A, B, d, ep, slabs, a_bytes, b_bytes, n_items, skew_cycles, tk, nullptr);
+}
+
+// The grouped dW launch: TN layout, fp32 partial slabs (general epilogue), every problem's geometry in `grp`.
+template <typename H>
+__global__ __launch_bounds__(512, 1) void gemm_p8_grouped_tn_kernel(P8Group grp, GemmDims d, EpiParams ep, int n_items,
+                                                                    int skew_cycles, unsigned* __restrict__ tk) {
+    p8_body<true, true, float, 0, H, true>((const H*)grp.a[0], (const H*)grp.b[0], d, ep, grp.slab[0], grp.a_bytes[0],
+                                           grp.b_bytes[0], n_items, skew_cycles, tk, &grp);
 }
 
 // =====================================================================================
@@ -1699,6 +1758,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// Reduction of a grouped launch's partial slabs: c_p[m, n] = sum_z slab_p[z][m][n] for every problem p (blockIdx.y),
+// summed in split order, so the result does not depend on which workgroup produced which partial.
+struct GroupedReduce {
+    const float* slab[P8_MAX_GROUP];
+    float* c[P8_MAX_GROUP];
+    int m[P8_MAX_GROUP], n[P8_MAX_GROUP], ldc[P8_MAX_GROUP];
+    int split;
+    float alpha;
+};
+__global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupedReduce r) {
+    const int p = blockIdx.y;
+    const int m_ = r.m[p], n_ = r.n[p], ldc = r.ldc[p];
+    const float* __restrict__ sl = r.slab[p];
+    float* __restrict__ c = r.c[p];
+    const int n4 = n_ >> 2;
+    const size_t total = (size_t)m_ * n4, slab = (size_t)m_ * n_;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int m = (int)(i / n4), n = (int)(i - (size_t)m * n4) * 4;
+        float4 acc = *(const float4*)(sl + (size_t)m * n_ + n);
+        for (int z = 1; z < r.split; ++z) {
+            const float4 v = *(const float4*)(sl + z * slab + (size_t)m * n_ + n);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc.x *= r.alpha; acc.y *= r.alpha; acc.z *= r.alpha; acc.w *= r.alpha;
+        *(float4*)(c + (size_t)m * ldc + n) = acc;
+    }
+}
+
 // =====================================================================================
 //                                        host
 // =====================================================================================
@@ -1843,6 +1930,115 @@ int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const fl
     hipLaunchKernelGGL(gemm_fp8_p8_kernel, dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, (const uint8_t*)a8, (const uint8_t*)b8, d,
                        ep, (unsigned)a_ext, (unsigned)b_ext, (int)tiles, rev_env, tk8);
     BF_CHECK_LAUNCH("bf_gemm_fp8");
+    return BF_OK;
+}
+
+// ---- grouped deep dW = dY^T X (the weight gradients of one transformer layer in one launch) ------------------------
+struct GroupedPlan { int split, kps; long tiles; size_t bytes; };
+static bool grouped_tn_plan(const bf_gemm_tn_problem* p, int count, int k, int cdt, GroupedPlan* plan) {
+    if (!p || count < 1 || count > P8_MAX_GROUP || !bf_is_half(cdt) || k < 16384 || (k % 32) != 0) return false;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("BIFOLD_DW_GROUPED"); on = e ? atoi(e) : 1; }
+    if (!on) return false;
+    if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+    if (pipe_env >= 0 && pipe_env != 8) return false;
+    long tiles = 0;
+    size_t elems = 0;
+    for (int i = 0; i < count; ++i) {
+        const bf_gemm_tn_problem& q = p[i];
+        if (q.m <= 0 || q.n <= 0 || (q.m & 7) || (q.n & 7) || (q.ld_dy & 7) || (q.ld_x & 7) || (q.ldc & 3) ||
+            q.ld_dy < q.m || q.ld_x < q.n || q.ldc < q.n || !q.dy || !q.x || !q.c || !bf_aligned16(q.dy) ||
+            !bf_aligned16(q.x) || !bf_aligned16(q.c))
+            return false;
+        if (((size_t)(k - 1) * q.ld_dy + q.m) * 2 >= (1ull << 32) || ((size_t)(k - 1) * q.ld_x + q.n) * 2 >= (1ull << 32))
+            return false;
+        tiles += (long)bf_cdiv(q.m, 256) * bf_cdiv(q.n, 256);
+        elems += (size_t)q.m * q.n;
+    }
+    const int n_cu = n_cus();
+    if (tiles > n_cu / 2) return false;                 // enough tiles to fill the chip without a K split: plain GEMMs
+    int split = (int)(n_cu / tiles);
+    if (split > 64) split = 64;
+    int kps = ((bf_cdiv(k, split) + 63) / 64) * 64;
+    split = bf_cdiv(k, kps);
+    if (split < 2) return false;
+    plan->split = split; plan->kps = kps; plan->tiles = tiles;
+    plan->bytes = (size_t)split * elems * sizeof(float);
+    return true;
+}
+
+extern "C" size_t bf_gemm_tn_grouped_workspace_bytes(const bf_gemm_tn_problem* p, int count, int k, int cdt) {
+    GroupedPlan plan;
+    return grouped_tn_plan(p, count, k, cdt, &plan) ? plan.bytes : 0;
+}
+
+extern "C" int bf_gemm_tn_grouped(const bf_gemm_tn_problem* p, int count, int k, int cdt, float alpha, void* workspace,
+                                  size_t workspace_bytes, bf_stream_t stream) {
+    GroupedPlan plan;
+    BF_REQUIRE(grouped_tn_plan(p, count, k, cdt, &plan), BF_EINVAL,
+               "bf_gemm_tn_grouped: this group does not take the grouped kernel (bf_gemm_tn_grouped_workspace_bytes "
+               "returns 0 for it: run the problems through bf_gemm one by one)");
+    BF_REQUIRE(workspace && workspace_bytes >= plan.bytes && bf_aligned16(workspace), BF_EWORKSPACE,
+               "bf_gemm_tn_grouped: needs %zu workspace bytes, got %zu", plan.bytes, workspace_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* tk8 = p8_ticket_set(s);
+    BF_REQUIRE(tk8 != nullptr, BF_ELAUNCH, "bf_gemm_tn_grouped: no ticket ring for this stream");
+    P8Group grp;
+    GroupedReduce red;
+    memset(&grp, 0, sizeof(grp));
+    memset(&red, 0, sizeof(red));
+    float* ws = (float*)workspace;
+    int base = 0, max_mn4 = 0;
+    for (int i = 0; i < count; ++i) {
+        const bf_gemm_tn_problem& q = p[i];
+        grp.a[i] = q.dy; grp.b[i] = q.x; grp.slab[i] = ws;
+        grp.m[i] = q.m; grp.n[i] = q.n; grp.lda[i] = q.ld_dy; grp.ldb[i] = q.ld_x;
+        grp.tiles_n[i] = bf_cdiv(q.n, 256);
+        grp.tile_base[i] = base;
+        base += bf_cdiv(q.m, 256) * bf_cdiv(q.n, 256);
+        grp.a_bytes[i] = (unsigned)(((size_t)(k - 1) * q.ld_dy + q.m) * 2);
+        grp.b_bytes[i] = (unsigned)(((size_t)(k - 1) * q.ld_x + q.n) * 2);
+        red.slab[i] = ws; red.c[i] = q.c; red.m[i] = q.m; red.n[i] = q.n; red.ldc[i] = q.ldc;
+        ws += (size_t)plan.split * q.m * q.n;
+        if (q.m * (q.n / 4) > max_mn4) max_mn4 = q.m * (q.n / 4);
+    }
+    grp.tile_base[count] = base;
+    grp.count = count;
+    red.split = plan.split; red.alpha = alpha;
+    GemmDims d{0, 0, k, 0, 0, 0, 0, plan.kps, 1};
+    EpiParams ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.alpha = 1.0f;
+    static int rev_env = -1;
+    if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
+    const int skew = rev_env | 2;                       // deep TN: prefetch distance 3 (both operands stream from HBM)
+    const long items = plan.tiles * plan.split;
+    const unsigned g8 = (unsigned)(n_cus() & ~7);
+    last_variant = 8;
+    if (cdt == BF_F16) {
+        static bool lds_ok = false;
+        if (!lds_ok) {
+            (void)hipFuncSetAttribute((const void*)gemm_p8_grouped_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * P8_STAGE + 16);
+            lds_ok = true;
+        }
+        hipLaunchKernelGGL(gemm_p8_grouped_tn_kernel<f16_t>, dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, grp, d, ep, (int)items,
+                           skew, tk8);
+    } else {
+        static bool lds_ok = false;
+        if (!lds_ok) {
+            (void)hipFuncSetAttribute((const void*)gemm_p8_grouped_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * P8_STAGE + 16);
+            lds_ok = true;
+        }
+        hipLaunchKernelGGL(gemm_p8_grouped_tn_kernel<bf16_t>, dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, grp, d, ep, (int)items,
+                           skew, tk8);
+    }
+    BF_CHECK_LAUNCH("bf_gemm_tn_grouped");
+    int rblocks = bf_cdiv(max_mn4, 256);
+    if (rblocks > 1024) rblocks = 1024;
+    hipLaunchKernelGGL(grouped_reduce_kernel, dim3((unsigned)rblocks, (unsigned)count), dim3(256), 0, s, red);
+    BF_CHECK_LAUNCH("bf_gemm_tn_grouped/reduce");
     return BF_OK;
 }
 

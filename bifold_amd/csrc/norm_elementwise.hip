@@ -270,27 +270,30 @@ __global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restric
     }
 }
 
-extern "C" int bf_add_layernorm_fwd(const float* x, const void* delta_bf16, const float* gamma, const float* beta,
+extern "C" int bf_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, const float* gamma, const float* beta,
                                     float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
                                     float eps, bf_stream_t stream) {
-    BF_REQUIRE(x && delta_bf16 && gamma && beta && x_out && y, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
+    BF_REQUIRE(x && delta && gamma && beta && x_out && y, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
     BF_REQUIRE(rows > 0 && (cols == 256 || cols == 512 || cols == 768 || cols == 1024), BF_EINVAL,
                "bf_add_layernorm_fwd: cols must be 256, 512, 768 or 1024 (got %d)", cols);
     BF_REQUIRE(bf_is_half(y_dtype) || y_dtype == BF_F32, BF_EINVAL, "bf_add_layernorm_fwd: bad y dtype");
-    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(delta_bf16) && bf_aligned16(x_out) && bf_aligned16(y) &&
+    BF_REQUIRE(bf_is_half(delta_dtype) && (y_dtype == BF_F32 || y_dtype == delta_dtype), BF_EINVAL,
+               "bf_add_layernorm_fwd: delta is a 16-bit tensor and a 16-bit y has its type (delta %d, y %d)", delta_dtype, y_dtype);
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(delta) && bf_aligned16(x_out) && bf_aligned16(y) &&
                    bf_aligned16(gamma) && bf_aligned16(beta), BF_EALIGN, "bf_add_layernorm_fwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bf_cdiv(rows, 8)), block(256);
-    // `delta` has y's type when y is a 16-bit tensor (the branch output of that compute dtype), bf16 next to an fp32 y
-#define ADDLN(TY, NCV) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV, std::conditional_t<std::is_same<TY, float>::value, bf16_t, TY>>), \
-                                          grid, block, 0, s, x, (const std::conditional_t<std::is_same<TY, float>::value, bf16_t, TY>*)delta_bf16, \
-                                          gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
-#define ADDLN_NC(TY)                                                                   \
+#define ADDLN(TY, NCV, TDL) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV, TDL>), grid, block, 0, s, x, (const TDL*)delta, \
+                                               gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
+#define ADDLN_NC(TY, TDL)                                                              \
     do {                                                                               \
-        if (cols == 256) ADDLN(TY, 1); else if (cols == 512) ADDLN(TY, 2);             \
-        else if (cols == 768) ADDLN(TY, 3); else ADDLN(TY, 4);                         \
+        if (cols == 256) ADDLN(TY, 1, TDL); else if (cols == 512) ADDLN(TY, 2, TDL);   \
+        else if (cols == 768) ADDLN(TY, 3, TDL); else ADDLN(TY, 4, TDL);               \
     } while (0)
-    if (y_dtype == BF_BF16) ADDLN_NC(bf16_t); else if (y_dtype == BF_F16) ADDLN_NC(f16_t); else ADDLN_NC(float);
+    if (y_dtype == BF_BF16) ADDLN_NC(bf16_t, bf16_t);
+    else if (y_dtype == BF_F16) ADDLN_NC(f16_t, f16_t);
+    else if (delta_dtype == BF_F16) ADDLN_NC(float, f16_t);
+    else ADDLN_NC(float, bf16_t);
 #undef ADDLN_NC
 #undef ADDLN
     BF_CHECK_LAUNCH("bf_add_layernorm_fwd");

@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         ((float4*)p)[i] = pv;
         ((float4*)m)[i] = mv;
         ((float4*)v)[i] = vv;
+        // the 16-bit copy is the rounding of the STORED fp32 master (what a cast of the arena gives): without the fence
+        // the compiler folds the last fma and the conversion into v_fma_mix*_f16, i.e. one rounding of the exact result
+        asm volatile("" : "+v"(pv.x), "+v"(pv.y), "+v"(pv.z), "+v"(pv.w));
         if (SHADOW) Vec4<TS>::store(shadow + i * 4, pv);
     }
 }

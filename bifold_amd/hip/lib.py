@@ -49,6 +49,12 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmTnProblem(C.Structure):
+    """Mirror of `struct bf_gemm_tn_problem` (include/bifold_hip.h)."""
+    _fields_ = [("dy", c_void_p), ("x", c_void_p), ("c", c_void_p),
+                ("m", c_int), ("n", c_int), ("ld_dy", c_int), ("ld_x", c_int), ("ldc", c_int)]
+
+
 # name -> (restype, argtypes); every symbol of include/bifold_hip.h
 PROTOTYPES = {
     "bf_abi_version": (c_int, []),
@@ -56,13 +62,15 @@ PROTOTYPES = {
     "bf_last_hip_error": (c_int, []),
     "bf_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                  c_void_p, c_int, c_int, c_float, c_void_p]),
-    "bf_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+    "bf_add_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_int, c_int, c_float, c_void_p]),
     "bf_layernorm_bwd_parts": (c_int, [c_int]),
     "bf_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_void_p]),
     "bf_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "bf_gemm_tn_grouped_workspace_bytes": (c_size_t, [POINTER(GemmTnProblem), c_int, c_int, c_int]),
+    "bf_gemm_tn_grouped": (c_int, [POINTER(GemmTnProblem), c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "bf_layernorm_fwd_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "bf_quantize_rows_fp8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "bf_gemm_fp8": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,

@@ -122,9 +122,9 @@ def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor,
     """x_out = x + delta (fp32 residual stream + the branch's 16-bit output), y = LN(x_out).  `x_out=None` updates x in
     place.  Returns (y, mean, rstd, x_out)."""
     _dev(x, "x"); _dev(delta, "delta"); _dev(gamma, "gamma"); _dev(beta, "beta")
-    want_delta = out_dtype if out_dtype in HALF else torch.bfloat16
-    if x.dtype != torch.float32 or delta.dtype != want_delta or x.shape != delta.shape:
-        raise TypeError(f"add_layernorm_fwd: x fp32 and delta {want_delta} of the same shape")
+    if (x.dtype != torch.float32 or delta.dtype not in HALF or x.shape != delta.shape
+            or (out_dtype in HALF and out_dtype != delta.dtype)):
+        raise TypeError("add_layernorm_fwd: x fp32, delta a 16-bit tensor of the same shape, a 16-bit y of delta's type")
     cols = x.shape[-1]
     rows = x.numel() // cols
     xo = x if x_out is None else x_out
@@ -133,7 +133,7 @@ def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor,
     if save_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib.bf_add_layernorm_fwd(_ptr(x), _ptr(delta), _ptr(gamma), _ptr(beta), _ptr(xo), _ptr(y), dtype_code(y),
+    check(lib.bf_add_layernorm_fwd(_ptr(x), _ptr(delta), dtype_code(delta), _ptr(gamma), _ptr(beta), _ptr(xo), _ptr(y), dtype_code(y),
                                    _ptr(mean), _ptr(rstd), rows, cols, eps, _stream()), "bf_add_layernorm_fwd")
     return y, mean, rstd, xo
 
@@ -272,6 +272,41 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
     if want_bf16_copy:
         return out, copy
     return out
+
+
+def gemm_tn_grouped(problems, alpha: float = 1.0) -> bool:
+    """problems: list of (dy [K, m], x [K, n], out fp32 [m, n]) -- out_p = alpha * dy_p^T x_p for every p in ONE launch of
+    the persistent kernel (the weight gradients of a transformer layer).  Returns False, having done nothing, when the
+    group does not qualify (bf_gemm_tn_grouped_workspace_bytes == 0): the caller then runs plain GEMMs."""
+    count = len(problems)
+    if count < 1 or count > 8:
+        return False
+    arr = (L.GemmTnProblem * count)()
+    k = None
+    for q, (dy, x, out) in zip(arr, problems):
+        dy, kd, m, ld_dy = _rows2d(dy, "dY")
+        x, kx, n, ld_x = _rows2d(x, "X")
+        out, om, on, ldc = _rows2d(out, "dW")
+        if dy.dtype != x.dtype or dy.dtype not in HALF or out.dtype != torch.float32 or kd != kx or (om, on) != (m, n):
+            return False
+        if k is None:
+            k, cdt = kd, dtype_code(dy)
+        elif kd != k or dtype_code(dy) != cdt:
+            return False
+        q.dy, q.x, q.c = dy.data_ptr(), x.data_ptr(), out.data_ptr()
+        q.m, q.n, q.ld_dy, q.ld_x, q.ldc = m, n, ld_dy, ld_x, ldc
+    need = lib.bf_gemm_tn_grouped_workspace_bytes(arr, count, k, cdt)
+    if not need:
+        return False
+    ws = torch.empty(need // 4, dtype=torch.float32, device=problems[0][0].device)
+    span = None
+    label = f"gemm_{_TAG[cdt]}_tn[p8g]"
+    if PROFILER is not None and PROFILER.wants(label):
+        span = _Span(label, sum(2.0 * k * q.m * q.n for q in arr))
+    check(lib.bf_gemm_tn_grouped(arr, count, k, cdt, float(alpha), ws.data_ptr(), need, _stream()), "bf_gemm_tn_grouped")
+    if span is not None:
+        span.close()
+    return True
 
 
 def colsum(x: torch.Tensor, out: Optional[torch.Tensor] = None, accumulate: bool = False):

@@ -75,11 +75,12 @@ int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
                      bf_stream_t stream);
 
 /* Residual add fused with the NEXT LayerNorm (models/clip/model.py:217-218 + :178-184; transformer.py:62-63 +
- * modules.py:11):  x_out = x + delta ;  y = LN(x_out).  delta = the bf16 output (bias included) of the branch's last
+ * modules.py:11):  x_out = x + delta ;  y = LN(x_out).  delta = the 16-bit output (delta_dtype = BF_BF16 / BF_F16, bias
+ * included; a 16-bit y has the same type) of the branch's last
  * GEMM -- out-proj or MLP fc2 -- which can then run its plain-bf16 epilogue instead of loading a fp32 residual tile
  * and storing a fp32 one.  x_out may alias x (frozen towers update the stream in place).  cols in {256, 512, 768,
  * 1024}; mean / rstd optional. */
-int bf_add_layernorm_fwd(const float* x, const void* delta_bf16, const float* gamma, const float* beta,
+int bf_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, const float* gamma, const float* beta,
                          float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
                          float eps, bf_stream_t stream);
 
@@ -177,6 +178,25 @@ int bf_gemm_set_variant(int variant);
 /* The bf16 kernel the calling thread's last bf_gemm launched: 8 / 4 / 0 as above, 1 = the
  * register-staged fallback, -1 = the exact fp32 kernel (profiling label, bench.py). */
 int bf_gemm_last_variant(void);
+
+/* A GROUP of deep weight-gradient GEMMs c_p[m_p, n_p] = alpha * dy_p^T x_p that share the contraction length k (the
+ * token count): the four dW of one transformer layer (models/transformer.py:19-24, models/modules.py:21-27 under
+ * autograd) in ONE launch of the persistent kernel plus one reduction.  On their own each of these GEMMs has too few
+ * 256 x 256 output tiles for 256 CUs and is split 16 - 64 ways along k, writing as many fp32 partial copies of its
+ * result; the union of a layer's tiles needs 5.  dy_p: [k, ld_dy] cdt (token-major dY), x_p: [k, ld_x] cdt, c_p fp32
+ * [m_p, ldc], overwritten.  bf_gemm_tn_grouped_workspace_bytes returns 0 when the group does not qualify (fp32
+ * operands, k < 16 384 or not a multiple of 32, m / n / ld not multiples of 8, more tiles than half the CUs, more than
+ * 8 problems): the caller then runs the problems through bf_gemm one by one.  Partials are summed in split order:
+ * the result is reproducible. */
+typedef struct bf_gemm_tn_problem {
+    const void* dy;
+    const void* x;
+    float* c;
+    int m, n, ld_dy, ld_x, ldc;
+} bf_gemm_tn_problem;
+size_t bf_gemm_tn_grouped_workspace_bytes(const bf_gemm_tn_problem* problems, int count, int k, int cdt);
+int bf_gemm_tn_grouped(const bf_gemm_tn_problem* problems, int count, int k, int cdt, float alpha, void* workspace,
+                       size_t workspace_bytes, bf_stream_t stream);
 
 /* Optional workspace for an un-split (split_k <= 1) bf16 GEMM: when the persistent 256x256 kernel
  * would leave most CUs idle in its last round of tiles, bf_gemm cuts the rows of that round off

@@ -255,6 +255,38 @@ def test_gemm_persistent_rounds(ops, L, gpu, layout, half):
         L.lib.bf_gemm_set_variant(-1)
 
 
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("shapes,k", [([(2048, 512), (512, 2048), (512, 512), (1536, 512)], 17600),      # a fusion layer's dW
+                                      ([(392, 776), (768, 264)], 16416)])                               # ragged tiles
+def test_grouped_weight_gradient_gemm(ops, L, gpu, half, shapes, k):
+    """bf_gemm_tn_grouped: the dW = dY^T X GEMMs of one layer in one launch of the persistent kernel, against fp64 products
+    of the same 16-bit operands, and bit-identical on a second run (partials are summed in split order)."""
+    g = torch.Generator(device=gpu).manual_seed(k)
+    probs, refs = [], []
+    for m, n in shapes:
+        dy = (torch.randn(k, m, device=gpu, generator=g) * 0.5).to(half)
+        x = torch.randn(k, n, device=gpu, generator=g).to(half)
+        out = torch.full((m, n), float("nan"), device=gpu)
+        probs.append((dy, x, out))
+        refs.append(dy.double().t() @ x.double())
+    arr = (L.GemmTnProblem * len(probs))()
+    for q, (dy, x, out) in zip(arr, probs):
+        q.dy, q.x, q.c, q.m, q.n = dy.data_ptr(), x.data_ptr(), out.data_ptr(), dy.shape[1], x.shape[1]
+        q.ld_dy, q.ld_x, q.ldc = dy.shape[1], x.shape[1], x.shape[1]
+    assert L.lib.bf_gemm_tn_grouped_workspace_bytes(arr, len(probs), k, ops.dtype_code(probs[0][0])) > 0
+    assert ops.gemm_tn_grouped(probs)
+    first = [out.clone() for _, _, out in probs]
+    for out, ref in zip(first, refs):
+        assert rel_err(out, ref) < 2e-6 * math.sqrt(k)
+    assert ops.gemm_tn_grouped(probs, alpha=0.5)
+    for (_, _, out), a in zip(probs, first):
+        assert torch.equal(out, a * 0.5)
+    # what does not qualify is left to the caller: fp32 operands, a short contraction
+    assert not ops.gemm_tn_grouped([(torch.randn(64, 16, device=gpu), torch.randn(64, 32, device=gpu),
+                                     torch.empty(16, 32, device=gpu))])
+    assert not ops.gemm_tn_grouped([(probs[0][0][:1024], probs[0][1][:1024], probs[0][2])])
+
+
 def test_gemm_tail_split_of_last_round(ops, L, gpu):
     """270 tiles of 256x256 on 256 CUs: bf_gemm cuts the rows of the under-filled last round off and runs
     them split along K through the workspace ops.gemm passes (bf_gemm_tail_workspace_bytes); the result
