@@ -890,6 +890,21 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
 //       no per-step barrier; 46 KB of LDS at L = 275, d = 32 (two to three workgroups per CU).
 // S and dP are computed twice (14 instead of 10 MFMAs per block, exp twice); both kernels read
 // their operands once more from HBM.  Same arithmetic per element as the single kernel.
+// LDS images of the resident split pair at d = 32: 64-byte rows WITHOUT the 16-byte pad (36.9 KB instead of 46 KB per
+// (batch, head) at 275 tokens: four workgroups per CU instead of three), the 16-byte chunk index XORed with bits 2-3 of
+// the row so that the 16 rows a ds_read_b128 group touches fall on distinct banks (rows r and r + 4 share a bank group
+// at a 64-byte stride).  Other head widths keep the padded rows (96-byte rows have no power-of-two chunk count).
+template <int D> struct ResImg {
+    static constexpr bool SWZ = (D == 32);
+    static constexpr int DP = (D + 31) / 32 * 32;
+    static constexpr int ROW_DP = SWZ ? DP * 2 : DP * 2 + 16;      // rows holding DP columns (the q kernel's K)
+    static constexpr int ROW_D = SWZ ? D * 2 : D * 2 + 16;         // rows holding D columns
+    // byte offset of 16-byte chunk `c` (+ `in` bytes inside it) of row `row` in an image of `rowb`-byte rows
+    static __device__ __forceinline__ int at(int row, int c, int rowb, int in = 0) {
+        return SWZ ? row * rowb + ((c ^ ((row >> 2) & 3)) << 4) + in : row * rowb + (c << 4) + in;
+    }
+};
+
 #ifdef ATTN_PROBE   // in-kernel phase stamps of the split backward (tools/attn_probe.py); not part of the product build
 #define ATTN_PROBE_WGS 16384
 __device__ unsigned long long attn_probe[ATTN_PROBE_WGS * 8];
@@ -914,8 +929,9 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;
     constexpr int DB = DP / 32;
-    constexpr int KROW = DP * 2 + 16;         // K rows padded to DP columns (zero) for the transposed reads
-    constexpr int VROW = D * 2 + 16;
+    using RI = ResImg<D>;
+    constexpr int KROW = RI::ROW_DP;          // K rows hold DP columns (zero beyond D) for the transposed reads
+    constexpr int VROW = RI::ROW_D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
     char* v_lds = smem + (size_t)Lp * KROW;
@@ -945,8 +961,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
             kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
             vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
         }
-        *(uint4*)(k_lds + j * KROW + c * 16) = kv;
-        if (c < D / 8) *(uint4*)(v_lds + j * VROW + c * 16) = vv;
+        *(uint4*)(k_lds + RI::at(j, c, KROW)) = kv;
+        if (c < D / 8) *(uint4*)(v_lds + RI::at(j, c, VROW)) = vv;
     }
 
     ATTN_STAMP(1);
@@ -999,8 +1015,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
         for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (j0 + r) * KROW + ks * 32 + hh * 16);
-            const typename H16<HT>::x8 vf = *(const typename H16<HT>::x8*)(v_lds + (j0 + r) * VROW + ks * 32 + hh * 16);
+            const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + RI::at(j0 + r, ks * 2 + hh, KROW));
+            const typename H16<HT>::x8 vf = *(const typename H16<HT>::x8*)(v_lds + RI::at(j0 + r, ks * 2 + hh, VROW));
             sacc = mfma_32x32x16(kf, qf[ks], sacc);
             pacc = mfma_32x32x16(vf, dof[ks], pacc);
         }
@@ -1035,7 +1051,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                const typename H16<HT>::x8 kt = tr_pair<HT>(k_lds + row0 * KROW + cb, k_lds + (row0 + 8) * KROW + cb);
+                const typename H16<HT>::x8 kt = tr_pair<HT>(k_lds + RI::at(row0, cb >> 4, KROW, cb & 15),
+                                                            k_lds + RI::at(row0 + 8, cb >> 4, KROW, cb & 15));
                 dqacc[db] = mfma_32x32x16(kt, pf, dqacc[db]);
             }
         }
@@ -1064,14 +1081,17 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #endif
 }
 
-template <int D, int MASK, typename HT>
-__global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
+// WPE: waves per SIMD the register allocation is held to.  4 (d = 32 only) = 128 registers, so that FOUR four-wave
+// workgroups share a CU like the unpadded LDS images allow (the free allocation takes 137 - 149 registers: three).
+template <int D, int MASK, typename HT, int WPE = 1>
+__global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
     const HT* __restrict__ qkv, const HT* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
     int L, int H, float scale) {
     constexpr int mask_mode = MASK;
     using Cf = BwdCfg<D>;
-    constexpr int KS = Cf::KS, DB = Cf::DB, ROW = Cf::ROW;
+    using RI = ResImg<D>;
+    constexpr int KS = Cf::KS, DB = Cf::DB, ROW = RI::ROW_D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nw = (L + 31) >> 5;                 // 32-query blocks of the sequence (all resident in LDS)
     const int Lp = nw * 32;
@@ -1099,8 +1119,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
             qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
             dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
         }
-        *(uint4*)(q_lds + i * ROW + c * 16) = qv;
-        *(uint4*)(do_lds + i * ROW + c * 16) = dv;
+        *(uint4*)(q_lds + RI::at(i, c, ROW)) = qv;
+        *(uint4*)(do_lds + RI::at(i, c, ROW)) = dv;
     }
     for (int i = threadIdx.x; i < Lp; i += nthreads) {
         float dl = 0.f, ls = 1e30f;
@@ -1150,8 +1170,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)(q_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
-            const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(do_lds + (qrow0 + r) * ROW + ks * 32 + hh * 16);
+            const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)(q_lds + RI::at(qrow0 + r, ks * 2 + hh, ROW));
+            const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(do_lds + RI::at(qrow0 + r, ks * 2 + hh, ROW));
             sacc = mfma_32x32x16(qa, kf[ks], sacc);
             pacc = mfma_32x32x16(da, vf[ks], pacc);
         }
@@ -1183,8 +1203,10 @@ __global__ __launch_bounds__(512) void attn_bwd_kv_kernel(
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + row0 * ROW + cb, do_lds + (row0 + 8) * ROW + cb);
-                const typename H16<HT>::x8 qtt = tr_pair<HT>(q_lds + row0 * ROW + cb, q_lds + (row0 + 8) * ROW + cb);
+                const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + RI::at(row0, cb >> 4, ROW, cb & 15),
+                                                             do_lds + RI::at(row0 + 8, cb >> 4, ROW, cb & 15));
+                const typename H16<HT>::x8 qtt = tr_pair<HT>(q_lds + RI::at(row0, cb >> 4, ROW, cb & 15),
+                                                             q_lds + RI::at(row0 + 8, cb >> 4, ROW, cb & 15));
                 dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
                 dkacc[db] = mfma_32x32x16(qtt, dsb[s], dkacc[db]);
             }
@@ -1791,8 +1813,9 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     // then dK/dV with the key on the lane); longer ones: the single tiled kernel below.
     {
         const int nq32 = bf_cdiv(seq, 32), lp = nq32 * 32;
-        const int dp = (head_dim + 31) / 32 * 32, row = head_dim * 2 + 16;
-        const size_t lds_q = (size_t)lp * ((dp * 2 + 16) + row);
+        const int dp = (head_dim + 31) / 32 * 32;
+        const int pad = head_dim == 32 ? 0 : 16, row = head_dim * 2 + pad;          // ResImg<D>: d = 32 rows are unpadded
+        const size_t lds_q = (size_t)lp * ((dp * 2 + pad) + row);
         const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4;
         static int split_env = -1;
         if (split_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SINGLE"); split_env = (e && atoi(e)) ? 0 : 1; }
@@ -1821,6 +1844,8 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             const int wpb = (wpb_env < nq32 ? wpb_env : nq32) < 8 ? (wpb_env < nq32 ? wpb_env : nq32) : 8;   // launch bound: 512 threads
             const int n_split = bf_cdiv(nq32, wpb) < split_env2 ? bf_cdiv(nq32, wpb) : split_env2;
             dim3 grid(batch * heads, n_split), block(wpb * 64);
+            static int kv_tight = -1;        // d = 32: the 128-register build of the kv kernel (four workgroups per CU)
+            if (kv_tight < 0) { const char* e = getenv("BIFOLD_ATTN_KV_TIGHT"); kv_tight = e ? atoi(e) : 1; }
 #define BWD_SPLIT2(DD, MM) BY_HALF(BWD_SPLIT3, DD, MM)
 #define BWD_SPLIT3(DD, MM, HT)                                                                      \
     do {                                                                                            \
@@ -1833,14 +1858,21 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         if (lds_kv > set_kv) {                                                                      \
             (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM, HT>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>, \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
             set_kv = lds_kv;                                                                        \
         }                                                                                           \
         hipLaunchKernelGGL((attn_bwd_q_kernel<DD, MM, HT>), grid, block, lds_q, s, (const HT*)qkv,  \
                            (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,   \
                            delta_ws, seq, heads, scale, lp);                                        \
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT>), grid, block, lds_kv, s, (const HT*)qkv, \
-                           (const HT*)dout, lse, (const float*)delta_ws, row_mask,              \
-                           (HT*)dqkv, seq, heads, scale);                                       \
+        if (kv_tight)                                                                               \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>), grid, block, lds_kv, s, (const HT*)qkv, \
+                               (const HT*)dout, lse, (const float*)delta_ws, row_mask,             \
+                               (HT*)dqkv, seq, heads, scale);                                      \
+        else                                                                                        \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT>), grid, block, lds_kv, s, (const HT*)qkv, \
+                               (const HT*)dout, lse, (const float*)delta_ws, row_mask,             \
+                               (HT*)dqkv, seq, heads, scale);                                      \
     } while (0)
 #define BWD_SPLIT(DD)                                                                               \
     do {                                                                                            \

@@ -19,15 +19,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--only", default="", help="comma-separated shape names")
     ap.add_argument("--family", default="clip", choices=["clip", "siglip"],
                     help="siglip: the long sequences of siglip_sequential at 384 px (B = 16, T = 3)")
     args = ap.parse_args()
     shapes = SHAPES if args.family == "clip" else SIGLIP_SHAPES
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
+    hdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     for name, B, L, H, D, mode in shapes:
-        qkv = torch.randn(B * L, 3 * H * D, device=dev, generator=g).bfloat16()
-        dout = torch.randn(B * L, H * D, device=dev, generator=g).bfloat16()
+        if args.only and name not in args.only.split(","):
+            continue
+        qkv = torch.randn(B * L, 3 * H * D, device=dev, generator=g).to(hdt)
+        dout = torch.randn(B * L, H * D, device=dev, generator=g).to(hdt)
         rm = None
         if mode == 2:       # siglip_sequential's mask: [text | T context frames of 577 rows | current frame], the
             rm = torch.ones(B, L, dtype=torch.int32, device=dev)      # first k ~ U{0..T} context frames valid
