@@ -229,7 +229,6 @@ def self_launch(args_list, gpus: int) -> int:
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("GPU_MAX_HW_QUEUES", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
     return subprocess.run(cmd, env=env).returncode

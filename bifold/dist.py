@@ -25,7 +25,7 @@ import torch.distributed as dist
 def init_process_group_from_env(device_backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, local_rank, world).  Reads the torchrun environment; a bare `python bench.py`
     is world 1 and needs no process group."""
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # see bifold_amd/__init__.py (before the first HIP call)
+    import bifold_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES -- the one place that does -- before the first HIP call)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

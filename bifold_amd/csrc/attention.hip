@@ -10,6 +10,7 @@
 //    query (or key) row with K/V (or Q/dO) tiles broadcast from LDS.  These are the exact
 //    (parity) mode, and the first-correct backward for the bf16 mode.
 #include "common.h"
+#include "tuning.h"
 
 #include <stdlib.h>
 
@@ -1675,15 +1676,12 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         const int lp = bf_cdiv(seq, 64) * 64;
         const int dp = (head_dim + 31) / 32 * 32;
         const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16));
-        static int fwd_res_env = -1;
-        if (fwd_res_env < 0) { const char* e = getenv("BIFOLD_ATTN_FWD_TILED"); fwd_res_env = (e && atoi(e)) ? 0 : 1; }
+        const int fwd_res_env = bf_tuning().attn_fwd_tiled ? 0 : 1;
         if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024) {
             dim3 rgrid(batch * heads), rblock(nq32 * 64);
-            static int nt_env = -1;
-            if (nt_env < 0) { const char* e = getenv("BIFOLD_ATTN_NT"); nt_env = e ? atoi(e) : 1; }
+            const int nt_env = bf_tuning().attn_nt;
             const int nt_loads = nt_env & 1;
-            static int kt_env = -1;      // 0: 64-key tiles always; 1: 32-key steps always; default: by the last tile's fill
-            if (kt_env < 0) { const char* e = getenv("BIFOLD_ATTN_FWD_KT32"); kt_env = e ? atoi(e) : 2; }
+            const int kt_env = bf_tuning().attn_fwd_kt32;      // 0: 64-key tiles always; 1: 32-key steps always; default: by the last tile's fill
             const bool half_steps = kt_env == 1 || (kt_env == 2 && mask_mode != BF_MASK_CAUSAL && (seq % 64) != 0 && (seq % 64) <= 32);
 #define FWD_RES2(DD, MM) BY_HALF(FWD_RES3, DD, MM)
 #define FWD_RES3(DD, MM, HT)                                                                       \
@@ -1779,8 +1777,7 @@ static size_t bwd_lds_of(int head_dim, int nw) {
 static int bwd_pick_nw(int seq, int head_dim, bool have_ws) {
     const int nw_all = bf_cdiv(seq, 32);
     int maxw = head_dim == 32 ? 16 : 8;
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_NW"); cap = e ? atoi(e) : 0; }
+    const int cap = bf_tuning().attn_bwd_nw;
     if (cap > 0 && cap < maxw && have_ws) maxw = cap;
     if (nw_all <= maxw && bwd_lds_of(head_dim, nw_all) <= 160 * 1024) return nw_all;
     if (!have_ws) return 0;
@@ -1817,15 +1814,11 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         const int pad = head_dim == 32 ? 0 : 16, row = head_dim * 2 + pad;          // ResImg<D>: d = 32 rows are unpadded
         const size_t lds_q = (size_t)lp * ((dp * 2 + pad) + row);
         const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4;
-        static int split_env = -1;
-        if (split_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SINGLE"); split_env = (e && atoi(e)) ? 0 : 1; }
+        const int split_env = bf_tuning().attn_bwd_single ? 0 : 1;
         // (short causal sequences stay on the single kernel: 72 vs 116 us at L = 77)
-        static int res_wide_env = -2;     // which head widths take the resident pair: A/B switch
-        if (res_wide_env == -2) { const char* e = getenv("BIFOLD_ATTN_BWD_RESIDENT_WIDE"); res_wide_env = e ? atoi(e) : 0; }   // 1: also d = 64; -1: d = 32 only
-        static int stream_min_env = -1;
-        if (stream_min_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_MIN_Q32"); stream_min_env = e ? atoi(e) : 1; }
-        static int stream_d32_env = -1;
-        if (stream_d32_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_D32"); stream_d32_env = e ? atoi(e) : 0; }
+        const int res_wide_env = bf_tuning().attn_bwd_resident_wide;   // which head widths take the resident pair: 1: also d = 64; -1: d = 32 only
+        const int stream_min_env = bf_tuning().attn_stream_min_q32;
+        const int stream_d32_env = bf_tuning().attn_stream_d32;
         // d = 48 joins d = 32 on the resident pair since its kernels are bounded at 512 threads (148-174 registers, no
         // scratch: 80.8 vs 92.9 us at 262 x 48); d = 64 stays on the streamed pair (300 x 64: 99 vs 134 us resident)
         const bool wide_ok = (head_dim == 32 && !stream_d32_env) || (head_dim == 48 && res_wide_env != -1) || res_wide_env > 0 ||
@@ -1838,14 +1831,11 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             // 32-row blocks slot, slot + n_split * wpb, ...  Default: ONE four-wave workgroup per (batch, head) -- one wave
             // per SIMD, three workgroups per CU by LDS, one K / V (Q / dO) image load per (batch, head).  (Five-wave
             // workgroups, one block per wave, measured 1.5 workgroups alive per CU: tools/attn_probe.py.)
-            static int wpb_env = -1, split_env2 = -1;
-            if (wpb_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_WPB"); wpb_env = e ? atoi(e) : 4; if (wpb_env < 1) wpb_env = 1; }
-            if (split_env2 < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_SPLIT"); split_env2 = e ? atoi(e) : 1; if (split_env2 < 1) split_env2 = 1; }
+            const int wpb_env = bf_tuning().attn_bwd_wpb, split_env2 = bf_tuning().attn_bwd_split;
             const int wpb = (wpb_env < nq32 ? wpb_env : nq32) < 8 ? (wpb_env < nq32 ? wpb_env : nq32) : 8;   // launch bound: 512 threads
             const int n_split = bf_cdiv(nq32, wpb) < split_env2 ? bf_cdiv(nq32, wpb) : split_env2;
             dim3 grid(batch * heads, n_split), block(wpb * 64);
-            static int kv_tight = -1;        // d = 32: the 128-register build of the kv kernel (four workgroups per CU)
-            if (kv_tight < 0) { const char* e = getenv("BIFOLD_ATTN_KV_TIGHT"); kv_tight = e ? atoi(e) : 1; }
+            const int kv_tight = bf_tuning().attn_kv_tight;   // d = 32: the 128-register build of the kv kernel (four workgroups per CU)
 #define BWD_SPLIT2(DD, MM) BY_HALF(BWD_SPLIT3, DD, MM)
 #define BWD_SPLIT3(DD, MM, HT)                                                                      \
     do {                                                                                            \
@@ -1891,13 +1881,10 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         }
     }
     {   // longer sequences: the same pair with the resident operand streamed through LDS in chunks
-        static int stream_env = -1;
-        if (stream_env < 0) { const char* e = getenv("BIFOLD_ATTN_BWD_STREAM"); stream_env = e ? atoi(e) : 1; }
+        const int stream_env = bf_tuning().attn_bwd_stream;
         const int nq32 = bf_cdiv(seq, 32);
-        static int stream_min_env = -1;
-        if (stream_min_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_MIN_Q32"); stream_min_env = e ? atoi(e) : 1; }
-        static int stream_d32_env = -1;
-        if (stream_d32_env < 0) { const char* e = getenv("BIFOLD_ATTN_STREAM_D32"); stream_d32_env = e ? atoi(e) : 0; }
+        const int stream_min_env = bf_tuning().attn_stream_min_q32;
+        const int stream_d32_env = bf_tuning().attn_stream_d32;
         if (half && stream_env && nq32 >= ((head_dim == 32 && !stream_d32_env) ? 9 : stream_min_env)) {
             // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
             // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)

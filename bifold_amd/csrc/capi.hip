@@ -1,7 +1,12 @@
 // Error plumbing and ABI version for libbifold_hip.
 #include "common.h"
 
+#include "tuning.h"
+
+#include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 static thread_local int g_hip_err = 0;
@@ -12,6 +17,51 @@ void bf_set_error(int hip_code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     g_hip_err = hip_code;
+}
+
+// ---- tuning knobs: one struct, read once (tuning.h) -----------------------------------------------------------------
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+BfTuning& bf_tuning() {
+    static BfTuning t;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        t.gemm_pipe.store(env_int("BIFOLD_GEMM_PIPE", -1));
+        t.gemm_group_m = env_int("BIFOLD_GEMM_GROUP_M", 16); if (t.gemm_group_m < 1) t.gemm_group_m = 1;
+        t.gemm_no_dma = getenv("BIFOLD_GEMM_NO_DMA") ? 1 : 0;
+        t.gemm_bm = env_int("BIFOLD_GEMM_BM", -1);
+        t.p8_min_m = env_int("BIFOLD_P8_MIN_M", 16384);
+        t.p8_min_tiles = env_int("BIFOLD_P8_MIN_TILES", -1);
+        t.p8_group_m = env_int("BIFOLD_P8_GROUP_M", 4); if (t.p8_group_m < 1) t.p8_group_m = 1;   // in-step A/B (round 2): 4 / 2 +0.5 %, 16 -1.7 % against 8
+        t.p8_grid = env_int("BIFOLD_P8_GRID", 0);
+        t.p8_revk = env_int("BIFOLD_P8_REVK", 1) ? 1 : 0;
+        t.p8_deep = env_int("BIFOLD_P8_DEEP", -1);
+        t.p8_nt = env_int("BIFOLD_P8_NT", 5) & 7;          // plain-16-bit and GELU-grad outputs non-temporal (round 2: 1 -> 5 +0.3 %)
+        t.p8_no_tail = getenv("BIFOLD_P8_NO_TAIL") ? 1 : 0;
+        t.p8_tail_k_nt = 2048; t.p8_tail_k_nn = 1 << 30;   // in-step A/B (round 2): NN tails at K >= 1536 / 512: +-0.1 %; NT at K >= 768: -2 %
+        if (const char* e = getenv("BIFOLD_P8_TAIL_K")) {
+            int a = 0, b = 0;
+            if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { t.p8_tail_k_nt = a; t.p8_tail_k_nn = b; }
+        }
+        t.fp8_p8 = env_int("BIFOLD_FP8_P8", 1);
+        t.dw_grouped = env_int("BIFOLD_DW_GROUPED", 1);
+        t.attn_fwd_tiled = env_int("BIFOLD_ATTN_FWD_TILED", 0) ? 1 : 0;
+        t.attn_nt = env_int("BIFOLD_ATTN_NT", 1);
+        t.attn_fwd_kt32 = env_int("BIFOLD_ATTN_FWD_KT32", 2);
+        t.attn_bwd_nw = env_int("BIFOLD_ATTN_BWD_NW", 0);
+        t.attn_bwd_single = env_int("BIFOLD_ATTN_BWD_SINGLE", 0) ? 1 : 0;
+        t.attn_bwd_resident_wide = env_int("BIFOLD_ATTN_BWD_RESIDENT_WIDE", 0);
+        t.attn_stream_min_q32 = env_int("BIFOLD_ATTN_STREAM_MIN_Q32", 1);
+        t.attn_stream_d32 = env_int("BIFOLD_ATTN_STREAM_D32", 0);
+        t.attn_bwd_wpb = env_int("BIFOLD_ATTN_BWD_WPB", 4); if (t.attn_bwd_wpb < 1) t.attn_bwd_wpb = 1;
+        t.attn_bwd_split = env_int("BIFOLD_ATTN_BWD_SPLIT", 1); if (t.attn_bwd_split < 1) t.attn_bwd_split = 1;
+        t.attn_kv_tight = env_int("BIFOLD_ATTN_KV_TIGHT", 1);
+        t.attn_bwd_stream = env_int("BIFOLD_ATTN_BWD_STREAM", 1);
+        t.ln_rows = env_int("BIFOLD_LN_ROWS", 2);
+    });
+    return t;
 }
 
 extern "C" int bf_abi_version(void) { return BF_ABI_VERSION; }

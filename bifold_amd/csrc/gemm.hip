@@ -18,6 +18,7 @@
 // range of output tiles with the N index fastest, so the blocks that share an A row
 // panel run on one XCD back to back.
 #include "common.h"
+#include "tuning.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -1789,13 +1790,12 @@ __global__ __launch_bounds__(256) void grouped_reduce_kernel(GroupedReduce r) {
 // =====================================================================================
 //                                        host
 // =====================================================================================
-static int pipe_env = -2;   // -2: read BIFOLD_GEMM_PIPE on first use; -1: automatic choice
 static thread_local int last_variant = -1;
 
 extern "C" int bf_gemm_last_variant(void) { return last_variant; }
 
-extern "C" int bf_gemm_set_variant(int variant) {
-    pipe_env = variant < 0 ? -1 : variant;
+extern "C" int bf_gemm_set_variant(int variant) {       // atomic: may be called while other threads run GEMMs
+    bf_tuning().gemm_pipe.store(variant < 0 ? -1 : variant);
     return BF_OK;
 }
 
@@ -1815,21 +1815,17 @@ static int n_cus() {
 // epilogue by splitk_reduce), so the job takes ~2.3 rounds instead of 3.
 struct P8TailPlan { int rows_main; int sub; size_t bytes; };
 static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
-    static int min_k_nt = -1, min_k_nn = -1;
-    if (min_k_nt < 0) {
-        const char* e = getenv("BIFOLD_P8_TAIL_K");        // "nt,nn" thresholds on K
-        min_k_nt = 2048; min_k_nn = 1 << 30;              // in-step A/B (round 2): NN tails at K >= 1536 / 512: +-0.1 %; NT at K >= 768: -2 %
-        if (e) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { min_k_nt = a; min_k_nn = b; } }
-    }
+    const BfTuning& T = bf_tuning();
+    const int min_k_nt = T.p8_tail_k_nt, min_k_nn = T.p8_tail_k_nn;
     if (!bf_is_half(g->cdt) || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
         g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 ||
         g->k < (g->b_kn ? min_k_nn : min_k_nt) || g->colsum_out)
         return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
-    if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+    const int pipe_env = T.gemm_pipe.load();
     if (pipe_env >= 0 && pipe_env != 8) return false;
     // dX = dY W (NN) runs on the persistent kernel too; its 512-wide outputs are 2.15-round shapes (550 tiles on
     // 256 CUs), but splitting their tails measured neutral, so it is opt-in (BIFOLD_P8_TAIL_K="2048,1536")
-    if (getenv("BIFOLD_P8_NO_TAIL")) return false;
+    if (T.p8_no_tail) return false;
     const int n_cu = n_cus();
     const long tiles_m = bf_cdiv(g->m, 256), tiles_n = bf_cdiv(g->n, 256);
     const long items = tiles_m * tiles_n;
@@ -1904,8 +1900,8 @@ static unsigned* p8_ticket_set(hipStream_t s) {
 // 1 when the shape is not its (the caller then runs its 128 x 128 kernel).
 int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const float* sb, void* c, int c_dtype,
                        const float* bias, int act, int m, int n, int k, int lda, int ldb, int ldc, bf_stream_t stream) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("BIFOLD_FP8_P8"); on = e ? atoi(e) : 1; }
+    const BfTuning& T = bf_tuning();
+    const int on = T.fp8_p8;
     const int n_cu = n_cus();
     const long tiles = (long)bf_cdiv(m, 256) * bf_cdiv(n, 256);
     if (!on || c_dtype != BF_BF16 || m < 16384 || tiles < n_cu / 2 || (k % 128) != 0 || (n % 8) != 0 || (ldc % 8) != 0 ||
@@ -1914,10 +1910,7 @@ int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const fl
     hipStream_t s = (hipStream_t)stream;
     unsigned* tk8 = p8_ticket_set(s);
     if (!tk8) return 1;
-    static int p8_group = -1, rev_env = -1, pol = -1;
-    if (p8_group < 0) { const char* e = getenv("BIFOLD_P8_GROUP_M"); p8_group = e ? atoi(e) : 4; if (p8_group < 1) p8_group = 1; }
-    if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
-    if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 5; }   // plain-bf16 and GELU-grad outputs non-temporal (in-step A/B, round 2: 1 -> 5 +0.3 %)
+    const int p8_group = T.p8_group_m, rev_env = T.p8_revk, pol = T.p8_nt;
     GemmDims d{m, n, k, lda, ldb, bf_cdiv(m, 256), bf_cdiv(n, 256), k, p8_group};
     Fp8P8Epi ep{(bf16_t*)c, sa, sb, bias, m, n, ldc, act, pol};
     const size_t a_ext = (size_t)(m - 1) * lda + k, b_ext = (size_t)(n - 1) * ldb + k;
@@ -1937,10 +1930,8 @@ int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const fl
 struct GroupedPlan { int split, kps; long tiles; size_t bytes; };
 static bool grouped_tn_plan(const bf_gemm_tn_problem* p, int count, int k, int cdt, GroupedPlan* plan) {
     if (!p || count < 1 || count > P8_MAX_GROUP || !bf_is_half(cdt) || k < 16384 || (k % 32) != 0) return false;
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("BIFOLD_DW_GROUPED"); on = e ? atoi(e) : 1; }
-    if (!on) return false;
-    if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+    if (!bf_tuning().dw_grouped) return false;
+    const int pipe_env = bf_tuning().gemm_pipe.load();
     if (pipe_env >= 0 && pipe_env != 8) return false;
     long tiles = 0;
     size_t elems = 0;
@@ -2009,9 +2000,7 @@ extern "C" int bf_gemm_tn_grouped(const bf_gemm_tn_problem* p, int count, int k,
     EpiParams ep;
     memset(&ep, 0, sizeof(ep));
     ep.alpha = 1.0f;
-    static int rev_env = -1;
-    if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
-    const int skew = rev_env | 2;                       // deep TN: prefetch distance 3 (both operands stream from HBM)
+    const int skew = bf_tuning().p8_revk | 2;                       // deep TN: prefetch distance 3 (both operands stream from HBM)
     const long items = plan.tiles * plan.split;
     const unsigned g8 = (unsigned)(n_cus() & ~7);
     last_variant = 8;
@@ -2127,11 +2116,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     ep.rows_out = g->rows_out; ep.row_off = g->row_off; ep.act = g->act;
     ep.accumulate = g->accumulate; ep.alpha = g->alpha;
     ep.colsum = nullptr;
-    {
-        static int pol = -1;      // bit mask, see EpiParams::store_policy (measured in-step: DESIGN.md §6)
-        if (pol < 0) { const char* e = getenv("BIFOLD_P8_NT"); pol = e ? atoi(e) & 7 : 5; }   // plain-bf16 and GELU-grad outputs non-temporal (in-step A/B, round 2: 1 -> 5 +0.3 %)
-        ep.store_policy = pol;
-    }
+    const BfTuning& T = bf_tuning();
+    ep.store_policy = T.p8_nt;      // bit mask, see EpiParams::store_policy (measured in-step: DESIGN.md §6)
     bool colsum_fused = false;
     BF_REQUIRE(!g->colsum_out || (g->rows_in == 0 && bf_aligned16(g->colsum_out)), BF_EINVAL,
                "bf_gemm: colsum_out needs rows_in == 0 and a 16-byte aligned pointer");
@@ -2145,8 +2131,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
 
     if (half) {
         const bool f16 = g->cdt == BF_F16;
-        static int group_m_env = -1;
-        if (group_m_env < 0) { const char* e = getenv("BIFOLD_GEMM_GROUP_M"); group_m_env = e ? atoi(e) : 16; if (group_m_env < 1) group_m_env = 1; }
+        const int group_m_env = T.gemm_group_m;
         GemmDims d{g->m, g->n, g->k, g->lda, g->ldb, tiles_m, tiles_n, kps, group_m_env};
         // every launch macro below ends in ..._H(..., H): H = the 16-bit operand type of the call; the output type is
         // float (f32out) or H
@@ -2169,8 +2154,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         const size_t a_ext = ((size_t)((g->trans_a ? g->k : g->m) - 1) * g->lda + (g->trans_a ? g->m : g->k)) * 2;
         const size_t b_ext = ((size_t)((g->b_kn ? g->k : g->n) - 1) * g->ldb + (g->b_kn ? g->n : g->k)) * 2;
         const bool dma_ok = ((g->trans_a && g->b_kn) || (g->k % 64) == 0) && a_ext < (1ull << 32) &&
-                            b_ext < (1ull << 32) && !getenv("BIFOLD_GEMM_NO_DMA");
-        if (pipe_env == -2) { const char* e = getenv("BIFOLD_GEMM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+                            b_ext < (1ull << 32) && !T.gemm_no_dma;
+        const int pipe_env = T.gemm_pipe.load();
         // Kernel choice (measured in-step at B = 256): the BK = 32 kernel runs 4
         // workgroups per CU, which overlaps the epilogue traffic of one tile with the MFMAs of the
         // others and wins on every NN / TN shape and on short-K NT; long-K, large NT GEMMs
@@ -2182,10 +2167,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         // The persistent 256x256 kernel wins in-step on the large-M NT GEMMs (vision / fusion
         // token GEMMs, every epilogue flavour); the text tower's (M = 19.7k, on the side stream
         // next to the vision tower) and the NN / TN shapes stay with the multi-workgroup kernels.
-        static int p8_min_m = -1;
-        if (p8_min_m < 0) { const char* e = getenv("BIFOLD_P8_MIN_M"); p8_min_m = e ? atoi(e) : 16384; }
-        static int p8_min_tiles = -1;      // at least this many 256x256 tiles (default: one per two CUs)
-        if (p8_min_tiles < 0) { const char* e = getenv("BIFOLD_P8_MIN_TILES"); p8_min_tiles = e ? atoi(e) : n_cus() / 2; }
+        const int p8_min_m = T.p8_min_m;
+        const int p8_min_tiles = T.p8_min_tiles >= 0 ? T.p8_min_tiles : n_cus() / 2;   // at least this many 256x256 tiles (default: one per two CUs)
         const bool p8_nt = !g->trans_a && !g->b_kn && g->m >= p8_min_m &&
                            (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= p8_min_tiles;
         // deep dW = dY^T X GEMMs whose (tile, split) items fill the CUs in exactly one round
@@ -2217,19 +2200,15 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             const int n_cu = n_cus();
             GemmDims d8 = d;
             d8.tiles_m = bf_cdiv(g->m, 256); d8.tiles_n = bf_cdiv(g->n, 256);
-            static int p8_group = -1;
-            if (p8_group < 0) { const char* e = getenv("BIFOLD_P8_GROUP_M"); p8_group = e ? atoi(e) : 4; if (p8_group < 1) p8_group = 1; }   // in-step A/B (round 2): 4 / 2 +0.5 %, 16 -1.7 % against 8
-            d8.group_m = p8_group;
+            d8.group_m = T.p8_group_m;
             const long items = (long)d8.tiles_m * d8.tiles_n * split;
             BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
             unsigned g8 = (unsigned)(n_cu & ~7);      // every CU draws; workgroups that find no ticket exit
-            if (const char* ge = getenv("BIFOLD_P8_GRID")) { const unsigned gg = (unsigned)atoi(ge); if (gg >= 1 && gg < g8) g8 = gg; }
+            if (T.p8_grid >= 1 && (unsigned)T.p8_grid < g8) g8 = (unsigned)T.p8_grid;
             // bit 0: alternate the K direction per round of tickets (operand fetches 338 -> 239 MB on the vision QKV
             // GEMM, no change in time: the re-fetches were Infinity-Cache hits); bit 1: prefetch distance 3, which
             // pays only where both operands stream from HBM, i.e. the deep dW = dY^T X GEMMs (+5 %; NT / NN -3..5 %)
-            static int rev_env = -1, deep_env = -2;
-            if (rev_env < 0) { const char* e = getenv("BIFOLD_P8_REVK"); rev_env = (e ? atoi(e) : 1) ? 1 : 0; }
-            if (deep_env == -2) { const char* e = getenv("BIFOLD_P8_DEEP"); deep_env = e ? atoi(e) : -1; }
+            const int rev_env = T.p8_revk, deep_env = T.p8_deep;
             const int deep = deep_env >= 0 ? (deep_env ? 1 : 0) : (g->trans_a && g->b_kn ? 1 : 0);
             const int skew = rev_env | (deep << 1);
             // which epilogue instantiation (the predicates of the kernel's EPI paths)
@@ -2273,8 +2252,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             const long t64 = (long)bf_cdiv(g->m, 64) * tiles_n * split;
             const double e128 = (double)t128 / ((double)((t128 + 1023) / 1024) * 1024.0);
             const double e64 = (double)t64 / ((double)((t64 + 1535) / 1536) * 1536.0);
-            static int bm_env = -2;
-            if (bm_env == -2) { const char* e = getenv("BIFOLD_GEMM_BM"); bm_env = e ? atoi(e) : -1; }
+            const int bm_env = T.gemm_bm;
             // measured: the 64-row tile does not pay even where it fills the slots better (more
             // L2 -> LDS bytes per FLOP), so it is opt-in (BIFOLD_GEMM_BM=64), K-contiguous A only
             (void)e128; (void)e64;

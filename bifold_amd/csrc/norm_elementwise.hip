@@ -2,6 +2,7 @@
 // All of these are HBM-bound: one wavefront (64 lanes) per row, 16-byte accesses,
 // wave-shuffle reductions, fp32 math.
 #include "common.h"
+#include "tuning.h"
 
 #include <type_traits>
 
@@ -149,7 +150,7 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
                BF_EALIGN, "bf_layernorm_fwd: pointers must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bf_cdiv(rows, 4)), block(256);
-    static const int ln_rows = []() { const char* e = getenv("BIFOLD_LN_ROWS"); return e ? atoi(e) : 2; }();
+    const int ln_rows = bf_tuning().ln_rows;
     if (x_dtype == BF_F32 && (cols == 512 || cols == 768 || cols == 1024) && ln_rows > 1 &&
         (bf_is_half(y_dtype) || y_dtype == BF_F32)) {
 #define LN_ROWS(TY, NC, R)                                                                       \

@@ -1,0 +1,42 @@
+// Every tuning knob of libbifold_hip in ONE place.  The knobs select kernels / geometries only (results are the same up
+// to summation order); they are read from the environment exactly once per process, on first use, under std::call_once
+// (thread-safe), and never change afterwards -- except `gemm_pipe`, which bf_gemm_set_variant may set at run time and is
+// an atomic.  Defaults are the values the in-step A/B measurements of DESIGN.md §6 settled on.
+#pragma once
+#include <atomic>
+
+struct BfTuning {
+    // ---- GEMM (gemm.hip)
+    std::atomic<int> gemm_pipe;   // BIFOLD_GEMM_PIPE        -1 automatic; 0 = 128x128x64, 4 = 128x128x32, 8 = persistent 256x256
+    int gemm_group_m;             // BIFOLD_GEMM_GROUP_M     row tiles per group of the 128x128 kernels' tile order (16)
+    int gemm_no_dma;              // BIFOLD_GEMM_NO_DMA      1: register-staged fallback kernel only (debug)
+    int gemm_bm;                  // BIFOLD_GEMM_BM          64: 64-row tiles in the BK = 32 kernel (opt-in), -1 off
+    int p8_min_m;                 // BIFOLD_P8_MIN_M         persistent kernel from this many rows (16384)
+    int p8_min_tiles;             // BIFOLD_P8_MIN_TILES     ... and this many 256x256 tiles (-1: half the CUs)
+    int p8_group_m;               // BIFOLD_P8_GROUP_M       row tiles per group of the persistent kernel's item order (4)
+    int p8_grid;                  // BIFOLD_P8_GRID          cap on the persistent grid (0: every CU)
+    int p8_revk;                  // BIFOLD_P8_REVK          alternate the K direction per round of tickets (1)
+    int p8_deep;                  // BIFOLD_P8_DEEP          prefetch distance 3: -1 = for TN only, 0 / 1 = never / always
+    int p8_nt;                    // BIFOLD_P8_NT            bit mask of non-temporal output stores (5)
+    int p8_no_tail;               // BIFOLD_P8_NO_TAIL       1: never cut an under-filled last round off as a split-K tail
+    int p8_tail_k_nt, p8_tail_k_nn;   // BIFOLD_P8_TAIL_K   "nt,nn": K thresholds of that tail split (2048, off)
+    int fp8_p8;                   // BIFOLD_FP8_P8           persistent e4m3 kernel (1)
+    int dw_grouped;               // BIFOLD_DW_GROUPED       grouped weight-gradient launch (1)
+    // ---- attention (attention.hip)
+    int attn_fwd_tiled;           // BIFOLD_ATTN_FWD_TILED   1: always the tiled forward (0)
+    int attn_nt;                  // BIFOLD_ATTN_NT          non-temporal QKV loads in the resident forward (1)
+    int attn_fwd_kt32;            // BIFOLD_ATTN_FWD_KT32    0 / 1 / 2: 64-key tiles / 32-key steps / by the last tile's fill (2)
+    int attn_bwd_nw;              // BIFOLD_ATTN_BWD_NW      cap on the waves of the single backward kernel (0: none)
+    int attn_bwd_single;          // BIFOLD_ATTN_BWD_SINGLE  1: never the split pair (0)
+    int attn_bwd_resident_wide;   // BIFOLD_ATTN_BWD_RESIDENT_WIDE   1: d = 64 on the resident pair too, -1: d = 32 only (0)
+    int attn_stream_min_q32;      // BIFOLD_ATTN_STREAM_MIN_Q32      streamed pair from this many 32-row blocks (1)
+    int attn_stream_d32;          // BIFOLD_ATTN_STREAM_D32  1: d = 32 on the streamed pair (0)
+    int attn_bwd_wpb;             // BIFOLD_ATTN_BWD_WPB     waves per workgroup of the resident pair (4)
+    int attn_bwd_split;           // BIFOLD_ATTN_BWD_SPLIT   workgroups per (batch, head) of the resident pair (1)
+    int attn_kv_tight;            // BIFOLD_ATTN_KV_TIGHT    128-register build of the d = 32 kv kernel (1)
+    int attn_bwd_stream;          // BIFOLD_ATTN_BWD_STREAM  streamed pair for long sequences (1)
+    // ---- LayerNorm (norm_elementwise.hip)
+    int ln_rows;                  // BIFOLD_LN_ROWS          rows per wave of the exact-width forward (2)
+};
+
+BfTuning& bf_tuning();

@@ -13,10 +13,10 @@
  *    name ends in _host; the caller owns all memory: the library never allocates, frees
  *    or synchronises;
  *  - process-wide state, all of it internal and none of it data: a thread-local error
- *    string; tuning knobs read ONCE per process from the environment on first use
- *    (BIFOLD_GEMM_PIPE, BIFOLD_P8_*, BIFOLD_ATTN_*, BIFOLD_LN_ROWS: kernel selection only,
- *    results are the same up to summation order) and the matching bf_gemm_set_variant hook
- *    (not thread-safe: call it before the threads that run GEMMs start); and, for the persistent
+ *    string; ONE table of tuning knobs (csrc/tuning.h: kernel selection and geometry only, results are the same up to
+ *    summation order) filled from the BIFOLD_* environment variables exactly once per process under std::call_once,
+ *    plus the bf_gemm_set_variant hook, which stores into an atomic of that table and may be called at any time from
+ *    any thread; and, for the persistent
  *    GEMM, a __device__ array of work-ticket counters (one copy per device) with a host-side table per
  *    device that hands each stream its own ring of counter sets: 16 streams per device hold rings at a
  *    time, a further stream takes over the least recently used ring after one hipDeviceSynchronize();
