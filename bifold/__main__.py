@@ -268,6 +268,12 @@ class Trainer:
         tower = getattr(self.model, "clip_encoder", None) or getattr(self.model, "siglip_model", None)
         if tower is not None:
             tower.check_token_ids()
+        scaler = getattr(self.model, "_grad_scaler", None)        # fp16 mode: static loss scale (models/gradscale.py)
+        if scaler is not None:
+            bad = scaler.overflowed()                             # one device read per epoch, like the loss above
+            if bad:
+                raise FloatingPointError(f"model.dtype=fp16: {bad} non-finite gradient elements in epoch {epoch} at "
+                                         f"loss scale {scaler.scale:g}; set model.loss_scale lower or model.dtype=bf16")
 
     def eval_epoch(self, epoch=None) -> Tuple[Optional[bool], Dict]:
         self.model.eval()
