@@ -30,6 +30,21 @@ __device__ __forceinline__ int paired_bh(int i, int n) {
     return ((s / G) * 8 + xcd) * G + t;
 }
 
+// LDS images of the resident split pair at d = 32: 64-byte rows WITHOUT the 16-byte pad (36.9 KB instead of 46 KB per
+// (batch, head) at 275 tokens: four workgroups per CU instead of three), the 16-byte chunk index XORed with bits 2-3 of
+// the row so that the 16 rows a ds_read_b128 group touches fall on distinct banks (rows r and r + 4 share a bank group
+// at a 64-byte stride).  Other head widths keep the padded rows (96-byte rows have no power-of-two chunk count).
+template <int D> struct ResImg {
+    static constexpr bool SWZ = (D == 32);
+    static constexpr int DP = (D + 31) / 32 * 32;
+    static constexpr int ROW_DP = SWZ ? DP * 2 : DP * 2 + 16;      // rows holding DP columns (the q kernel's K)
+    static constexpr int ROW_D = SWZ ? D * 2 : D * 2 + 16;         // rows holding D columns
+    // byte offset of 16-byte chunk `c` (+ `in` bytes inside it) of row `row` in an image of `rowb`-byte rows
+    static __device__ __forceinline__ int at(int row, int c, int rowb, int in = 0) {
+        return SWZ ? row * rowb + ((c ^ ((row >> 2) & 3)) << 4) + in : row * rowb + (c << 4) + in;
+    }
+};
+
 __device__ __forceinline__ size_t qkv_off(int b, int i, int which, int h, int L, int H, int D) {
     return (((size_t)b * L + i) * 3 + which) * (size_t)H * D + (size_t)h * D;
 }
@@ -616,6 +631,200 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
 }
 
 // =====================================================================================
+//   d = 32 forward, PERSISTENT and double-buffered: K / V of the next (batch, head) arrive by
+//   LDS-DMA while the current one is consumed
+// =====================================================================================
+// attn_fwd_res_kernel's time is its memory time PLUS its compute time (t = 37 us + bytes / 4.25 TB/s): a
+// workgroup loads its K / V image, then computes.  Here a workgroup keeps TWO images (64-byte rows without padding,
+// XOR-swizzled like ResImg<32>: 2 x 36.9 KB at 275 tokens, two workgroups per CU as before) and walks (batch, head)
+// items: right after the barrier that opens item i it issues `buffer_load ... lds` for item i + 1 into the other image
+// (fire and forget: no registers, no ds_write pass); the only wait for it is the one in front of the next barrier, a
+// whole key loop later (the next item's Q fragments are requested when the key loop ends: 80 registers leave no room
+// to hold them across it).  The output tile leaves straight from
+// the accumulators -- the two half-waves swap 8-byte pieces so that every lane stores 16 bytes -- because the idle K
+// image it used to be turned through is now busy receiving.  Same arithmetic and order as attn_fwd_res_kernel<32, 0, 1>.
+// The transposed V^T fragment reads of the persistent kernel go out as inline assembly: the compiler's wait-count pass
+// puts `s_waitcnt vmcnt(0)` in front of a ds_read_b64_tr_b16 builtin while an LDS-DMA is in flight (it cannot tell
+// that the DMA writes the OTHER image), which is exactly the overlap this kernel exists for.
+__device__ __forceinline__ void tr_issue(uint2& lo, uint2& hi, const char* p0, const char* p1) {
+    typedef __attribute__((address_space(3))) const char* lds_cp;
+    const unsigned a0 = (unsigned)(size_t)(lds_cp)p0, a1 = (unsigned)(size_t)(lds_cp)p1;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1));
+}
+
+template <typename HT>
+__global__ __launch_bounds__(1024, 6) void attn_fwd_pd32_kernel(
+    const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse, int L, int H, float scale, int Lp,
+    int n_items, unsigned qkv_bytes) {
+    constexpr int D = 32, KS = 2, ROWB = 64;
+    using RI = ResImg<32>;
+    typedef typename H16<HT>::x8 H8;
+    typedef typename H16<HT>::x4 H4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int img = Lp * ROWB;                          // one K (or V) image; buffer f: K at f * 2 img, V behind it
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;                     // == Lp / 32: one wave per 32-query block
+    const int q0 = wave * 32;
+    const int G = gridDim.x;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    // Per-lane values are re-derived from an OPAQUE copy of the lane id in each phase of an item (DMA issue, key loop,
+    // output): hoisted out of the item loop they pushed the kernel past its 80 registers, and a spill reload is a VMEM
+    // instruction -- its s_waitcnt vmcnt(0) sits behind the LDS-DMA just issued (the counter is in order) and
+    // serialises exactly the transfer this kernel wants in flight under the key loop.
+    auto opaque_lane = [&]() { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); return l; };
+
+    // 4 nw pieces of 1 KB per item (2 nw of K, then 2 nw of V), four per wave; a piece is 16 rows x 64 B, lane l lands
+    // in slot l & 3 of row l >> 2 and therefore fetches chunk slot ^ swizzle(row).  Rows L .. Lp - 1 read whatever
+    // follows in the buffer (the next sample's tokens, or zeros past its end): their scores are masked to -inf below.
+    auto issue = [&](int v, int f) {
+        const int lane = opaque_lane();
+        const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pc = wave * 4 + i;
+            const int which = pc >= 2 * nw ? 2 : 1;
+            const int lp = pc - (which == 2 ? 2 * nw : 0);
+            const int row = lp * 16 + (lane >> 2);
+            const int c = (lane & 3) ^ ((row >> 2) & 3);
+            const unsigned voff = (unsigned)((qkv_off(b, row, which, h, L, H, D) + (size_t)c * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)(smem + f * 2 * img + (which == 2 ? img : 0) + lp * 1024), 16,
+                                                     voff, 0, 0, 0);
+        }
+    };
+    auto load_q = [&](int v, uint4 (&q)[KS]) {
+        const int lane = opaque_lane();
+        const int qi = q0 + (lane & 31);
+        const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            q[ks] = qi < L ? *(const uint4*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + (lane >> 5) * 8)
+                           : make_uint4(0, 0, 0, 0);
+    };
+
+    int v = blockIdx.x, f = 0;
+    if (v >= n_items) return;
+    uint4 qraw[KS];
+    issue(v, 0);
+    load_q(v, qraw);
+    const float sl2 = scale * 1.44269504088896340736f;
+
+    while (true) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's image pieces and Q (and the previous item's stores)
+        __syncthreads();                                   // everybody's pieces are in; everybody has left the other image
+        const int vn = v + G;
+        if (vn < n_items) issue(vn, f ^ 1);
+        f32x16 oacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        {
+            const int lane = opaque_lane();
+            const int r = lane & 31, hh = lane >> 5;
+            const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+            const char* k_lds = smem + f * 2 * img;
+            const char* v_lds = k_lds + img;
+            H8 qf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const H8*)&qraw[ks];
+            for (int j0 = 0; j0 < L; j0 += 32) {
+                f32x16 sacc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const H8 kf = *(const H8*)(k_lds + RI::at(j0 + r, ks * 2 + hh, ROWB));
+                    sacc = mfma_32x32x16(kf, qf[ks], sacc);
+                }
+                if (j0 + 32 > L) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (key >= L) sacc[e] = -INFINITY;
+                    }
+                }
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+                const float m_new = fmaxf(m, tmax);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+                f32x2 psum2 = {0.f, 0.f};
+                const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 t = {sacc[e], sacc[e + 1]};
+                    t = __builtin_elementwise_fma(t, sl2v, mneg);
+                    f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    sacc[e] = p2[0];
+                    sacc[e + 1] = p2[1];
+                    psum2 += p2;
+                }
+                float psum = psum2[0] + psum2[1];
+                psum += __shfl_xor(psum, 32, 64);
+                l = l * alpha + psum;
+                m = m_new;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+                const int cb = (16 * (g16 & 1) + 4 * p4) * 2;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    uint2 vlo, vhi;
+                    const int row0 = j0 + 16 * s2 + 4 * hh + q4;
+                    tr_issue(vlo, vhi, v_lds + RI::at(row0, cb >> 4, ROWB, cb & 15),
+                             v_lds + RI::at(row0 + 8, cb >> 4, ROWB, cb & 15));
+                    H8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[8 * s2 + e];
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo), "+v"(vhi));
+                    const uint4 vq = make_uint4(vlo.x, vlo.y, vhi.x, vhi.y);
+                    oacc = mfma_32x32x16(*(const H8*)&vq, pf, oacc);
+                }
+            }
+        }
+
+        // O^T accumulator: lane (r, hh) holds d = 8 g + 4 hh + {0..3} of query row r.  The half-waves swap pieces so
+        // that lane (r, 0) owns d 0-7 and 16-23, lane (r, 1) d 8-15 and 24-31: two 16-byte stores per lane, no LDS.
+        {
+            const int lane = opaque_lane();
+            const int r = lane & 31, hh = lane >> 5;
+            const int qi = q0 + r;
+            const bool q_live = qi < L;
+            const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
+            const float inv = q_live ? 1.0f / l : 0.f;
+            uint2 own[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                H4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = (HT)(oacc[4 * g + e] * inv);
+                own[g] = *(const uint2*)&o4;
+            }
+            uint4 st[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const unsigned ax = own[2 * k].x, ay = own[2 * k].y, bx = own[2 * k + 1].x, by = own[2 * k + 1].y;
+                const unsigned gx = (unsigned)__shfl_xor((int)(hh ? ax : bx), 32, 64);
+                const unsigned gy = (unsigned)__shfl_xor((int)(hh ? ay : by), 32, 64);
+                st[k].x = hh ? gx : ax; st[k].y = hh ? gy : ay;
+                st[k].z = hh ? bx : gx; st[k].w = hh ? by : gy;
+            }
+            if (q_live) {
+                HT* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D + hh * 8;
+                *(uint4*)op = st[0];
+                *(uint4*)(op + 16) = st[1];
+                if (lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
+            }
+        }
+        if (vn >= n_items) break;
+        load_q(vn, qraw);             // the next item's Q rows: in flight across the stores above and the barrier below
+        v = vn;
+        f ^= 1;
+    }
+}
+
+// =====================================================================================
 //                               bf16 MFMA backward
 // =====================================================================================
 // One workgroup per (batch, head); wave w owns the 32 keys [32w, 32w+32) and keeps dK^T and
@@ -891,21 +1100,6 @@ __global__ __launch_bounds__(BwdCfg<D>::MAXW * 64) void attn_bwd_mfma_kernel(
 //       no per-step barrier; 46 KB of LDS at L = 275, d = 32 (two to three workgroups per CU).
 // S and dP are computed twice (14 instead of 10 MFMAs per block, exp twice); both kernels read
 // their operands once more from HBM.  Same arithmetic per element as the single kernel.
-// LDS images of the resident split pair at d = 32: 64-byte rows WITHOUT the 16-byte pad (36.9 KB instead of 46 KB per
-// (batch, head) at 275 tokens: four workgroups per CU instead of three), the 16-byte chunk index XORed with bits 2-3 of
-// the row so that the 16 rows a ds_read_b128 group touches fall on distinct banks (rows r and r + 4 share a bank group
-// at a 64-byte stride).  Other head widths keep the padded rows (96-byte rows have no power-of-two chunk count).
-template <int D> struct ResImg {
-    static constexpr bool SWZ = (D == 32);
-    static constexpr int DP = (D + 31) / 32 * 32;
-    static constexpr int ROW_DP = SWZ ? DP * 2 : DP * 2 + 16;      // rows holding DP columns (the q kernel's K)
-    static constexpr int ROW_D = SWZ ? D * 2 : D * 2 + 16;         // rows holding D columns
-    // byte offset of 16-byte chunk `c` (+ `in` bytes inside it) of row `row` in an image of `rowb`-byte rows
-    static __device__ __forceinline__ int at(int row, int c, int rowb, int in = 0) {
-        return SWZ ? row * rowb + ((c ^ ((row >> 2) & 3)) << 4) + in : row * rowb + (c << 4) + in;
-    }
-};
-
 #ifdef ATTN_PROBE   // in-kernel phase stamps of the split backward (tools/attn_probe.py); not part of the product build
 #define ATTN_PROBE_WGS 16384
 __device__ unsigned long long attn_probe[ATTN_PROBE_WGS * 8];
@@ -1677,6 +1871,33 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         const int dp = (head_dim + 31) / 32 * 32;
         const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16));
         const int fwd_res_env = bf_tuning().attn_fwd_tiled ? 0 : 1;
+        // d = 32 without a mask (the fusion transformer of rgb_clip): the persistent, double-buffered kernel
+        const size_t pd_lds = (size_t)2 * (nq32 * 32) * 128;
+        const size_t qkv_ext = (size_t)batch * seq * 3 * heads * head_dim * 2;
+        if (fwd_res_env && bf_tuning().attn_fwd_pd && head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 <= 16 &&
+            pd_lds <= 80 * 1024 && qkv_ext < (1ull << 32)) {
+            int n_cu = 0, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+            const int per_cu = (int)((160 * 1024) / pd_lds) < 2 ? 1 : 2;
+            int grid_pd = n_cu * per_cu;
+            if (grid_pd > batch * heads) grid_pd = batch * heads;
+#define FWD_PD(HT)                                                                                 \
+    do {                                                                                          \
+        static size_t lds_set = 0;                                                                \
+        if (pd_lds > lds_set) {                                                                   \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_pd32_kernel<HT>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);   \
+            lds_set = pd_lds;                                                                     \
+        }                                                                                         \
+        hipLaunchKernelGGL((attn_fwd_pd32_kernel<HT>), dim3(grid_pd), dim3(nq32 * 64), pd_lds, s, (const HT*)qkv, \
+                           (HT*)out, lse, seq, heads, scale, nq32 * 32, batch * heads, (unsigned)qkv_ext); \
+    } while (0)
+            if (f16) FWD_PD(f16_t); else FWD_PD(bf16_t);
+#undef FWD_PD
+            BF_CHECK_LAUNCH("bf_attention_fwd");
+            return BF_OK;
+        }
         if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024) {
             dim3 rgrid(batch * heads), rblock(nq32 * 64);
             const int nt_env = bf_tuning().attn_nt;

@@ -321,6 +321,22 @@ def test_colsum_and_cast(ops, gpu):
 
 
 # ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("B,Lq,H", [(40, 275, 16), (70, 100, 8), (33, 64, 16)])
+def test_attention_fwd_persistent_walks_many_items(ops, gpu, half, B, Lq, H):
+    """attn_fwd_pd32_kernel (d = 32, no mask): more (batch, head) items than resident workgroups (2 per CU), so every
+    workgroup walks several items through its two LDS images -- checked against the fp64 formula on the GPU (torch)."""
+    D = 32
+    g = torch.Generator(device=gpu).manual_seed(B * 1000 + Lq)
+    qkv = torch.randn(B * Lq, 3 * H * D, device=gpu, generator=g).to(half)
+    out, lse = ops.attention_fwd(qkv, B, Lq, H, D, D ** -0.5, 0, None, need_lse=True)
+    q, k, v = qkv.double().reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * D ** -0.5
+    ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Lq, H * D)
+    assert rel_err(out.float(), ref) < (2 ** -7 if half == torch.bfloat16 else 2 ** -9)
+    assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-5
+
+
 def ref_attention(qkv, B, Lq, H, D, scale, mode, row_mask):
     q, k, v = qkv.double().reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
     s = q @ k.transpose(-1, -2) * scale
