@@ -87,17 +87,21 @@ def pmc_summary_path():
     return found[-1] if found else None
 
 
-def kernel_stats_path():
-    """The newest committed `rocprofv3 --kernel-trace --stats` summary of this command (tools/prof_summary.py)."""
+def kernel_stats_path(tag: str = "fp16"):
+    """The newest committed `rocprofv3 --kernel-trace --stats` summary of this command (tools/prof_summary.py): the
+    SERIAL one of this dtype when there is one (tools/serial_stats.sh: side streams folded in, like the roofline sample
+    below, so that a kernel's duration is its own), else the concurrent step's."""
     import glob
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats*.txt")))
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_serial_kernel_stats_{tag}.txt")))
+    if not found:
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_stats*.txt")))
     return found[-1] if found else None
 
 
-def rocprof_nt_average_us():
+def rocprof_nt_average_us(tag: str = "fp16"):
     """Launch-weighted average duration of the NT instantiations of gemm_bf16_p8_kernel in the committed rocprof
     summary: what `roofline.avg_us` (HIP events around the host call) has to agree with."""
-    path = kernel_stats_path()
+    path = kernel_stats_path(tag)
     if path is None:
         return None
     calls, ms = 0.0, 0.0
@@ -144,7 +148,7 @@ def profiled_traffic(dom: str):
     rel = os.path.relpath(path, ROOT)
     tot_n, tot_b = 0, 0.0
     for line in open(path):
-        if line.startswith("gemm_bf16_p8_kernel<0,0,") or line.startswith("gemm_bf16_p8_kernel<false, false,"):
+        if line.startswith("gemm_bf16_p8_kernel<0,0") or line.startswith("gemm_bf16_p8_kernel<false, false,"):
             f = line.split(">")[1].split()
             n, read_corr, write = int(f[0]), float(f[3]), float(f[4])
             tot_n += n
@@ -504,7 +508,7 @@ def main():
                                                 f"folded into the main stream ({serial_ms:.2f} ms/step that way): kernel "
                                                 "durations as the profiler sees them; share_of_step = this kernel's ms per "
                                                 "step / the timed ms_per_step")),
-                                    "rocprof": rocprof_nt_average_us()}
+                                    "rocprof": rocprof_nt_average_us({"f16": "fp16"}.get(tag, tag))}
             line["kernels"] = {k: {"launches": v["launches"], "avg_us": round(v["avg_us"], 1),
                                    "tflops": round(v["tflops"], 1),
                                    "share_of_step": round(v["ms"] / timed_steps / ms, 4)}
