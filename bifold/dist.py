@@ -122,6 +122,7 @@ class GradSync:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.on_gpu = flat_grad.is_cuda
+        self.avg_native = (not dist.is_initialized()) or dist.get_backend(group) == "nccl"    # ReduceOp.AVG is RCCL's
         self.side = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
         self.pending: List = []
         if coalesce is None:
@@ -168,13 +169,17 @@ class GradSync:
             return
         for a, b in spans:
             view = self.grad[a:b]
-            if self.on_gpu:
+            if self.on_gpu and self.avg_native:
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream())
                 self.side.wait_event(ready)
                 with torch.cuda.stream(self.side):
                     work = dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
                 self.pending.append(work)
+            elif self.on_gpu:            # a backend without AVG on device tensors (gloo: a rehearsal of N ranks on ONE GPU)
+                torch.cuda.current_stream().synchronize()
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                view.div_(self.world)
             else:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 view.div_(self.world)

@@ -244,3 +244,86 @@ def test_backward_hooks_drive_rccl_allreduce_world1(gpu, tmp_path):
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", BIFOLD_DDP_COALESCE="1")
     r = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DDP-HOOKS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+DDP2_SCRIPT = """
+import os, sys, warnings
+import torch
+sys.path.insert(0, sys.argv[1])
+from bifold import dist as bdist
+from bifold.losses import Losses
+from bifold.models import Models
+from bifold.models.clip_encoder import CLIP_CONFIGS
+rank, local_rank, world = bdist.init_process_group_from_env(os.environ["TEST_BACKEND"])
+assert world == 2
+dev = torch.device("cuda", 0)                       # BOTH ranks on the one GPU of the box
+CLIP_CONFIGS["t"] = dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+                         context_length=77, vocab_size=512, transformer_width=64, transformer_heads=1, transformer_layers=2)
+for dtype, tol in (("fp32", 2e-5), ("fp16", 5e-3)):
+    cfg = dict(name="rgb_clip", image_size=64, is_bimanual=False, requires_graph=False, text_encoder="t", patch_size=16,
+               depth=3, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
+               pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype=dtype)
+    torch.manual_seed(0)                            # identical replicas on both ranks
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = Models.get_by_name(cfg, device=dev).to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    full = {"rgb": torch.randn(8, 3, 64, 64, generator=g).to(dev),
+            "instruction": torch.randint(1, 500, (8, 77), generator=g).int().to(dev)}
+    for k in ("pick", "place"):
+        full[k + "_heatmap"] = torch.rand(8, 64, 64, generator=g).to(dev)
+    mine = {k: v[4 * rank:4 * rank + 4].contiguous() for k, v in full.items()}
+    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=False, mask_pick_heatmap=False))
+    # the single-process gradient of the whole batch (what the average of the two ranks' gradients must equal)
+    loss_fn(model(full), full)[0].backward()
+    torch.cuda.synchronize()
+    want = model.trainable_arena().grad.clone()
+    model.trainable_arena().grads_pending = False
+    sync = bdist.gradient_sync_for(model)
+    loss_fn(model(mine), mine)[0].backward()        # the real fused backward drives the hooks; buckets leave as layers finish
+    sync.finish()
+    torch.cuda.synchronize()
+    got = model.trainable_arena().grad
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    assert err < tol, (dtype, err)
+    model._grad_hooks.clear()
+    print("rank", rank, dtype, "rel err", err, flush=True)
+torch.distributed.barrier()
+torch.distributed.destroy_process_group()
+print("DDP2-OK", rank)
+"""
+
+
+def test_two_ranks_average_gradients_of_the_real_backward(gpu, tmp_path):
+    """N > 1 on the data path: TWO ranks (both on this box's one GPU) run the real fused backward on their halves of a
+    batch, the hooks send the arena slices through the process group, and every rank ends with the single-process
+    gradient of the whole batch -- in the fp32 mode and in the fp16 mode (slices are un-scaled before they leave).
+    RCCL is tried first (it may refuse two ranks on one device); gloo on device tensors is the fallback: the
+    collective's transport differs, the bucket plan, hooks, stream ordering and loss-scale handling are the product's."""
+    import socket
+    script = tmp_path / "ddp_world2.py"
+    script.write_text(DDP2_SCRIPT)
+    tried = {}
+    for backend in ("nccl", "gloo"):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", RANK=str(rank),
+                       LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", TEST_BACKEND=backend, BIFOLD_DDP_COALESCE="1")
+            procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                          stderr=subprocess.PIPE, text=True))
+        outs = []
+        for p in procs:
+            try:
+                o, e = p.communicate(timeout=300)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                o, e = p.communicate()
+            outs.append((p.returncode, o, e))
+        tried[backend] = outs
+        if all(rc == 0 and "DDP2-OK" in o for rc, o, _ in outs):
+            print("two ranks on one GPU over", backend)
+            return
+    raise AssertionError({b: [(rc, o[-500:], e[-1500:]) for rc, o, e in v] for b, v in tried.items()})
