@@ -1218,20 +1218,22 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
         // dS^T (rows = keys, lane = query); masked scores carry no gradient
         const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
         const f32x2 sl2v = {sl2, sl2}, scalev = {scale, scale};
+        // (the edge test is wave-uniform: inside the element loop it became a scalar branch per PAIR of scores, eight per
+        // block, and fenced the exponentials of one pair off from the next; one branch per block, straight-line bodies)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {                   // packed fp32: two scores per VALU instruction
             const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
             const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-            f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
-            if (edge) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int key = j0 + ((e + u) & 3) + 8 * ((e + u) >> 2) + 4 * hh;
-                    if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) ds2[u] = 0.f;
-                }
-            }
+            const f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
             sacc[e] = ds2[0];
             sacc[e + 1] = ds2[1];
+        }
+        if (edge) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[e] = 0.f;
+            }
         }
         if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
 #pragma unroll
@@ -1577,16 +1579,16 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_q_stream_kernel(
             for (int e = 0; e < 16; e += 2) {
                 const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
                 const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
-                if (edge) {
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int key = j0 + ((e + u) & 3) + 8 * ((e + u) >> 2) + 4 * hh;
-                        if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) ds2[u] = 0.f;
-                    }
-                }
+                const f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
                 sacc[e] = ds2[0];
                 sacc[e + 1] = ds2[1];
+            }
+            if (edge) {                                   // one branch per block (see attn_bwd_q_kernel)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[e] = 0.f;
+                }
             }
             if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
 #pragma unroll
