@@ -421,6 +421,9 @@ def main():
         # magnitude larger than at random initialisation (max |logit| 0.17 there), which is what "relative" divides by
         parity_trained = parity_vs_oracle(model, sample)
         parity_trained["after_steps"] = opt.step_count
+        parity_trained["against"] = parity_trained["against"].replace(
+            "same random-init weights and inputs, checked before the first optimisation step",
+            f"the weights after {opt.step_count} optimisation steps (state_dict handed to the oracle), same inputs")
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
