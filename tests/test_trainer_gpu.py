@@ -108,6 +108,28 @@ def test_trainer_clip_warmup_eval_save_and_resume(gpu, run_home, monkeypatch):
         assert (got - v).abs().max().item() <= 1e-6 * (v.abs().max().item() + 1e-12) + 1e-9, k
 
 
+def test_trainer_default_fp16_mode_trains_and_reports_overflow(gpu, run_home, capsys):
+    """`python -m bifold` with the shipped `model.dtype: fp16`: the loss-scaled backward trains (mean loss falls over
+    the epochs, no non-finite gradient counted), and a loss scale far beyond binary16's range is REPORTED -- the
+    Trainer reads the scaler's overflow counter at the end of the epoch and raises instead of stepping on."""
+    import bifold.__main__ as M
+    import re
+    import warnings
+    ov = [o for o in OVERRIDES if not o.startswith(("model.dtype=", "epochs=", "gradient_clip="))] + ["epochs=4"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = M.main(list(ov))
+    assert t.model.compute_dtype == torch.float16 and t.model._grad_scaler.overflowed() == 0
+    means = [float(x) for x in re.findall(r"mean loss ([0-9.]+)", capsys.readouterr().out)]
+    assert len(means) == 4 and means[-1] < means[0], means
+    os.chdir(str(run_home))
+    bad = [o for o in ov if not o.startswith(("epochs=", "scheduler="))] + ["epochs=1", "model.loss_scale=1e30", "seed=5"]
+    tb, _ = _trainer(bad)
+    tb.prepare_train()
+    with pytest.raises(FloatingPointError, match="non-finite gradient"):
+        tb.train_epoch(0)
+
+
 def test_a_reference_shaped_checkpoint_resumes(gpu, run_home):
     """A `last.pth` written by the reference's Trainer.save_model (torch.optim.Adam state, `epoch` = next epoch,
     `random_states` 4-tuple) loads: start epoch, RNG streams, weights, optimiser moments."""
