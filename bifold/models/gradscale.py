@@ -35,6 +35,7 @@ class StaticGradScale:
         self.scale = 1.0
         self.nonfinite: Optional[torch.Tensor] = None
         self._buckets: Optional[List[Tuple[int, int]]] = None
+        self._arena = None
         self._depth = 0
 
     def _plan(self):
@@ -56,7 +57,7 @@ class StaticGradScale:
         if self.setting is not None:
             self.scale = self.setting
         else:
-            n = max(t.numel() for t in d_heats if t is not None)
+            n = max((t.numel() for t in d_heats if t is not None), default=1)
             self.scale = 2.0 ** (math.ceil(math.log2(max(n, 1))) + 6)
         return self.scale
 
