@@ -365,9 +365,19 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;       // sl2 > 0: max commutes with the scale
         const float m_new = fmaxf(m, tmax);
-        // m_new is finite for every live query: tile 0 always holds an unmasked key
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+        // lazy reference point (see attn_fwd_res_kernel): m moves, and l / the accumulators are rescaled, only when a
+        // row has risen more than 2^6 above it
+        if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {
+            const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m - m_to);
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+            m = m_new;
+        }
+        const float m_use = (m == -INFINITY) ? 0.f : m;
         // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
         // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
         f32x2 psum2 = {0.f, 0.f};
@@ -385,12 +395,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
             }
         float psum = psum2[0] + psum2[1];
         psum += __shfl_xor(psum, 32, 64);
-        l = l * alpha + psum;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+        l += psum;
 
         // ---- O^T += V^T P^T : P^T accumulator registers are the B operand ---------------
 #pragma unroll
@@ -552,9 +557,23 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+        // LAZY reference point: the running maximum m is moved -- and l / the output accumulators rescaled -- only when
+        // some row of the wave has risen more than 2^6 above it (or has none yet); otherwise the probabilities of this
+        // block are taken against the old m (p <= 64: harmless in fp32 sums and in both 16-bit formats) and the 8-16
+        // packed multiplies of the rescale, its exponential and the bookkeeping are skipped: after the first block
+        // that is almost every block.  The normalisation at the end uses the same m, so the result is unchanged.
         const float m_new = fmaxf(m, tmax);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+        if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {
+            const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m - m_to);
+            l *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+            m = m_new;
+        }
+        const float m_use = (m == -INFINITY) ? 0.f : m;
         // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
         // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
         f32x2 psum2 = {0.f, 0.f};
@@ -572,12 +591,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
             }
         float psum = psum2[0] + psum2[1];
         psum += __shfl_xor(psum, 32, 64);
-        l = l * alpha + psum;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+        l += psum;
 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -748,8 +762,15 @@ __global__ __launch_bounds__(1024, 6) void attn_fwd_pd32_kernel(
                 for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
                 const float m_new = fmaxf(m, tmax);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+                if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {     // lazy reference point:
+                    const float m_to = (m_new == -INFINITY) ? 0.f : m_new;                        // see attn_fwd_res_kernel
+                    const float alpha = __builtin_amdgcn_exp2f(m - m_to);
+                    l *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+                    m = m_new;
+                }
+                const float m_use = (m == -INFINITY) ? 0.f : m;
                 f32x2 psum2 = {0.f, 0.f};
                 const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
 #pragma unroll
@@ -763,10 +784,7 @@ __global__ __launch_bounds__(1024, 6) void attn_fwd_pd32_kernel(
                 }
                 float psum = psum2[0] + psum2[1];
                 psum += __shfl_xor(psum, 32, 64);
-                l = l * alpha + psum;
-                m = m_new;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+                l += psum;
                 const int cb = (16 * (g16 & 1) + 4 * p4) * 2;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {

@@ -48,7 +48,7 @@ BfTuning& bf_tuning() {
         t.fp8_p8 = env_int("BIFOLD_FP8_P8", 1);
         t.dw_grouped = env_int("BIFOLD_DW_GROUPED", 1);
         t.attn_fwd_tiled = env_int("BIFOLD_ATTN_FWD_TILED", 0) ? 1 : 0;
-        t.attn_fwd_pd = env_int("BIFOLD_ATTN_FWD_PD", 1);
+        t.attn_fwd_pd = env_int("BIFOLD_ATTN_FWD_PD", 0);
         t.attn_nt = env_int("BIFOLD_ATTN_NT", 1);
         t.attn_fwd_kt32 = env_int("BIFOLD_ATTN_FWD_KT32", 2);
         t.attn_bwd_nw = env_int("BIFOLD_ATTN_BWD_NW", 0);
