@@ -1235,14 +1235,14 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
         }
         // dS^T (rows = keys, lane = query); masked scores carry no gradient
         const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
-        const f32x2 sl2v = {sl2, sl2}, scalev = {scale, scale};
+        const f32x2 sl2v = {sl2, sl2};       // (the factor `scale` of dS is applied ONCE, to dQ at the end: 8 packed multiplies less per block)
         // (the edge test is wave-uniform: inside the element loop it became a scalar branch per PAIR of scores, eight per
         // block, and fenced the exponentials of one pair off from the next; one branch per block, straight-line bodies)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {                   // packed fp32: two scores per VALU instruction
             const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
             const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-            const f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
+            const f32x2 ds2 = p2 * (f32x2){pacc[e], pacc[e + 1]};
             sacc[e] = ds2[0];
             sacc[e + 1] = ds2[1];
         }
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
                 if (d0 < D) {
                     typename H16<HT>::x4 o4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o4[e] = (HT)dqacc[db][4 * g + e];
+                    for (int e = 0; e < 4; ++e) o4[e] = (HT)(dqacc[db][4 * g + e] * scale);
                     *(typename H16<HT>::x4*)(dq + d0) = o4;
                 }
             }
@@ -1390,12 +1390,14 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
             sacc = mfma_32x32x16(qa, kf[ks], sacc);
             pacc = mfma_32x32x16(da, vf[ks], pacc);
         }
-        const f32x2 sl2v = {sl2, sl2}, onv = {lane_on, lane_on}, scalev = {scale, scale};
+        // Two multiplies of the round-2 kernel are gone from this loop: the dead-key mask (a key >= L pollutes only its
+        // own lane's dK / dV columns, which are never stored) and the factor `scale` of dS (applied once, to dK at the end)
+        const f32x2 sl2v = {sl2, sl2};
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {                   // packed fp32: two scores per VALU instruction
             const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
-            f32x2 p2 = (f32x2){__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} * onv;
-            f32x2 ds2 = p2 * ((f32x2){pacc[e], pacc[e + 1]} * scalev);
+            f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            f32x2 ds2 = p2 * (f32x2){pacc[e], pacc[e + 1]};
             if (mask_mode != BF_MASK_NONE) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -1439,7 +1441,7 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
                 if (d0 < D) {
                     typename H16<HT>::x4 k4, v4;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { k4[e] = (HT)dkacc[db][4 * g + e]; v4[e] = (HT)dvacc[db][4 * g + e]; }
+                    for (int e = 0; e < 4; ++e) { k4[e] = (HT)(dkacc[db][4 * g + e] * scale); v4[e] = (HT)dvacc[db][4 * g + e]; }
                     *(typename H16<HT>::x4*)(dkp + d0) = k4;
                     *(typename H16<HT>::x4*)(dvp + d0) = v4;
                 }
