@@ -649,7 +649,9 @@ def resize_normalize_rgb(raw, mask, size: int, mean, std):
     mask fill 77 -> v2.ToImage -> v2.Resize(size, BICUBIC, antialias) -> v2.CenterCrop(size) ->
     v2.ToDtype(float32, scale=True) -> v2.Normalize.  raw uint8 [B, H, W, 3].  PARITY UNPINNED: torchvision is
     absent, so its documented pipeline is restated over torch's own uint8 antialiased bicubic
-    F.interpolate -- the kernel torchvision dispatches to for uint8 CPU images."""
+    F.interpolate -- the kernel torchvision dispatches to for uint8 CPU images.  Second witness (round 3): PIL's
+    antialiased BICUBIC, which the reference itself calls for `raw_rgb` (processor.py:263), agrees to one grey level
+    (two below a 2x shrink) on < 1 % of the pixels: tests/test_processor.py."""
     x = torch.as_tensor(raw)
     if mask is not None:
         m = torch.as_tensor(mask).reshape(x.shape[0], x.shape[1], x.shape[2], 1).float()

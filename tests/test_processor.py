@@ -57,6 +57,35 @@ def test_pixel_augmentation_matches_reference():
     assert never is None and p is None
 
 
+def _camera_frames(h, w, n=2):
+    g = torch.Generator().manual_seed(h * w)
+    base = torch.rand(n, 3, h // 8 + 1, w // 8 + 1, generator=g)
+    raw = (torch.nn.functional.interpolate(base, size=(h, w), mode="bilinear") * 255).round().clamp(0, 255)
+    raw = (raw + torch.randint(-12, 13, raw.shape, generator=g)).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+    return raw, g
+
+
+@pytest.mark.parametrize("h,w,size", [(480, 640, 224), (300, 300, 224), (224, 224, 224), (720, 540, 384), (100, 160, 224)])
+def test_oracle_resize_is_witnessed_by_pil_bicubic(h, w, size):
+    """torchvision is absent, so the oracle's `resize_normalize_rgb` cannot be pinned by the reference's own
+    `rgb_transform`.  A second witness that IS here: PIL's antialiased BICUBIC, the routine the reference calls for
+    `raw_rgb` (processor.py:263, `self.resize(Image.fromarray(rgb))`) and the one torchvision's uint8 tensor path is
+    written to agree with.  Same sizes, same centre crop: at most one grey level apart when shrinking by 2x or more, two
+    otherwise, on well under 1 % of the pixels (the two fixed-point schemes round ties differently)."""
+    from PIL import Image
+    from oracle import bifold_oracle as O
+    raw, _ = _camera_frames(h, w, n=1)
+    want = O.resize_normalize_rgb(raw, None, size, MEAN, STD)[0]
+    new_h, new_w = (size, int(size * w / h)) if h <= w else (int(size * h / w), size)
+    img = np.asarray(Image.fromarray(raw[0].numpy()).resize((new_w, new_h), Image.Resampling.BICUBIC))
+    top, left = int(round((new_h - size) / 2.0)), int(round((new_w - size) / 2.0))
+    img = torch.from_numpy(img[top:top + size, left:left + size].astype(np.float32)).permute(2, 0, 1) / 255.0
+    pil = (img - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1)
+    lsb = (pil - want).abs() * torch.tensor(STD).view(3, 1, 1) * 255.0
+    assert float(lsb.max()) <= (1.01 if min(h, w) >= 2 * size or min(h, w) == size else 2.01)
+    assert float((lsb > 0.5).float().mean()) < 0.01
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("h,w,size", [(480, 640, 224), (300, 300, 224), (224, 224, 224), (720, 540, 384), (100, 160, 224)])
 def test_resize_normalize_rgb_matches_torch_uint8_bicubic(gpu, observed, h, w, size):
