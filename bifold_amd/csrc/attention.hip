@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #define KT 64                                 // keys per LDS tile
+#define IMG_U 5                               // resident kernels: image-load requests a thread keeps in flight (x2 operands)
 
 // Workgroup -> (batch, head).  Consecutive workgroup ids go to consecutive XCDs (8 private L2s).  With
 // d = 32 a head's slice of a token row is 64 bytes, half a 128-byte line: the other half belongs to the
@@ -487,15 +488,31 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const bool q_live = qi < L;
     const int nthreads = blockDim.x;
 
-    for (int idx = threadIdx.x; idx < Lp * (DP / 8); idx += nthreads) {
-        const int j = idx / (DP / 8), c = idx - j * (DP / 8);
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (j < L && c < D / 8) {
-            kv = ld16(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
-            vv = ld16(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+    {   // image load in batches: every request of a thread in flight before its first LDS write (attn_bwd_q_kernel)
+        constexpr int CH = DP / 8;
+        const int total = Lp * CH;
+        for (int base = threadIdx.x; base < total; base += IMG_U * nthreads) {
+            uint4 kv[IMG_U], vv[IMG_U];
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int idx = base + u * nthreads;
+                const int j = idx / CH, c = idx - j * CH;
+                kv[u] = make_uint4(0, 0, 0, 0); vv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < total && j < L && c < D / 8) {
+                    kv[u] = ld16(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+                    vv[u] = ld16(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int idx = base + u * nthreads;
+                const int j = idx / CH, c = idx - j * CH;
+                if (idx < total) {
+                    if (c < D / 8) *(uint4*)(k_lds + j * KROW + c * 16) = kv[u];
+                    *(uint4*)(v_lds + j * VROW + c * 16) = vv[u];
+                }
+            }
         }
-        if (c < D / 8) *(uint4*)(k_lds + j * KROW + c * 16) = kv;
-        *(uint4*)(v_lds + j * VROW + c * 16) = vv;
     }
 
     typename H16<HT>::x8 qf[KS];
@@ -1167,50 +1184,92 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     const int nthreads = blockDim.x;
     ATTN_STAMP(0);
 
-    for (int idx = threadIdx.x; idx < Lp * (DP / 8); idx += nthreads) {
-        const int j = idx / (DP / 8), c = idx - j * (DP / 8);
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (j < L && c < D / 8) {
-            kv = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
-            vv = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+    // Operands of a 32-query block: the lane's 16-byte pieces of its Q, dO and O rows (delta = rowsum(dO * O) from the
+    // pieces the two half-waves hold), lse, the row mask.  Requested ONE BLOCK AHEAD: read at the top of each block
+    // they were a trip to memory of 3.6 us per block in front of nine key steps of 4.3 us (tools/attn_probe.py).
+    typename H16<HT>::x8 q_nx[KS], do_nx[KS], o_nx[KS];
+    float lse_nx = 1e30f;
+    bool mask_nx = false;
+    auto fetch_block = [&](int bk) {
+        const int qn = bk * 32 + r;
+        lse_nx = 1e30f; mask_nx = false;
+        if (bk < nblk && qn < L) {
+            const size_t oo = ((size_t)b * L + qn) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                q_nx[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, qn, 0, h, L, H, D) + ks * 16 + hh * 8);
+                do_nx[ks] = *(const typename H16<HT>::x8*)(dout + oo + ks * 16 + hh * 8);
+                o_nx[ks] = *(const typename H16<HT>::x8*)(out + oo + ks * 16 + hh * 8);
+            }
+            lse_nx = lse[((size_t)b * H + h) * L + qn];
+            mask_nx = mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qn] == 0;
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { q_nx[ks][e] = (HT)0.f; do_nx[ks][e] = (HT)0.f; o_nx[ks][e] = (HT)0.f; }
         }
-        *(uint4*)(k_lds + RI::at(j, c, KROW)) = kv;
-        if (c < D / 8) *(uint4*)(v_lds + RI::at(j, c, VROW)) = vv;
+    };
+    const int blk_first = blockIdx.y * wpb + slot;
+    fetch_block(blk_first);
+
+    // The image load in BATCHES of IMG_U requests per thread, all issued before the first LDS write: as a plain loop
+    // (load, wait, write, next) its 4.5 rounds at 275 x 32 were 4.5 dependent trips to memory -- 8 of the 28 us a
+    // workgroup lives (tools/attn_probe.py), during which it holds its LDS and computes nothing.
+    {
+        constexpr int CH = DP / 8;
+        const int total = Lp * CH;
+        for (int base = threadIdx.x; base < total; base += IMG_U * nthreads) {
+            uint4 kv[IMG_U], vv[IMG_U];
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int idx = base + u * nthreads;
+                const int j = idx / CH, c = idx - j * CH;
+                kv[u] = make_uint4(0, 0, 0, 0); vv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < total && j < L && c < D / 8) {
+                    kv[u] = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
+                    vv[u] = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int idx = base + u * nthreads;
+                const int j = idx / CH, c = idx - j * CH;
+                if (idx < total) {
+                    *(uint4*)(k_lds + RI::at(j, c, KROW)) = kv[u];
+                    if (c < D / 8) *(uint4*)(v_lds + RI::at(j, c, VROW)) = vv[u];
+                }
+            }
+        }
     }
 
     ATTN_STAMP(1);
     __syncthreads();
     ATTN_STAMP(2);
-    for (int blk = blockIdx.y * wpb + slot; blk < nblk; blk += blk_stride) {
+#ifdef ATTN_PROBE
+    unsigned long long probe_pro = 0, probe_key = 0, probe_nblk = 0;
+#endif
+    for (int blk = blk_first; blk < nblk; blk += blk_stride) {
+#ifdef ATTN_PROBE
+    const unsigned long long probe_t0 = wall_clock64();
+#endif
     const int q0 = blk * 32;
     const int qi = q0 + r;
     const bool q_live = qi < L;
+    // this block's operands were requested a block ago (the first: before the image load)
     typename H16<HT>::x8 qf[KS], dof[KS];
-    float delta = 0.f, lse_q = 1e30f;
-    bool row_masked = false;
-    if (q_live) {
-        const size_t oo = ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
+    float delta = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
-            dof[ks] = *(const typename H16<HT>::x8*)(dout + oo + ks * 16 + hh * 8);
-        }
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = q_nx[ks]; dof[ks] = do_nx[ks];
 #pragma unroll
-        for (int c = 0; c < D / 8; ++c) {
-            const typename H16<HT>::x8 ov = *(const typename H16<HT>::x8*)(out + oo + c * 8);
-            const typename H16<HT>::x8 gv = *(const typename H16<HT>::x8*)(dout + oo + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) delta = fmaf((float)ov[e], (float)gv[e], delta);
-        }
-        lse_q = lse[((size_t)b * H + h) * L + qi];
-        row_masked = mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qi] == 0;
-        if (hh == 0) delta_ws[((size_t)b * H + h) * L + qi] = delta;
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { qf[ks][e] = (HT)0.f; dof[ks][e] = (HT)0.f; }
+        for (int e = 0; e < 8; ++e) delta = fmaf((float)o_nx[ks][e], (float)do_nx[ks][e], delta);
     }
+    delta += __shfl_xor(delta, 32, 64);          // the two half-waves hold the two halves of a row
+    const float lse_q = lse_nx;
+    const bool row_masked = mask_nx;
+    if (q_live && hh == 0) delta_ws[((size_t)b * H + h) * L + qi] = delta;
+    fetch_block(blk + blk_stride);                // the next block's operands travel under this block's key loop
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
     const float s_init = -lse_q * inv_scale;
@@ -1221,6 +1280,10 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #pragma unroll
         for (int e = 0; e < 16; ++e) dqacc[db][e] = 0.f;
     const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
+#ifdef ATTN_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long probe_t1 = wall_clock64();
+#endif
 
     for (int j0 = 0; j0 < key_end; j0 += 32) {
         f32x16 sacc, pacc;
@@ -1273,6 +1336,12 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
         }
     }
 
+#ifdef ATTN_PROBE
+    {
+        const unsigned long long probe_t2 = wall_clock64();
+        probe_pro += probe_t1 - probe_t0; probe_key += probe_t2 - probe_t1; probe_nblk += 1;
+    }
+#endif
     if (q_live) {
         HT* dq = dqkv + qkv_off(b, qi, 0, h, L, H, D);
 #pragma unroll
@@ -1293,6 +1362,13 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #ifdef ATTN_PROBE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATTN_STAMP(4);
+    {   // slots 5-7: wave 0's summed 100 MHz ticks in the per-block prologue (operand loads until they have arrived), the
+        // key loops and the dQ stores
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;
+        if (threadIdx.x == 0 && wg_ < ATTN_PROBE_WGS) {
+            attn_probe[wg_ * 8 + 5] = probe_pro; attn_probe[wg_ * 8 + 6] = probe_key; attn_probe[wg_ * 8 + 7] = probe_nblk;
+        }
+    }
 #endif
 }
 
@@ -1310,15 +1386,20 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nw = (L + 31) >> 5;                 // 32-query blocks of the sequence (all resident in LDS)
     const int Lp = nw * 32;
+    // Q and dO images interleaved by 32-row block (Q block i, dO block i, Q block i + 1, ...): the dO operand of a
+    // block sits a compile-time 32 * ROW bytes behind the Q operand, so one address register serves both
+    constexpr int BLK = 2 * 32 * ROW, DO_OFF = 32 * ROW;
     char* q_lds = smem;
-    char* do_lds = q_lds + (size_t)Lp * ROW + 64;
-    float* lse_s = (float*)(do_lds + (size_t)Lp * ROW + 64);
+    float* lse_s = (float*)(smem + (size_t)Lp * 2 * ROW + 128);
     float* del_s = lse_s + Lp;
     int* msk_s = (int*)(del_s + Lp);
 
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;                   // key blocks of this wave: see attn_bwd_q_kernel
-    const int slot = ((int)(threadIdx.x >> 6) + (int)(blockIdx.x % (unsigned)wpb)) % wpb;
+    // (the wave index through readfirstlane: the block loops below then run on scalar registers -- as a per-lane value
+    // the query-block counter, its wrap-around and every LDS base were vector arithmetic, 20 instructions per block)
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slot = (wave_u + (int)(blockIdx.x % (unsigned)wpb)) % wpb;
     const int blk_stride = gridDim.y * wpb;
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
@@ -1327,15 +1408,49 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
 
-    for (int idx = threadIdx.x; idx < Lp * (D / 8); idx += nthreads) {
-        const int i = idx / (D / 8), c = idx - i * (D / 8);
-        uint4 qv = make_uint4(0, 0, 0, 0), dv = qv;
-        if (i < L) {
-            qv = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
-            dv = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
+    constexpr bool PF = (WPE != 4);     // the 128-register build has no room for the 16 registers of a block in flight
+    typename H16<HT>::x8 k_nx[KS], v_nx[KS];
+    auto fetch_keys = [&](int wn) {
+        const int kn = wn * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (wn < nw && kn < L) {
+                k_nx[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, kn, 1, h, L, H, D) + ks * 16 + hh * 8);
+                v_nx[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, kn, 2, h, L, H, D) + ks * 16 + hh * 8);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { k_nx[ks][e] = (HT)0.f; v_nx[ks][e] = (HT)0.f; }
+            }
         }
-        *(uint4*)(q_lds + RI::at(i, c, ROW)) = qv;
-        *(uint4*)(do_lds + RI::at(i, c, ROW)) = dv;
+    };
+    const int w_first = blockIdx.y * wpb + slot;
+    fetch_keys(w_first);
+    {   // image load in batches (see attn_bwd_q_kernel)
+        constexpr int CH = D / 8;
+        const int total = Lp * CH;
+        for (int base = threadIdx.x; base < total; base += IMG_U * nthreads) {
+            uint4 qv[IMG_U], dv[IMG_U];
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int idx = base + u * nthreads;
+                const int i = idx / CH, c = idx - i * CH;
+                qv[u] = make_uint4(0, 0, 0, 0); dv[u] = make_uint4(0, 0, 0, 0);
+                if (idx < total && i < L) {
+                    qv[u] = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
+                    dv[u] = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) {
+                const int idx = base + u * nthreads;
+                const int i = idx / CH, c = idx - i * CH;
+                if (idx < total) {
+                    char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
+                    *(uint4*)dst = qv[u];
+                    *(uint4*)(dst + DO_OFF) = dv[u];
+                }
+            }
+        }
     }
     for (int i = threadIdx.x; i < Lp; i += nthreads) {
         float dl = 0.f, ls = 1e30f;
@@ -1345,22 +1460,31 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
             dl = delta_ws[((size_t)b * H + h) * L + i];
             mk = (mask_mode == BF_MASK_QUERY_ROW) ? (row_mask[(size_t)b * L + i] == 0) : 0;
         }
-        lse_s[i] = ls; del_s[i] = dl; msk_s[i] = mk;
+        // stored as the accumulators' initial values (-lse / scale, -delta): the block loop loads them straight into the
+        // MFMA's C registers (they were 24 sign flips and 8 packed multiplies per block)
+        lse_s[i] = -ls * inv_scale; del_s[i] = -dl; msk_s[i] = mk;
+    }
+    // Lane-constant byte offsets inside a 32-row block of the Q / dO images: a block starts at a multiple of 32 rows,
+    // which the swizzle (bits 2-3 of the row) does not see, so the per-block address is one scalar base plus these
+    // (recomputed per block they were another 25 vector instructions).
+    // (rows 16 apart swizzle alike, so the second half of a block is the first plus 16 * ROW: an instruction offset)
+    int a_off[KS], t_off[DB][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = RI::at(r, ks * 2 + hh, ROW);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+        t_off[db][0] = RI::at(4 * hh + q4, cb >> 4, ROW, cb & 15);
+        t_off[db][1] = RI::at(4 * hh + q4 + 8, cb >> 4, ROW, cb & 15);
     }
     __syncthreads();
-    for (int w = blockIdx.y * wpb + slot; w < nw; w += blk_stride) {
+    // K / V fragments of a key block, requested one block ahead (the first: before the image load) -- see attn_bwd_q_kernel
+    for (int w = w_first; w < nw; w += blk_stride) {
     const int key = w * 32 + r;
     typename H16<HT>::x8 kf[KS], vf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        if (key < L) {
-            kf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 1, h, L, H, D) + ks * 16 + hh * 8);
-            vf[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[ks][e] = (HT)0.f; vf[ks][e] = (HT)0.f; }
-        }
-    }
+    for (int ks = 0; ks < KS; ++ks) { kf[ks] = k_nx[ks]; vf[ks] = v_nx[ks]; }
+    if (PF) fetch_keys(w + blk_stride);
     f32x16 dkacc[DB], dvacc[DB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
@@ -1379,14 +1503,15 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
         for (int g = 0; g < 4; ++g) {
             const float4 l4 = *(const float4*)(lse_s + qrow0 + 8 * g + 4 * hh);
             const float4 d4 = *(const float4*)(del_s + qrow0 + 8 * g + 4 * hh);
-            sacc[4 * g + 0] = -l4.x * inv_scale; sacc[4 * g + 1] = -l4.y * inv_scale;
-            sacc[4 * g + 2] = -l4.z * inv_scale; sacc[4 * g + 3] = -l4.w * inv_scale;
-            pacc[4 * g + 0] = -d4.x; pacc[4 * g + 1] = -d4.y; pacc[4 * g + 2] = -d4.z; pacc[4 * g + 3] = -d4.w;
+            sacc[4 * g + 0] = l4.x; sacc[4 * g + 1] = l4.y; sacc[4 * g + 2] = l4.z; sacc[4 * g + 3] = l4.w;
+            pacc[4 * g + 0] = d4.x; pacc[4 * g + 1] = d4.y; pacc[4 * g + 2] = d4.z; pacc[4 * g + 3] = d4.w;
         }
+        const char* q_blk = q_lds + qb * BLK;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)(q_lds + RI::at(qrow0 + r, ks * 2 + hh, ROW));
-            const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(do_lds + RI::at(qrow0 + r, ks * 2 + hh, ROW));
+            const char* pa = q_blk + a_off[ks];
+            const typename H16<HT>::x8 qa = *(const typename H16<HT>::x8*)pa;
+            const typename H16<HT>::x8 da = *(const typename H16<HT>::x8*)(pa + DO_OFF);
             sacc = mfma_32x32x16(qa, kf[ks], sacc);
             pacc = mfma_32x32x16(da, vf[ks], pacc);
         }
@@ -1416,14 +1541,12 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
             for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int row0 = qrow0 + 16 * s + 4 * hh + q4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                const typename H16<HT>::x8 dot = tr_pair<HT>(do_lds + RI::at(row0, cb >> 4, ROW, cb & 15),
-                                                             do_lds + RI::at(row0 + 8, cb >> 4, ROW, cb & 15));
-                const typename H16<HT>::x8 qtt = tr_pair<HT>(q_lds + RI::at(row0, cb >> 4, ROW, cb & 15),
-                                                             q_lds + RI::at(row0 + 8, cb >> 4, ROW, cb & 15));
+                const char* t0 = q_blk + t_off[db][0] + s * 16 * ROW;
+                const char* t1 = q_blk + t_off[db][1] + s * 16 * ROW;
+                const typename H16<HT>::x8 dot = tr_pair<HT>(t0 + DO_OFF, t1 + DO_OFF);
+                const typename H16<HT>::x8 qtt = tr_pair<HT>(t0, t1);
                 dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
                 dkacc[db] = mfma_32x32x16(qtt, dsb[s], dkacc[db]);
             }
@@ -1447,6 +1570,7 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
                 }
             }
     }
+    if (!PF) fetch_keys(w + blk_stride);
     }   // key blocks of this wave
 }
 
@@ -2078,6 +2202,10 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             const int wpb = (wpb_env < nq32 ? wpb_env : nq32) < 8 ? (wpb_env < nq32 ? wpb_env : nq32) : 8;   // launch bound: 512 threads
             const int n_split = bf_cdiv(nq32, wpb) < split_env2 ? bf_cdiv(nq32, wpb) : split_env2;
             dim3 grid(batch * heads, n_split), block(wpb * 64);
+            const int wkv_env = bf_tuning().attn_bwd_wpb_kv;
+            const int wpb_kv = (wkv_env < nq32 ? wkv_env : nq32) < 8 ? (wkv_env < nq32 ? wkv_env : nq32) : 8;
+            const int n_split_kv = bf_cdiv(nq32, wpb_kv) < split_env2 ? bf_cdiv(nq32, wpb_kv) : split_env2;
+            dim3 grid_kv(batch * heads, n_split_kv), block_kv(wpb_kv * 64);
             const int kv_tight = bf_tuning().attn_kv_tight;   // d = 32: the 128-register build of the kv kernel (four workgroups per CU)
 #define BWD_SPLIT2(DD, MM) BY_HALF(BWD_SPLIT3, DD, MM)
 #define BWD_SPLIT3(DD, MM, HT)                                                                      \
@@ -2099,11 +2227,11 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
                            (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,   \
                            delta_ws, seq, heads, scale, lp);                                        \
         if (kv_tight)                                                                               \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>), grid, block, lds_kv, s, (const HT*)qkv, \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>), grid_kv, block_kv, lds_kv, s, (const HT*)qkv, \
                                (const HT*)dout, lse, (const float*)delta_ws, row_mask,             \
                                (HT*)dqkv, seq, heads, scale);                                      \
         else                                                                                        \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT>), grid, block, lds_kv, s, (const HT*)qkv, \
+            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT>), grid_kv, block_kv, lds_kv, s, (const HT*)qkv, \
                                (const HT*)dout, lse, (const float*)delta_ws, row_mask,             \
                                (HT*)dqkv, seq, heads, scale);                                      \
     } while (0)

@@ -56,7 +56,8 @@ BfTuning& bf_tuning() {
         t.attn_bwd_resident_wide = env_int("BIFOLD_ATTN_BWD_RESIDENT_WIDE", 0);
         t.attn_stream_min_q32 = env_int("BIFOLD_ATTN_STREAM_MIN_Q32", 1);
         t.attn_stream_d32 = env_int("BIFOLD_ATTN_STREAM_D32", 0);
-        t.attn_bwd_wpb = env_int("BIFOLD_ATTN_BWD_WPB", 4); if (t.attn_bwd_wpb < 1) t.attn_bwd_wpb = 1;
+        t.attn_bwd_wpb = env_int("BIFOLD_ATTN_BWD_WPB", 3); if (t.attn_bwd_wpb < 1) t.attn_bwd_wpb = 1;
+        t.attn_bwd_wpb_kv = env_int("BIFOLD_ATTN_BWD_WPB_KV", 4); if (t.attn_bwd_wpb_kv < 1) t.attn_bwd_wpb_kv = 1;
         t.attn_bwd_split = env_int("BIFOLD_ATTN_BWD_SPLIT", 1); if (t.attn_bwd_split < 1) t.attn_bwd_split = 1;
         t.attn_kv_tight = env_int("BIFOLD_ATTN_KV_TIGHT", 1);
         t.attn_bwd_stream = env_int("BIFOLD_ATTN_BWD_STREAM", 1);

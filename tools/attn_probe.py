@@ -30,6 +30,10 @@ names = ["load issue + LDS write (0->1)", "barrier wait (1->2)", "key loop (2->3
 segs = [a[:, 1] - a[:, 0], a[:, 2] - a[:, 1], a[:, 3] - a[:, 2], a[:, 4] - a[:, 3], a[:, 4] - a[:, 0]]
 for nm, sgm in zip(names, segs):
     print(f"  {nm:34s} mean {us(sgm.mean()):7.2f} us  p10 {us(np.percentile(sgm,10)):7.2f}  p50 {us(np.percentile(sgm,50)):7.2f}  p90 {us(np.percentile(sgm,90)):7.2f}")
+# slots 5-7: wave 0's summed ticks in the per-block prologues (until the operand loads have arrived) and key loops, blocks
+nb = np.maximum(a[:, 7], 1)
+print(f"  wave 0, per 32-query block: prologue (q / dO / O loads arrived) {us((a[:, 5] / nb).mean()):.2f} us, "
+      f"nine key steps {us((a[:, 6] / nb).mean()):.2f} us = {us((a[:, 6] / nb).mean()) / 9 * 1e3:.0f} ns per step; blocks per wave {a[:, 7].mean():.2f}")
 # concurrency: average number of workgroups alive
 life = (a[:, 4] - a[:, 0]).sum()
 print(f"  average workgroups alive: {life / max(a[:,4].max() - t0, 1):.1f}  (= {life / max(a[:,4].max() - t0, 1) / 256:.2f} per CU)")
