@@ -50,6 +50,48 @@ __device__ __forceinline__ size_t qkv_off(int b, int i, int which, int h, int L,
     return (((size_t)b * L + i) * 3 + which) * (size_t)H * D + (size_t)h * D;
 }
 
+// Image load of the resident kernels: `total` (row, 16-byte chunk) items of TWO operands, item idx = row * CH + chunk,
+// thread t takes items t, t + nthreads, ...  All requests of a thread are in flight before its first LDS write (as a
+// plain load-wait-write loop the 4.5 rounds of a 275 x 32 image were 4.5 dependent trips to memory: 8 of the 28 us a
+// workgroup lived, tools/attn_probe.py), in batches of at most IMG_U rounds; only the last round is predicated.  `ld`
+// and `wr` get (row, chunk, a, b); with a workgroup-uniform base pointer and a 32-bit byte offset inside `ld` the
+// loads take the scalar-base form (the 64-bit per-lane address arithmetic was ~20 instructions per request, a fifth of
+// the forward kernel's vector instructions).
+typedef unsigned img_u32x4 __attribute__((ext_vector_type(4)));
+struct ImgPair { img_u32x4 a, b; };          // native vectors, passed by value: references to HIP's uint4 kept the batch in scratch
+template <int N, int CH, bool PRED_LAST, typename LoadFn, typename WriteFn>
+__device__ __forceinline__ void img_rounds(int first, int nthreads, int total, LoadFn&& ld, WriteFn&& wr) {
+    img_u32x4 va[N], vb[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int idx = first + u * nthreads;
+        va[u] = (img_u32x4){0u, 0u, 0u, 0u}; vb[u] = va[u];
+        if (!(PRED_LAST && u == N - 1) || idx < total) { const ImgPair pr = ld(idx / CH, idx % CH); va[u] = pr.a; vb[u] = pr.b; }
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const int idx = first + u * nthreads;
+        if (!(PRED_LAST && u == N - 1) || idx < total) wr(idx / CH, idx % CH, va[u], vb[u]);
+    }
+}
+template <int CH, typename LoadFn, typename WriteFn>
+__device__ __forceinline__ void img_load(int tid, int nthreads, int total, LoadFn&& ld, WriteFn&& wr) {
+    int rounds = (total + nthreads - 1) / nthreads;         // workgroup-uniform
+    int first = tid;
+    while (rounds > IMG_U) {
+        img_rounds<IMG_U, CH, false>(first, nthreads, total, ld, wr);
+        first += IMG_U * nthreads; rounds -= IMG_U;
+    }
+    switch (rounds) {
+        case 5: img_rounds<5, CH, true>(first, nthreads, total, ld, wr); break;
+        case 4: img_rounds<4, CH, true>(first, nthreads, total, ld, wr); break;
+        case 3: img_rounds<3, CH, true>(first, nthreads, total, ld, wr); break;
+        case 2: img_rounds<2, CH, true>(first, nthreads, total, ld, wr); break;
+        case 1: img_rounds<1, CH, true>(first, nthreads, total, ld, wr); break;
+        default: break;
+    }
+}
+
 // =====================================================================================
 //                      simple kernels (fp32 math; T = storage dtype)
 // =====================================================================================
@@ -488,8 +530,30 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const bool q_live = qi < L;
     const int nthreads = blockDim.x;
 
-    {   // image load in batches: every request of a thread in flight before its first LDS write (attn_bwd_q_kernel)
-        constexpr int CH = DP / 8;
+    const unsigned row_bytes = 3u * (unsigned)H * D * 2u;                                 // one token of the packed QKV buffer
+    const char* k_src = (const char*)(qkv + qkv_off(b, 0, 1, h, L, H, D));              // workgroup-uniform bases
+    const char* v_src = (const char*)(qkv + qkv_off(b, 0, 2, h, L, H, D));
+    if (DP == D) {
+        constexpr int CH = D / 8;
+        // the zero rows [L, Lp) first (nobody else writes them), then the L live rows without a per-item row test
+        for (int idx = threadIdx.x; idx < (Lp - L) * CH; idx += nthreads) {
+            const int j = L + idx / CH, c = idx % CH;
+            *(uint4*)(k_lds + j * KROW + c * 16) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(v_lds + j * VROW + c * 16) = make_uint4(0, 0, 0, 0);
+        }
+        img_load<CH>(threadIdx.x, nthreads, L * CH,
+                     [&](int j, int c) -> ImgPair {
+                         const unsigned off = (unsigned)j * row_bytes + (unsigned)c * 16u;
+                         if (nt_loads) return ImgPair{__builtin_nontemporal_load((const img_u32x4*)(k_src + off)),
+                                                      __builtin_nontemporal_load((const img_u32x4*)(v_src + off))};
+                         return ImgPair{*(const img_u32x4*)(k_src + off), *(const img_u32x4*)(v_src + off)};
+                     },
+                     [&](int j, int c, img_u32x4 a, img_u32x4 bb) {
+                         *(img_u32x4*)(k_lds + j * KROW + c * 16) = a;
+                         *(img_u32x4*)(v_lds + j * VROW + c * 16) = bb;
+                     });
+    } else {
+        constexpr int CH = DP / 8;              // d = 48: V rows carry zero pad columns
         const int total = Lp * CH;
         for (int base = threadIdx.x; base < total; base += IMG_U * nthreads) {
             uint4 kv[IMG_U], vv[IMG_U];
@@ -519,7 +583,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (q_live) {
-            const uint4 qq = ld16(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + hh * 8);
+            const uint4 qq = ld16((const HT*)(k_src - (size_t)H * D * 2 + ((unsigned)qi * row_bytes + (unsigned)(ks * 32 + hh * 16))));
             qf[ks] = *(const typename H16<HT>::x8*)&qq;
         } else {
 #pragma unroll
@@ -1190,18 +1254,26 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     typename H16<HT>::x8 q_nx[KS], do_nx[KS], o_nx[KS];
     float lse_nx = 1e30f;
     bool mask_nx = false;
+    // workgroup-uniform base pointers + 32-bit byte offsets: the loads take the scalar-base form
+    const unsigned row_bytes = 3u * (unsigned)H * D * 2u, orow_bytes = (unsigned)H * D * 2u;
+    const char* q_src = (const char*)(qkv + qkv_off(b, 0, 0, h, L, H, D));
+    const char* k_src = q_src + orow_bytes;
+    const char* v_src = k_src + orow_bytes;
+    const char* do_src = (const char*)(dout + (size_t)b * L * H * D + (size_t)h * D);
+    const char* o_src = (const char*)(out + (size_t)b * L * H * D + (size_t)h * D);
+    const float* lse_src = lse + ((size_t)b * H + h) * L;
     auto fetch_block = [&](int bk) {
         const int qn = bk * 32 + r;
         lse_nx = 1e30f; mask_nx = false;
         if (bk < nblk && qn < L) {
-            const size_t oo = ((size_t)b * L + qn) * (size_t)H * D + (size_t)h * D;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                q_nx[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, qn, 0, h, L, H, D) + ks * 16 + hh * 8);
-                do_nx[ks] = *(const typename H16<HT>::x8*)(dout + oo + ks * 16 + hh * 8);
-                o_nx[ks] = *(const typename H16<HT>::x8*)(out + oo + ks * 16 + hh * 8);
+                const unsigned in_row = (unsigned)(ks * 32 + hh * 16);
+                q_nx[ks] = *(const typename H16<HT>::x8*)(q_src + ((unsigned)qn * row_bytes + in_row));
+                do_nx[ks] = *(const typename H16<HT>::x8*)(do_src + ((unsigned)qn * orow_bytes + in_row));
+                o_nx[ks] = *(const typename H16<HT>::x8*)(o_src + ((unsigned)qn * orow_bytes + in_row));
             }
-            lse_nx = lse[((size_t)b * H + h) * L + qn];
+            lse_nx = lse_src[qn];
             mask_nx = mask_mode == BF_MASK_QUERY_ROW && row_mask[(size_t)b * L + qn] == 0;
         } else {
 #pragma unroll
@@ -1213,10 +1285,24 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     const int blk_first = blockIdx.y * wpb + slot;
     fetch_block(blk_first);
 
-    // The image load in BATCHES of IMG_U requests per thread, all issued before the first LDS write: as a plain loop
-    // (load, wait, write, next) its 4.5 rounds at 275 x 32 were 4.5 dependent trips to memory -- 8 of the 28 us a
-    // workgroup lives (tools/attn_probe.py), during which it holds its LDS and computes nothing.
-    {
+    // image load (img_load: every request in flight before the first LDS write, scalar bases)
+    if (DP == D) {
+        constexpr int CH = D / 8;
+        for (int idx = threadIdx.x; idx < (Lp - L) * CH; idx += nthreads) {       // zero rows [L, Lp)
+            const int j = L + idx / CH, c = idx % CH;
+            *(uint4*)(k_lds + RI::at(j, c, KROW)) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(v_lds + RI::at(j, c, VROW)) = make_uint4(0, 0, 0, 0);
+        }
+        img_load<CH>(threadIdx.x, nthreads, L * CH,
+                     [&](int j, int c) -> ImgPair {
+                         const unsigned off = (unsigned)j * row_bytes + (unsigned)c * 16u;
+                         return ImgPair{*(const img_u32x4*)(k_src + off), *(const img_u32x4*)(v_src + off)};
+                     },
+                     [&](int j, int c, img_u32x4 a, img_u32x4 bb) {
+                         *(img_u32x4*)(k_lds + RI::at(j, c, KROW)) = a;
+                         *(img_u32x4*)(v_lds + RI::at(j, c, VROW)) = bb;
+                     });
+    } else {
         constexpr int CH = DP / 8;
         const int total = Lp * CH;
         for (int base = threadIdx.x; base < total; base += IMG_U * nthreads) {
@@ -1227,8 +1313,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
                 const int j = idx / CH, c = idx - j * CH;
                 kv[u] = make_uint4(0, 0, 0, 0); vv[u] = make_uint4(0, 0, 0, 0);
                 if (idx < total && j < L && c < D / 8) {
-                    kv[u] = *(const uint4*)(qkv + qkv_off(b, j, 1, h, L, H, D) + c * 8);
-                    vv[u] = *(const uint4*)(qkv + qkv_off(b, j, 2, h, L, H, D) + c * 8);
+                    kv[u] = *(const uint4*)(k_src + ((unsigned)j * row_bytes + (unsigned)c * 16u));
+                    vv[u] = *(const uint4*)(v_src + ((unsigned)j * row_bytes + (unsigned)c * 16u));
                 }
             }
 #pragma unroll
@@ -1268,7 +1354,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     delta += __shfl_xor(delta, 32, 64);          // the two half-waves hold the two halves of a row
     const float lse_q = lse_nx;
     const bool row_masked = mask_nx;
-    if (q_live && hh == 0) delta_ws[((size_t)b * H + h) * L + qi] = delta;
+    if (q_live && hh == 0) (delta_ws + ((size_t)b * H + h) * L)[qi] = delta;
     fetch_block(blk + blk_stride);                // the next block's operands travel under this block's key loop
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
@@ -1409,14 +1495,20 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
     const float sl2 = scale * 1.44269504088896340736f;
 
     constexpr bool PF = (WPE != 4);     // the 128-register build has no room for the 16 registers of a block in flight
+    const unsigned row_bytes = 3u * (unsigned)H * D * 2u, orow_bytes = (unsigned)H * D * 2u;
+    const char* q_src = (const char*)(qkv + qkv_off(b, 0, 0, h, L, H, D));       // workgroup-uniform bases
+    const char* k_src = q_src + orow_bytes;
+    const char* v_src = k_src + orow_bytes;
+    const char* do_src = (const char*)(dout + (size_t)b * L * H * D + (size_t)h * D);
     typename H16<HT>::x8 k_nx[KS], v_nx[KS];
     auto fetch_keys = [&](int wn) {
         const int kn = wn * 32 + r;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (wn < nw && kn < L) {
-                k_nx[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, kn, 1, h, L, H, D) + ks * 16 + hh * 8);
-                v_nx[ks] = *(const typename H16<HT>::x8*)(qkv + qkv_off(b, kn, 2, h, L, H, D) + ks * 16 + hh * 8);
+                const unsigned off = (unsigned)kn * row_bytes + (unsigned)(ks * 32 + hh * 16);
+                k_nx[ks] = *(const typename H16<HT>::x8*)(k_src + off);
+                v_nx[ks] = *(const typename H16<HT>::x8*)(v_src + off);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { k_nx[ks][e] = (HT)0.f; v_nx[ks][e] = (HT)0.f; }
@@ -1425,32 +1517,24 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
     };
     const int w_first = blockIdx.y * wpb + slot;
     fetch_keys(w_first);
-    {   // image load in batches (see attn_bwd_q_kernel)
+    {   // image load (img_load: every request in flight before the first LDS write, scalar bases)
         constexpr int CH = D / 8;
-        const int total = Lp * CH;
-        for (int base = threadIdx.x; base < total; base += IMG_U * nthreads) {
-            uint4 qv[IMG_U], dv[IMG_U];
-#pragma unroll
-            for (int u = 0; u < IMG_U; ++u) {
-                const int idx = base + u * nthreads;
-                const int i = idx / CH, c = idx - i * CH;
-                qv[u] = make_uint4(0, 0, 0, 0); dv[u] = make_uint4(0, 0, 0, 0);
-                if (idx < total && i < L) {
-                    qv[u] = *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + c * 8);
-                    dv[u] = *(const uint4*)(dout + ((size_t)b * L + i) * (size_t)H * D + (size_t)h * D + c * 8);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < IMG_U; ++u) {
-                const int idx = base + u * nthreads;
-                const int i = idx / CH, c = idx - i * CH;
-                if (idx < total) {
-                    char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
-                    *(uint4*)dst = qv[u];
-                    *(uint4*)(dst + DO_OFF) = dv[u];
-                }
-            }
+        for (int idx = threadIdx.x; idx < (Lp - L) * CH; idx += nthreads) {       // zero rows [L, Lp)
+            const int i = L + idx / CH, c = idx % CH;
+            char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
+            *(uint4*)dst = make_uint4(0, 0, 0, 0);
+            *(uint4*)(dst + DO_OFF) = make_uint4(0, 0, 0, 0);
         }
+        img_load<CH>(threadIdx.x, nthreads, L * CH,
+                     [&](int i, int c) -> ImgPair {
+                         return ImgPair{*(const img_u32x4*)(q_src + ((unsigned)i * row_bytes + (unsigned)c * 16u)),
+                                        *(const img_u32x4*)(do_src + ((unsigned)i * orow_bytes + (unsigned)c * 16u))};
+                     },
+                     [&](int i, int c, img_u32x4 a, img_u32x4 bb) {
+                         char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
+                         *(img_u32x4*)dst = a;
+                         *(img_u32x4*)(dst + DO_OFF) = bb;
+                     });
     }
     for (int i = threadIdx.x; i < Lp; i += nthreads) {
         float dl = 0.f, ls = 1e30f;
@@ -2179,8 +2263,9 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         const int nq32 = bf_cdiv(seq, 32), lp = nq32 * 32;
         const int dp = (head_dim + 31) / 32 * 32;
         const int pad = head_dim == 32 ? 0 : 16, row = head_dim * 2 + pad;          // ResImg<D>: d = 32 rows are unpadded
-        const size_t lds_q = (size_t)lp * ((dp * 2 + pad) + row);
-        const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4;
+        const size_t lds_pad = (size_t)bf_tuning().attn_lds_pad;      // occupancy experiments only
+        const size_t lds_q = (size_t)lp * ((dp * 2 + pad) + row) + lds_pad;
+        const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4 + lds_pad;
         const int split_env = bf_tuning().attn_bwd_single ? 0 : 1;
         // (short causal sequences stay on the single kernel: 72 vs 116 us at L = 77)
         const int res_wide_env = bf_tuning().attn_bwd_resident_wide;   // which head widths take the resident pair: 1: also d = 64; -1: d = 32 only
