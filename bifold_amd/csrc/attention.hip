@@ -1227,10 +1227,15 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     constexpr int KROW = RI::ROW_DP;          // K rows hold DP columns (zero beyond D) for the transposed reads
     constexpr int VROW = RI::ROW_D;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // K and V images interleaved by 32-row block (K block i, V block i, K block i + 1, ...): V sits a compile-time
+    // 32 * KROW bytes behind K, and a block starts at a multiple of 32 rows, which the swizzle does not see -- the
+    // key loop's addresses are one scalar block base plus lane constants (they were 12 vector instructions per block)
+    constexpr int BLK = 32 * (KROW + VROW), V_OFF = 32 * KROW;
     char* k_lds = smem;
-    char* v_lds = smem + (size_t)Lp * KROW;
+    auto k_at = [&](int j, int c) -> char* { return k_lds + (j >> 5) * BLK + RI::at(j & 31, c, KROW); };
+    auto v_at = [&](int j, int c) -> char* { return k_lds + (j >> 5) * BLK + V_OFF + RI::at(j & 31, c, VROW); };
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
@@ -1284,14 +1289,23 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     };
     const int blk_first = blockIdx.y * wpb + slot;
     fetch_block(blk_first);
+    int ka_off[KS], va_off[KS], kt_off[DB][2];         // lane constants of the key loop's LDS addresses
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { ka_off[ks] = RI::at(r, ks * 2 + hh, KROW); va_off[ks] = RI::at(r, ks * 2 + hh, VROW); }
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+        kt_off[db][0] = RI::at(4 * hh + q4, cb >> 4, KROW, cb & 15);
+        kt_off[db][1] = RI::at(4 * hh + q4 + 8, cb >> 4, KROW, cb & 15);
+    }
 
     // image load (img_load: every request in flight before the first LDS write, scalar bases)
     if (DP == D) {
         constexpr int CH = D / 8;
         for (int idx = threadIdx.x; idx < (Lp - L) * CH; idx += nthreads) {       // zero rows [L, Lp)
             const int j = L + idx / CH, c = idx % CH;
-            *(uint4*)(k_lds + RI::at(j, c, KROW)) = make_uint4(0, 0, 0, 0);
-            *(uint4*)(v_lds + RI::at(j, c, VROW)) = make_uint4(0, 0, 0, 0);
+            *(uint4*)k_at(j, c) = make_uint4(0, 0, 0, 0);
+            *(uint4*)v_at(j, c) = make_uint4(0, 0, 0, 0);
         }
         img_load<CH>(threadIdx.x, nthreads, L * CH,
                      [&](int j, int c) -> ImgPair {
@@ -1299,8 +1313,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
                          return ImgPair{*(const img_u32x4*)(k_src + off), *(const img_u32x4*)(v_src + off)};
                      },
                      [&](int j, int c, img_u32x4 a, img_u32x4 bb) {
-                         *(img_u32x4*)(k_lds + RI::at(j, c, KROW)) = a;
-                         *(img_u32x4*)(v_lds + RI::at(j, c, VROW)) = bb;
+                         *(img_u32x4*)k_at(j, c) = a;
+                         *(img_u32x4*)v_at(j, c) = bb;
                      });
     } else {
         constexpr int CH = DP / 8;
@@ -1322,8 +1336,8 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
                 const int idx = base + u * nthreads;
                 const int j = idx / CH, c = idx - j * CH;
                 if (idx < total) {
-                    *(uint4*)(k_lds + RI::at(j, c, KROW)) = kv[u];
-                    if (c < D / 8) *(uint4*)(v_lds + RI::at(j, c, VROW)) = vv[u];
+                    *(uint4*)k_at(j, c) = kv[u];
+                    if (c < D / 8) *(uint4*)v_at(j, c) = vv[u];
                 }
             }
         }
@@ -1372,13 +1386,14 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #endif
 
     for (int j0 = 0; j0 < key_end; j0 += 32) {
+        const char* kblk = k_lds + (j0 >> 5) * BLK;
         f32x16 sacc, pacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + RI::at(j0 + r, ks * 2 + hh, KROW));
-            const typename H16<HT>::x8 vf = *(const typename H16<HT>::x8*)(v_lds + RI::at(j0 + r, ks * 2 + hh, VROW));
+            const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(kblk + ka_off[ks]);
+            const typename H16<HT>::x8 vf = *(const typename H16<HT>::x8*)(kblk + V_OFF + (KROW == VROW ? ka_off[ks] : va_off[ks]));
             sacc = mfma_32x32x16(kf, qf[ks], sacc);
             pacc = mfma_32x32x16(vf, dof[ks], pacc);
         }
@@ -1411,12 +1426,9 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
             typename H16<HT>::x8 pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[8 * s + e];
-            const int row0 = j0 + 16 * s + 4 * hh + q4;
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                const typename H16<HT>::x8 kt = tr_pair<HT>(k_lds + RI::at(row0, cb >> 4, KROW, cb & 15),
-                                                            k_lds + RI::at(row0 + 8, cb >> 4, KROW, cb & 15));
+                const typename H16<HT>::x8 kt = tr_pair<HT>(kblk + kt_off[db][0] + s * 16 * KROW, kblk + kt_off[db][1] + s * 16 * KROW);
                 dqacc[db] = mfma_32x32x16(kt, pf, dqacc[db]);
             }
         }
