@@ -10,11 +10,15 @@
 //    query (or key) row with K/V (or Q/dO) tiles broadcast from LDS.  These are the exact
 //    (parity) mode, and the first-correct backward for the bf16 mode.
 #include "common.h"
+#include <type_traits>
 #include "tuning.h"
 
 #include <stdlib.h>
 
 #define KT 64                                 // keys per LDS tile
+#ifndef ATTN_Q_PAIRS
+#define ATTN_Q_PAIRS false                    // attn_bwd_q_kernel: two key blocks in flight per wave (measured neutral: 363 vs 365 us the pair, step equal)
+#endif
 #define IMG_U 5                               // resident kernels: image-load requests a thread keeps in flight (x2 operands)
 
 // Workgroup -> (batch, head).  Consecutive workgroup ids go to consecutive XCDs (8 private L2s).  With
@@ -1214,7 +1218,7 @@ extern "C" int bf_debug_attn_probe(unsigned long long* out) {
 #define ATTN_STAMP(slot) do {} while (0)
 #endif
 
-template <int D, int MASK, typename HT>
+template <int D, int MASK, typename HT, bool PAIRS = ATTN_Q_PAIRS>
 __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
@@ -1385,9 +1389,11 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
     const unsigned long long probe_t1 = wall_clock64();
 #endif
 
-    for (int j0 = 0; j0 < key_end; j0 += 32) {
+    // One key block in three pieces, so that TWO blocks can be in flight per wave: the S / dP products of the second
+    // run on the matrix pipe while the vector pipe turns the first into dS (with 3 waves per SIMD a wave that works
+    // through one dependent chain at a time left the SIMD idle 44 % of the kernel: SQ_ACTIVE_INST_ANY, tools/attn_pmc.sh)
+    auto scores = [&](int j0, f32x16& sacc, f32x16& pacc) {
         const char* kblk = k_lds + (j0 >> 5) * BLK;
-        f32x16 sacc, pacc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { sacc[e] = s_init; pacc[e] = -delta; }
 #pragma unroll
@@ -1397,11 +1403,13 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
             sacc = mfma_32x32x16(kf, qf[ks], sacc);
             pacc = mfma_32x32x16(vf, dof[ks], pacc);
         }
-        // dS^T (rows = keys, lane = query); masked scores carry no gradient
-        const bool edge = (j0 + 32 > L) || (mask_mode == BF_MASK_CAUSAL && j0 + 31 > q0);
-        const f32x2 sl2v = {sl2, sl2};       // (the factor `scale` of dS is applied ONCE, to dQ at the end: 8 packed multiplies less per block)
-        // (the edge test is wave-uniform: inside the element loop it became a scalar branch per PAIR of scores, eight per
-        // block, and fenced the exponentials of one pair off from the next; one branch per block, straight-line bodies)
+    };
+    // dS^T (rows = keys, lane = query); masked scores carry no gradient.  (The factor `scale` of dS is applied ONCE, to
+    // dQ at the end.  The edge test is wave-uniform and per block: inside the element loop it was a scalar branch per
+    // pair of scores.)
+    auto to_ds = [&](int j0, f32x16& sacc, const f32x16& pacc, auto edge_c) {
+        constexpr bool EDGE = decltype(edge_c)::value;
+        const f32x2 sl2v = {sl2, sl2};
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {                   // packed fp32: two scores per VALU instruction
             const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
@@ -1410,7 +1418,7 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
             sacc[e] = ds2[0];
             sacc[e + 1] = ds2[1];
         }
-        if (edge) {
+        if (EDGE) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
@@ -1421,6 +1429,9 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
         }
+    };
+    auto add_dq = [&](int j0, const f32x16& sacc) {
+        const char* kblk = k_lds + (j0 >> 5) * BLK;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             typename H16<HT>::x8 pf;
@@ -1432,6 +1443,27 @@ __global__ __launch_bounds__(512) void attn_bwd_q_kernel(
                 dqacc[db] = mfma_32x32x16(kt, pf, dqacc[db]);
             }
         }
+    };
+    // blocks [0, clean_end) need no edge handling: whole inside the sequence and (causal) strictly below the diagonal
+    const int clean_end = (mask_mode == BF_MASK_CAUSAL) ? min(L & ~31, q0) : (L & ~31);
+    int j0 = 0;
+    if (PAIRS && D == 32) {              // (wider heads: 64 more registers would cost a wave per SIMD)
+        for (; j0 + 64 <= clean_end; j0 += 64) {
+            f32x16 sa, pa, sb, pb;
+            scores(j0, sa, pa);
+            scores(j0 + 32, sb, pb);
+            to_ds(j0, sa, pa, std::false_type{});
+            add_dq(j0, sa);
+            to_ds(j0 + 32, sb, pb, std::false_type{});
+            add_dq(j0 + 32, sb);
+        }
+    }
+    for (; j0 < key_end; j0 += 32) {
+        f32x16 sacc, pacc;
+        scores(j0, sacc, pacc);
+        if (j0 + 32 <= clean_end) to_ds(j0, sacc, pacc, std::false_type{});
+        else to_ds(j0, sacc, pacc, std::true_type{});
+        add_dq(j0, sacc);
     }
 
 #ifdef ATTN_PROBE
