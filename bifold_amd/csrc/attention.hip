@@ -1703,6 +1703,317 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
 }
 
 // =====================================================================================
+//   d = 32, unmasked, <= 288 tokens: the backward in ONE pass (S, dP and the exponentials once)
+// =====================================================================================
+// The split pair above computes S, dP and P twice (14 MFMAs and 2 x 16 exponentials per 32 x 32 block) and loads two
+// operand images per (batch, head).  On this SIMD the matrix and the vector work of a kernel ADD (tools/micro/valu_rate.hip:
+// a key step of 6 MFMAs and 56 vector instructions takes the sum of the two at 1, 2, 3 and 4 waves per SIMD alike), so the
+// lever is the instruction count: one pass is 10 MFMAs and 16 exponentials per block.  What the pair avoided is the
+// reduction of dQ over key blocks that live in different waves; here it is small and deterministic:
+//   * one workgroup of THREE waves per (batch, head); wave w owns key blocks w, w + 3, w + 6 (275 tokens = 9 blocks:
+//     balanced) with their K / V fragments and dK^T / dV^T accumulators in registers for the whole kernel;
+//   * the three waves walk the query blocks TOGETHER.  Per query block a wave goes through its key blocks (key on the
+//     lane: S / dP with the row constants as initial accumulators, P and dS are the B operands of dV^T += dO^T P and
+//     dK^T += Q^T dS) and adds dS K of each into ONE partial dQ of the block (dS crosses LDS once, transposed, through a
+//     per-wave 2-KB image; K rows from a swizzled image);
+//   * the three partial dQ blocks (fp32, 4 KB each) meet in LDS; the wave whose turn it is (block mod 3) sums them in wave
+//     order, scales, converts and stores whole 64-byte row segments.  Two workgroup barriers per query block, each a
+//     whole block of work away from the accesses it orders.
+// LDS: Q / dO blocks interleaved 36.9 KB + K image 18.4 KB + dS images 6 KB + partials 12 KB + row constants 2.3 KB =
+// 76 KB: two workgroups per CU.  Registers: 96 accumulators + 48 fragments + the block's working set.
+struct Fused32 {
+    static constexpr int ROW = 64, BLK = 2 * 32 * ROW, DO_OFF = 32 * ROW;
+    static size_t lds_bytes(int nw) {
+        const size_t lp = (size_t)nw * 32;
+        return lp * 2 * ROW + lp * ROW + 2 * lp * 4 + 3 * 2048 + 3 * 4096;
+    }
+};
+template <typename HT>
+__global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
+    const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout, const float* __restrict__ lse,
+    HT* __restrict__ dqkv, int L, int H, float scale) {
+    constexpr int D = 32, KS = 2, ROW = Fused32::ROW, BLK = Fused32::BLK, DO_OFF = Fused32::DO_OFF, NKB = 3;
+    using RI = ResImg<32>;
+    using X8 = typename H16<HT>::x8;
+    using X4 = typename H16<HT>::x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nw = (L + 31) >> 5, Lp = nw * 32;
+    char* q_lds = smem;                                    // Q block i, dO block i, Q block i + 1, ...
+    char* k_img = q_lds + (size_t)Lp * 2 * ROW;            // K rows, swizzled (B operand of dQ)
+    float* lse_s = (float*)(k_img + (size_t)Lp * ROW);     // -lse / scale
+    float* del_s = lse_s + Lp;                             // -delta
+    char* ds_img = (char*)(del_s + Lp);                    // per wave: dS^T [key][query], 64-byte rows, 8-byte chunks swizzled
+    float* dq_x = (float*)(ds_img + 3 * 2048);             // per wave: partial dQ [query][d] fp32
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
+    const int nthreads = blockDim.x;
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+
+    const unsigned row_bytes = 3u * (unsigned)H * D * 2u, orow_bytes = (unsigned)H * D * 2u;
+    const char* q_src = (const char*)(qkv + qkv_off(b, 0, 0, h, L, H, D));       // workgroup-uniform bases
+    const char* k_src = q_src + orow_bytes;
+    const char* v_src = k_src + orow_bytes;
+    const char* do_src = (const char*)(dout + (size_t)b * L * H * D + (size_t)h * D);
+    const char* o_src = (const char*)(out + (size_t)b * L * H * D + (size_t)h * D);
+    const float* lse_src = lse + ((size_t)b * H + h) * L;
+
+    // ---- everything that comes from memory, requested at once ------------------------------------------------------
+    X8 vf[NKB][KS];                 // (the K fragments come from the K image: 24 registers the block loop has no room for)
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) {
+        const int key = (w + 3 * i) * 32 + r;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (key < L) {
+                const unsigned off = (unsigned)key * row_bytes + (unsigned)(ks * 32 + hh * 16);
+                vf[i][ks] = *(const X8*)(v_src + off);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vf[i][ks][e] = (HT)0.f;
+            }
+        }
+    }
+    // lse of rows t and t + 192 (a register each until the images are written)
+    float lse_r[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = (int)threadIdx.x + u * 192;
+        lse_r[u] = i < L ? lse_src[i] : 1e30f;
+    }
+    {
+        constexpr int CH = D / 8, U = 6;                  // 275 rows x 4 chunks over 192 threads = 5.7 rounds: ONE batch
+        for (int idx = threadIdx.x; idx < (Lp - L) * CH; idx += nthreads) {       // zero rows [L, Lp)
+            const int i = L + idx / CH, c = idx % CH;
+            char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
+            *(uint4*)dst = make_uint4(0, 0, 0, 0);
+            *(uint4*)(dst + DO_OFF) = make_uint4(0, 0, 0, 0);
+            *(uint4*)(k_img + RI::at(i, c, ROW)) = make_uint4(0, 0, 0, 0);
+        }
+        // item = (row, 16-byte chunk): Q, dO, K chunks into their images, and the O chunk for delta = rowsum(dO * O) -- the
+        // four chunks of a row sit in four neighbouring lanes, summed by two lane exchanges
+        const int total = L * CH;
+        for (int base = threadIdx.x; base < total; base += U * nthreads) {
+            img_u32x4 vq[U], vd[U], vk[U], vo[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * nthreads;
+                const int i = idx / CH, c = idx % CH;
+                vq[u] = (img_u32x4){0u, 0u, 0u, 0u}; vd[u] = vq[u]; vk[u] = vq[u]; vo[u] = vq[u];
+                if (idx < total) {
+                    const unsigned off = (unsigned)i * row_bytes + (unsigned)c * 16u, ooff = (unsigned)i * orow_bytes + (unsigned)c * 16u;
+                    vq[u] = *(const img_u32x4*)(q_src + off);
+                    vk[u] = *(const img_u32x4*)(k_src + off);
+                    vd[u] = *(const img_u32x4*)(do_src + ooff);
+                    vo[u] = *(const img_u32x4*)(o_src + ooff);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * nthreads;
+                const int i = idx / CH, c = idx % CH;
+                const X8 gv = *(const X8*)&vd[u], ov = *(const X8*)&vo[u];
+                float dl = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
+                dl += __shfl_xor(dl, 1, 64);
+                dl += __shfl_xor(dl, 2, 64);
+                if (idx < total) {
+                    char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
+                    *(img_u32x4*)dst = vq[u];
+                    *(img_u32x4*)(dst + DO_OFF) = vd[u];
+                    *(img_u32x4*)(k_img + RI::at(i, c, ROW)) = vk[u];
+                    if (c == 0) del_s[i] = -dl;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = (int)threadIdx.x + u * 192;
+        if (i < Lp) {
+            lse_s[i] = -lse_r[u] * inv_scale;
+            if (i >= L) del_s[i] = 0.f;
+        }
+    }
+    // ---- lane constants ------------------------------------------------------------------------------------------------
+    int a_off[KS], t_off[2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_off[ks] = RI::at(r, ks * 2 + hh, ROW);
+    {
+        const int cb = (16 * (g16 & 1) + 4 * p4) * 2;
+        t_off[0] = RI::at(4 * hh + q4, cb >> 4, ROW, cb & 15);
+        t_off[1] = RI::at(4 * hh + q4 + 8, cb >> 4, ROW, cb & 15);
+    }
+    char* my_img = ds_img + w * 2048;
+    // dS^T image: row = key (64 bytes = 32 queries), 8-byte chunk c of row k at chunk c ^ ((k >> 1) & 7): the 16 lanes a
+    // ds_write_b64 group serves (16 consecutive keys) then fall on distinct bank pairs
+    int dsw_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dsw_off[g] = r * 64 + (((2 * g + hh) ^ ((r >> 1) & 7)) << 3);
+    int dsr_off[2][2], kb_off[2];       // A operand of dQ: the image read transposed; B operand: K rows read transposed
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int krow = 16 * s2 + 8 * hh + q4 + 4 * u;
+            dsr_off[s2][u] = krow * 64 + (((4 * (g16 & 1) + p4) ^ ((krow >> 1) & 7)) << 3);
+        }
+    {
+        const int cd = (16 * (g16 & 1) + 4 * p4) * 2;
+        kb_off[0] = RI::at(8 * hh + q4, cd >> 4, ROW, cd & 15);
+        kb_off[1] = RI::at(8 * hh + q4 + 4, cd >> 4, ROW, cd & 15);
+    }
+    f32x16 dkacc[NKB], dvacc[NKB];
+#pragma unroll
+    for (int i = 0; i < NKB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[i][e] = 0.f; dvacc[i][e] = 0.f; }
+    __syncthreads();
+
+    for (int qb = 0; qb < nw; ++qb) {
+        const char* q_blk = q_lds + qb * BLK;
+        const float* lrow = lse_s + qb * 32 + 4 * hh;
+        const float* drow = del_s + qb * 32 + 4 * hh;
+        f32x16 dq;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NKB; ++i) {
+            const int kb = w + 3 * i;
+            if (kb < nw) {
+                f32x16 sacc, pacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 l4 = *(const float4*)(lrow + 8 * g);
+                    const float4 d4 = *(const float4*)(drow + 8 * g);
+                    sacc[4 * g + 0] = l4.x; sacc[4 * g + 1] = l4.y; sacc[4 * g + 2] = l4.z; sacc[4 * g + 3] = l4.w;
+                    pacc[4 * g + 0] = d4.x; pacc[4 * g + 1] = d4.y; pacc[4 * g + 2] = d4.z; pacc[4 * g + 3] = d4.w;
+                }
+                const char* krows = k_img + kb * 32 * ROW;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const char* pa = q_blk + a_off[ks];
+                    const X8 qa = *(const X8*)pa;
+                    const X8 da = *(const X8*)(pa + DO_OFF);
+                    const X8 kfr = *(const X8*)(krows + a_off[ks]);
+                    sacc = mfma_32x32x16(qa, kfr, sacc);
+                    pacc = mfma_32x32x16(da, vf[i][ks], pacc);
+                }
+                const f32x2 sl2v = {sl2, sl2};
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    const f32x2 ds2 = p2 * (f32x2){pacc[e], pacc[e + 1]};
+                    sacc[e] = p2[0]; sacc[e + 1] = p2[1];
+                    pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
+                }
+                // a key beyond L has zero K / V rows but exp(-lse) != 0: its dS column would reach dQ (dK / dV of
+                // that lane are never stored).  Only the last key block can hold such lanes.
+                if (kb * 32 + 32 > L) {
+                    const bool dead = kb * 32 + r >= L;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pacc[e] = dead ? 0.f : pacc[e];
+                }
+                X8 pb[2], dsb[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
+                // dS^T image for dQ (the converted values: 4 consecutive queries of this lane's key per 8-byte store)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    X4 v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = dsb[g >> 1][4 * (g & 1) + e];
+                    *(X4*)(my_img + dsw_off[g]) = v4;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char* t0 = q_blk + t_off[0] + s * 16 * ROW;
+                    const char* t1 = q_blk + t_off[1] + s * 16 * ROW;
+                    const X8 dot = tr_pair<HT>(t0 + DO_OFF, t1 + DO_OFF);
+                    const X8 qtt = tr_pair<HT>(t0, t1);
+                    dvacc[i] = mfma_32x32x16(dot, pb[s], dvacc[i]);
+                    dkacc[i] = mfma_32x32x16(qtt, dsb[s], dkacc[i]);
+                }
+                // dQ_qb += dS K_kb: A = the image read transposed (sum over the key = lane index), B = K rows
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const X8 a = tr_pair<HT>(my_img + dsr_off[s][0], my_img + dsr_off[s][1]);
+                    const X8 kb2 = tr_pair<HT>(krows + kb_off[0] + s * 16 * ROW, krows + kb_off[1] + s * 16 * ROW);
+                    dq = mfma_32x32x16(a, kb2, dq);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the image is rewritten by the next key block
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);    // one key block at a time: interleaved, their working sets do not fit
+            }
+        }
+        // ---- the three partial dQ blocks meet in LDS; wave (qb mod 3) sums and stores ---------------------------------
+        __syncthreads();                              // the previous block's partials have been read
+        {
+            float* mine = dq_x + w * 1024;            // [query 0..31][d 0..31]
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ql = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                mine[ql * 32 + r] = dq[e];
+            }
+        }
+        __syncthreads();
+        if (w == qb % 3) {
+            const int row = lane >> 1, half = lane & 1;
+            const int qi = qb * 32 + row;
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 v0 = *(const float4*)(dq_x + 0 * 1024 + row * 32 + half * 16 + j * 4);
+                const float4 v1 = *(const float4*)(dq_x + 1 * 1024 + row * 32 + half * 16 + j * 4);
+                const float4 v2 = *(const float4*)(dq_x + 2 * 1024 + row * 32 + half * 16 + j * 4);
+                acc[4 * j + 0] = (v0.x + v1.x) + v2.x; acc[4 * j + 1] = (v0.y + v1.y) + v2.y;
+                acc[4 * j + 2] = (v0.z + v1.z) + v2.z; acc[4 * j + 3] = (v0.w + v1.w) + v2.w;
+            }
+            if (qi < L) {
+                HT* dst = dqkv + qkv_off(b, qi, 0, h, L, H, D) + half * 16;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    X8 o8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = (HT)(acc[8 * j + e] * scale);
+                    *(X8*)(dst + 8 * j) = o8;
+                }
+            }
+        }
+    }
+
+    // ---- dK, dV of this wave's key blocks -------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) {
+        const int key = (w + 3 * i) * 32 + r;
+        if (key < L) {
+            HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+            HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 8 * g + 4 * hh;
+                X4 k4, v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { k4[e] = (HT)(dkacc[i][4 * g + e] * scale); v4[e] = (HT)dvacc[i][4 * g + e]; }
+                *(X4*)(dkp + d0) = k4;
+                *(X4*)(dvp + d0) = v4;
+            }
+        }
+    }
+}
+
+// =====================================================================================
 //   The split pair for sequences that do NOT fit LDS (SigLIP towers at 384 px: 576 tokens;
 //   the sequential fusion: 642 - 2 950 tokens): same two kernels, the resident operand streamed
 // =====================================================================================
@@ -2319,6 +2630,26 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         // scratch: 80.8 vs 92.9 us at 262 x 48); d = 64 stays on the streamed pair (300 x 64: 99 vs 134 us resident)
         const bool wide_ok = (head_dim == 32 && !stream_d32_env) || (head_dim == 48 && res_wide_env != -1) || res_wide_env > 0 ||
                              nq32 < stream_min_env;
+        // d = 32 without a mask, 3 - 9 blocks (the 275-token fusion of config A): the one-pass kernel
+        if (half && head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 >= 3 && nq32 <= 9 && bf_tuning().attn_bwd_fused) {
+            const size_t lds_f = Fused32::lds_bytes(nq32) + lds_pad;
+            dim3 grid(batch * heads), block(192);
+#define BWD_FUSED(HT)                                                                                    \
+    do {                                                                                                 \
+        static size_t set_f = 0;                                                                         \
+        if (lds_f > set_f) {                                                                             \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_fused32_kernel<HT>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);           \
+            set_f = lds_f;                                                                               \
+        }                                                                                                \
+        hipLaunchKernelGGL((attn_bwd_fused32_kernel<HT>), grid, block, lds_f, s, (const HT*)qkv,         \
+                           (const HT*)out, (const HT*)dout, lse, (HT*)dqkv, seq, heads, scale);          \
+    } while (0)
+            if (f16) BWD_FUSED(f16_t); else BWD_FUSED(bf16_t);
+#undef BWD_FUSED
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            return BF_OK;
+        }
         if (half && split_env && wide_ok && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
             !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
             // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);

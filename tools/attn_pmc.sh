@@ -13,10 +13,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for f in glob.glob("gpurun_out/attn_pmc/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = "q" if "attn_bwd_q" in k else "kv" if "attn_bwd_kv" in k else "fwd" if "attn_fwd" in k else None
+        k = "fused" if "fused32" in k else "q" if "attn_bwd_q" in k else "kv" if "attn_bwd_kv" in k else "fwd" if "attn_fwd" in k else None
         if k is None: continue
         a = agg[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
-for k in ("fwd", "q", "kv"):
+for k in ("fwd", "q", "kv", "fused"):
     print(k, {c: round(v[1] / v[0]) for c, v in sorted(agg[k].items())})
 PY
 rm -rf $out/p*/

@@ -12,7 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define REP16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
 
-enum { M_MUL, M_PKMUL, M_PKFMA, M_EXP, M_CVT, M_MAX3, M_MFMA, M_MFMA_EXP, M_MFMA_MUL, M_SPLIT, N_MODES };
+enum { M_MUL, M_PKMUL, M_PKFMA, M_EXP, M_CVT, M_MAX3, M_MFMA, M_MFMA_EXP, M_MFMA_MUL, M_SPLIT, M_CHAIN, M_MFMA_MUL_AGPR, M_MFMA_AGPR, N_MODES };
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, int iters) {
@@ -71,6 +71,31 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, float* sink, 
                     for (int v = 0; v < 8; ++v) asm volatile("v_mul_f32 %0, %1, %1" : "=v"(r[(2 * u + v) & 15]) : "v"(a[(2 * u + v) & 15]));
                 }
             }
+        } else if (MODE == M_MFMA_MUL_AGPR || MODE == M_MFMA_AGPR) {   // the same with the accumulators in AGPRs (inline asm)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc1) : "v"(fa), "v"(fb));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc0) : "v"(fa), "v"(fb));
+                if (MODE == M_MFMA_MUL_AGPR) {
+#pragma unroll
+                    for (int v = 0; v < 8; ++v) asm volatile("v_mul_f32 %0, %1, %1" : "=v"(r[(2 * u + v) & 15]) : "v"(a[(2 * u + v) & 15]));
+                }
+            }
+        } else if (MODE == M_CHAIN) {       // the backward key step's shape: 4 MFMAs (two chains of two) -> 16 exp + 16 mul + 8 cvt on
+                                            // their results -> 2 MFMAs fed by the converted values, accumulating across trips
+            f32x16 s0 = {0}, s1 = {0};
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fa, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, s1, 0, 0, 0);
+            f16x8 p0, p1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pe = __builtin_amdgcn_exp2f(s0[e] * 0.125f) * s1[e];
+                if (e < 8) p0[e] = (_Float16)pe; else p1[e - 8] = (_Float16)pe;
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, p0, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, p1, acc0, 0, 0, 0);
         } else if (MODE == M_SPLIT) {       // even waves: 8 MFMAs; odd waves: 16 exp -- do two waves of a SIMD overlap?
             if (((wave >> 2) & 1) == 0) {
 #pragma unroll
@@ -124,6 +149,12 @@ int main() {
         run<M_MFMA_EXP>("8 x (mfma + 2 exp), one wave", waves, out, sink, 8);
         run<M_MFMA_MUL>("8 x (mfma + 8 mul), one wave", waves, out, sink, 8);
     }
+    for (int waves : {4, 8, 16}) {
+        run<M_MFMA_AGPR>("8 x mfma, AGPR accumulators", waves, out, sink, 8);
+        run<M_MFMA_MUL_AGPR>("8 x (mfma + 8 mul), AGPR accumulators", waves, out, sink, 8);
+    }
+    for (int waves : {4, 8, 12, 16})
+        run<M_CHAIN>("key step: 4 mfma > 16 exp+16 mul+8 cvt > 2 mfma", waves, out, sink, 1);
     run<M_SPLIT>("8 mfma | 16 exp on paired waves", 8, out, sink, 1);
     run<M_SPLIT>("8 mfma | 16 exp on paired waves", 16, out, sink, 1);
     return 0;
