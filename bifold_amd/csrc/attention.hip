@@ -1942,18 +1942,14 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
                     dvacc[i] = mfma_32x32x16(dot, pb[s], dvacc[i]);
                     dkacc[i] = mfma_32x32x16(qtt, dsb[s], dkacc[i]);
                 }
-                // dQ_qb += dS K_kb: A = the image read transposed (sum over the key = lane index), B = K rows
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // dQ_qb += dS K_kb: A = the image read transposed (sum over the key = lane index), B = K rows.  (No fence
+                // between the image's stores and these reads: a wave's LDS instructions execute in issue order.)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const X8 a = tr_pair<HT>(my_img + dsr_off[s][0], my_img + dsr_off[s][1]);
                     const X8 kb2 = tr_pair<HT>(krows + kb_off[0] + s * 16 * ROW, krows + kb_off[1] + s * 16 * ROW);
                     dq = mfma_32x32x16(a, kb2, dq);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the image is rewritten by the next key block
-                __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_sched_barrier(0);    // one key block at a time: interleaved, their working sets do not fit
             }
         }
