@@ -744,6 +744,9 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 // (any output type, residual / aux / copies / row remap / split-K slabs), 1 = plain bf16 (alpha, bias,
 // activation, optional pre-activation copy), 2 = bf16 GELU-grad.  One kernel with all three paths sat at
 // the 256-register limit and spilled differently with every edit.
+#ifndef P8_SOFF
+#define P8_SOFF 1                     // persistent GEMM: K advance of K-contiguous operands in the DMA's scalar offset, fragment offsets hoisted (0: round 2's loop)
+#endif
 template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, bool GROUPED = false>
 __device__ __forceinline__ void p8_body(
     const H* __restrict__ A, const H* __restrict__ B, const GemmDims& d, const EpiParams& ep,
@@ -845,22 +848,38 @@ __device__ __forceinline__ void p8_body(
         }
         asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(vb[0]), "+v"(vb[1]));   // live in registers, not rematerialised
     };
+    // (round 3: for a K-CONTIGUOUS operand the K advance goes into the instruction's SCALAR offset -- no vector add per
+    // piece.  The descriptor's range check sees the per-lane offset, which alone says whether the row exists, so rows past
+    // the end of the matrix still read as zeros; a K-STRIDED operand keeps the vector add: its token tail is cut off by
+    // the check on the sum.  With the fragment offsets below this takes the main loop from ~17 to ~5 vector instructions
+    // per wave and stage; on this SIMD they come straight out of the MFMA time.)
     auto issue_a = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
         const unsigned delta = A_KS ? (unsigned)ks * 64u * (unsigned)lda : (unsigned)ks * 64u;
         char* dst = smem + (s & 3) * P8_STAGE + wave * 2048;
 #pragma unroll
-        for (int p = 0; p < P8_ABL_PIECES; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + p * 1024), 16, va[p] + delta, 0, 0, 0);
+        for (int p = 0; p < P8_ABL_PIECES; ++p) {
+            if (A_KS || !P8_SOFF) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + p * 1024), 16, va[p] + delta, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_ptr)(dst + p * 1024), 16, va[p], delta, 0, 0);
+        }
     };
     auto issue_b = [&](const P8Item& w, int s) {
         const int ks = w.rev ? w.nk - 1 - s : s;
         const unsigned delta = B_KS ? (unsigned)ks * 64u * (unsigned)ldb : (unsigned)ks * 64u;
         char* dst = smem + (s & 3) * P8_STAGE + 16384 + wave * 2048;
 #pragma unroll
-        for (int p = 0; p < P8_ABL_PIECES; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + p * 1024), 16, vb[p] + delta, 0, 0, 0);
+        for (int p = 0; p < P8_ABL_PIECES; ++p) {
+            if (B_KS || !P8_SOFF) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + p * 1024), 16, vb[p] + delta, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + p * 1024), 16, vb[p], delta, 0, 0);
+        }
     };
+    // lane-constant byte offsets of this wave's first A / B fragment inside a stage (K-contiguous operands: the other
+    // fragments are 16 rows = 1 024 bytes apart, which the swizzle does not see): a stage's addresses are its scalar
+    // slot base plus these
+    unsigned fa_off = 0, fb_off = 0;
+    if (!A_KS) { const int row = wm * 128 + (lane & 15); fa_off = (unsigned)(row * 64 + (((lane >> 4) ^ kc32_swz(row)) << 4)); }
+    if (!B_KS) { const int row = wn * 64 + (lane & 15); fb_off = (unsigned)(16384 + row * 64 + (((lane >> 4) ^ kc32_swz(row)) << 4)); }
+    asm volatile("" : "+v"(fa_off), "+v"(fb_off));
 
     P8Item w;
     [[maybe_unused]] int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
@@ -937,9 +956,13 @@ __device__ __forceinline__ void p8_body(
             // ---------------- phase a
             typename H16<H>::x8 bfr[4], af[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = bf16_frag32<B_KS, H>(lb, wn * 64 + j * 16, lane);
+            for (int j = 0; j < 4; ++j)
+                bfr[j] = (B_KS || !P8_SOFF) ? bf16_frag32<B_KS, H>(lb, wn * 64 + j * 16, lane)
+                                            : *(const typename H16<H>::x8*)(la + fb_off + j * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = bf16_frag32<A_KS, H>(la, wm * 128 + i * 16, lane);
+            for (int i = 0; i < 4; ++i)
+                af[i] = (A_KS || !P8_SOFF) ? bf16_frag32<A_KS, H>(la, wm * 128 + i * 16, lane)
+                                           : *(const typename H16<H>::x8*)(la + fa_off + i * 1024);
             if (more && !deep) issue_a(w, s + 2);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_setprio(1);
@@ -953,7 +976,9 @@ __device__ __forceinline__ void p8_body(
             // ---------------- phase b
             typename H16<H>::x8 ag[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ag[i] = bf16_frag32<A_KS, H>(la, wm * 128 + 64 + i * 16, lane);
+            for (int i = 0; i < 4; ++i)
+                ag[i] = (A_KS || !P8_SOFF) ? bf16_frag32<A_KS, H>(la, wm * 128 + 64 + i * 16, lane)
+                                           : *(const typename H16<H>::x8*)(la + fa_off + 4096 + i * 1024);
             if (!deep) {
                 if (more) {
                     issue_b(w, s + 2);
