@@ -436,6 +436,29 @@ def test_attention_bwd(ops, gpu, B, Lq, H, D, mode, cdt):
     assert rel_err(dqkv.float(), leaf.grad) < (2e-5 if cdt == torch.float32 else 2e-2)
 
 
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("B,Lq,H", [(2, 65, 2), (3, 96, 4), (2, 100, 2), (5, 197, 3), (2, 257, 2), (37, 275, 16), (2, 288, 4)])
+def test_attention_bwd_one_pass_kernel_over_ragged_lengths(ops, gpu, half, B, Lq, H):
+    """d = 32 without a mask, 3 - 9 key blocks: attn_bwd_fused32_kernel (waves with 1, 2 or 3 key blocks, a last
+    block of 1 - 32 live keys, more workgroups than CU slots) against the fp64 formula -- and against the two-kernel
+    pair's tolerance, since both must hold the same bound."""
+    D = 32
+    g = torch.Generator().manual_seed(Lq * 7 + H)
+    qkv = round_to(torch.randn(B * Lq, 3 * H * D, generator=g) * 1.5, half)
+    dout = round_to(torch.randn(B * Lq, H * D, generator=g), half)
+    leaf = qkv.double().requires_grad_(True)
+    ref_o, _ = ref_attention(leaf, B, Lq, H, D, D ** -0.5, 0, None)
+    ref_o.backward(dout.double())
+    qg = qkv.to(gpu).to(half)
+    out, lse = ops.attention_fwd(qg, B, Lq, H, D, D ** -0.5, 0, None, need_lse=True)
+    dqkv = ops.attention_bwd(qg, out, dout.to(gpu).to(half), lse, B, Lq, H, D, D ** -0.5, 0, None)
+    got, want = dqkv.float().cpu().view(B, Lq, 3, H, D), leaf.grad.float().view(B, Lq, 3, H, D)
+    for which, name in enumerate(("dQ", "dK", "dV")):
+        assert rel_err(got[:, :, which], want[:, :, which]) < 2e-2, name
+    again = ops.attention_bwd(qg, out, dout.to(gpu).to(half), lse, B, Lq, H, D, D ** -0.5, 0, None)
+    assert torch.equal(again, dqkv)                         # partial dQ blocks are summed in wave order: bit-reproducible
+
+
 @pytest.mark.parametrize("B,Lq,H,D,spans", [(2, 600, 2, 48, [(64, 256)]), (1, 1290, 1, 64, [(0, 33), (577, 1154)]),
                                             (2, 700, 1, 32, [(100, 420), (650, 700)])])
 def test_attention_bwd_with_whole_masked_segments(ops, gpu, B, Lq, H, D, spans):
