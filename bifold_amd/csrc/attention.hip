@@ -2450,7 +2450,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         // 32-query wave (the sequences of this model family); otherwise the tiled kernel
         const int lp = bf_cdiv(seq, 64) * 64;
         const int dp = (head_dim + 31) / 32 * 32;
-        const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16));
+        const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16)) + (size_t)bf_tuning().attn_lds_pad;   // (+ occupancy experiments)
         const int fwd_res_env = bf_tuning().attn_fwd_tiled ? 0 : 1;
         // d = 32 without a mask (the fusion transformer of rgb_clip): the persistent, double-buffered kernel
         const size_t pd_lds = (size_t)2 * (nq32 * 32) * 128;
@@ -2479,7 +2479,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             BF_CHECK_LAUNCH("bf_attention_fwd");
             return BF_OK;
         }
-        if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024) {
+        if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024 + (size_t)bf_tuning().attn_lds_pad) {
             dim3 rgrid(batch * heads), rblock(nq32 * 64);
             const int nt_env = bf_tuning().attn_nt;
             const int nt_loads = nt_env & 1;
