@@ -1754,6 +1754,9 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
 
+#ifdef ATTN_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < ATTN_PROBE_WGS) attn_probe[blockIdx.x * 8 + 0] = wall_clock64();
+#endif
     const unsigned row_bytes = 3u * (unsigned)H * D * 2u, orow_bytes = (unsigned)H * D * 2u;
     const char* q_src = (const char*)(qkv + qkv_off(b, 0, 0, h, L, H, D));       // workgroup-uniform bases
     const char* k_src = q_src + orow_bytes;
@@ -1875,7 +1878,15 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
         for (int e = 0; e < 16; ++e) { dkacc[i][e] = 0.f; dvacc[i][e] = 0.f; }
     __syncthreads();
 
+#ifdef ATTN_PROBE
+    unsigned long long pr_compute = 0, pr_barrier = 0, pr_sum = 0;
+    const unsigned pr_wg = blockIdx.x;
+    if (threadIdx.x == 0 && pr_wg < ATTN_PROBE_WGS) attn_probe[pr_wg * 8 + 1] = wall_clock64();
+#endif
     for (int qb = 0; qb < nw; ++qb) {
+#ifdef ATTN_PROBE
+        const unsigned long long pr_t0 = wall_clock64();
+#endif
         const char* q_blk = q_lds + qb * BLK;
         const float* lrow = lse_s + qb * 32 + 4 * hh;
         const float* drow = del_s + qb * 32 + 4 * hh;
@@ -1954,7 +1965,13 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
             }
         }
         // ---- the three partial dQ blocks meet in LDS; wave (qb mod 3) sums and stores ---------------------------------
+#ifdef ATTN_PROBE
+        const unsigned long long pr_t1 = wall_clock64();
+#endif
         __syncthreads();                              // the previous block's partials have been read
+#ifdef ATTN_PROBE
+        const unsigned long long pr_t2 = wall_clock64();
+#endif
         {
             float* mine = dq_x + w * 1024;            // [query 0..31][d 0..31]
 #pragma unroll
@@ -1963,7 +1980,14 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
                 mine[ql * 32 + r] = dq[e];
             }
         }
+#ifdef ATTN_PROBE
+        const unsigned long long pr_t3 = wall_clock64();
+#endif
         __syncthreads();
+#ifdef ATTN_PROBE
+        const unsigned long long pr_t4 = wall_clock64();
+        pr_compute += (pr_t1 - pr_t0) + (pr_t3 - pr_t2); pr_barrier += (pr_t2 - pr_t1) + (pr_t4 - pr_t3);
+#endif
         if (w == qb % 3) {
             const int row = lane >> 1, half = lane & 1;
             const int qi = qb * 32 + row;
@@ -1989,6 +2013,11 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
         }
     }
 
+#ifdef ATTN_PROBE
+    if (threadIdx.x == 0 && pr_wg < ATTN_PROBE_WGS) {
+        attn_probe[pr_wg * 8 + 2] = pr_compute; attn_probe[pr_wg * 8 + 3] = pr_barrier; attn_probe[pr_wg * 8 + 4] = wall_clock64();
+    }
+#endif
     // ---- dK, dV of this wave's key blocks -------------------------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < NKB; ++i) {
