@@ -1710,14 +1710,14 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
 // a key step of 6 MFMAs and 56 vector instructions takes the sum of the two at 1, 2, 3 and 4 waves per SIMD alike), so the
 // lever is the instruction count: one pass is 10 MFMAs and 16 exponentials per block.  What the pair avoided is the
 // reduction of dQ over key blocks that live in different waves; here it is small and deterministic:
-//   * one workgroup of THREE waves per (batch, head); wave w owns key blocks w, w + 3, w + 6 (275 tokens = 9 blocks:
+//   * one workgroup of three KEY waves (+ a helper wave, below) per (batch, head); wave w owns key blocks w, w + 3, w + 6 (275 tokens = 9 blocks:
 //     balanced) with their K / V fragments and dK^T / dV^T accumulators in registers for the whole kernel;
 //   * the three waves walk the query blocks TOGETHER.  Per query block a wave goes through its key blocks (key on the
 //     lane: S / dP with the row constants as initial accumulators, P and dS are the B operands of dV^T += dO^T P and
 //     dK^T += Q^T dS) and adds dS K of each into ONE partial dQ of the block (dS crosses LDS once, transposed, through a
 //     per-wave 2-KB image; K rows from a swizzled image);
-//   * the three partial dQ blocks (fp32, 4 KB each) meet in LDS; the wave whose turn it is (block mod 3) sums them in wave
-//     order, scales, converts and stores whole 64-byte row segments.  Two workgroup barriers per query block, each a
+//   * the three partial dQ blocks (fp32, 4 KB each) meet in LDS; the helper wave sums them in wave order, scales,
+//     converts and stores whole 64-byte row segments while the key waves go on.  Two workgroup barriers per query block, each a
 //     whole block of work away from the accesses it orders.
 // LDS: Q / dO blocks interleaved 36.9 KB + K image 18.4 KB + dS images 6 KB + partials 12 KB + row constants 2.3 KB =
 // 76 KB: two workgroups per CU.  Registers: 96 accumulators + 48 fragments + the block's working set.
@@ -1729,7 +1729,7 @@ struct Fused32 {
     }
 };
 template <typename HT>
-__global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
+__global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
     const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout, const float* __restrict__ lse,
     HT* __restrict__ dqkv, int L, int H, float scale) {
     constexpr int D = 32, KS = 2, ROW = Fused32::ROW, BLK = Fused32::BLK, DO_OFF = Fused32::DO_OFF, NKB = 3;
@@ -1751,6 +1751,10 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
     const int nthreads = blockDim.x;
+    // wave 3 is a HELPER: it owns no keys; it takes part in the loads and then sums and stores the three partial dQ blocks of
+    // every query block while the three key waves are already in the next one (the sum was 10 % of a key wave's time, and
+    // the wave whose turn it was kept the other two at the barrier).  8 waves per CU = the two per SIMD 218 registers allow.
+    const bool helper = w == 3;
     const float inv_scale = 1.0f / scale;
     const float sl2 = scale * 1.44269504088896340736f;
 
@@ -1772,7 +1776,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
         const int key = (w + 3 * i) * 32 + r;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (key < L) {
+            if (key < L && !helper) {
                 const unsigned off = (unsigned)key * row_bytes + (unsigned)(ks * 32 + hh * 16);
                 vf[i][ks] = *(const X8*)(v_src + off);
             } else {
@@ -1781,15 +1785,15 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
             }
         }
     }
-    // lse of rows t and t + 192 (a register each until the images are written)
+    // lse of rows t and t + 256 (a register each until the images are written)
     float lse_r[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int i = (int)threadIdx.x + u * 192;
+        const int i = (int)threadIdx.x + u * 256;
         lse_r[u] = i < L ? lse_src[i] : 1e30f;
     }
     {
-        constexpr int CH = D / 8, U = 6;                  // 275 rows x 4 chunks over 192 threads = 5.7 rounds: ONE batch
+        constexpr int CH = D / 8, U = 5;                  // 275 rows x 4 chunks over 256 threads = 4.3 rounds: ONE batch
         for (int idx = threadIdx.x; idx < (Lp - L) * CH; idx += nthreads) {       // zero rows [L, Lp)
             const int i = L + idx / CH, c = idx % CH;
             char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
@@ -1837,7 +1841,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int i = (int)threadIdx.x + u * 192;
+        const int i = (int)threadIdx.x + u * 256;
         if (i < Lp) {
             lse_s[i] = -lse_r[u] * inv_scale;
             if (i >= L) del_s[i] = 0.f;
@@ -1896,7 +1900,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
 #pragma unroll
         for (int i = 0; i < NKB; ++i) {
             const int kb = w + 3 * i;
-            if (kb < nw) {
+            if (kb < nw && !helper) {
                 f32x16 sacc, pacc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1972,7 +1976,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
 #ifdef ATTN_PROBE
         const unsigned long long pr_t2 = wall_clock64();
 #endif
-        {
+        if (!helper) {
             float* mine = dq_x + w * 1024;            // [query 0..31][d 0..31]
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1988,7 +1992,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
         const unsigned long long pr_t4 = wall_clock64();
         pr_compute += (pr_t1 - pr_t0) + (pr_t3 - pr_t2); pr_barrier += (pr_t2 - pr_t1) + (pr_t4 - pr_t3);
 #endif
-        if (w == qb % 3) {
+        if (helper) {
             const int row = lane >> 1, half = lane & 1;
             const int qi = qb * 32 + row;
             float acc[16];
@@ -2022,7 +2026,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_fused32_kernel(
 #pragma unroll
     for (int i = 0; i < NKB; ++i) {
         const int key = (w + 3 * i) * 32 + r;
-        if (key < L) {
+        if (key < L && !helper) {
             HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
             HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
 #pragma unroll
@@ -2658,7 +2662,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         // d = 32 without a mask, 3 - 9 blocks (the 275-token fusion of config A): the one-pass kernel
         if (half && head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 >= 3 && nq32 <= 9 && bf_tuning().attn_bwd_fused) {
             const size_t lds_f = Fused32::lds_bytes(nq32) + lds_pad;
-            dim3 grid(batch * heads), block(192);
+            dim3 grid(batch * heads), block(256);
 #define BWD_FUSED(HT)                                                                                    \
     do {                                                                                                 \
         static size_t set_f = 0;                                                                         \
