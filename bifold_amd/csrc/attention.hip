@@ -1709,23 +1709,25 @@ __global__ __launch_bounds__(512, WPE) void attn_bwd_kv_kernel(
 // operand images per (batch, head).  On this SIMD the matrix and the vector work of a kernel ADD (tools/micro/valu_rate.hip:
 // a key step of 6 MFMAs and 56 vector instructions takes the sum of the two at 1, 2, 3 and 4 waves per SIMD alike), so the
 // lever is the instruction count: one pass is 10 MFMAs and 16 exponentials per block.  What the pair avoided is the
-// reduction of dQ over key blocks that live in different waves; here it is small and deterministic:
-//   * one workgroup of three KEY waves (+ a helper wave, below) per (batch, head); wave w owns key blocks w, w + 3, w + 6 (275 tokens = 9 blocks:
-//     balanced) with their K / V fragments and dK^T / dV^T accumulators in registers for the whole kernel;
-//   * the three waves walk the query blocks TOGETHER.  Per query block a wave goes through its key blocks (key on the
-//     lane: S / dP with the row constants as initial accumulators, P and dS are the B operands of dV^T += dO^T P and
-//     dK^T += Q^T dS) and adds dS K of each into ONE partial dQ of the block (dS crosses LDS once, transposed, through a
-//     per-wave 2-KB image; K rows from a swizzled image);
-//   * the three partial dQ blocks (fp32, 4 KB each) meet in LDS; the helper wave sums them in wave order, scales,
-//     converts and stores whole 64-byte row segments while the key waves go on.  Two workgroup barriers per query block, each a
-//     whole block of work away from the accesses it orders.
-// LDS: Q / dO blocks interleaved 36.9 KB + K image 18.4 KB + dS images 6 KB + partials 12 KB + row constants 2.3 KB =
-// 76 KB: two workgroups per CU.  Registers: 96 accumulators + 48 fragments + the block's working set.
+// reduction of dQ over key blocks that live in different waves; here it needs no reduction at all:
+//   * one workgroup of three KEY waves and one HELPER wave per (batch, head).  Key wave w owns key blocks w, w + 3, w + 6
+//     (275 tokens = 9 blocks: balanced) with their V fragments and dK^T / dV^T accumulators in registers for the whole
+//     kernel (key on the lane: S / dP with the row constants as initial accumulators; P and dS are the B operands of
+//     dV^T += dO^T P and dK^T += Q^T dS);
+//   * the waves walk the query blocks together, one key block per step.  In a step a key wave leaves dS of its block,
+//     converted and transposed, in a 2-KB LDS image (two buffers per wave; 8-byte chunks swizzled); after the step's barrier
+//     the helper wave adds dS K of the three images, in wave order, into ITS accumulator of the query block's dQ (A = an
+//     image read transposed, B = K rows from a swizzled image) while the key waves are in the next step;
+//   * after three steps the helper scales, converts and stores the finished dQ block through its own 2 KB of LDS (whole
+//     64-byte row segments).  One accumulator, fixed order: bit-reproducible.  One workgroup barrier per step.
+// LDS: Q / dO blocks interleaved 36.9 KB + K image 18.4 KB + dS images 12 KB + row constants 2.3 KB + 2 KB = 72 KB: two
+// workgroups per CU, 8 waves = the two per SIMD that 218 registers (96 accumulators + 24 fragments + a block's working
+// set) allow.
 struct Fused32 {
     static constexpr int ROW = 64, BLK = 2 * 32 * ROW, DO_OFF = 32 * ROW;
     static size_t lds_bytes(int nw) {
         const size_t lp = (size_t)nw * 32;
-        return lp * 2 * ROW + lp * ROW + 2 * lp * 4 + 3 * 2048 + 3 * 4096;
+        return lp * 2 * ROW + lp * ROW + 2 * lp * 4 + 2 * 3 * 2048 + 2048;
     }
 };
 template <typename HT>
@@ -1742,8 +1744,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
     char* k_img = q_lds + (size_t)Lp * 2 * ROW;            // K rows, swizzled (B operand of dQ)
     float* lse_s = (float*)(k_img + (size_t)Lp * ROW);     // -lse / scale
     float* del_s = lse_s + Lp;                             // -delta
-    char* ds_img = (char*)(del_s + Lp);                    // per wave: dS^T [key][query], 64-byte rows, 8-byte chunks swizzled
-    float* dq_x = (float*)(ds_img + 3 * 2048);             // per wave: partial dQ [query][d] fp32
+    char* ds_img = (char*)(del_s + Lp);                    // 2 buffers x 3 key waves: dS^T [key][query], 64-byte rows, 8-byte chunks swizzled
+    char* dq_x = ds_img + 2 * 3 * 2048;                    // the helper's 2 KB: a finished dQ block on its way to row-contiguous stores
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1856,7 +1858,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
         t_off[0] = RI::at(4 * hh + q4, cb >> 4, ROW, cb & 15);
         t_off[1] = RI::at(4 * hh + q4 + 8, cb >> 4, ROW, cb & 15);
     }
-    char* my_img = ds_img + w * 2048;
     // dS^T image: row = key (64 bytes = 32 queries), 8-byte chunk c of row k at chunk c ^ ((k >> 1) & 7): the 16 lanes a
     // ds_write_b64 group serves (16 consecutive keys) then fall on distinct bank pairs
     int dsw_off[4];
@@ -1887,20 +1888,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
     const unsigned pr_wg = blockIdx.x;
     if (threadIdx.x == 0 && pr_wg < ATTN_PROBE_WGS) attn_probe[pr_wg * 8 + 1] = wall_clock64();
 #endif
+    int step = 0;                                       // key-block steps so far: image buffer = step & 1
+    f32x16 dq;                                          // helper: dQ of the current query block, over all nine key blocks
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[e] = 0.f;
     for (int qb = 0; qb < nw; ++qb) {
-#ifdef ATTN_PROBE
-        const unsigned long long pr_t0 = wall_clock64();
-#endif
         const char* q_blk = q_lds + qb * BLK;
         const float* lrow = lse_s + qb * 32 + 4 * hh;
         const float* drow = del_s + qb * 32 + 4 * hh;
-        f32x16 dq;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < NKB; ++i) {
+        for (int i = 0; i < NKB; ++i, ++step) {
+            char* img_buf = ds_img + (step & 1) * (3 * 2048);
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t0 = wall_clock64();
+#endif
             const int kb = w + 3 * i;
             if (kb < nw && !helper) {
+                char* my_img = img_buf + w * 2048;
                 f32x16 sacc, pacc;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1940,7 +1944,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
-                // dS^T image for dQ (the converted values: 4 consecutive queries of this lane's key per 8-byte store)
+                // dS^T image for the helper's dQ (the converted values: 4 consecutive queries of this lane's key per 8-byte store)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     X4 v4;
@@ -1957,62 +1961,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
                     dvacc[i] = mfma_32x32x16(dot, pb[s], dvacc[i]);
                     dkacc[i] = mfma_32x32x16(qtt, dsb[s], dkacc[i]);
                 }
-                // dQ_qb += dS K_kb: A = the image read transposed (sum over the key = lane index), B = K rows.  (No fence
-                // between the image's stores and these reads: a wave's LDS instructions execute in issue order.)
+            }
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t1 = wall_clock64();
+#endif
+            __syncthreads();        // the three images of this step are written; the helper is done with the other buffer
+#ifdef ATTN_PROBE
+            pr_compute += pr_t1 - pr_t0; pr_barrier += wall_clock64() - pr_t1;
+#endif
+            if (helper) {           // dQ_qb += dS K of the three key blocks of this step, in wave order: A = an image read
+                                    // transposed (sum over the key = lane index), B = K rows read transposed
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const X8 a = tr_pair<HT>(my_img + dsr_off[s][0], my_img + dsr_off[s][1]);
-                    const X8 kb2 = tr_pair<HT>(krows + kb_off[0] + s * 16 * ROW, krows + kb_off[1] + s * 16 * ROW);
-                    dq = mfma_32x32x16(a, kb2, dq);
+                for (int wv = 0; wv < 3; ++wv) {
+                    const int kbw = wv + 3 * i;
+                    if (kbw < nw) {
+                        const char* im = img_buf + wv * 2048;
+                        const char* krows = k_img + kbw * 32 * ROW;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const X8 a = tr_pair<HT>(im + dsr_off[s][0], im + dsr_off[s][1]);
+                            const X8 kb2 = tr_pair<HT>(krows + kb_off[0] + s * 16 * ROW, krows + kb_off[1] + s * 16 * ROW);
+                            dq = mfma_32x32x16(a, kb2, dq);
+                        }
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);    // one key block at a time: interleaved, their working sets do not fit
             }
         }
-        // ---- the three partial dQ blocks meet in LDS; wave (qb mod 3) sums and stores ---------------------------------
-#ifdef ATTN_PROBE
-        const unsigned long long pr_t1 = wall_clock64();
-#endif
-        __syncthreads();                              // the previous block's partials have been read
-#ifdef ATTN_PROBE
-        const unsigned long long pr_t2 = wall_clock64();
-#endif
-        if (!helper) {
-            float* mine = dq_x + w * 1024;            // [query 0..31][d 0..31]
+        if (helper) {               // the finished dQ block: through the helper's own 2 KB (a wave's LDS traffic is in order)
+            HT* hs = (HT*)dq_x;     // so that a lane stores 32 contiguous bytes of a row
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ql = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                mine[ql * 32 + r] = dq[e];
+                hs[ql * 32 + r] = (HT)(dq[e] * scale);
+                dq[e] = 0.f;
             }
-        }
-#ifdef ATTN_PROBE
-        const unsigned long long pr_t3 = wall_clock64();
-#endif
-        __syncthreads();
-#ifdef ATTN_PROBE
-        const unsigned long long pr_t4 = wall_clock64();
-        pr_compute += (pr_t1 - pr_t0) + (pr_t3 - pr_t2); pr_barrier += (pr_t2 - pr_t1) + (pr_t4 - pr_t3);
-#endif
-        if (helper) {
             const int row = lane >> 1, half = lane & 1;
             const int qi = qb * 32 + row;
-            float acc[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 v0 = *(const float4*)(dq_x + 0 * 1024 + row * 32 + half * 16 + j * 4);
-                const float4 v1 = *(const float4*)(dq_x + 1 * 1024 + row * 32 + half * 16 + j * 4);
-                const float4 v2 = *(const float4*)(dq_x + 2 * 1024 + row * 32 + half * 16 + j * 4);
-                acc[4 * j + 0] = (v0.x + v1.x) + v2.x; acc[4 * j + 1] = (v0.y + v1.y) + v2.y;
-                acc[4 * j + 2] = (v0.z + v1.z) + v2.z; acc[4 * j + 3] = (v0.w + v1.w) + v2.w;
-            }
+            const X8 lo = *(const X8*)(hs + row * 32 + half * 16), hi = *(const X8*)(hs + row * 32 + half * 16 + 8);
             if (qi < L) {
                 HT* dst = dqkv + qkv_off(b, qi, 0, h, L, H, D) + half * 16;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    X8 o8;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o8[e] = (HT)(acc[8 * j + e] * scale);
-                    *(X8*)(dst + 8 * j) = o8;
-                }
+                *(X8*)dst = lo;
+                *(X8*)(dst + 8) = hi;
             }
         }
     }
