@@ -747,7 +747,7 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 #ifndef P8_SOFF
 #define P8_SOFF 1                     // persistent GEMM: K advance of K-contiguous operands in the DMA's scalar offset, fragment offsets hoisted (0: round 2's loop)
 #endif
-template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, bool GROUPED = false>
+template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, bool GROUPED = false, int BK = 32>
 __device__ __forceinline__ void p8_body(
     const H* __restrict__ A, const H* __restrict__ B, const GemmDims& d, const EpiParams& ep,
     float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
@@ -810,7 +810,8 @@ __device__ __forceinline__ void p8_body(
         }
         w.m0 = tm * 256; w.n0 = tn * 256;
         w.kbeg = w.z * d.k_per_split;
-        w.nk = (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 31) >> 5;
+        w.nk = BK == 64 ? (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 63) >> 6
+                        : (min(d.k, w.kbeg + d.k_per_split) - w.kbeg + 31) >> 5;
         // Every other ROUND of an XCD's tickets walks K backwards: the panels two consecutive rounds share (the W
         // panels of the next row group, the A panels of the next column tiles) are then first touched where the
         // previous round left them in the L2, instead of at the end that was evicted longest ago.  The direction is
@@ -881,6 +882,64 @@ __device__ __forceinline__ void p8_body(
     if (!B_KS) { const int row = wn * 64 + (lane & 15); fb_off = (unsigned)(16384 + row * 64 + (((lane >> 4) ^ kc32_swz(row)) << 4)); }
     asm volatile("" : "+v"(fa_off), "+v"(fb_off));
 
+    // ---- BK = 64 main loop ("full lines", K-contiguous operands only; round 4) -----------------------------------
+    // The BK = 32 stages above are 64-byte LDS rows, so a DMA piece fetches 16 rows x HALF a 128-byte line: twice the
+    // requests per byte on the L2 path, which this loop loads to a third of its peak.  Here a K tile is 64 deep: a row
+    // is one whole line (8 chunks of 16 B; chunk c of row r sits at position c ^ ((r >> 1) & 7): conflict-free for
+    // ds_read_b128's 16-lane groups), a piece is 8 rows x 128 B, and the ring is TWO 64 KB tiles (A 32 KB | B 32 KB),
+    // refilled by REGION as soon as a region's last reader is two phases past it:
+    //   phase 0 reads A0 (rows 0-63 of the wave's 128) + B0 (cols 0-31 of its 64) and multiplies A0 x B0,
+    //   phase 1 reads B1 -> A0 x B1,   phase 2 reads A1 -> A1 x B1,   phase 3 reads nothing -> A1 x B0 (B0 kept);
+    //   phase 0 issues B1 of tile t+1, phase 1 A1 of t+1, phase 2 B0 of t+2, phase 3 A0 of t+2 (2 pieces per wave
+    //   each): every region has 5-6 phases of flight time out of two buffers, and 8 pieces per wave are in flight.
+    // A wave waits (counted vmcnt) for its own pieces of the region that is read in the NEXT phase; the two barriers
+    // in between publish them to both wave groups (which run one barrier apart, as in the BK = 32 loop).
+    unsigned va6[2][2] = {{0, 0}, {0, 0}}, vb6[2][2] = {{0, 0}, {0, 0}};   // per-lane byte offsets: [region half][piece]
+    unsigned fa6[2] = {0, 0}, fb6[2] = {0, 0};                           // fragment offsets of k block 0 / 1 inside a tile
+    auto a_rel6 = [&](int h, int p) { return (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + p * 8; };
+    auto b_rel6 = [&](int h, int p) { return (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + p * 8; };
+    auto lane_off6 = [&](int ld, int r0, int k0, int rel) {
+        const int row = rel + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        return (unsigned)(((size_t)(r0 + row) * ld + k0 + ch * 8) * 2);
+    };
+    auto set_bases6 = [&](const P8Item& it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                va6[h][p] = lane_off6(lda, it.m0, it.kbeg, a_rel6(h, p));
+                vb6[h][p] = lane_off6(ldb, it.n0, it.kbeg, b_rel6(h, p));
+            }
+        asm volatile("" : "+v"(va6[0][0]), "+v"(va6[0][1]), "+v"(va6[1][0]), "+v"(va6[1][1]),
+                          "+v"(vb6[0][0]), "+v"(vb6[0][1]), "+v"(vb6[1][0]), "+v"(vb6[1][1]));
+    };
+    // region (operand, half) of K tile tt of item `it` -> ring buffer tt & 1; `any`: addresses from scratch (item boundary)
+    auto issue6 = [&](const P8Item& it, int tt, int is_b, int h, bool any) {
+        const int ks = it.rev ? it.nk - 1 - tt : tt;
+        const unsigned delta = (unsigned)ks * 128u;
+        char* dst = smem + (tt & 1) * 65536 + (is_b ? 32768 + b_rel6(h, 0) * 128 : a_rel6(h, 0) * 128);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            unsigned v;
+            if (any) v = is_b ? lane_off6(ldb, it.n0, it.kbeg, b_rel6(h, p)) : lane_off6(lda, it.m0, it.kbeg, a_rel6(h, p));
+            else v = is_b ? vb6[h][p] : va6[h][p];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rb : ra, (lds_void_ptr)(dst + p * 1024), 16, v, delta, 0, 0);
+        }
+    };
+    auto issue_tile6_any = [&](const P8Item& it, int tt) {
+        issue6(it, tt, 1, 0, true); issue6(it, tt, 0, 0, true); issue6(it, tt, 1, 1, true); issue6(it, tt, 0, 1, true);
+    };
+    if constexpr (BK == 64) {
+        static_assert(BK != 64 || (!A_KS && !B_KS && !GROUPED), "the BK = 64 loop takes K-contiguous operands");
+        const int sw = (lane >> 1) & 7;                    // (row >> 1) & 7 of the lane's fragment row (bases are multiples of 16)
+        fa6[0] = (unsigned)(wm * 16384 + (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4));
+        fb6[0] = (unsigned)(32768 + wn * 8192 + (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4));
+        fa6[1] = fa6[0] ^ 64u;                             // chunk 4 + c: position bit 2 flipped
+        fb6[1] = fb6[0] ^ 64u;
+        asm volatile("" : "+v"(fa6[0]), "+v"(fa6[1]), "+v"(fb6[0]), "+v"(fb6[1]));
+    }
+
     P8Item w;
     [[maybe_unused]] int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
     unsigned pend = 0;                 // thread 0: the ticket drawn for the next item
@@ -890,17 +949,21 @@ __device__ __forceinline__ void p8_body(
     unsigned nxt = 0;
     if (!decode(first, w)) { finish(); return; }
     bind(w);
-    issue_a_any(w, 0); issue_b_any(w, 0);
-    if (w.nk > 1) { issue_a_any(w, 1); issue_b_any(w, 1); }
+    if constexpr (BK == 64) {
+        issue_tile6_any(w, 0);
+    } else {
+        issue_a_any(w, 0); issue_b_any(w, 0);
+        if (w.nk > 1) { issue_a_any(w, 1); issue_b_any(w, 1); }
+    }
 
     while (true) {
-        set_bases(w);
+        if constexpr (BK == 64) set_bases6(w); else set_bases(w);
         f32x4 acc[4][8];          // acc[j][i]: n tile j (16 cols), m tile i (16 rows); swapped roles
         // A plain residual (C = A B^T + bias + R, the transformer's skip connections) is loaded
         // INTO the accumulators here: 32 loads in flight at once, their latency under the wait for
         // the first stages, instead of 16 dependent load -> add -> store rounds in the epilogue
         // (measured: 55k cycles per tile for the epilogue of a residual GEMM).
-        const bool res_init = ep.residual && !slabs && ep.act == BF_ACT_NONE && ep.alpha == 1.0f &&
+        const bool res_init = EPI == 0 && ep.residual && !slabs && ep.act == BF_ACT_NONE && ep.alpha == 1.0f &&
                               ep.resid_mod == 0 && ep.rows_in == 0;
         if (res_init) {
 #pragma unroll
@@ -933,7 +996,9 @@ __device__ __forceinline__ void p8_body(
         // slot, (s - 1) & 3, was last read two barrier intervals earlier by the lagging group.  The ring stays 4 slots
         // (the LDS is full); what changes is that three stages instead of two are in flight, i.e. ~50 % more time for
         // a load that misses the L2 to arrive before a wave waits for it.
-        if (deep && w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }
+        if constexpr (BK != 64) {
+            if (deep && w.nk > 2) { issue_a(w, 2); issue_b(w, 2); }
+        }
         if (wm == 1) __builtin_amdgcn_s_barrier();          // group 1 runs one slot behind
         const int nk = w.nk;
 #ifdef P8_PROBE
@@ -948,6 +1013,99 @@ __device__ __forceinline__ void p8_body(
         // which drained the DMA ring once per item)
         unsigned lane_zero;
         asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+        if constexpr (BK == 64) {
+            typedef typename H16<H>::x8 F8;
+            const int draw_tile = nk > 4 ? nk - 4 : 0;
+            for (int t = 0; t < nk; ++t) {
+                const char* tb = smem + (t & 1) * 65536;
+                const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+                if (t == draw_tile && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
+                // B0, A0 of tile 1: what phases 2 / 3 of "tile -1" would have issued.  (Inside the loop: in front of it
+                // hipcc flushes vmcnt(0) in the loop preheader -- it cannot see that the asm wait above covered the
+                // residual loads into the accumulators -- and the four pieces would be waited for on the spot.)
+                if (t == 0 && n1) { issue6(w, 1, 1, 0, false); issue6(w, 1, 0, 0, false); }
+                F8 fa[2][4], fb0[2][2], fb1[2][2];     // [k block][16-row tile]
+                // ---------------- phase 0: A0 x B0
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb0[kb][j] = *(const F8*)(tb + fb6[kb] + j * 2048);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[kb][i] = *(const F8*)(tb + fa6[kb] + i * 2048);
+                if (n1) {
+                    issue6(w, t + 1, 1, 1, false);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // B1 of this tile landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][i] = mfma_16x16x32(fb0[kb][j], fa[kb][i], acc[j][i]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- phase 1: A0 x B1
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb1[kb][j] = *(const F8*)(tb + fb6[kb] + 4096 + j * 2048);
+                if (n1) {
+                    issue6(w, t + 1, 0, 1, false);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A1 of this tile landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[2 + j][i] = mfma_16x16x32(fb1[kb][j], fa[kb][i], acc[2 + j][i]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- phase 2: A1 x B1
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[kb][i] = *(const F8*)(tb + fa6[kb] + 8192 + i * 2048);
+                if (n2) issue6(w, t + 2, 1, 0, false);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[2 + j][4 + i] = mfma_16x16x32(fb1[kb][j], fa[kb][i], acc[2 + j][4 + i]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- phase 3: A1 x B0 (no reads)
+                if (n2) {
+                    issue6(w, t + 2, 0, 0, false);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // A0, B0 of tile t + 1 landed
+                } else if (n1) {
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][4 + i] = mfma_16x16x32(fb0[kb][j], fa[kb][i], acc[j][4 + i]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        } else
         for (int s = 0; s < nk; ++s) {
             const char* la = smem + (s & 3) * P8_STAGE;
             const char* lb = la + 16384;
@@ -1024,13 +1182,21 @@ __device__ __forceinline__ void p8_body(
         const bool has_next = decode(nxt, nx);
         if (has_next) {
             bind(nx);
-            issue_a_any(nx, 0); issue_b_any(nx, 0);
-            if (nx.nk > 1) { issue_a_any(nx, 1); issue_b_any(nx, 1); }
+            if constexpr (BK == 64) {
+                issue_tile6_any(nx, 0);
+            } else {
+                issue_a_any(nx, 0); issue_b_any(nx, 0);
+                if (nx.nk > 1) { issue_a_any(nx, 1); issue_b_any(nx, 1); }
+            }
         }
 #ifdef P8_PROBE
         const unsigned long long pc2 = clock64();
 #endif
 
+        // (the epilogue's per-lane values are derived from an OPAQUE copy of the lane id made here, so that the compiler
+        // cannot hoist them above the main loop, where every register is spoken for: round 4, BK = 64 loop)
+        int lane_ep = lane;
+        asm volatile("" : "+v"(lane_ep));
         // Epilogue through LDS: in the MFMA layout a wave-instruction's 64 lanes own 16 rows x 4
         // separate 16-byte groups, i.e. 64 scattered requests per store (measured: ~780 cycles per
         // store instruction and wave, the epilogue as long as a K = 768 main loop).  Each wave
@@ -1049,13 +1215,13 @@ __device__ __forceinline__ void p8_body(
         // ~780 cycles per store -- as much as a whole K = 768 main loop per tile.
         // Plain bf16 outputs (alpha / bias / activation only): do the math in the MFMA layout, turn
         // the tile around as bf16 (half the LDS bytes: ds_write runs at ~80 B/clk per CU) in two
-        // 64-row halves, and store 8 columns per lane.
+        // 64-row halves, and store 8 columns per lane_ep.
         constexpr bool fast16 = EPI == 1 || EPI == 3;
         if constexpr (fast16) {
             float4 bj[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = w.n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                const int n = w.n0 + wn * 64 + j * 16 + (lane_ep >> 4) * 4;
                 bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
             using AM = ActMath<H>;
@@ -1066,7 +1232,7 @@ __device__ __forceinline__ void p8_body(
                 H* dst = PASS == 0 ? (H*)ep.pre : (H*)ep.c;
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    const int lr = ii * 16 + (lane & 15);
+                    const int lr = ii * 16 + (lane_ep & 15);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const f32x4 a = acc[j][HALF * 4 + ii];
@@ -1086,7 +1252,7 @@ __device__ __forceinline__ void p8_body(
                         }
                         typename H16<H>::x4 pk;
                         pk[0] = (H)v[0]; pk[1] = (H)v[1]; pk[2] = (H)v[2]; pk[3] = (H)v[3];
-                        const int cc4 = j * 4 + (lane >> 4);
+                        const int cc4 = j * 4 + (lane_ep >> 4);
                         *(typename H16<H>::x4*)(stg + lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3)) = pk;
                     }
                 }
@@ -1094,7 +1260,7 @@ __device__ __forceinline__ void p8_body(
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int lr = t * 8 + (lane >> 3), c16 = lane & 7;
+                    const int lr = t * 8 + (lane_ep >> 3), c16 = lane_ep & 7;
                     const uint4 q = *(const uint4*)(stg + lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4));
                     const int m = w.m0 + wm * 128 + HALF * 64 + lr;
                     const int n = w.n0 + wn * 64 + c16 * 8;
@@ -1113,7 +1279,7 @@ __device__ __forceinline__ void p8_body(
                     constexpr int Q = decltype(q_)::value;          // rows [32 Q, 32 Q + 32) of the wave's 128
 #pragma unroll
                     for (int i2 = 0; i2 < 2; ++i2) {
-                        const int lr = i2 * 16 + (lane & 15);
+                        const int lr = i2 * 16 + (lane_ep & 15);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const f32x4 a = acc[j][Q * 2 + i2];
@@ -1127,7 +1293,7 @@ __device__ __forceinline__ void p8_body(
                                 pk[e] = (H)gv;
                                 gk[e] = (H)gp;
                             }
-                            const int cc4 = j * 4 + (lane >> 4);
+                            const int cc4 = j * 4 + (lane_ep >> 4);
                             const int off = lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3);
                             *(typename H16<H>::x4*)(stg + off) = pk;
                             *(typename H16<H>::x4*)(stg + 4096 + off) = gk;
@@ -1137,7 +1303,7 @@ __device__ __forceinline__ void p8_body(
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const int lr = t * 8 + (lane >> 3), c16 = lane & 7;
+                        const int lr = t * 8 + (lane_ep >> 3), c16 = lane_ep & 7;
                         const int off = lr * 128 + ((c16 ^ ((lr >> 1) & 7)) << 4);
                         const uint4 qa = *(const uint4*)(stg + off);
                         const uint4 qg = *(const uint4*)(stg + 4096 + off);
@@ -1168,16 +1334,16 @@ __device__ __forceinline__ void p8_body(
             constexpr int C = decltype(cc_)::value;
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
-                const int lr = ii * 16 + (lane & 15);
+                const int lr = ii * 16 + (lane_ep & 15);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int cc = j * 4 + (lane >> 4);
+                    const int cc = j * 4 + (lane_ep >> 4);
                     *(f32x4*)(stg + lr * 256 + ((cc ^ (lr & 15)) << 4)) = acc[j][2 * C + ii];
                 }
             }
         };
         // dX = (dY W) * gelu'(pre) with a bf16 result (the MLP's input gradient): all 16 rows of
-        // `pre` this lane needs are requested at once (64 registers of raw bf16), so the tile pays
+        // `pre` this lane_ep needs are requested at once (64 registers of raw bf16), so the tile pays
         // one load latency instead of sixteen; lean body, fully unrolled.
         constexpr bool fastgrad = EPI == 2;
         if constexpr (fastgrad) {
@@ -1185,8 +1351,8 @@ __device__ __forceinline__ void p8_body(
             uint4 apre[16];
 #pragma unroll
             for (int ct = 0; ct < 16; ++ct) {
-                const int m = w.m0 + wm * 128 + ct * 8 + (lane >> 3);
-                const int n = w.n0 + wn * 64 + (lane & 7) * 8;
+                const int m = w.m0 + wm * 128 + ct * 8 + (lane_ep >> 3);
+                const int n = w.n0 + wn * 64 + (lane_ep & 7) * 8;
                 apre[ct] = (m < ep.m && n < ep.n) ? *(const uint4*)((const H*)ep.aux + (size_t)m * ep.ld_aux + n)
                                                   : make_uint4(0, 0, 0, 0);
             }
@@ -1200,7 +1366,7 @@ __device__ __forceinline__ void p8_body(
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const int lr = t * 8 + (lane >> 3), c2 = (lane & 7) * 2;
+                    const int lr = t * 8 + (lane_ep >> 3), c2 = (lane_ep & 7) * 2;
                     const f32x4 q0 = *(const f32x4*)(stg + lr * 256 + ((c2 ^ (lr & 15)) << 4));
                     const f32x4 q1 = *(const f32x4*)(stg + lr * 256 + (((c2 + 1) ^ (lr & 15)) << 4));
                     const int m = w.m0 + wm * 128 + C * 32 + lr;
@@ -1241,16 +1407,16 @@ __device__ __forceinline__ void p8_body(
                     cs[e] += __shfl_xor(cs[e], 16, 64);
                     cs[e] += __shfl_xor(cs[e], 32, 64);
                 }
-                const int n = w.n0 + wn * 64 + (lane & 7) * 8;
-                if (lane < 8 && n < ep.n) {
+                const int n = w.n0 + wn * 64 + (lane_ep & 7) * 8;
+                if (lane_ep < 8 && n < ep.n) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) atomicAdd(ep.colsum + n + e, cs[e]);
                 }
             }
         } else {
-        float b8[8];                   // the lane's 8 columns are the same for every row of the tile
+        float b8[8];                   // the lane_ep's 8 columns are the same for every row of the tile
         {
-            const int n = w.n0 + wn * 64 + (lane & 7) * 8;
+            const int n = w.n0 + wn * 64 + (lane_ep & 7) * 8;
             if (ep.bias && !slab && n < epn) Vec8<float>::load(ep.bias + n, b8);
             else {
 #pragma unroll
@@ -1269,7 +1435,7 @@ __device__ __forceinline__ void p8_body(
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int lr = t * 8 + (lane >> 3), c2 = (lane & 7) * 2;
+                const int lr = t * 8 + (lane_ep >> 3), c2 = (lane_ep & 7) * 2;
                 const f32x4 q0 = *(const f32x4*)(stg + lr * 256 + ((c2 ^ (lr & 15)) << 4));
                 const f32x4 q1 = *(const f32x4*)(stg + lr * 256 + (((c2 + 1) ^ (lr & 15)) << 4));
                 const int m = w.m0 + wm * 128 + c * 32 + lr;
@@ -1302,12 +1468,12 @@ __device__ __forceinline__ void p8_body(
     finish();
 }
 
-template <bool A_KS, bool B_KS, typename TC, int EPI, typename H>
+template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, int BK = 32>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const H* __restrict__ A, const H* __restrict__ B, GemmDims d, EpiParams ep,
     float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
     unsigned* __restrict__ tk) {
-    p8_body<A_KS, B_KS, TC, EPI, H, false>(A, B, d, ep, slabs, a_bytes, b_bytes, n_items, skew_cycles, tk, nullptr);
+    p8_body<A_KS, B_KS, TC, EPI, H, false, BK>(A, B, d, ep, slabs, a_bytes, b_bytes, n_items, skew_cycles, tk, nullptr);
 }
 
 // The grouped dW launch: TN layout, fp32 partial slabs (general epilogue), every problem's geometry in `grp`.
@@ -1847,7 +2013,7 @@ static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
         g->k < (g->b_kn ? min_k_nn : min_k_nt) || g->colsum_out)
         return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
     const int pipe_env = T.gemm_pipe.load();
-    if (pipe_env >= 0 && pipe_env != 8) return false;
+    if (pipe_env >= 0 && pipe_env != 8 && pipe_env != 9) return false;
     // dX = dY W (NN) runs on the persistent kernel too; its 512-wide outputs are 2.15-round shapes (550 tiles on
     // 256 CUs), but splitting their tails measured neutral, so it is opt-in (BIFOLD_P8_TAIL_K="2048,1536")
     if (T.p8_no_tail) return false;
@@ -1957,7 +2123,7 @@ static bool grouped_tn_plan(const bf_gemm_tn_problem* p, int count, int k, int c
     if (!p || count < 1 || count > P8_MAX_GROUP || !bf_is_half(cdt) || k < 16384 || (k % 32) != 0) return false;
     if (!bf_tuning().dw_grouped) return false;
     const int pipe_env = bf_tuning().gemm_pipe.load();
-    if (pipe_env >= 0 && pipe_env != 8) return false;
+    if (pipe_env >= 0 && pipe_env != 8 && pipe_env != 9) return false;
     long tiles = 0;
     size_t elems = 0;
     for (int i = 0; i < count; ++i) {
@@ -2207,6 +2373,12 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                                          : (pipe_env >= 0 ? pipe_env : ((p8_nt || p8_tn || p8_nn) ? 8 : (long_nt ? 0 : 4)));
         // the persistent kernel draws its items from a per-stream ring of ticket sets; a process that uses
         // more streams than there are rings runs the extra streams' GEMMs on the other kernels
+        // variant 9 = the persistent kernel with the BK = 64 full-line main loop for NT (K-contiguous operands, K a
+        // multiple of 64); BIFOLD_P8_BK64 makes it the automatic choice for those shapes
+        bool bk64 = T.p8_bk64 != 0;
+        if (variant == 9 || (force_variant == 8 && pipe_env == 9)) { variant = 8; bk64 = true; }
+        else if (pipe_env == 8) bk64 = false;
+        bk64 = bk64 && !g->trans_a && !g->b_kn && (g->k % 64) == 0 && (kps % 64) == 0;
         unsigned* tk8 = variant == 8 ? p8_ticket_set(s) : nullptr;
         if (variant == 8 && !tk8) variant = long_nt ? 0 : 4;
         last_variant = 1;   // register-staged fallback unless one of the LDS-DMA kernels below takes it
@@ -2243,31 +2415,39 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                 else if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) epi = 1;
                 else if ((g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->pre) epi = 2;
             }
-#define LAUNCH_P8E(AKS, BKS, TC, EPI, H)                                                            \
+#define LAUNCH_P8E(AKS, BKS, TC, EPI, H, BKV)                                                       \
     do {                                                                                          \
-        static bool lds_ok = false;                                                               \
-        if (!lds_ok) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC, EPI, H>,     \
+        static bool lds_ok[P8_TK_DEVICES];  /* > 64 KB of dynamic LDS must be opted into, once per device */ \
+        int dev_ = 0;                                                                             \
+        (void)hipGetDevice(&dev_);                                                                \
+        if (dev_ < 0 || dev_ >= P8_TK_DEVICES || !lds_ok[dev_]) {                                 \
+            (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<AKS, BKS, TC, EPI, H, BKV>, \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE + 16);  \
-            lds_ok = true;                                                                        \
+            if (dev_ >= 0 && dev_ < P8_TK_DEVICES) lds_ok[dev_] = true;                           \
         }                                                                                         \
-        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC, EPI, H>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, (const H*)g->a, (const H*)g->b, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
+        hipLaunchKernelGGL((gemm_bf16_p8_kernel<AKS, BKS, TC, EPI, H, BKV>), dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, (const H*)g->a, (const H*)g->b, d8, ep, slabs, ab, bb, (int)items, skew, tk8); \
     } while (0)
-#define LAUNCH_P8_H(AKS, BKS, H)                                                                    \
+#define LAUNCH_P8_HB(AKS, BKS, H, BKV)                                                              \
     do {                                                                                          \
-        if (f32out) LAUNCH_P8E(AKS, BKS, float, 0, H);                                            \
-        else if (epi == 1) LAUNCH_P8E(AKS, BKS, H, 1, H);                                         \
-        else if (epi == 2) LAUNCH_P8E(AKS, BKS, H, 2, H);                                         \
-        else if (epi == 3) LAUNCH_P8E(AKS, BKS, H, 3, H);                                         \
-        else LAUNCH_P8E(AKS, BKS, H, 0, H);                                                       \
+        if (f32out) LAUNCH_P8E(AKS, BKS, float, 0, H, BKV);                                       \
+        else if (epi == 1) LAUNCH_P8E(AKS, BKS, H, 1, H, BKV);                                    \
+        else if (epi == 2) LAUNCH_P8E(AKS, BKS, H, 2, H, BKV);                                    \
+        else if (epi == 3) LAUNCH_P8E(AKS, BKS, H, 3, H, BKV);                                    \
+        else LAUNCH_P8E(AKS, BKS, H, 0, H, BKV);                                                  \
     } while (0)
+#define LAUNCH_P8_H(AKS, BKS, H) LAUNCH_P8_HB(AKS, BKS, H, 32)
+#define LAUNCH_P8_H64(AKS, BKS, H) LAUNCH_P8_HB(AKS, BKS, H, 64)
 #define LAUNCH_P8(AKS, BKS) BY_HALF(LAUNCH_P8_H, AKS, BKS)
-            if (!g->trans_a && !g->b_kn) LAUNCH_P8(false, false);
+            if (!g->trans_a && !g->b_kn) {
+                if (bk64) BY_HALF(LAUNCH_P8_H64, false, false); else LAUNCH_P8(false, false);
+            }
             else if (!g->trans_a && g->b_kn) LAUNCH_P8(false, true);
             else if (g->trans_a && g->b_kn) LAUNCH_P8(true, true);
             else LAUNCH_P8(true, false);
 #undef LAUNCH_P8E
+#undef LAUNCH_P8_HB
 #undef LAUNCH_P8_H
+#undef LAUNCH_P8_H64
 #undef LAUNCH_P8
         } else if (dma_ok && (variant == 4 || (variant == 8 && !long_nt))) {
             last_variant = 4;

@@ -10,7 +10,24 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    TS* __restrict__ shadow, size_t n4, float lr,
                                                    float beta1, float beta2, float eps, float wd,
                                                    int decoupled, float step_size, float sqrt_bc2,
-                                                   const float* __restrict__ gscale) {
+                                                   const float* __restrict__ gscale,
+                                                   const unsigned* __restrict__ skip_flag,
+                                                   const float* __restrict__ skipped_dev, float skipped_known,
+                                                   int step) {
+    // Guarded step (fp16 mode's dynamic loss scale): a non-zero device flag -- non-finite gradient elements counted by
+    // bf_scale_check during this backward, MAX-reduced over the ranks -- makes the whole launch a no-op for p / m / v
+    // and the 16-bit copy, like torch.cuda.amp.GradScaler.step skipping optimizer.step(), without a host read.
+    if (skip_flag && skip_flag[0] != 0u) return;
+    // A skipped step does not count for Adam's bias corrections.  The host computed step_size / sqrt_bc2 for
+    // `step` = its own count minus the skips it KNEW of; skips since then (a device counter) are taken off here.
+    if (skipped_dev) {
+        const float extra = skipped_dev[0] - skipped_known;
+        if (extra > 0.5f) {
+            const double t = fmax(1.0, (double)step - (double)extra);
+            step_size = (float)((double)lr / (1.0 - pow((double)beta1, t)));
+            sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, t));
+        }
+    }
     const float gs = gscale ? gscale[0] : 1.0f;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 pv = ((const float4*)p)[i];
@@ -46,6 +63,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 extern "C" int bf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
                             int shadow_dtype, size_t count, int step, float lr, float beta1, float beta2, float eps,
                             float weight_decay, int decoupled, const float* grad_scale_dev,
+                            const unsigned* skip_flag_dev, const float* skipped_dev, float skipped_known,
                             bf_stream_t stream) {
     BF_REQUIRE(count > 0 && (count & 3) == 0, BF_EINVAL,
                "bf_adam_step: the arena length must be a multiple of 4 (got %zu)", count);
@@ -65,13 +83,16 @@ extern "C" int bf_adam_step(float* param, const float* grad, float* exp_avg, flo
     hipStream_t s = (hipStream_t)stream;
     if (shadow && shadow_dtype == BF_F16)
         hipLaunchKernelGGL((adam_kernel<true, f16_t>), grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (f16_t*)shadow,
-                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
+                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev,
+                           skip_flag_dev, skipped_dev, skipped_known, step);
     else if (shadow)
         hipLaunchKernelGGL((adam_kernel<true, bf16_t>), grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)shadow,
-                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
+                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev,
+                           skip_flag_dev, skipped_dev, skipped_known, step);
     else
         hipLaunchKernelGGL((adam_kernel<false, bf16_t>), grid, block, 0, s, param, grad, exp_avg, exp_avg_sq, (bf16_t*)nullptr,
-                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev);
+                           n4, lr, beta1, beta2, eps, weight_decay, decoupled, step_size, sqrt_bc2, grad_scale_dev,
+                           skip_flag_dev, skipped_dev, skipped_known, step);
     BF_CHECK_LAUNCH("bf_adam_step");
     return BF_OK;
 }
@@ -185,7 +206,9 @@ extern "C" int bf_clip_grad_norm(float* grad, size_t count, float max_norm, floa
 // x *= scale in place, counting the non-finite results: the two ends of the fp16 mode's loss scaling (the gradient
 // entering the tail's backward is multiplied by S, every slice of the gradient arena by 1 / S when it completes).
 __global__ __launch_bounds__(256) void scale_check_kernel(float* __restrict__ x, size_t n4, size_t count, float c,
+                                                          const float* __restrict__ c_dev,
                                                           unsigned* __restrict__ nonfinite) {
+    if (c_dev) c = c_dev[0];
     unsigned bad = 0;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         float4 v = ((float4*)x)[i];
@@ -212,7 +235,61 @@ extern "C" int bf_scale_check(float* x, size_t count, float scale, unsigned* non
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(scale_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, count, scale,
-                       nonfinite_count);
+                       (const float*)nullptr, nonfinite_count);
     BF_CHECK_LAUNCH("bf_scale_check");
+    return BF_OK;
+}
+
+extern "C" int bf_scale_check_dev(float* x, size_t count, const float* scale_dev, unsigned* nonfinite_count,
+                                  bf_stream_t stream) {
+    BF_REQUIRE(x && count > 0 && scale_dev, BF_EINVAL, "bf_scale_check_dev: bad args");
+    BF_REQUIRE(bf_aligned16(x), BF_EALIGN, "bf_scale_check_dev: unaligned pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_check_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, n4, count, 1.0f,
+                       scale_dev, nonfinite_count);
+    BF_CHECK_LAUNCH("bf_scale_check_dev");
+    return BF_OK;
+}
+
+// End of a guarded step: the loss scale backs off after an overflow and grows back (never past `max_scale`) after
+// `growth_interval` clean steps; the per-step flag is folded into the running totals and cleared.  One thread.
+//   state[0] = S, [1] = 1 / S, [2] = clean steps since the last change, [3] = steps skipped so far,
+//   state[4] = non-finite gradient elements seen so far (diagnostics), [5] = overflows at S == min_scale
+__global__ void gradscale_update_kernel(float* __restrict__ st, unsigned* __restrict__ flag, float backoff,
+                                        float growth, int growth_interval, float min_scale, float max_scale) {
+    const unsigned bad = flag[0];
+    float S = st[0];
+    if (bad) {
+        if (S <= min_scale) st[5] += 1.0f;
+        S = fmaxf(S * backoff, min_scale);
+        st[2] = 0.0f;
+        st[3] += 1.0f;
+        st[4] += (float)bad;
+    } else {
+        const float clean = st[2] + 1.0f;
+        if (clean >= (float)growth_interval && S < max_scale) {
+            S = fminf(S * growth, max_scale);
+            st[2] = 0.0f;
+        } else {
+            st[2] = clean;
+        }
+    }
+    st[0] = S;
+    st[1] = 1.0f / S;
+    flag[0] = 0u;
+}
+
+extern "C" int bf_gradscale_update(float* state, unsigned* nonfinite_flag, float backoff, float growth,
+                                   int growth_interval, float min_scale, float max_scale, bf_stream_t stream) {
+    BF_REQUIRE(state && nonfinite_flag, BF_EINVAL, "bf_gradscale_update: null state / flag");
+    BF_REQUIRE(backoff > 0.f && backoff < 1.f && growth >= 1.f && growth_interval >= 1 && min_scale > 0.f &&
+                   max_scale >= min_scale, BF_EINVAL, "bf_gradscale_update: bad schedule (backoff %g growth %g every %d, "
+               "scale in [%g, %g])", backoff, growth, growth_interval, min_scale, max_scale);
+    hipLaunchKernelGGL(gradscale_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state, nonfinite_flag, backoff,
+                       growth, growth_interval, min_scale, max_scale);
+    BF_CHECK_LAUNCH("bf_gradscale_update");
     return BF_OK;
 }

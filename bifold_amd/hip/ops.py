@@ -561,18 +561,42 @@ def bce_mean_bwd(heat, target, gscale: torch.Tensor):
 
 # ----------------------------------------------------------------------------- optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, step, lr, beta1, beta2, eps, weight_decay,
-              decoupled, grad_scale=None):
+              decoupled, grad_scale=None, skip_flag=None, skipped=None, skipped_known: float = 0.0):
+    """`skip_flag` (int32 [1]) non-zero -> the launch changes nothing; `skipped` (fp32 [1]) = steps dropped so far on the
+    device, `skipped_known` the part of them `step` already leaves out (bf_adam_step)."""
+    if skip_flag is not None and skip_flag.dtype != torch.int32:
+        raise TypeError("adam_step: skip_flag int32")
+    if skipped is not None and skipped.dtype != torch.float32:
+        raise TypeError("adam_step: skipped float32")
     check(lib.bf_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(shadow),
                            dtype_code(shadow) if shadow is not None else L.BF16, param.numel(), step, lr, beta1, beta2, eps, weight_decay, int(decoupled),
-                           _ptr(grad_scale), _stream()), "bf_adam_step")
+                           _ptr(grad_scale), _ptr(skip_flag), _ptr(skipped), float(skipped_known), _stream()), "bf_adam_step")
 
 
-def scale_check_(x: torch.Tensor, scale: float, nonfinite: Optional[torch.Tensor] = None) -> None:
-    """x *= scale in place (fp32, contiguous); `nonfinite` (int32 [1], optional) counts inf / nan results."""
+def scale_check_(x: torch.Tensor, scale, nonfinite: Optional[torch.Tensor] = None) -> None:
+    """x *= scale in place (fp32, contiguous); `scale` a number or a device fp32 scalar (the dynamic loss scale);
+    `nonfinite` (int32 [1], optional) counts inf / nan results."""
     _dev(x, "x")
     if x.dtype != torch.float32 or (nonfinite is not None and nonfinite.dtype != torch.int32):
         raise TypeError("scale_check_: x float32, nonfinite int32")
-    check(lib.bf_scale_check(_ptr(x), x.numel(), float(scale), _ptr(nonfinite), _stream()), "bf_scale_check")
+    if isinstance(scale, torch.Tensor):
+        _dev(scale, "scale")
+        if scale.dtype != torch.float32 or scale.numel() < 1:
+            raise TypeError("scale_check_: a device scale is one fp32 element")
+        check(lib.bf_scale_check_dev(_ptr(x), x.numel(), _ptr(scale), _ptr(nonfinite), _stream()), "bf_scale_check_dev")
+    else:
+        check(lib.bf_scale_check(_ptr(x), x.numel(), float(scale), _ptr(nonfinite), _stream()), "bf_scale_check")
+
+
+def gradscale_update_(state: torch.Tensor, flag: torch.Tensor, backoff: float, growth: float, growth_interval: int,
+                      min_scale: float, max_scale: float) -> None:
+    """End of a guarded step: device-side loss-scale schedule (bf_gradscale_update); clears `flag`."""
+    _dev(state, "state")
+    _dev(flag, "flag")
+    if state.dtype != torch.float32 or state.numel() < 8 or flag.dtype != torch.int32:
+        raise TypeError("gradscale_update_: state fp32 [8], flag int32 [1]")
+    check(lib.bf_gradscale_update(_ptr(state), _ptr(flag), float(backoff), float(growth), int(growth_interval),
+                                  float(min_scale), float(max_scale), _stream()), "bf_gradscale_update")
 
 
 def sumsq(x: torch.Tensor) -> torch.Tensor:

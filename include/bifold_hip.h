@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 6
+#define BF_ABI_VERSION 7
 
 enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
@@ -390,10 +390,18 @@ int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_ef
  *   parameters (the cdt operands of next step's GEMMs).
  *   grad_scale_dev (optional device fp32 scalar) multiplies the gradient first
  *   (gradient clipping, __main__.py:148-149; DDP averaging).
+ *   skip_flag_dev (optional device counter): non-zero -> the launch leaves param / moments / shadow untouched
+ *   (the BF_F16 mode's guarded step: a backward that produced a non-finite gradient is dropped like
+ *   torch.cuda.amp.GradScaler drops optimizer.step(), with no host read; the reference trains in fp32,
+ *   __main__.py:138-152, and has no counterpart).  skipped_dev (optional device fp32 scalar) = steps dropped so
+ *   far; `step` is the caller's count minus the `skipped_known` drops it knew of when it computed the count, and
+ *   the kernel takes skipped_dev[0] - skipped_known more off for the bias corrections (a dropped step does not
+ *   advance Adam's t).
  * ---------------------------------------------------------------------- */
 int bf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* shadow,
                  int shadow_dtype, size_t count, int step, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int decoupled, const float* grad_scale_dev,
+                 const unsigned* skip_flag_dev, const float* skipped_dev, float skipped_known,
                  bf_stream_t stream);
 
 /* sum of squares of x (fp32 [count]) -> out[0] (fp32; partial_ws >= 1024 floats). */
@@ -415,6 +423,17 @@ int bf_clip_grad_norm(float* grad, size_t count, float max_norm, float* ws, floa
  * subnormal), and each slice of the gradient arena by 1 / S as the backward completes it.  The reference trains in
  * fp32 (__main__.py:135-150) and has no counterpart. */
 int bf_scale_check(float* x, size_t count, float scale, unsigned* nonfinite_count, bf_stream_t stream);
+/* The same with the factor read from device memory (scale_dev[0]): the dynamic loss scale lives on the device. */
+int bf_scale_check_dev(float* x, size_t count, const float* scale_dev, unsigned* nonfinite_count,
+                       bf_stream_t stream);
+/* End of a guarded optimiser step (after bf_adam_step with skip_flag_dev = nonfinite_flag): device-side schedule of
+ * the loss scale, no host read.  state (fp32 [8]): [0] S, [1] 1 / S, [2] clean steps since the last change, [3] steps
+ * dropped so far, [4] non-finite gradient elements seen so far, [5] overflows that found S already at min_scale.
+ * flag != 0: S = max(S * backoff, min_scale), [3] += 1; else after growth_interval clean steps S = min(S * growth,
+ * max_scale).  The flag is cleared.  Counterpart of torch.cuda.amp.GradScaler.update(); nothing in the reference
+ * (fp32 training, __main__.py:138-152). */
+int bf_gradscale_update(float* state, unsigned* nonfinite_flag, float backoff, float growth, int growth_interval,
+                        float min_scale, float max_scale, bf_stream_t stream);
 
 /* Inverted dropout with a replayable mask: y[i] (+)= keep(seed, i) ? x[i] / (1 - p) : 0, keep = a pure function
  * of (seed, element index) (splitmix64, 24 bits against p * 2^24), so the backward pass regenerates the mask from

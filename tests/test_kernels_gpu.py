@@ -102,10 +102,11 @@ def ref_gemm(a, b, trans_a, b_kn):
     return A @ B
 
 
-@pytest.fixture(params=[-1, 8], ids=["auto", "p8"])
+@pytest.fixture(params=[-1, 8, 9], ids=["auto", "p8", "p8bk64"])
 def gemm_variant(request, L):
-    """Run the bf16 GEMM tests twice: with the automatic kernel choice and with the persistent
-    256x256 kernel forced (bf_gemm_set_variant), which the automatic choice only picks for M >= 32768."""
+    """Run the bf16 GEMM tests three times: with the automatic kernel choice, with the persistent
+    256x256 kernel forced (bf_gemm_set_variant), which the automatic choice only picks for M >= 32768, and with
+    its BK = 64 full-line main loop forced (variant 9: NT calls whose K is a multiple of 64)."""
     L.lib.bf_gemm_set_variant(request.param)
     yield request.param
     L.lib.bf_gemm_set_variant(-1)
@@ -234,22 +235,25 @@ def test_gemm_gelu_grad_and_remap(ops, L, gpu, cdt, gemm_variant):
 
 
 @pytest.mark.parametrize("half", HALF)
-@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
-def test_gemm_persistent_rounds(ops, L, gpu, layout, half):
+@pytest.mark.parametrize("layout,k,variant", [("nt", 192, 8), ("nn", 192, 8), ("tn", 96, 8),
+                                              ("nt", 64, 9), ("nt", 128, 9), ("nt", 192, 9), ("nt", 448, 9)])
+def test_gemm_persistent_rounds(ops, L, gpu, layout, k, variant, half):
     """More 256x256 work items than CUs (the persistent kernel loops, the next item's first
-    stages are in flight during the epilogue), ragged M / N tails, 3 K stages, bf16 and fp32 out."""
+    stages are in flight during the epilogue), ragged M / N tails, 3 K stages, bf16 and fp32 out.
+    Variant 9 = the BK = 64 main loop at 1 / 2 / 3 / 7 K tiles (its region refills start and drain differently)."""
     trans_a, b_kn = layout[0] == "t", layout[1] == "n"
-    m, n, k = 5000, 3592, 96
+    m, n = 5000, 3592
     g = torch.Generator().manual_seed(77)
     a = round_to(torch.randn((k, m) if trans_a else (m, k), generator=g), half)
     b = round_to(torch.randn((k, n) if b_kn else (n, k), generator=g), half)
     bias = torch.randn(n, generator=g)
     ref = ref_gemm(a, b, trans_a, b_kn) + bias.double()
-    L.lib.bf_gemm_set_variant(8)
+    L.lib.bf_gemm_set_variant(variant)
     try:
         for odt, tol in ((torch.float32, 1e-5), (half, 2 ** -8 if half == torch.bfloat16 else 2 ** -11)):
             out = ops.gemm(a.to(gpu).to(half), b.to(gpu).to(half), trans_a=trans_a, b_kn=b_kn,
                            bias=bias.to(gpu), out_dtype=odt, split_k=1)
+            assert L.lib.bf_gemm_last_variant() == 8
             assert rel_err(out.float(), ref) < tol
     finally:
         L.lib.bf_gemm_set_variant(-1)
