@@ -58,6 +58,12 @@ class SyntheticLoader:
         self.strategy = str(cfg.processor.get("strategy", "gmm"))
         self.siglip = model_name.startswith("siglip")
         self.context = int(model_cfg.get("context_length", 0) or 0) if model_name == "siglip_sequential" else 0
+        # fault injection for the fp16 guard's tests (global step indices, counted over epochs): a poisoned batch carries
+        # one +inf target pixel -> a non-finite loss gradient -> the step must be dropped on the device; a skipped batch
+        # is generated (the random stream advances) but not served -- the clean run the poisoned one must equal.
+        self.poison_steps = {int(x) for x in (dataset_cfg.get("poison_steps", None) or [])}
+        self.skip_steps = {int(x) for x in (dataset_cfg.get("skip_steps", None) or [])}
+        self.served = 0
 
     def __len__(self):
         return self.steps
@@ -88,6 +94,11 @@ class SyntheticLoader:
             pixels = {n: torch.randint(1, s, (b, 2), generator=g, device=dev).float() for n in names}
             sample.update(pixels)
             sample.update(heatmap_targets(pixels, s, self.sigma, self.strategy))
+            step, self.served = self.served, self.served + 1
+            if step in self.skip_steps:
+                continue
+            if step in self.poison_steps:
+                sample[f"{names[0]}_heatmap"][0, 0, 0] = float("inf")
             yield sample
 
 
@@ -268,12 +279,20 @@ class Trainer:
         tower = getattr(self.model, "clip_encoder", None) or getattr(self.model, "siglip_model", None)
         if tower is not None:
             tower.check_token_ids()
-        scaler = getattr(self.model, "_grad_scaler", None)        # fp16 mode: static loss scale (models/gradscale.py)
+        scaler = getattr(self.model, "_grad_scaler", None)        # fp16 mode: guarded step (models/gradscale.py)
         if scaler is not None:
-            bad = scaler.overflowed()                             # one device read per epoch, like the loss above
-            if bad:
-                raise FloatingPointError(f"model.dtype=fp16: {bad} non-finite gradient elements in epoch {epoch} at "
-                                         f"loss scale {scaler.scale:g}; set model.loss_scale lower or model.dtype=bf16")
+            # one device read per epoch, like the loss above.  A backward that overflowed binary16 was DROPPED on the
+            # device (parameters and moments untouched, loss scale halved) -- nothing to repair here; the counters are
+            # identical on every rank (the flag is MAX-reduced), so all ranks report / raise together.
+            seen = scaler.read()
+            dropped = scaler.overflowed()
+            if dropped and self.rank == 0:
+                print(f"epoch {epoch}: model.dtype=fp16 dropped {dropped} optimiser step(s) with non-finite gradients; "
+                      f"loss scale now {seen['scale']:g}")
+            if seen["at_floor"]:
+                raise FloatingPointError(f"model.dtype=fp16: gradients overflow even at loss scale {seen['scale']:g} "
+                                         f"({seen['at_floor']} step(s) in or before epoch {epoch}): the run diverged, or "
+                                         f"needs model.dtype=bf16")
 
     def eval_epoch(self, epoch=None) -> Tuple[Optional[bool], Dict]:
         self.model.eval()

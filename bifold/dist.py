@@ -96,6 +96,12 @@ def gradient_sync_for(model, group: Optional[dist.ProcessGroup] = None) -> "Grad
     depth = model.pick_place.fusion.depth
     sync = GradSync(arena.grad, layer_buckets(names, offsets, depth, arena.count), depth, group)
     model.register_grad_ready_hook(sync.on_ready)
+    # fp16 mode: the overflow flag that guards the optimiser step (models/gradscale.py) must read the same on every
+    # rank, or one replica drops a step the others apply -- it travels (MAX) behind the last gradient bucket
+    from .models.gradscale import scaler_of
+    scaler = scaler_of(model)
+    if scaler is not None:
+        sync.flag_getter = lambda: scaler.nonfinite
     return sync
 
 
@@ -125,6 +131,7 @@ class GradSync:
         self.avg_native = (not dist.is_initialized()) or dist.get_backend(group) == "nccl"    # ReduceOp.AVG is RCCL's
         self.side = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
         self.pending: List = []
+        self.flag_getter = None          # () -> int32 [1] tensor MAX-reduced with the final bucket, or None
         if coalesce is None:
             coalesce = int(os.environ.get("BIFOLD_DDP_COALESCE", "4"))
         self.coalesce = max(1, coalesce)
@@ -184,13 +191,32 @@ class GradSync:
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 view.div_(self.world)
 
+    def _launch_flag(self) -> None:
+        flag = self.flag_getter() if self.flag_getter is not None else None
+        if flag is None or (self.world == 1 and os.environ.get("BIFOLD_FORCE_PG") != "1") or \
+                os.environ.get("BIFOLD_DDP_DRYRUN") == "1":
+            return
+        if self.on_gpu and self.avg_native:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+            self.pending.append(work)
+        else:
+            if self.on_gpu:
+                torch.cuda.current_stream().synchronize()
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+
     def on_ready(self, layer: int) -> None:
         if layer >= 0:
             spans = self.plan.get(layer)
             if spans:
                 self._launch(spans)
-        elif self.final:
-            self._launch(self.final)
+        else:
+            if self.final:
+                self._launch(self.final)
+            self._launch_flag()           # after the last un-scaling of this backward: the count is complete
 
     def finish(self) -> None:
         """Make the compute stream wait for every outstanding bucket."""

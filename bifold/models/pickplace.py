@@ -421,7 +421,7 @@ def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride
 
 
 def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstride: int, heat, w_eff, rows_ws,
-                      d_heats, d_tok, dtok_bstride: int, batch: int, grad_scale: float = 1.0):
+                      d_heats, d_tok, dtok_bstride: int, batch: int, grad_scale=None):
     """Backward of decoder_heads_fwd: writes d_tok (fp32 view like tok; token 0 gets zeros) and every
     decoder parameter gradient into the arena.  Returns the event after which the decoder gradients are
     complete: the per-head collapse backward runs on the side stream.  `grad_scale` (fp16 mode, models/gradscale.py)
@@ -436,7 +436,7 @@ def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstrid
             g_low[h].zero_()
         else:
             ops.decoder_upsample_sigmoid_bwd(heat[h], d_heats[h].contiguous(), U, batch, pp.grid, out=g_low[h])
-    if grad_scale != 1.0:
+    if grad_scale is not None:                             # a number or the scaler's device scalar
         ops.scale_check_(g_low, grad_scale)
     g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
     g_b = torch.empty(nh, dtype=torch.float32, device=dev)
@@ -474,7 +474,7 @@ def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch:
 
 
 def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heats, on_layer_done=None,
-                       grad_scale: float = 1.0):
+                       grad_scale=None):
     """Backward of fusion_decoder_fwd: writes every fusion / decoder parameter gradient into the
     arena and returns d(fusion input) fp32 [B*seq, dim] (all of it times `grad_scale`)."""
     dim = pp.dim
@@ -636,9 +636,9 @@ class RGBTailFn(torch.autograd.Function):
         cdt = model.compute_dtype
         g = A.grad_view
         dim = pp.dim
-        gs = scaler_of(model)                                  # fp16: static loss scale (models/gradscale.py)
+        gs = scaler_of(model)                                  # fp16: loss scale (models/gradscale.py)
         ready = gs.ready if gs is not None else model._grad_ready
-        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else 1.0)
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else None)
         d_rgb = ops.fusion_assemble_bwd(dx, cdt, g(model.text_token).view(-1),
                                         g(model.text_pos_embedding).view(-1, dim),
                                         g(model.rgb_pos_embedding).view(-1, dim),
@@ -702,9 +702,9 @@ class SegmentTailFn(torch.autograd.Function):
         cdt = model.compute_dtype
         g = A.grad_view
         dim = pp.dim
-        gs = scaler_of(model)                                  # fp16: static loss scale (models/gradscale.py)
+        gs = scaler_of(model)                                  # fp16: loss scale (models/gradscale.py)
         ready = gs.ready if gs is not None else model._grad_ready
-        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else 1.0)
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else None)
         d_type = g(pp.fusion.token_type_embeddings.weight)
         d_type.zero_()
         leads = {id(sg["lead"]): sg["lead"] for sg in c.segments}

@@ -55,6 +55,7 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros_like(arena.flat)
         self.step_count = 0
         self.grad_scale: Optional[torch.Tensor] = None       # device scalar: clip coef and/or 1/world
+        self._scaler_sd = None                               # fp16 scaler state of a loaded checkpoint, until the scaler exists
 
     # -- Trainer-facing API ---------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False) -> None:
@@ -76,24 +77,46 @@ class FusedAdam:
             raise NotImplementedError("closures are not supported")
         g = self.param_groups[0]
         self.step_count += 1
+        # fp16 mode (models/gradscale.py): the step is GUARDED by the device-side overflow flag of this backward --
+        # non-zero leaves parameters, moments and the 16-bit copy untouched, and a dropped step does not advance
+        # Adam's t: `step_count` counts calls, the device counts drops, the kernel takes the difference.
+        gs = getattr(self.arena, "grad_scaler", None)
+        if gs is not None and gs.state is not None and self._scaler_sd is not None:
+            gs.load_state_dict(self._scaler_sd)            # a checkpoint loaded before the scaler existed
+            self._scaler_sd = None
+        flag, skipped, known = gs.guard() if gs is not None and gs.state is not None else (None, None, 0.0)
         ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.arena.shadow,
-                      self.step_count, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                      self.decoupled, self.grad_scale)
+                      self.step_count - int(known), g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                      self.decoupled, self.grad_scale, flag, skipped, known)
+        if flag is not None:
+            gs.update()
         self.arena.mark_synced()
         self.arena.grads_pending = False
+
+    def _applied_steps(self) -> int:
+        """Optimiser steps that changed the parameters (calls minus the steps the fp16 guard dropped)."""
+        gs = getattr(self.arena, "grad_scaler", None)
+        if gs is None or gs.state is None:
+            return self.step_count
+        return self.step_count - gs.read()["skipped"]
 
     # -- checkpoint format of torch.optim.Adam --------------------------------------------
     def state_dict(self) -> Dict:
         state = {}
-        if self.step_count > 0:
+        applied = self._applied_steps()
+        if applied > 0:
             for i, p in enumerate(self.params):
                 o, cnt = self.arena.offsets[self.arena.name_of(p)]
-                state[i] = {"step": torch.tensor(float(self.step_count)),
+                state[i] = {"step": torch.tensor(float(applied)),
                             "exp_avg": self.exp_avg[o:o + cnt].view(p.shape).clone(),
                             "exp_avg_sq": self.exp_avg_sq[o:o + cnt].view(p.shape).clone()}
         group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
         group["params"] = list(range(len(self.params)))
-        return {"state": state, "param_groups": [group]}
+        out = {"state": state, "param_groups": [group]}
+        gs = getattr(self.arena, "grad_scaler", None)
+        if gs is not None and gs.state is not None:       # extra key: torch.optim.Adam.load_state_dict ignores it
+            out["bifold_grad_scaler"] = gs.state_dict()
+        return out
 
     def load_state_dict(self, sd: Dict) -> None:
         group = sd["param_groups"][0]
@@ -110,6 +133,15 @@ class FusedAdam:
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ; FusedAdam keeps one step counter")
         self.step_count = steps.pop() if steps else 0
+        gs = getattr(self.arena, "grad_scaler", None)
+        self._scaler_sd = sd.get("bifold_grad_scaler")
+        if gs is not None and gs.state is not None:
+            if self._scaler_sd is not None:
+                gs.load_state_dict(self._scaler_sd)
+                self._scaler_sd = None
+            else:
+                gs.skipped_known = 0.0                     # the loaded step count is net of drops
+                gs.state[3] = 0.0
 
 
 # ---- torch.nn.utils.clip_grad_norm_(model.parameters(), c), unchanged at the call site -----------

@@ -148,6 +148,59 @@ def test_model_hooks_drive_gradsync_world2_gloo():
     assert dict(out) == {0: True, 1: True}
 
 
+def _flag_worker(rank, world, port, out):
+    """fp16 mode under data parallelism: the overflow flag that guards the optimiser step is MAX-reduced behind the
+    last gradient bucket, so a backward that overflowed on ONE rank drops the step on EVERY rank (and a clean step
+    stays clean).  Real model hooks, host arena, gloo."""
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from bifold import dist as bdist
+    from bifold.models import Models
+    from bifold.models.clip_encoder import CLIP_CONFIGS
+    from bifold.models.gradscale import scaler_of
+    bdist.init_process_group_from_env("gloo")
+    CLIP_CONFIGS["tiny-ddp"] = dict(embed_dim=32, image_resolution=64, vision_layers=1, vision_width=64,
+                                    vision_patch_size=16, context_length=77, vocab_size=64, transformer_width=64,
+                                    transformer_heads=1, transformer_layers=1)
+    cfg = dict(name="rgb_clip", image_size=64, is_bimanual=False, requires_graph=False, text_encoder="tiny-ddp",
+               patch_size=16, depth=3, heads=2, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
+               pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype="fp16")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = Models.get_by_name(cfg, device=torch.device("cpu"))
+    arena = _HostArena(model.trainable_params())
+    model.trainable_arena = lambda: arena
+    sync = bdist.gradient_sync_for(model)
+    scaler = scaler_of(model)
+    assert scaler is not None and sync.flag_getter is not None
+    scaler._plan()                                     # what the first backward does: the flag exists
+    assert arena.grad_scaler is scaler
+    depth = model.pick_place.fusion.depth
+    seen = []
+    for step, bad_rank in enumerate((1, None, 0)):
+        arena.grad.fill_(float(rank + 1))
+        if bad_rank == rank:
+            scaler.nonfinite[0] = 7 + rank                 # this rank's un-scaling counted non-finite results
+        for i in reversed(range(depth)):
+            model._grad_ready(i)
+        model._grad_ready(-1)
+        sync.finish()
+        seen.append(int(scaler.nonfinite.item()))
+        scaler.nonfinite.zero_()                           # bf_gradscale_update's last act
+    out[rank] = seen == [8, 0, 7] and bool(torch.allclose(arena.grad, torch.full_like(arena.grad, 1.5)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overflow_flag_reaches_every_rank_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_flag_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def test_bench_self_launches_its_ranks(tmp_path):
     """`python bench.py --gpus 2` with no torchrun environment must start its two ranks itself (the driver's
     command).  Without a GPU each rank stops at "needs an MI355X" -- AFTER it has joined the 2-rank rendezvous the

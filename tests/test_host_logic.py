@@ -45,7 +45,7 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     assert L.lib.bf_layernorm_fwd(None, 0, None, None, None, 0, None, None, 4, 30, 1e-5, None) == -1
     assert L.lib.bf_attention_fwd(None, None, None, None, 1, 8, 1, 40, 1.0, 0, 1, None) == -1   # head_dim 40
     assert b"head_dim" in L.lib.bf_last_error()
-    assert L.lib.bf_adam_step(None, None, None, None, None, 1, 6, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None) == -1
+    assert L.lib.bf_adam_step(None, None, None, None, None, 1, 6, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None, None, None, 0.0, None) == -1
     assert L.lib.bf_scale_check(None, 0, 1.0, None, None) == -1
     g.m = g.n = g.k = 64; g.lda = g.ldb = g.ldc = 64; g.cdt, g.c_dtype = L.F16, L.BF16      # 16-bit output of another type
     assert L.lib.bf_gemm(C.byref(g), None) == -1 and b"c_dtype" in L.lib.bf_last_error()

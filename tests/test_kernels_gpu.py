@@ -744,6 +744,56 @@ def test_scale_check_scales_in_place_and_counts_nonfinite(ops, gpu):
     assert torch.equal(y, y0 * 0.5)
 
 
+def test_guarded_adam_step_drops_flagged_steps_and_keeps_its_own_count(ops, gpu):
+    """The fp16 mode's guarded step (round 4): bf_adam_step with a non-zero device flag changes NOTHING (parameters,
+    moments, 16-bit copy); bf_gradscale_update then halves the device-side scale, counts the drop and clears the
+    flag; later steps take the drop off Adam's t on the device -- the result equals torch.optim.Adam fed only the
+    clean gradients, although the host kept counting 1, 2, 3 ... and never read anything back."""
+    g = torch.Generator().manual_seed(21)
+    n = 4096
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=1e-3)
+    p, m, v = p0.to(gpu), torch.zeros(n, device=gpu), torch.zeros(n, device=gpu)
+    shadow = torch.zeros(n, dtype=torch.float16, device=gpu)
+    state = torch.zeros(8, device=gpu)
+    state[0], state[1] = 2.0 ** 20, 2.0 ** -20
+    flag = torch.zeros(1, dtype=torch.int32, device=gpu)
+    sched = dict(backoff=0.5, growth=2.0, growth_interval=2, min_scale=1.0, max_scale=2.0 ** 20)
+    drops = {2, 3, 6}
+    for call in range(1, 9):
+        gr = torch.randn(n, generator=g)
+        before = (p.clone(), m.clone(), v.clone(), shadow.clone())
+        if call in drops:
+            gd = gr.to(gpu)
+            gd[5] = float("nan")
+            flag.fill_(3)                          # what bf_scale_check would have counted
+        else:
+            gd = gr.to(gpu)
+            ref_p.grad = gr.clone()
+            opt.step()
+        ops.adam_step(p, gd, m, v, shadow, call, 1e-3, 0.9, 0.999, 1e-8, 0.0, False, None, flag, state[3:4], 0.0)
+        ops.gradscale_update_(state, flag, **sched)
+        if call in drops:
+            for a, b in zip(before, (p, m, v, shadow)):
+                assert torch.equal(a, b)
+        assert flag.item() == 0
+    assert torch.isfinite(p).all()
+    assert rel_err(p, ref_p.detach()) < 1e-6
+    st = state.tolist()
+    # 2^20 -> (drop) 2^19 -> (drop) 2^18 -> two clean steps: 2^19 -> (drop) 2^18 -> two clean steps: 2^19
+    assert st[3] == 3 and st[4] == 9 and st[0] == 2.0 ** 19 and st[1] == 2.0 ** -19 and st[5] == 0
+    # the scale read from the device: x *= state[0]
+    x = torch.ones(8, device=gpu)
+    ops.scale_check_(x, state[0:1], flag)
+    assert torch.equal(x.cpu(), torch.full((8,), 2.0 ** 19)) and flag.item() == 0
+    # at the floor an overflow is recorded as such
+    state[0] = 1.0
+    flag.fill_(1)
+    ops.gradscale_update_(state, flag, **sched)
+    assert state[0].item() == 1.0 and state[5].item() == 1
+
+
 # ------------------------------------------------------------------ either side of the step
 def _postproc():
     import os

@@ -108,10 +108,12 @@ def test_trainer_clip_warmup_eval_save_and_resume(gpu, run_home, monkeypatch):
         assert (got - v).abs().max().item() <= 1e-6 * (v.abs().max().item() + 1e-12) + 1e-9, k
 
 
-def test_trainer_default_fp16_mode_trains_and_reports_overflow(gpu, run_home, capsys):
+def test_trainer_default_fp16_mode_trains_and_survives_overflow(gpu, run_home, capsys):
     """`python -m bifold` with the shipped `model.dtype: fp16`: the loss-scaled backward trains (mean loss falls over
-    the epochs, no non-finite gradient counted), and a loss scale far beyond binary16's range is REPORTED -- the
-    Trainer reads the scaler's overflow counter at the end of the epoch and raises instead of stepping on."""
+    the epochs, no step dropped); with a loss scale far beyond binary16's range every backward overflows and every
+    step is DROPPED on the device -- parameters and moments stay bit for bit what they were, the scale halves per
+    step, the Trainer reports the drops at the end of the epoch and does not raise (round 3 applied the non-finite
+    gradients and raised an epoch later)."""
     import bifold.__main__ as M
     import re
     import warnings
@@ -119,15 +121,52 @@ def test_trainer_default_fp16_mode_trains_and_reports_overflow(gpu, run_home, ca
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         t = M.main(list(ov))
-    assert t.model.compute_dtype == torch.float16 and t.model._grad_scaler.overflowed() == 0
+    assert t.model.compute_dtype == torch.float16 and t.model._grad_scaler.read()["skipped"] == 0
     means = [float(x) for x in re.findall(r"mean loss ([0-9.]+)", capsys.readouterr().out)]
     assert len(means) == 4 and means[-1] < means[0], means
     os.chdir(str(run_home))
     bad = [o for o in ov if not o.startswith(("epochs=", "scheduler="))] + ["epochs=1", "model.loss_scale=1e30", "seed=5"]
     tb, _ = _trainer(bad)
     tb.prepare_train()
-    with pytest.raises(FloatingPointError, match="non-finite gradient"):
-        tb.train_epoch(0)
+    before = tb.optimizer.arena.flat.clone()
+    tb.train_epoch(0)
+    n = len(tb.train_dataloader)
+    seen = tb.model._grad_scaler.read()
+    assert seen["skipped"] == n and seen["at_floor"] == 0 and abs(seen["scale"] / (1e30 * 0.5 ** n) - 1) < 1e-6
+    assert torch.equal(tb.optimizer.arena.flat, before)                      # nothing was applied
+    assert not tb.optimizer.exp_avg.any() and not tb.optimizer.exp_avg_sq.any()
+    assert f"dropped {n} optimiser step" in capsys.readouterr().out
+    assert tb.optimizer.state_dict()["state"] == {}                          # Adam's t is still 0
+
+
+def test_fp16_run_with_one_poisoned_batch_equals_the_clean_run_minus_that_step(gpu, run_home, capsys):
+    """One batch of a fp16 training run carries an inf target pixel (`train_dataset.poison_steps`): its backward is
+    non-finite, the device-side guard drops exactly that optimiser step and halves the loss scale, and the run ends
+    with finite parameters equal to those of the run that never saw the batch (`train_dataset.skip_steps`) -- same
+    weights, same Adam moments, same step count.  No host read happens inside the epoch."""
+    base = [o for o in OVERRIDES if not o.startswith(("model.dtype=", "epochs=", "gradient_clip=", "scheduler=",
+                                                      "eval_epochs=", "save_epochs="))] + \
+           ["epochs=1", "scheduler=none", "eval_epochs=null", "save_epochs=null", "train_dataset.length=96"]
+    tp, _ = _trainer(base + ["train_dataset.poison_steps=[4]"])
+    tp.prepare_train()
+    tp.train_epoch(0)
+    os.chdir(str(run_home))
+    tc, _ = _trainer(base + ["train_dataset.skip_steps=[4]"])
+    tc.prepare_train()
+    tc.train_epoch(0)
+    sp, sc = tp.model._grad_scaler.read(), tc.model._grad_scaler.read()
+    assert sp["skipped"] == 1 and sp["nonfinite"] > 0 and sc["skipped"] == 0
+    assert sp["scale"] == sc["scale"] / 2
+    assert "dropped 1 optimiser step" in capsys.readouterr().out
+    a, b = tp.optimizer.arena.flat, tc.optimizer.arena.flat
+    assert torch.isfinite(a).all() and torch.isfinite(tp.optimizer.exp_avg).all() and torch.isfinite(tp.optimizer.exp_avg_sq).all()
+    # the seven later steps ran at half the loss scale: a power of two, so only binary16's subnormal tail can differ
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()
+    assert (tp.optimizer.exp_avg - tc.optimizer.exp_avg).abs().max().item() <= 1e-3 * tc.optimizer.exp_avg.abs().max().item()
+    n = len(tp.train_dataloader)
+    assert tp.optimizer.step_count == n and tc.optimizer.step_count == n - 1
+    assert tp.optimizer.state_dict()["state"][0]["step"].item() == n - 1      # a dropped step does not advance Adam's t
+    assert tp.optimizer.state_dict()["bifold_grad_scaler"]["scale"] == sp["scale"]
 
 
 def test_a_reference_shaped_checkpoint_resumes(gpu, run_home):
