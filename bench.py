@@ -192,10 +192,11 @@ def cpu_baseline(steps: int = 10, warmup: int = 3, batch: int = 4):
                       f"steps, median {med:.2f} s/step, torch threads = cores"}
 
 
-def parity_vs_oracle(model, sample, n: int = 4):
+def parity_vs_oracle(model, sample, n: int = 4, kind: str = "a"):
     """north_star's accuracy gate on the benchmarked configuration itself: the first `n` samples of the timed batch
     (samples are independent in the forward) through the CPU oracle in fp32 with the model's current weights,
-    against the heatmaps the HIP path produced for them INSIDE the full batch."""
+    against the heatmaps the HIP path produced for them INSIDE the full batch.  `kind`: "a" / "vitl14" -> the
+    rgb_clip oracle, "siglip_seq" -> the siglip_sequential oracle (12-layer towers, 16 fusion heads, bimanual)."""
     from oracle import bifold_oracle as O
     model.eval()
     with torch.no_grad():
@@ -203,9 +204,12 @@ def parity_vs_oracle(model, sample, n: int = 4):
     state = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     sub = {k: v[:n].detach().cpu() for k, v in sample.items() if isinstance(v, torch.Tensor)}
     with torch.no_grad():
-        ref = O.rgb_clip_forward(state, sub, heads=model.pick_place.fusion.heads)
+        if kind == "siglip_seq":
+            ref = O.siglip_sequential_forward(state, sub, 12, model.pick_place.fusion.heads, True)
+        else:
+            ref = O.rgb_clip_forward(state, sub, heads=model.pick_place.fusion.heads)
     worst_rel, worst_abs, mse, logit_rel = 0.0, 0.0, 0.0, 0.0
-    for k in ("pick_heatmap", "place_heatmap"):
+    for k in sorted(k for k in ref if k.endswith("_heatmap")):
         got, want = out[k][:n].double().cpu(), ref[k].double()
         worst_abs = max(worst_abs, (got - want).abs().max().item())
         worst_rel = max(worst_rel, ((got - want).abs().max() / (want.abs().max() + 1e-30)).item())
@@ -244,9 +248,13 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
-    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16", "fp32"],
-                    help="16-bit MFMA operand type of the step (fp32 = the exact parity mode); fp16 = CLIP's native "
-                         "dtype with a loss-scaled backward, the mode that meets the 1e-3 gate on logits")
+    ap.add_argument("--dtype", default=None, choices=["fp16", "bf16", "fp32"],
+                    help="16-bit MFMA operand type of the step (fp32 = the exact parity mode); default fp16 = CLIP's "
+                         "native dtype with a loss-scaled backward, the mode that meets the 1e-3 gate on logits "
+                         "(--config fp8: bf16, the only mode its e4m3 towers pair with)")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the `alt` object: the same step in bf16 (BASELINE configs[1]'s label) for 10 steps after "
+                         "the timed region, with its own parity check")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-stride", type=int, default=0,
@@ -291,27 +299,35 @@ def main():
     big = args.config == "vitl14"
     seq = args.config == "siglip_seq"
     fp8 = args.config == "fp8"
+    if args.dtype is None:
+        args.dtype = "bf16" if args.config == "fp8" else "fp16"
     tag = {"fp16": "f16", "bf16": "bf16", "fp32": "f32"}[args.dtype]
-    if fp8 and args.dtype != "bf16":
-        raise SystemExit("--config fp8 is the bf16 step with e4m3 towers")
-    cfg = dict(name="rgb_clip", image_size=336 if big else 224, is_bimanual=False, requires_graph=False,
-               text_encoder="ViT-L/14@336px" if big else "ViT-B/16", patch_size=14 if big else 16, depth=8,
-               heads=16, mlp_ratio=4, dropout=0.0,
-               text_dropout=0.0, rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
-               fusion_model="concat_transformer", dtype="fp8" if fp8 else args.dtype)
-    if seq:
-        cfg = dict(name="siglip_sequential", image_size=384, is_bimanual=True, requires_graph=False, patch_size=16,
-                   automodel_name="google/siglip-base-patch16-384", dim=768, emb_dropout=0.0, lora=args.lora, r=8,
-                   lora_alpha=32, lora_dropout=0.0, target_modules=["q_proj", "v_proj"], threshold=0.5,
-                   text_encoder=None, pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer",
-                   depth=8, heads=16, mlp_ratio=4, dropout=0.0, dtype=args.dtype, context_length=4)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")           # random-init CLIP (no network for weights)
-        model = Models.get_by_name(cfg, device=dev).to(dev)
-    model.train()
-    loss_fn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=seq, mask_pick_heatmap=False))
-    opt = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
-                                 params=[p for p in model.parameters() if p.requires_grad])
+    if fp8 and args.dtype not in (None, "bf16"):
+        raise SystemExit("--config fp8 is the bf16 step with e4m3 towers (drop --dtype or pass --dtype bf16)")
+    def build(dtype: str):
+        """(model, loss, optimiser) of the benchmarked configuration in compute mode `dtype`, identical random init."""
+        torch.manual_seed(3407)                   # identical replicas on every rank, identical weights in every mode
+        cfg = dict(name="rgb_clip", image_size=336 if big else 224, is_bimanual=False, requires_graph=False,
+                   text_encoder="ViT-L/14@336px" if big else "ViT-B/16", patch_size=14 if big else 16, depth=8,
+                   heads=16, mlp_ratio=4, dropout=0.0,
+                   text_dropout=0.0, rgb_dropout=0.0, pick_place_model="pick_place_convdecoder",
+                   fusion_model="concat_transformer", dtype="fp8" if fp8 else dtype)
+        if seq:
+            cfg = dict(name="siglip_sequential", image_size=384, is_bimanual=True, requires_graph=False, patch_size=16,
+                       automodel_name="google/siglip-base-patch16-384", dim=768, emb_dropout=0.0, lora=args.lora, r=8,
+                       lora_alpha=32, lora_dropout=0.0, target_modules=["q_proj", "v_proj"], threshold=0.5,
+                       text_encoder=None, pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer",
+                       depth=8, heads=16, mlp_ratio=4, dropout=0.0, dtype=dtype, context_length=4)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")       # random-init CLIP (no network for weights)
+            mdl = Models.get_by_name(cfg, device=dev).to(dev)
+        mdl.train()
+        lfn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=seq, mask_pick_heatmap=False))
+        optim = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
+                                       params=[p for p in mdl.parameters() if p.requires_grad])
+        return mdl, lfn, optim
+
+    model, loss_fn, opt = build(args.dtype)
     if seq:
         sample = synthetic_sequential_batch(args.batch, dev, seed=3407 + rank)
     else:
@@ -356,9 +372,14 @@ def main():
             torch.cuda.synchronize()
 
     parity = None
-    check_parity = world == 1 and not args.no_parity and not big and not seq     # (fp8: its looser error is reported too)
+    # (fp8: its looser error is reported too; vitl14 / siglip_seq: a 2-sample prefix -- the oracle's forward at those
+    # sizes takes seconds per sample on the host; LoRA adapters start at B = 0 but their keys are PEFT's, not the
+    # oracle's: skipped there and said so)
+    check_parity = world == 1 and not args.no_parity and not (seq and args.lora)
+    pkind = "siglip_seq" if seq else ("vitl14" if big else "a")
+    pn = 2 if (big or seq) else 4
     if check_parity:
-        parity = parity_vs_oracle(model, sample)       # untimed, before any training step
+        parity = parity_vs_oracle(model, sample, pn, pkind)       # untimed, before any training step
     for _ in range(args.warmup):
         step()
     fence()
@@ -419,11 +440,37 @@ def main():
     if check_parity:
         # the same check on the weights AFTER the optimisation steps above: logits of a trained model are an order of
         # magnitude larger than at random initialisation (max |logit| 0.17 there), which is what "relative" divides by
-        parity_trained = parity_vs_oracle(model, sample)
+        parity_trained = parity_vs_oracle(model, sample, pn, pkind)
         parity_trained["after_steps"] = opt.step_count
         parity_trained["against"] = parity_trained["against"].replace(
             "same random-init weights and inputs, checked before the first optimisation step",
             f"the weights after {opt.step_count} optimisation steps (state_dict handed to the oracle), same inputs")
+
+    # BASELINE configs[1] is labelled "bf16"; the headline runs in the dtype that meets north_star's logit gate.  So the
+    # line carries BOTH: `alt` = the same step, same weights at initialisation, same batch, in bf16 -- 3 warm-up + 10
+    # timed steps AFTER everything above (its own model and optimiser; nothing of it inside the headline's timed
+    # region) and its own 4-sample parity check.
+    alt = None
+    if world == 1 and args.config == "a" and args.dtype == "fp16" and not args.no_alt and not args.host_fed:
+        del model, opt
+        torch.cuda.empty_cache()
+        model, loss_fn, opt = build("bf16")
+        alt_parity = parity_vs_oracle(model, sample) if check_parity else None
+        for _ in range(3):
+            step()
+        fence()
+        ta = time.perf_counter()
+        for _ in range(10):
+            aloss = step()
+        fence()
+        alt_elapsed = time.perf_counter() - ta
+        alt = {"dtype": "bf16", "value": round(args.batch * 10 / alt_elapsed, 2), "unit": "samples/s",
+               "ms_per_step": round(1e2 * alt_elapsed, 3), "steps": 10, "warmup": 3,
+               "step_roofline_frac": round(args.batch * 10 / alt_elapsed * GF_PER_SAMPLE / 1e3 / PEAK_BF16_TFLOPS, 4),
+               "final_loss": float(aloss.item()), "parity": alt_parity,
+               "note": "BASELINE configs[1]'s own label; same step, same initial weights and batch; run after the "
+                       "headline's timed region.  Not the headline because its logits miss north_star's 1e-3 gate "
+                       "at random initialisation (operand rounding 2^-9 against fp16's 2^-11)"}
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -524,6 +571,8 @@ def main():
             line["parity"] = parity
         if parity_trained is not None:
             line["parity_trained"] = parity_trained
+        if alt is not None:
+            line["alt"] = alt
         if world == 1 and not args.no_cpu_baseline and not big and not seq and not fp8:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

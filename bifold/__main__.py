@@ -113,6 +113,38 @@ def shard_dataloader(dl, rank: int, world: int, seed: int):
                       collate_fn=dl.collate_fn, drop_last=dl.drop_last, pin_memory=True)
 
 
+class _TrackedPixelError:
+    """What `best.pth` selection needs when the reference's `bifold.metrics` package (host-side numpy / torchmetrics /
+    scipy: out of this build's scope) is not importable: ONE number per evaluation, the mean distance in pixels
+    between the predicted and the annotated pixel over the heads, lower is better, reported under the configured
+    `tracked_metric` name.  It has the call surface `eval_epoch_pixel` uses (`reset`, call, `summary`, `best_eval`);
+    it is not the reference's metric suite -- put the reference checkout behind this build for that."""
+
+    def __init__(self, cfg):
+        self.name = str(cfg["tracked_metric"] if isinstance(cfg, dict) else cfg.tracked_metric)
+        self.best_eval: Optional[float] = None
+        self.total, self.count = 0.0, 0
+        print(f"bifold.metrics is not on the path: tracking the mean pixel error as {self.name!r} for best.pth only")
+
+    def reset(self):
+        self.total, self.count = 0.0, 0
+
+    def __call__(self, action, sample, raw_output=None):
+        for head, pred in vars(action).items():
+            want = sample[head].detach().float().cpu().numpy().reshape(len(pred), -1, 2)
+            keep = want.min(axis=(1, 2)) > 0
+            if keep.any():
+                d = np.linalg.norm(np.round(want[keep]) - np.asarray(pred)[keep, None, :], axis=-1).min(axis=1)
+                self.total, self.count = self.total + float(d.sum()), self.count + int(keep.sum())
+
+    def summary(self):
+        value = self.total / max(self.count, 1)
+        improved = self.best_eval is None or value < self.best_eval
+        if improved:
+            self.best_eval = value
+        return improved, {self.name: value}
+
+
 class Trainer:
     def __init__(self, cfg: ConfigNode, overrides=()):
         self.cfg = cfg
@@ -173,55 +205,61 @@ class Trainer:
             from bifold.metrics import Metrics          # the reference's, if on the path
             return Metrics(self.cfg.metrics)
         except ImportError:
-            from .pixel_metrics import PixelMetrics
-            return PixelMetrics(self.cfg.metrics)
+            return _TrackedPixelError(self.cfg.metrics)
 
     # ------------------------------------------------------------------ reference Trainer surface
+    @staticmethod
+    def _due(every, epoch: int) -> bool:
+        """`eval_epochs` / `save_epochs`: every N-th finished epoch, off when null or 0."""
+        return bool(every) and (epoch + 1) % int(every) == 0
+
     def train(self):
-        if self.start_epoch < self.cfg.epochs:
-            for epoch in range(self.start_epoch, self.cfg.epochs):
-                self.train_epoch(epoch)
-                if self.cfg.eval_epochs and (epoch + 1) % self.cfg.eval_epochs == 0:
-                    has_improved, _ = self.eval_epoch(epoch)
-                    if has_improved:
-                        self.save_model(epoch, is_best=True)
-                if self.cfg.save_epochs and (epoch + 1) % self.cfg.save_epochs == 0:
-                    self.save_model(epoch)
-            self.save_model(self.cfg.epochs - 1)
-            if self.world > 1:
-                torch.distributed.barrier()       # rank 0's last.pth is complete before anyone re-reads it
-        elif self.rank == 0:
-            print(f"checkpoint is already at epoch {self.start_epoch} >= epochs={self.cfg.epochs}: nothing to train")
+        """Epoch loop of the reference (bifold/__main__.py:68-80): train, evaluate every `eval_epochs` (an improved
+        tracked metric -> best.pth), write last.pth every `save_epochs` and once more after the final epoch."""
+        last = int(self.cfg.epochs) - 1
+        if self.start_epoch > last:
+            if self.rank == 0:
+                print(f"checkpoint is already at epoch {self.start_epoch} >= epochs={self.cfg.epochs}: nothing to train")
+            return
+        for epoch in range(self.start_epoch, last + 1):
+            self.train_epoch(epoch)
+            if self._due(self.cfg.eval_epochs, epoch) and self.eval_epoch(epoch)[0]:
+                self.save_model(epoch, is_best=True)
+            if self._due(self.cfg.save_epochs, epoch):
+                self.save_model(epoch)
+        self.save_model(last)
+        if self.world > 1:
+            torch.distributed.barrier()       # rank 0's last.pth is complete before anyone re-reads it
 
     def eval(self):
+        """Final evaluation (bifold/__main__.py:82-104): metrics of the chosen checkpoint, printed, and merged into
+        `eval_<dataset>.yaml` in the run directory -- entries of an earlier run that this one did not compute are
+        carried over, entries that changed are pointed out."""
         self.load_model(load_best=self.cfg.load_best)
-        eval_file = f"eval_{self.cfg.test_dataset.name}.yaml"
-        _, metric_dict = self.eval_epoch()
+        results = self.eval_epoch()[1]
         if self.rank != 0:
-            return metric_dict
-        for k, val in metric_dict.items():
-            if isinstance(val, dict):
-                for sub_k, sub_val in val.items():
-                    print(f"{k} {sub_k}:\t{sub_val:.2f}")
-            else:
-                print(f"{k}:\t{val:.2f}")
-        if os.path.isfile(eval_file):
-            with open(eval_file) as f:
-                old = yaml.load(f, Loader=yaml.Loader) or {}
-            for k, val in old.items():
-                if k not in metric_dict:
-                    metric_dict[k] = val
-                elif val != metric_dict[k]:
-                    print(f"Old value for {k} = {val} ; New value {metric_dict[k]}")
-        with open(eval_file, "w") as f:
-            yaml.dump(metric_dict, f)
-        return metric_dict
+            return results
+        for name, value in results.items():
+            rows = [(f"{name} {sub}", v) for sub, v in value.items()] if isinstance(value, dict) else [(name, value)]
+            for label, v in rows:
+                print(f"{label}:\t{v:.2f}")
+        path = f"eval_{self.cfg.test_dataset.name}.yaml"
+        previous = {}
+        if os.path.isfile(path):
+            with open(path) as f:
+                previous = yaml.load(f, Loader=yaml.Loader) or {}
+        for name, was in previous.items():
+            if name in results and results[name] != was:
+                print(f"Old value for {name} = {was} ; New value {results[name]}")
+            results.setdefault(name, was)
+        with open(path, "w") as f:
+            yaml.dump(results, f)
+        return results
 
     def seed_randomness(self):
-        random.seed(self.cfg.seed)
-        np.random.seed(self.cfg.seed)
-        torch.manual_seed(self.cfg.seed)
-        torch.cuda.manual_seed_all(self.cfg.seed)
+        seed = int(self.cfg.seed)                        # the four generators the reference seeds (:106-110)
+        for seeder in (random.seed, np.random.seed, torch.manual_seed, torch.cuda.manual_seed_all):
+            seeder(seed)
 
     def prepare_train(self):
         params_non_frozen = filter(lambda p: p.requires_grad, self.model.parameters())
@@ -233,6 +271,20 @@ class Trainer:
         if self.world > 1 or os.environ.get("BIFOLD_FORCE_PG") == "1":
             self.sync = bdist.gradient_sync_for(self.model)
         self.load_model()
+
+    def _require_gradients(self) -> None:
+        """`debug: true` (bifold/__main__.py:143-146): every trainable parameter must have received a gradient."""
+        orphans = [n for n, p in self.model.named_parameters() if p.requires_grad and p.grad is None]
+        if orphans:
+            raise ValueError(f"Parameter {orphans[0]} might not have gradient attached!")
+
+    def _log_step(self, epoch, loss, parts) -> None:
+        """The reference's per-step wandb records (bifold/__main__.py:154-159): loss + epoch, each head's loss, each
+        group's learning rate -- one record each, like there."""
+        records = [{"loss": loss, "epoch": epoch}] + [{name: value} for name, value in parts.items()]
+        records += [{f"lr_{j}": group["lr"]} for j, group in enumerate(self.optimizer.param_groups)]
+        for record in records:
+            self.writer.log(record)
 
     def train_epoch(self, epoch=None):
         self.model.train()
@@ -251,9 +303,7 @@ class Trainer:
             assert loss is not None
             loss.backward()
             if self.cfg.debug:
-                for name, param in self.model.named_parameters():
-                    if param.requires_grad and param.grad is None:
-                        raise ValueError(f"Parameter {name} might not have gradient attached!")
+                self._require_gradients()
             if self.sync is not None:
                 self.sync.finish()                # averaged gradients before they are clipped / applied
             if self.cfg.gradient_clip is not None:
@@ -262,11 +312,7 @@ class Trainer:
             if self.scheduler is not None:
                 self.scheduler.step()
             if self.writer:
-                self.writer.log({"loss": loss, "epoch": epoch})
-                for k, val in intermediate_losses.items():
-                    self.writer.log({k: val})
-                for j, param_group in enumerate(self.optimizer.param_groups):
-                    self.writer.log({f"lr_{j}": param_group["lr"]})
+                self._log_step(epoch, loss, intermediate_losses)
             # the reference calls loss.item() every step (a device sync); keep a device-side running sum
             # instead and read it once per epoch
             total = loss.detach() if total is None else total + loss.detach()
@@ -295,25 +341,29 @@ class Trainer:
                                          f"needs model.dtype=bf16")
 
     def eval_epoch(self, epoch=None) -> Tuple[Optional[bool], Dict]:
+        """(has_improved, metrics).  Inside training (`epoch` given), or with `simulator=null`, the pixel metrics;
+        `simulator=softgym` outside training asks for rollouts in the reference's `bifold.env` (bifold/__main__.py:
+        165-187), which stay outside this build."""
         self.model.eval()
-        has_improved = None
-        if epoch is not None or self.cfg.simulator is None:
-            has_improved, metric_dict = self.eval_epoch_pixel(epoch)
-        elif self.cfg.simulator == "softgym":
-            # SoftGym / PyFlex rollouts are the reference's bifold.env (CUDA-only FleX libraries): outside this
-            # build.  Said loudly, and the run still ends cleanly after training (checkpoints are written).
+        during_training = epoch is not None
+        simulator = self.cfg.simulator
+        if during_training or simulator is None:
+            has_improved, metrics = self.eval_epoch_pixel(epoch)
+        elif simulator == "softgym":
+            # SoftGym / PyFlex rollouts need the CUDA-only FleX libraries.  Said loudly, and the run still ends
+            # cleanly after training (checkpoints are written).
             if self.rank == 0:
                 print("simulator=softgym: simulator rollouts need the reference's bifold.env package and PyFlex; "
                       "SKIPPING the final simulator evaluation (pass simulator=null for the pixel metrics)")
-            metric_dict = {}
+            has_improved, metrics = None, {}
         else:
-            raise ValueError(f"Simulator {self.cfg.simulator} not supported")
+            raise ValueError(f"Simulator {simulator} not supported")
         if self.writer:
-            for k, val in metric_dict.items():
-                self.writer.log({k: val})
-        if epoch is not None:
-            assert has_improved is not None, "has_improved boolean must be specified during training"
-        return has_improved, metric_dict
+            for name, value in metrics.items():
+                self.writer.log({name: value})
+        if during_training and has_improved is None:
+            raise AssertionError("has_improved boolean must be specified during training")
+        return has_improved, metrics
 
     def eval_epoch_pixel(self, epoch):
         """bifold/__main__.py:189-238: `get_action` on every test batch (arg-max + mask snap on the device,
@@ -331,56 +381,65 @@ class Trainer:
         return self.metrics.summary()
 
     # ------------------------------------------------------------------ checkpoints (reference schema)
+    # Files and keys are the reference's (bifold/__main__.py:272-325), so either Trainer resumes the other's run:
+    # checkpoints/{last,best}.pth = {"epoch": next epoch, "random_states": (python, numpy, torch, cuda), "model",
+    # "optimizer", ["scheduler"], ["best_eval"]}.
+    CKPT_DIR = "checkpoints"
+
+    @classmethod
+    def _ckpt(cls, best: bool) -> str:
+        return os.path.join(cls.CKPT_DIR, "best.pth" if best else "last.pth")
+
+    @staticmethod
+    def _rng_snapshot():
+        cuda = torch.cuda.get_rng_state() if torch.cuda.is_available() else None
+        return (random.getstate(), np.random.get_state(), torch.get_rng_state(), cuda)
+
+    @staticmethod
+    def _rng_restore(states) -> None:
+        py, npy, cpu, cuda = states
+        random.setstate(py)
+        np.random.set_state(npy)
+        torch.set_rng_state(cpu.cpu())
+        if cuda is not None:
+            torch.cuda.set_rng_state(cuda.cpu())
+
     def load_model(self, load_best=False):
-        if load_best and os.path.isfile(os.path.join("checkpoints", "best.pth")):
-            checkpoint_file = os.path.join("checkpoints", "best.pth")
-        elif os.path.isfile(os.path.join("checkpoints", "last.pth")):
-            checkpoint_file = os.path.join("checkpoints", "last.pth")
-        else:
+        candidates = ([self._ckpt(True)] if load_best else []) + [self._ckpt(False)]
+        path = next((c for c in candidates if os.path.isfile(c)), None)
+        if path is None:
             if self.cfg.eval_only and not self.cfg.debug:
                 raise FileNotFoundError("Cannot evaluate with untrained model")
             self.start_epoch = 0
             return
-        checkpoint = torch.load(checkpoint_file, map_location=self.device, weights_only=False)
-        self.start_epoch = checkpoint["epoch"]
-        states = checkpoint["random_states"]
-        random.setstate(states[0])
-        np.random.set_state(states[1])
-        torch.set_rng_state(states[2].cpu())
-        if states[3] is not None:
-            torch.cuda.set_rng_state(states[3].cpu())
-        self.model.load_state_dict(checkpoint["model"])
+        ck = torch.load(path, map_location=self.device, weights_only=False)
+        self.start_epoch = ck["epoch"]
+        self._rng_restore(ck["random_states"])
+        self.model.load_state_dict(ck["model"])
         if not self.cfg.eval_only:
-            self.optimizer.load_state_dict(checkpoint["optimizer"])
-            if self.scheduler is not None and "scheduler" in checkpoint:
-                self.scheduler.load_state_dict(checkpoint["scheduler"])
-            if "best_eval" in checkpoint:
-                self.metrics.best_eval = checkpoint["best_eval"]
+            self.optimizer.load_state_dict(ck["optimizer"])
+            if self.scheduler is not None and "scheduler" in ck:
+                self.scheduler.load_state_dict(ck["scheduler"])
+            self.metrics.best_eval = ck.get("best_eval", self.metrics.best_eval)
         if self.rank == 0:
-            print(f"Loaded model from checkpoint {checkpoint_file}")
+            print(f"Loaded model from checkpoint {path}")
 
     def save_model(self, epoch, is_best=False):
-        if self.rank != 0:
+        if self.rank != 0:                               # replicas are identical: one writer
             return
-        os.makedirs("checkpoints", exist_ok=True)
-        model_path = os.path.join("checkpoints", "best.pth" if is_best else "last.pth")
-        state_dict = {
-            "epoch": epoch + 1,
-            "random_states": (random.getstate(), np.random.get_state(), torch.get_rng_state(),
-                              torch.cuda.get_rng_state() if torch.cuda.is_available() else None),
-            "model": self.model.state_dict(),
-            "optimizer": self.optimizer.state_dict(),
-        }
+        os.makedirs(self.CKPT_DIR, exist_ok=True)
+        ck = dict(epoch=epoch + 1, random_states=self._rng_snapshot(), model=self.model.state_dict(),
+                  optimizer=self.optimizer.state_dict())
         if self.scheduler is not None:
-            state_dict["scheduler"] = self.scheduler.state_dict()
+            ck["scheduler"] = self.scheduler.state_dict()
         if self.metrics.best_eval is not None:
-            state_dict["best_eval"] = self.metrics.best_eval
-        torch.save(state_dict, model_path)
+            ck["best_eval"] = self.metrics.best_eval
+        torch.save(ck, self._ckpt(is_best))
 
     def move_sample_to_device(self, sample):
-        for k, val in sample.items():
-            if isinstance(val, torch.Tensor):
-                sample[k] = val.to(self.device, non_blocking=True)
+        """H2D of a collated sample (bifold/__main__.py:327-332); synthetic batches are born in HBM and pass through."""
+        sample.update({k: v.to(self.device, non_blocking=True) for k, v in sample.items()
+                       if isinstance(v, torch.Tensor) and v.device != self.device})
         return sample
 
 

@@ -406,10 +406,16 @@ def _training_step_vs_oracle(gpu, cfg_of, sample, ref_forward, bim, dtypes, seed
     return seen
 
 
-# gates of the full-width training-step tests: north_star's 1e-3 on heatmaps and loss for every mode; the 16-bit modes'
-# gradients carry their operand rounding (bf16 2^-9, fp16 2^-11) through 8 layers of backward -- ~3x observed
-STEP_GATES = {"fp32": dict(heat=1e-3, loss=1e-3, grad=1e-3), "bf16": dict(heat=1e-3, loss=1e-3, grad=3e-2),
-              "fp16": dict(heat=1e-3, loss=1e-3, grad=1e-2)}
+# Gates of the full-width training-step tests.  north_star's bar -- 1e-3 relative on LOGITS and HEATMAPS against the
+# CPU path -- is asserted as such for the fp32 (exact) mode and for fp16, the shipped default (observed at full size:
+# logits 2.4e-4 / 7.4e-4, heatmaps <= 5e-5).  bf16 meets it on heatmaps and loss only: its logits carry the 2^-9
+# operand rounding (observed 2.4e-3 / 7.0e-3) and are held to the bound 1e-2 here, i.e. KNOWN to miss the gate, which
+# is why bf16 is not the default.  Gradients are not part of north_star's gate; the 16-bit
+# modes' carry their operand rounding (bf16 2^-9, fp16 2^-11) through 8 layers of backward and are bounded at ~3x
+# what was observed (1.0-1.3e-3 fp16, 5-7e-3 bf16) so that a regression shows.
+STEP_GATES = {"fp32": dict(heat=1e-3, logit=1e-3, loss=1e-3, grad=1e-3),
+              "bf16": dict(heat=1e-3, logit=1e-2, loss=1e-3, grad=3e-2),
+              "fp16": dict(heat=1e-3, logit=1e-3, loss=1e-3, grad=1e-2)}
 
 
 def test_siglip_sequential_384_t4_training_step_matches_oracle(gpu, observed):

@@ -5,6 +5,10 @@ import ctypes, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bifold_amd.hip import ops, lib as L
 dev = torch.device("cuda:0")
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else -1      # 8 = BK 32 loop, 9 = BK 64 full-line loop, -1 = the library's choice
+hdt = torch.float16 if (len(sys.argv) > 2 and sys.argv[2] == "fp16") else torch.bfloat16
+L.lib.bf_gemm_set_variant(variant)
+print(f"# variant {variant}, {hdt}")
 g = torch.Generator(device=dev).manual_seed(0)
 fn = L.lib.bf_debug_p8_probe
 fn.restype = ctypes.c_int
@@ -18,10 +22,11 @@ shapes = [
     ("fus fc1", 70400, 2048, 512, dict(bias=1, act=L.ACT_ERF_GELU)),
     ("fus out+res", 70400, 512, 512, dict(bias=1, res=1)),
     ("fus fc2+res", 70400, 512, 2048, dict(bias=1, res=1)),
+    ("big 8k", 8192, 8192, 8192, dict()),
 ]
 for name, m, n, k, o in shapes:
-    a = torch.randn(m, k, device=dev, generator=g).bfloat16()
-    b = (torch.randn(n, k, device=dev, generator=g) * k ** -0.5).bfloat16()
+    a = torch.randn(m, k, device=dev, generator=g).to(hdt)
+    b = (torch.randn(n, k, device=dev, generator=g) * k ** -0.5).to(hdt)
     kw = {}
     if o.get("bias"):
         kw["bias"] = torch.randn(n, device=dev, generator=g)
@@ -44,8 +49,9 @@ for name, m, n, k, o in shapes:
     buf = (ctypes.c_ulonglong * 16)()
     fn(buf)
     clk = buf[0] / max(buf[1], 1) * 100
+    per64 = buf[0] / max(k // 64, 1)
     tiles = ((m + 255) // 256) * ((n + 255) // 256)
     per_tile = buf[0] + buf[3] + buf[6]
     print(f"{name:12s} {m}x{n}x{k}: {ms*1e3:7.1f} us {2*m*n*k/ms/1e9:5.0f} TF/s | tiles {tiles} = {tiles/256:.2f} rounds | main {buf[0]:6d} cyc "
-          f"({buf[0]/max(buf[2],1):5.0f}/stage, ideal 1024) clock {clk:4.0f} MHz | prologue issue {buf[5]:5d} | epilogue {buf[3]-buf[5]:6d} | "
+          f"({per64:5.0f} per 64 of K, ideal 2048) clock {clk:4.0f} MHz | prologue issue {buf[5]:5d} | epilogue {buf[3]-buf[5]:6d} | "
           f"next-item wait {buf[6]:6d} | sum/tile {per_tile} cyc = {per_tile/clk:.1f} us -> x rounds {per_tile/clk*tiles/256:.0f} us", flush=True)

@@ -1,6 +1,7 @@
-"""Pixel-space evaluation metrics for `Trainer.eval_epoch_pixel` when the reference's
-`bifold.metrics` package (CPU numpy / torchmetrics / scipy; SURVEY.md §2 "out of scope") is not on the
-path next to this build.
+"""NOT part of the product (SURVEY.md §2 marks metrics OUT OF SCOPE; moved out of the `bifold` package in round 4).
+A host-side stand-in for the reference's `bifold.metrics` package, kept as a tool for runs without a reference
+checkout: `python -m bifold` itself only tracks the mean annotated-pixel distance for `best.pth` (bifold/__main__.py,
+`_TrackedPixelError`) unless `bifold.metrics` is importable.
 
 Only the two families that act on the [B, 2] pixel actions are restated -- `kp_mse` and `ap_<k>`
 (bifold/metrics/__init__.py:103-126, 176-213), including their normalisation quirks, because they are
