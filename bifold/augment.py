@@ -90,3 +90,27 @@ def augment_batch(sample: Dict[str, torch.Tensor], image_size: int, cfg=None, rn
             out[k] = ops.affine_nearest(x.float(), par)
     out["augmentation"] = par
     return out
+
+
+def process_depth(depth: torch.Tensor, mask: Optional[torch.Tensor], cfg=None, train: bool = True,
+                  rng=np.random) -> torch.Tensor:
+    """Processor._process_depth (reference bifold/data/processor.py:59-78, 122-124) for a batch of depth frames that
+    are already at the model's resolution: DepthScale in training when `depth_augmentations.random_depth_shift`
+    (one uniform draw per frame from numpy's generator, like the reference's per-sample call), MaskDepth when
+    `mask_depth`, float32, TruncatedDepthStandardization when `standardize_depth` -- two launches on the device
+    (bf_depth_prepare, bf_depth_standardize).  depth / mask: fp32 [B, 1, S, S] or [B, S, S] in HBM.
+    `add_depth_noise` is open3d's Redwood noise simulator (data/depth_augmentations.py:20-32), host-side third-party
+    code outside this build: asked for, it raises by name."""
+    get = (lambda k, d=None: (cfg.get(k, d) if cfg is not None else d))
+    da = get("depth_augmentations", {}) or {}
+    if train and da.get("add_depth_noise", False):
+        raise NotImplementedError("depth_augmentations.add_depth_noise uses open3d's DepthNoiseSimulator on the host "
+                                  "(data/depth_augmentations.py:20-32); not part of this build")
+    shift = None
+    if train and da.get("random_depth_shift", False):
+        lo, hi = float(da.get("min_shift", -0.2)), float(da.get("max_shift", 0.2))
+        shift = torch.tensor([rng.uniform(lo, hi) for _ in range(depth.shape[0])], dtype=torch.float32,
+                             device=depth.device)
+    use_mask = mask if get("mask_depth", True) else None
+    return ops.depth_frames(depth.float(), use_mask.float() if use_mask is not None else None, shift,
+                            standardize=bool(get("standardize_depth", False)))

@@ -744,6 +744,14 @@ extern "C" int bf_debug_p8_probe(unsigned long long* out) {
 // (any output type, residual / aux / copies / row remap / split-K slabs), 1 = plain bf16 (alpha, bias,
 // activation, optional pre-activation copy), 2 = bf16 GELU-grad.  One kernel with all three paths sat at
 // the 256-register limit and spilled differently with every edit.
+#ifndef P8_EPI_DIRECT
+#define P8_EPI_DIRECT 0               // 1: plain 16-bit epilogue with 16-byte stores straight from the accumulators (v_permlane16_swap), no LDS turn.
+                                      // Measured round 4 (tools/ab_gemm_libs.sh, twelve NT shapes): 3.17-3.20 ms against 3.09 through LDS -- a store
+                                      // instruction of 16 rows x 64 B costs more than the LDS turn that makes it 8 rows x 128 B saves.  Kept for A/B.
+#endif
+#ifndef P9_PHASES
+#define P9_PHASES 2                   // BK = 64 main loop: MFMA blocks per K tile (4 x 16 MFMAs, or 2 x 32 with half the barriers)
+#endif
 #ifndef P8_SOFF
 #define P8_SOFF 1                     // persistent GEMM: K advance of K-contiguous operands in the DMA's scalar offset, fragment offsets hoisted (0: round 2's loop)
 #endif
@@ -1016,6 +1024,89 @@ __device__ __forceinline__ void p8_body(
         if constexpr (BK == 64) {
             typedef typename H16<H>::x8 F8;
             const int draw_tile = nk > 4 ? nk - 4 : 0;
+#if P9_PHASES == 2
+            // Two MFMA blocks of 32 per K tile (half the barriers of the four-block loop below):
+            //   block 0 reads A0 + B0 + B1 (16 fragments) -> A0 x B0, A0 x B1;  block 1 reads A1 (8) -> A1 x B1, A1 x B0.
+            //   block 0 issues A1 of tile t+1 (its region was last read in block 1 of tile t-1), block 1 issues B0, B1,
+            //   A0 of tile t+2 (last read in block 0 of this tile): every region is refilled one block after its last
+            //   read, which is legal because a wave retires its reads (lgkmcnt(0)) BEFORE the barrier that ends its
+            //   load section -- the other group, one barrier behind, has then retired the same block's reads too before
+            //   anyone reaches the next load section.  8 pieces per wave stay in flight; a region has 2-3 blocks
+            //   (2 600 - 3 900 cycles) between issue and first read.
+            for (int t = 0; t < nk; ++t) {
+                const char* tb = smem + (t & 1) * 65536;
+                const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+                if (t == draw_tile && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
+                if (t == 0 && n1) { issue6(w, 1, 1, 0, false); issue6(w, 1, 1, 1, false); issue6(w, 1, 0, 0, false); }
+                F8 fa[2][4], fb0[2][2], fb1[2][2];
+                // ---------------- block 0
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb0[kb][j] = *(const F8*)(tb + fb6[kb] + j * 2048);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[kb][i] = *(const F8*)(tb + fa6[kb] + i * 2048);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) fb1[kb][j] = *(const F8*)(tb + fb6[kb] + 4096 + j * 2048);
+                if (n1) {
+                    issue6(w, t + 1, 0, 1, false);                       // A1 of tile t + 1
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // A1 of this tile landed
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][i] = mfma_16x16x32(fb0[kb][j], fa[kb][i], acc[j][i]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[2 + j][i] = mfma_16x16x32(fb1[kb][j], fa[kb][i], acc[2 + j][i]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+                // ---------------- block 1
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[kb][i] = *(const F8*)(tb + fa6[kb] + 8192 + i * 2048);
+                if (n2) {
+                    issue6(w, t + 2, 1, 0, false); issue6(w, t + 2, 1, 1, false); issue6(w, t + 2, 0, 0, false);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // B0, B1, A0 of tile t + 1 landed
+                } else if (n1) {
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[2 + j][4 + i] = mfma_16x16x32(fb1[kb][j], fa[kb][i], acc[2 + j][4 + i]);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][4 + i] = mfma_16x16x32(fb0[kb][j], fa[kb][i], acc[j][4 + i]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_barrier();
+            }
+#else
             for (int t = 0; t < nk; ++t) {
                 const char* tb = smem + (t & 1) * 65536;
                 const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
@@ -1105,6 +1196,7 @@ __device__ __forceinline__ void p8_body(
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_s_barrier();
             }
+#endif
         } else
         for (int s = 0; s < nk; ++s) {
             const char* la = smem + (s & 3) * P8_STAGE;
@@ -1230,6 +1322,9 @@ __device__ __forceinline__ void p8_body(
                 constexpr int HALF = decltype(h_)::value;
                 constexpr int PASS = decltype(pass_)::value;
                 H* dst = PASS == 0 ? (H*)ep.pre : (H*)ep.c;
+#ifdef P8_PROBE
+                const unsigned long long ph0 = clock64();
+#endif
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int lr = ii * 16 + (lane_ep & 15);
@@ -1258,6 +1353,9 @@ __device__ __forceinline__ void p8_body(
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+#ifdef P8_PROBE
+                const unsigned long long ph1 = clock64();
+#endif
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int lr = t * 8 + (lane_ep >> 3), c16 = lane_ep & 7;
@@ -1268,6 +1366,63 @@ __device__ __forceinline__ void p8_body(
                 }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+#ifdef P8_PROBE
+                if (bid == 0 && threadIdx.x == 0 && round == 1) {     // wave 0: conversion + LDS writes | LDS reads + store issue
+                    p8_probe[8 + HALF * 2] = ph1 - ph0;
+                    p8_probe[9 + HALF * 2] = clock64() - ph1;
+                }
+#endif
+            };
+            // Round 4: the same stores WITHOUT the trip through LDS.  In the (swapped-role) MFMA layout a lane holds 4
+            // consecutive columns of one row per 16-column tile j, i.e. 8 bytes after conversion; v_permlane16_swap
+            // trades the j+1 half of the even 16-lane rows against the j half of the odd ones, after which every lane
+            // holds 8 CONSECUTIVE columns (16 bytes) of its row: one store instruction = 16 rows x 64 contiguous
+            // bytes, 16 store instructions per wave and pass as before, no ds_write / ds_read / lgkmcnt wait between
+            // the accumulators and the stores.
+            auto direct_pass = [&](auto pass_) {
+                constexpr int PASS = decltype(pass_)::value;
+                H* dst = PASS == 0 ? (H*)ep.pre : (H*)ep.c;
+                const int g = lane_ep >> 4;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = w.m0 + wm * 128 + i * 16 + (lane_ep & 15);
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = jp * 2 + jj;
+                            const f32x4 a = acc[j][i];
+                            float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
+                                          fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
+                            if (PASS == 1) {
+                                if (ep.act == BF_ACT_QUICK_GELU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = AM::quick(v[e]);
+                                } else if (ep.act == BF_ACT_TANH_GELU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = AM::tanh_gelu(v[e]);
+                                } else if (ep.act == BF_ACT_ERF_GELU) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
+                                }
+                            }
+                            typename H16<H>::x4 h4;
+                            h4[0] = (H)v[0]; h4[1] = (H)v[1]; h4[2] = (H)v[2]; h4[3] = (H)v[3];
+                            const uint2 u = *(const uint2*)&h4;
+                            pk[jj][0] = u.x; pk[jj][1] = u.y;
+                        }
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {       // odd rows of tile j <-> even rows of tile j + 1
+                            const auto r = __builtin_amdgcn_permlane16_swap(pk[0][d], pk[1][d], false, false);
+                            pk[0][d] = r[0]; pk[1][d] = r[1];
+                        }
+                        const int n = w.n0 + wn * 64 + (jp * 2 + (g & 1)) * 16 + (g >> 1) * 8;
+                        if (m < ep.m && n < ep.n)
+                            store16(dst + (size_t)m * ep.ldc + n, make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]),
+                                    ep.store_policy & 1);
+                    }
+                }
             };
             const bool want_pre = ep.pre && (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU ||
                                              ep.act == BF_ACT_TANH_GELU);
@@ -1321,6 +1476,9 @@ __device__ __forceinline__ void p8_body(
                 quarter_pair(std::integral_constant<int, 1>{});
                 quarter_pair(std::integral_constant<int, 2>{});
                 quarter_pair(std::integral_constant<int, 3>{});
+            } else if constexpr (P8_EPI_DIRECT != 0) {
+                if (want_pre) direct_pass(std::integral_constant<int, 0>{});
+                direct_pass(std::integral_constant<int, 1>{});
             } else {
             if (want_pre) {
                 half_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});

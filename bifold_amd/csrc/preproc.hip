@@ -164,3 +164,156 @@ extern "C" int bf_affine_nearest(const float* in, float* out, const float* param
     BF_CHECK_LAUNCH("bf_affine_nearest");
     return BF_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Depth frames (the rest of it): the reference's depth transform chain on DataLoader workers
+// (bifold/data/processor.py:59-78) = DepthScale (+ one random shift per frame, data/depth_augmentations.py:35-43),
+// MaskDepth (x mask, :46-51), [torchvision Resize / CenterCrop: the identity at the model's own resolution, which is
+// what this path takes], ToDtype(float32), TruncatedDepthStandardization (:6-17): sort the frame, drop the lowest and
+// highest `thresh` share, subtract the mean of the rest and divide by sqrt(its unbiased variance + 1e-6).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void depth_prepare_kernel(const float* __restrict__ depth, const float* __restrict__ mask,
+                                                            const float* __restrict__ shift, float* __restrict__ out,
+                                                            int batch, int pixels) {
+    const size_t total = (size_t)batch * pixels;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float v = depth[i];
+        if (shift) v += shift[i / pixels];
+        if (mask) v *= mask[i];
+        out[i] = v;
+    }
+}
+
+// order-preserving map of fp32 bit patterns onto unsigned integers (-0 < +0 like the bit patterns sort; torch.sort
+// treats them as equal, which cannot change a mean or a variance)
+__device__ __forceinline__ unsigned depth_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float depth_unkey(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// One workgroup per frame.  The two cut VALUES (ranks lo and hi - 1 of the sorted frame) come from a radix select --
+// four passes of 8 bits over the frame, both ranks in the same pass -- instead of a sort: the trimmed statistics need
+// the values between the cuts and HOW MANY copies of each cut value fall inside [lo, hi) (masked depth frames are
+// mostly exact zeros, so the cuts usually sit inside a run of ties).  Sums in fp64, so the result does not depend on
+// the summation order.
+#define DEPTH_WG 1024
+__global__ __launch_bounds__(DEPTH_WG) void depth_standardize_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                     float* __restrict__ stats, int n, int lo, int hi) {
+    __shared__ unsigned hist[2][256];
+    __shared__ unsigned sel_prefix[2], sel_rank[2];
+    __shared__ unsigned long long cnt[4];
+    __shared__ double red[DEPTH_WG / 64];
+    __shared__ double bc[2];
+    const float* xf = x + (size_t)blockIdx.x * n;
+    float* yf = y + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    if (tid == 0) { sel_prefix[0] = sel_prefix[1] = 0u; sel_rank[0] = (unsigned)lo; sel_rank[1] = (unsigned)(hi - 1); }
+    unsigned maskbits = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) { hist[0][tid] = 0u; hist[1][tid] = 0u; }
+        __syncthreads();
+        const unsigned p0 = sel_prefix[0], p1 = sel_prefix[1];
+        for (int i = tid; i < n; i += DEPTH_WG) {
+            const unsigned k = depth_key(xf[i]);
+            const unsigned b = (k >> shift) & 255u;
+            if ((k & maskbits) == p0) atomicAdd(&hist[0][b], 1u);
+            if ((k & maskbits) == p1) atomicAdd(&hist[1][b], 1u);
+        }
+        __syncthreads();
+        if (tid < 2) {                       // one thread per rank walks its 256 bins
+            unsigned r = sel_rank[tid], b = 0;
+            for (; b < 255u; ++b) {
+                const unsigned c = hist[tid][b];
+                if (r < c) break;
+                r -= c;
+            }
+            sel_rank[tid] = r;
+            sel_prefix[tid] |= b << shift;
+        }
+        maskbits |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned k_lo = sel_prefix[0], k_hi = sel_prefix[1];
+    const float v_lo = depth_unkey(k_lo), v_hi = depth_unkey(k_hi);
+    // counts below / at the cuts, sum of the values strictly between them
+    if (tid < 4) cnt[tid] = 0ull;
+    __syncthreads();
+    unsigned lt_lo = 0, eq_lo = 0, lt_hi = 0;
+    double s = 0.0;
+    for (int i = tid; i < n; i += DEPTH_WG) {
+        const float v = xf[i];
+        const unsigned k = depth_key(v);
+        lt_lo += k < k_lo; eq_lo += k == k_lo; lt_hi += k < k_hi;
+        if (k > k_lo && k < k_hi) s += (double)v;
+    }
+    atomicAdd(&cnt[0], (unsigned long long)lt_lo);
+    atomicAdd(&cnt[1], (unsigned long long)eq_lo);
+    atomicAdd(&cnt[2], (unsigned long long)lt_hi);
+    auto block_sum = [&](double v) -> double {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        for (int w = 0; w < DEPTH_WG / 64; ++w) t += red[w];
+        return t;
+    };
+    const double mid = block_sum(s);
+    const long long nin = (long long)hi - lo;
+    long long c_lo, c_hi;
+    if (k_lo == k_hi) { c_lo = nin; c_hi = 0; }
+    else {
+        const long long le_lo = (long long)cnt[0] + (long long)cnt[1];
+        c_lo = (le_lo < hi ? le_lo : hi) - lo;
+        c_hi = (long long)hi - (long long)cnt[2];
+    }
+    const double mean = (mid + (double)c_lo * (double)v_lo + (double)c_hi * (double)v_hi) / (double)nin;
+    double q = 0.0;
+    for (int i = tid; i < n; i += DEPTH_WG) {
+        const float v = xf[i];
+        const unsigned k = depth_key(v);
+        if (k > k_lo && k < k_hi) { const double d = (double)v - mean; q += d * d; }
+    }
+    double ss = block_sum(q);
+    ss += (double)c_lo * ((double)v_lo - mean) * ((double)v_lo - mean) + (double)c_hi * ((double)v_hi - mean) * ((double)v_hi - mean);
+    const double var = nin > 1 ? ss / (double)(nin - 1) : 0.0;          // torch.var: unbiased
+    if (tid == 0) { bc[0] = mean; bc[1] = 1.0 / sqrt(var + 1e-6); }
+    __syncthreads();
+    const float mf = (float)bc[0], rf = (float)bc[1];
+    for (int i = tid; i < n; i += DEPTH_WG) yf[i] = (xf[i] - mf) * rf;
+    if (stats && tid == 0) { stats[blockIdx.x * 2] = mf; stats[blockIdx.x * 2 + 1] = (float)var; }
+}
+
+}  // namespace
+
+extern "C" int bf_depth_prepare(const float* depth, const float* mask, const float* shift, float* out, int batch,
+                                int pixels, bf_stream_t stream) {
+    BF_REQUIRE(depth && out, BF_EINVAL, "bf_depth_prepare: null pointer");
+    BF_REQUIRE(batch >= 0 && pixels > 0, BF_EINVAL, "bf_depth_prepare: bad shape");
+    if (batch == 0) return BF_OK;
+    const size_t total = (size_t)batch * pixels;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(depth_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, depth, mask, shift,
+                       out, batch, pixels);
+    BF_CHECK_LAUNCH("bf_depth_prepare");
+    return BF_OK;
+}
+
+extern "C" int bf_depth_standardize(const float* x, float* y, float* stats, int batch, int pixels, int lo, int hi,
+                                    bf_stream_t stream) {
+    BF_REQUIRE(x && y, BF_EINVAL, "bf_depth_standardize: null pointer");
+    BF_REQUIRE(batch >= 0 && pixels > 0 && lo >= 0 && hi <= pixels && lo < hi, BF_EINVAL,
+               "bf_depth_standardize: need 0 <= lo < hi <= pixels (%d %d %d)", lo, hi, pixels);
+    if (batch == 0) return BF_OK;
+    hipLaunchKernelGGL(depth_standardize_kernel, dim3((unsigned)batch), dim3(DEPTH_WG), 0, (hipStream_t)stream, x, y, stats,
+                       pixels, lo, hi);
+    BF_CHECK_LAUNCH("bf_depth_standardize");
+    return BF_OK;
+}

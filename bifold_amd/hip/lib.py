@@ -116,6 +116,8 @@ PROTOTYPES = {
     "bf_decoder_project_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_scale_check": (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
+    "bf_depth_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bf_depth_standardize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_scale_check_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "bf_gradscale_update": (c_int, [c_void_p, c_void_p, c_float, c_float, c_int, c_float, c_float, c_void_p]),
     "bf_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_int, c_float,

@@ -708,6 +708,30 @@ def resize_normalize_rgb(raw: torch.Tensor, mask: Optional[torch.Tensor], size: 
     return out
 
 
+def depth_frames(depth: torch.Tensor, mask: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+                 standardize: bool = False, thresh: float = 0.1) -> torch.Tensor:
+    """The reference's depth transform chain at the model's own resolution (data/processor.py:59-78): DepthScale
+    (`shift` [B], one per frame) + MaskDepth (`mask` [B, 1, S, S] / [B, S, S]) + float32 + optionally
+    TruncatedDepthStandardization.  depth fp32 [B, 1, S, S] or [B, S, S] -> fp32 of the same shape."""
+    _dev(depth, "depth")
+    if depth.dtype != torch.float32:
+        raise TypeError("depth_frames: depth float32")
+    d = depth.contiguous()
+    b = d.shape[0]
+    pixels = d[0].numel() if b else 1
+    for name, t, want in (("mask", mask, d.numel()), ("shift", shift, b)):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != want or not t.is_cuda):
+            raise TypeError(f"depth_frames: {name} float32 on the device with {want} elements")
+    out = torch.empty_like(d)
+    check(lib.bf_depth_prepare(_ptr(d), _ptr(mask.contiguous()) if mask is not None else None,
+                               _ptr(shift.contiguous()) if shift is not None else None, _ptr(out), b, pixels, _stream()),
+          "bf_depth_prepare")
+    if standardize:
+        lo, hi = int(thresh * pixels), int((1 - thresh) * pixels)        # depth_augmentations.py:12-16, verbatim arithmetic
+        check(lib.bf_depth_standardize(_ptr(out), _ptr(out), None, b, pixels, lo, hi, _stream()), "bf_depth_standardize")
+    return out
+
+
 def affine_nearest(x: torch.Tensor, params: torch.Tensor) -> torch.Tensor:
     """x fp32 [N, C, H, W], params fp32 [N, 3] = (angle degrees, dx, dy) on the device -> the warped copy
     (v2.functional.affine with its defaults; Processor._spatial_augmentation)."""

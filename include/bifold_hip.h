@@ -496,6 +496,18 @@ int bf_resize_normalize_rgb(const uint8_t* raw, const float* mask, uint8_t* tmp_
                             bf_stream_t stream);
 int bf_affine_nearest(const float* in, float* out, const float* params, int n_images, int channels,
                       int height, int width, bf_stream_t stream);
+
+/* Depth frames of the sample dict on the device (data/processor.py:59-78, 122-124): DepthScale + MaskDepth --
+ * out = (depth + shift[b]) * mask, data/depth_augmentations.py:35-51 (shift [batch] or NULL, mask [batch, pixels] or
+ * NULL) -- and TruncatedDepthStandardization (data/depth_augmentations.py:6-17): per frame, with the frame sorted,
+ * y = (x - mean(sorted[lo:hi])) / sqrt(var(sorted[lo:hi]) + 1e-6), var unbiased; lo = int(thresh * pixels),
+ * hi = int((1 - thresh) * pixels) as the reference computes them (the caller passes the integers).  stats (optional,
+ * [batch, 2]) receives the trimmed mean and variance.  x may alias y.  The torchvision Resize / CenterCrop between the
+ * two is the identity at the model's own resolution, which is the case this path takes. */
+int bf_depth_prepare(const float* depth, const float* mask, const float* shift, float* out, int batch, int pixels,
+                     bf_stream_t stream);
+int bf_depth_standardize(const float* x, float* y, float* stats, int batch, int pixels, int lo, int hi,
+                         bf_stream_t stream);
 int bf_heatmap_pick(const float* heat, const float* mask, int32_t* xy, float* conf, int n_maps,
                     int size, bf_stream_t stream);
 int bf_gaussian_targets(const float* points, const int32_t* counts, float* heat, int n_maps,

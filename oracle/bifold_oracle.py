@@ -667,6 +667,32 @@ def resize_normalize_rgb(raw, mask, size: int, mean, std):
     return (img - mean) / std
 
 
+def depth_frames(depth, mask=None, shift=None, standardize: bool = False, thresh: float = 0.1):
+    """The depth transform chain of the reference's Processor for frames at the model's own resolution
+    (bifold/data/processor.py:59-78, where torchvision's Resize / CenterCrop are the identity): DepthScale --
+    `depth + shift`, one draw per frame (data/depth_augmentations.py:35-43) -- MaskDepth -- `depth * mask`
+    (:46-51) -- float32, and TruncatedDepthStandardization (:6-17): with the frame's values sorted, drop
+    int(thresh * n) from the bottom and keep up to int((1 - thresh) * n), subtract the mean of that slice and divide by
+    sqrt(its unbiased variance + 1e-6).  depth [B, S, S] float32.  PINNED: tests/golden/depth.npz is a run of the
+    reference's own classes (oracle/gen_processor_golden.py)."""
+    d = np.asarray(depth, dtype=np.float32)
+    if shift is not None:
+        d = d + np.asarray(shift, dtype=np.float32).reshape(-1, 1, 1)
+    if mask is not None:
+        d = d * np.asarray(mask, dtype=np.float32)
+    d = d.astype(np.float32)
+    if not standardize:
+        return d
+    out = np.empty_like(d)
+    for b in range(d.shape[0]):
+        frame = torch.from_numpy(d[b])
+        srt = torch.sort(frame.reshape(-1), dim=0)[0]
+        n = srt.shape[0]
+        srt = srt[int(thresh * n):int((1 - thresh) * n)]
+        out[b] = ((frame - srt.mean()) / torch.sqrt(srt.var() + 1e-6)).numpy()
+    return out
+
+
 def affine_nearest(x, angle: float, dx: float, dy: float):
     """v2.functional.affine(x, angle, translate=[dx, dy], scale=1.0, shear=[0.0]) with its defaults (nearest, zero
     fill, centre of the image) as Processor._spatial_augmentation calls it (processor.py:333-341).  PARITY UNPINNED

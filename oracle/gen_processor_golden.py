@@ -7,6 +7,10 @@
                                plus edge cases (case, punctuation, digits, apostrophes, repeated blanks)
   tests/golden/augment.npz     `Processor._aug_pixel` (data/processor.py:344-354) on annotated pixels for fixed
                                (angle, dx, dy), including an out-of-frame case (AssertionError -> valid = 0)
+  tests/golden/depth.npz       the depth transform chain without its torchvision links (data/processor.py:59-78):
+                               `DepthScale`, `MaskDepth`, float32, `TruncatedDepthStandardization`
+                               (data/depth_augmentations.py:6-17, 35-51) on frames with tie runs at the cuts
+                               (masked zeros), distinct values, and a constant frame
 
 Stubs (none on the arithmetic): `ftfy` is absent -- `fix_text` is the identity on the ASCII templates used here;
 `torchvision` / `open3d` / `plotly` / `trimesh` are import-time only.  The image half of the augmentation
@@ -89,6 +93,45 @@ def augment_fixture():
     print(f"wrote augment.npz: {len(cases)} cases, {sum(valid)} in frame")
 
 
+def depth_fixture():
+    """The reference's own classes, run in the order Processor.__init__ composes them (processor.py:59-78); the
+    Resize / CenterCrop links in between are torchvision's (absent) and the identity at the frames' own size."""
+    from bifold.data import depth_augmentations as DA
+    S, B = 96, 6
+    g = torch.Generator().manual_seed(3416)
+    depth = (torch.rand(B, S, S, generator=g) * 0.6 + 0.9).numpy().astype(np.float32)      # metres from the camera
+    mask = np.zeros((B, S, S), dtype=np.float32)
+    for b, frac in enumerate((0.35, 0.05, 0.93, 0.5, 1.0, 0.0)):      # cloth coverage: cuts inside / outside the zero run
+        k = int(round(frac * S))
+        mask[b, :k, :] = 1.0
+    mask[3] = (torch.rand(S, S, generator=g) > 0.5).float().numpy()
+    depth[4] = 1.25                                                   # constant frame: variance 0
+    depth[2].reshape(-1)[::7] = depth[2, 0, 0]                        # ties away from zero
+    np.random.seed(3417)
+    scale, masker, standardize = DA.DepthScale(-0.2, 0.2), DA.MaskDepth(), DA.TruncatedDepthStandardization()
+    scaled, masked, out = [], [], []
+    for b in range(B):
+        sample = {"depth": depth[b].copy(), "mask": mask[b] if b != 5 else None}
+        before = sample["depth"].copy()
+        sample = scale(sample)
+        assert sample["depth"].dtype == np.float32
+        scaled.append(sample["depth"].copy())
+        m = masker(sample)                                            # [S, S, 1]
+        assert m.shape == (S, S, 1)
+        t = torch.from_numpy(np.ascontiguousarray(m[:, :, 0])).to(torch.float32)     # v2.ToImage + ToDtype(float32)
+        masked.append(t.numpy().copy())
+        out.append(standardize(t).numpy())
+    np.random.seed(3417)                                              # replay DepthScale's draws (one uniform per frame)
+    shifts = [np.float32(np.random.uniform(-0.2, 0.2)) for _ in range(B)]
+    for b in range(B):                                                # numpy adds the python float as a float32
+        assert np.array_equal(scaled[b], depth[b] + shifts[b]), b
+    np.savez_compressed(os.path.join(GOLD, "depth.npz"), depth=depth, mask=mask, has_mask=np.array([1, 1, 1, 1, 1, 0]),
+                        shift=np.array(shifts, dtype=np.float32), masked=np.array(masked, dtype=np.float32),
+                        standardized=np.array(out, dtype=np.float32), thresh=np.array(0.1))
+    print(f"wrote depth.npz: {B} frames of {S}x{S}, shifts {np.round(shifts, 4).tolist()}")
+
+
 if __name__ == "__main__":
     tokenizer_fixture()
     augment_fixture()
+    depth_fixture()

@@ -166,3 +166,52 @@ def test_augment_batch_moves_images_and_annotations_together(gpu):
         assert (out["rgb"][b:b + 1].cpu() != want).float().mean().item() < 2e-3
         moved, inside = aug_pixel(pick[b:b + 1].clone(), -angle, dx, dy, S - 1)
         assert inside and torch.allclose(out["pick"][b], moved[0], atol=1e-4)
+
+
+# ------------------------------------------------------------------ depth frames
+def _depth_fixture():
+    return np.load(os.path.join(GOLD, "depth.npz"))
+
+
+def test_oracle_depth_chain_matches_reference_run():
+    """tests/golden/depth.npz = the reference's DepthScale / MaskDepth / TruncatedDepthStandardization run on six frames
+    (tie runs at the cuts, ties away from zero, a constant frame, no mask); the oracle's restatement reproduces it."""
+    from oracle import bifold_oracle as O
+    z = _depth_fixture()
+    mask = np.where(z["has_mask"][:, None, None] > 0, z["mask"], 1.0).astype(np.float32)
+    got_m = O.depth_frames(z["depth"], mask, z["shift"])
+    assert np.array_equal(got_m, z["masked"])
+    got = O.depth_frames(z["depth"], mask, z["shift"], standardize=True, thresh=float(z["thresh"]))
+    assert np.allclose(got, z["standardized"], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_depth_frames_kernels_match_reference_run_and_oracle(gpu, observed):
+    """bf_depth_prepare + bf_depth_standardize (radix select of the two cut values, tie counts, fp64 trimmed moments)
+    against the reference-run fixture, then against the oracle on 224-px frames: masked cloth (a long run of exact
+    zeros through the lower cut), random masks, constant frames."""
+    from bifold_amd.hip import ops
+    from oracle import bifold_oracle as O
+    z = _depth_fixture()
+    mask = np.where(z["has_mask"][:, None, None] > 0, z["mask"], 1.0).astype(np.float32)
+    d, m, sh = (torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in (z["depth"], mask, z["shift"]))
+    assert torch.equal(ops.depth_frames(d, m, sh).cpu(), torch.from_numpy(z["masked"]))
+    got = ops.depth_frames(d, m, sh, standardize=True, thresh=float(z["thresh"])).cpu().numpy()
+    err = np.abs(got - z["standardized"]).max() / np.abs(z["standardized"]).max()
+    assert err < 2e-6, err
+    g = torch.Generator().manual_seed(41)
+    B, S = 8, 224
+    depth = torch.rand(B, 1, S, S, generator=g) + 0.8
+    mask = torch.zeros(B, 1, S, S)
+    for b in range(B):
+        mask[b, 0, : 20 + 25 * b] = 1.0
+    mask[5] = (torch.rand(1, S, S, generator=g) > 0.3).float()
+    depth[6] = 2.0
+    mask[6] = 1.0
+    shift = torch.rand(B, generator=g) * 0.4 - 0.2
+    ref = O.depth_frames(depth[:, 0].numpy(), mask[:, 0].numpy(), shift.numpy(), standardize=True)
+    got = ops.depth_frames(depth.to(gpu), mask.to(gpu), shift.to(gpu), standardize=True)
+    assert got.shape == depth.shape
+    err2 = np.abs(got[:, 0].cpu().numpy() - ref).max() / np.abs(ref).max()
+    observed("depth_frames", fixture=float(err), oracle_224=float(err2))
+    assert err2 < 2e-6, err2

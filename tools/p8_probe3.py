@@ -54,4 +54,4 @@ for name, m, n, k, o in shapes:
     per_tile = buf[0] + buf[3] + buf[6]
     print(f"{name:12s} {m}x{n}x{k}: {ms*1e3:7.1f} us {2*m*n*k/ms/1e9:5.0f} TF/s | tiles {tiles} = {tiles/256:.2f} rounds | main {buf[0]:6d} cyc "
           f"({per64:5.0f} per 64 of K, ideal 2048) clock {clk:4.0f} MHz | prologue issue {buf[5]:5d} | epilogue {buf[3]-buf[5]:6d} | "
-          f"next-item wait {buf[6]:6d} | sum/tile {per_tile} cyc = {per_tile/clk:.1f} us -> x rounds {per_tile/clk*tiles/256:.0f} us", flush=True)
+          f"next-item wait {buf[6]:6d} | epi halves (cvt+ds_write / ds_read+store) {buf[8]}/{buf[9]} {buf[10]}/{buf[11]} | sum/tile {per_tile} cyc = {per_tile/clk:.1f} us -> x rounds {per_tile/clk*tiles/256:.0f} us", flush=True)
