@@ -735,8 +735,12 @@ struct P8Group {
 
 #ifdef P8_PROBE
 __device__ unsigned long long p8_probe[16];
+__device__ unsigned long long p8_probe_sec[8];      // BK64 loop: load 0 / MFMA 0 / load 1 / MFMA 1 cycles of wave 0 and of wave 4
 extern "C" int bf_debug_p8_probe(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_probe), sizeof(p8_probe)) == hipSuccess ? 0 : 1;
+}
+extern "C" int bf_debug_p8_probe_sec(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_probe_sec), sizeof(p8_probe_sec)) == hipSuccess ? 0 : 1;
 }
 #endif
 
@@ -906,18 +910,32 @@ __device__ __forceinline__ void p8_body(
     unsigned fa6[2] = {0, 0}, fb6[2] = {0, 0};                           // fragment offsets of k block 0 / 1 inside a tile
     auto a_rel6 = [&](int h, int p) { return (wave >> 2) * 128 + h * 64 + (wave & 3) * 16 + p * 8; };
     auto b_rel6 = [&](int h, int p) { return (wave >> 1) * 64 + h * 32 + (wave & 1) * 16 + p * 8; };
-    auto lane_off6 = [&](int ld, int r0, int k0, int rel) {
-        const int row = rel + (lane >> 3);
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
-        return (unsigned)(((size_t)(r0 + row) * ld + k0 + ch * 8) * 2);
-    };
+    // A piece is 8 rows x 128 B: lane l fetches row rel + (l >> 3), chunk (l & 7) ^ ((row >> 1) & 7).  rel is a multiple of
+    // 8 whose bit 3 is the piece index p, so the chunk is (l & 7) ^ (l >> 4) ^ (p << 2): the per-lane part of an offset is
+    // one of TWO values per operand, computed once per kernel (one 32-bit multiply each); an item adds a wave-uniform
+    // term.  (Until this was split up, every item computed eight offsets with a 64-bit multiply each, and eight more in
+    // front of the next item's first DMA: 1 750 cycles per item.)
+    unsigned la6[2] = {0, 0}, lb6[2] = {0, 0};
+    if constexpr (BK == 64) {
+        const unsigned ch0 = (unsigned)((lane & 7) ^ (lane >> 4));
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            la6[p] = (unsigned)(lane >> 3) * (unsigned)lda * 2u + ((ch0 ^ (unsigned)(p << 2)) << 4);
+            lb6[p] = (unsigned)(lane >> 3) * (unsigned)ldb * 2u + ((ch0 ^ (unsigned)(p << 2)) << 4);
+        }
+        asm volatile("" : "+v"(la6[0]), "+v"(la6[1]), "+v"(lb6[0]), "+v"(lb6[1]));
+    }
+    // wave-uniform byte offset of relative row `rel` of an item's tile (the row part stays in the VECTOR offset of the
+    // DMA, where the descriptor's range check sees it: rows past the end of the matrix read as zeros)
+    auto a_base6 = [&](const P8Item& it, int rel) { return ((unsigned)(it.m0 + rel) * (unsigned)lda + (unsigned)it.kbeg) * 2u; };
+    auto b_base6 = [&](const P8Item& it, int rel) { return ((unsigned)(it.n0 + rel) * (unsigned)ldb + (unsigned)it.kbeg) * 2u; };
     auto set_bases6 = [&](const P8Item& it) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                va6[h][p] = lane_off6(lda, it.m0, it.kbeg, a_rel6(h, p));
-                vb6[h][p] = lane_off6(ldb, it.n0, it.kbeg, b_rel6(h, p));
+                va6[h][p] = la6[p] + a_base6(it, a_rel6(h, p));
+                vb6[h][p] = lb6[p] + b_base6(it, b_rel6(h, p));
             }
         asm volatile("" : "+v"(va6[0][0]), "+v"(va6[0][1]), "+v"(va6[1][0]), "+v"(va6[1][1]),
                           "+v"(vb6[0][0]), "+v"(vb6[0][1]), "+v"(vb6[1][0]), "+v"(vb6[1][1]));
@@ -930,7 +948,7 @@ __device__ __forceinline__ void p8_body(
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             unsigned v;
-            if (any) v = is_b ? lane_off6(ldb, it.n0, it.kbeg, b_rel6(h, p)) : lane_off6(lda, it.m0, it.kbeg, a_rel6(h, p));
+            if (any) v = is_b ? lb6[p] + b_base6(it, b_rel6(h, p)) : la6[p] + a_base6(it, a_rel6(h, p));
             else v = is_b ? vb6[h][p] : va6[h][p];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(is_b ? rb : ra, (lds_void_ptr)(dst + p * 1024), 16, v, delta, 0, 0);
         }
@@ -1039,6 +1057,11 @@ __device__ __forceinline__ void p8_body(
                 if (t == draw_tile && threadIdx.x == 0) pend = atomicAdd(tk + xl + lane_zero, 1u);
                 if (t == 0 && n1) { issue6(w, 1, 1, 0, false); issue6(w, 1, 1, 1, false); issue6(w, 1, 0, 0, false); }
                 F8 fa[2][4], fb0[2][2], fb1[2][2];
+#ifdef P8_PROBE
+                // section stamps (lgkmcnt is 0 at each of them: after a barrier that every wave reached with its reads
+                // retired): load 0 | MFMA 0 | load 1 | MFMA 1, summed over the item's K tiles
+                const unsigned long long q0 = clock64();
+#endif
                 // ---------------- block 0
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -1061,6 +1084,9 @@ __device__ __forceinline__ void p8_body(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+                const unsigned long long q1 = clock64();
+#endif
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -1076,6 +1102,9 @@ __device__ __forceinline__ void p8_body(
                         for (int i = 0; i < 4; ++i) acc[2 + j][i] = mfma_16x16x32(fb1[kb][j], fa[kb][i], acc[2 + j][i]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+                const unsigned long long q2 = clock64();
+#endif
                 // ---------------- block 1
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -1090,6 +1119,9 @@ __device__ __forceinline__ void p8_body(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+                const unsigned long long q3 = clock64();
+#endif
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
@@ -1105,6 +1137,15 @@ __device__ __forceinline__ void p8_body(
                         for (int i = 0; i < 4; ++i) acc[j][4 + i] = mfma_16x16x32(fb0[kb][j], fa[kb][i], acc[j][4 + i]);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+                if (bid == 0 && (threadIdx.x & 255) == 0 && round == 1) {      // wave 0 (group 0) and wave 4 (group 1)
+                    const int o = 16 + (threadIdx.x >> 8) * 4;
+                    const unsigned long long q4 = clock64();
+                    if (t == 0) { p8_probe_sec[o - 16] = 0; p8_probe_sec[o - 15] = 0; p8_probe_sec[o - 14] = 0; p8_probe_sec[o - 13] = 0; }
+                    p8_probe_sec[o - 16] += q1 - q0; p8_probe_sec[o - 15] += q2 - q1;
+                    p8_probe_sec[o - 14] += q3 - q2; p8_probe_sec[o - 13] += q4 - q3;
+                }
+#endif
             }
 #else
             for (int t = 0; t < nk; ++t) {
@@ -1265,6 +1306,21 @@ __device__ __forceinline__ void p8_body(
         const unsigned long long pc1 = clock64(), pw1 = wall_clock64();
 #endif
 
+        // (the epilogue's per-lane values are derived from an OPAQUE copy of the lane id made here, so that the compiler
+        // cannot hoist them above the main loop, where every register is spoken for: round 4, BK = 64 loop)
+        int lane_ep = lane;
+        asm volatile("" : "+v"(lane_ep));
+        // The plain 16-bit epilogue's bias values are requested HERE, in front of the next item's DMA pieces: vmcnt
+        // retires in order, so loaded after them the first use of the bias waited for the whole first K tile of the
+        // next item to arrive (~900 cycles per item in the probe).
+        [[maybe_unused]] float4 bj[4];
+        if constexpr (EPI == 1 || EPI == 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = w.n0 + wn * 64 + j * 16 + (lane_ep >> 4) * 4;
+                bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         // next item's first stages go out before this item's epilogue
         P8Item nx;
         ++round;
@@ -1285,10 +1341,6 @@ __device__ __forceinline__ void p8_body(
         const unsigned long long pc2 = clock64();
 #endif
 
-        // (the epilogue's per-lane values are derived from an OPAQUE copy of the lane id made here, so that the compiler
-        // cannot hoist them above the main loop, where every register is spoken for: round 4, BK = 64 loop)
-        int lane_ep = lane;
-        asm volatile("" : "+v"(lane_ep));
         // Epilogue through LDS: in the MFMA layout a wave-instruction's 64 lanes own 16 rows x 4
         // separate 16-byte groups, i.e. 64 scattered requests per store (measured: ~780 cycles per
         // store instruction and wave, the epilogue as long as a K = 768 main loop).  Each wave
@@ -1310,13 +1362,15 @@ __device__ __forceinline__ void p8_body(
         // 64-row halves, and store 8 columns per lane_ep.
         constexpr bool fast16 = EPI == 1 || EPI == 3;
         if constexpr (fast16) {
-            float4 bj[4];
+            using AM = ActMath<H>;
+            // staging offsets of the lane's four 8-byte pieces of a row (one per 16-column tile j), hoisted: the XOR
+            // swizzle does not see the 16-row block (ii), which rides in the instruction's immediate offset
+            unsigned wo4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = w.n0 + wn * 64 + j * 16 + (lane_ep >> 4) * 4;
-                bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int lr0 = lane_ep & 15, cc4 = j * 4 + (lane_ep >> 4);
+                wo4[j] = (unsigned)(lr0 * 128 + (((cc4 >> 1) ^ ((lr0 >> 1) & 7)) << 4) + ((cc4 & 1) << 3));
             }
-            using AM = ActMath<H>;
             // pass 0 writes the pre-activation copy the backward pass needs (ep.pre), pass 1 the result
             auto half_tile = [&](auto h_, auto pass_) {
                 constexpr int HALF = decltype(h_)::value;
@@ -1327,7 +1381,6 @@ __device__ __forceinline__ void p8_body(
 #endif
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
-                    const int lr = ii * 16 + (lane_ep & 15);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const f32x4 a = acc[j][HALF * 4 + ii];
@@ -1347,8 +1400,7 @@ __device__ __forceinline__ void p8_body(
                         }
                         typename H16<H>::x4 pk;
                         pk[0] = (H)v[0]; pk[1] = (H)v[1]; pk[2] = (H)v[2]; pk[3] = (H)v[3];
-                        const int cc4 = j * 4 + (lane_ep >> 4);
-                        *(typename H16<H>::x4*)(stg + lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3)) = pk;
+                        *(typename H16<H>::x4*)(stg + wo4[j] + ii * 2048) = pk;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1434,7 +1486,6 @@ __device__ __forceinline__ void p8_body(
                     constexpr int Q = decltype(q_)::value;          // rows [32 Q, 32 Q + 32) of the wave's 128
 #pragma unroll
                     for (int i2 = 0; i2 < 2; ++i2) {
-                        const int lr = i2 * 16 + (lane_ep & 15);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const f32x4 a = acc[j][Q * 2 + i2];
@@ -1448,10 +1499,8 @@ __device__ __forceinline__ void p8_body(
                                 pk[e] = (H)gv;
                                 gk[e] = (H)gp;
                             }
-                            const int cc4 = j * 4 + (lane_ep >> 4);
-                            const int off = lr * 128 + (((cc4 >> 1) ^ ((lr >> 1) & 7)) << 4) + ((cc4 & 1) << 3);
-                            *(typename H16<H>::x4*)(stg + off) = pk;
-                            *(typename H16<H>::x4*)(stg + 4096 + off) = gk;
+                            *(typename H16<H>::x4*)(stg + wo4[j] + i2 * 2048) = pk;
+                            *(typename H16<H>::x4*)(stg + 4096 + wo4[j] + i2 * 2048) = gk;
                         }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2536,7 +2585,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         bool bk64 = T.p8_bk64 != 0;
         if (variant == 9 || (force_variant == 8 && pipe_env == 9)) { variant = 8; bk64 = true; }
         else if (pipe_env == 8) bk64 = false;
-        bk64 = bk64 && !g->trans_a && !g->b_kn && (g->k % 64) == 0 && (kps % 64) == 0;
+        bk64 = bk64 && !g->trans_a && !g->b_kn && (g->k % 64) == 0 && (kps % 64) == 0 &&
+               a_ext + 512ull * (size_t)g->lda < (1ull << 32) && b_ext + 512ull * (size_t)g->ldb < (1ull << 32);   // 32-bit offsets of the tile rows past M / N
         unsigned* tk8 = variant == 8 ? p8_ticket_set(s) : nullptr;
         if (variant == 8 && !tk8) variant = long_nt ? 0 : 4;
         last_variant = 1;   // register-staged fallback unless one of the LDS-DMA kernels below takes it

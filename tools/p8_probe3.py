@@ -49,9 +49,15 @@ for name, m, n, k, o in shapes:
     buf = (ctypes.c_ulonglong * 16)()
     fn(buf)
     clk = buf[0] / max(buf[1], 1) * 100
+    sec = (ctypes.c_ulonglong * 8)()
+    if hasattr(L.lib, "bf_debug_p8_probe_sec"):
+        L.lib.bf_debug_p8_probe_sec(sec)
+    nt64 = max(k // 64, 1)
+    secs = " | per K tile, load0/mfma0/load1/mfma1: w0 " + "/".join(f"{sec[i] / nt64:.0f}" for i in range(4)) + \
+           " w4 " + "/".join(f"{sec[4 + i] / nt64:.0f}" for i in range(4))
     per64 = buf[0] / max(k // 64, 1)
     tiles = ((m + 255) // 256) * ((n + 255) // 256)
     per_tile = buf[0] + buf[3] + buf[6]
     print(f"{name:12s} {m}x{n}x{k}: {ms*1e3:7.1f} us {2*m*n*k/ms/1e9:5.0f} TF/s | tiles {tiles} = {tiles/256:.2f} rounds | main {buf[0]:6d} cyc "
           f"({per64:5.0f} per 64 of K, ideal 2048) clock {clk:4.0f} MHz | prologue issue {buf[5]:5d} | epilogue {buf[3]-buf[5]:6d} | "
-          f"next-item wait {buf[6]:6d} | epi halves (cvt+ds_write / ds_read+store) {buf[8]}/{buf[9]} {buf[10]}/{buf[11]} | sum/tile {per_tile} cyc = {per_tile/clk:.1f} us -> x rounds {per_tile/clk*tiles/256:.0f} us", flush=True)
+          f"next-item wait {buf[6]:6d} | epi halves (cvt+ds_write / ds_read+store) {buf[8]}/{buf[9]} {buf[10]}/{buf[11]} | sum/tile {per_tile} cyc = {per_tile/clk:.1f} us -> x rounds {per_tile/clk*tiles/256:.0f} us" + secs, flush=True)
