@@ -38,6 +38,7 @@ BfTuning& bf_tuning() {
         t.p8_grid = env_int("BIFOLD_P8_GRID", 0);
         t.p8_revk = env_int("BIFOLD_P8_REVK", 1) ? 1 : 0;
         t.p8_bk64 = env_int("BIFOLD_P8_BK64", 1);         // round 4 same-box A/B of the step: 7 234 / 7 255 -> 7 423 / 7 386 samples/s
+        t.p8_bk64_nn = env_int("BIFOLD_P8_BK64_NN", 1);
         t.p8_deep = env_int("BIFOLD_P8_DEEP", -1);
         t.p8_nt = env_int("BIFOLD_P8_NT", 5) & 7;          // plain-16-bit and GELU-grad outputs non-temporal (round 2: 1 -> 5 +0.3 %)
         t.p8_no_tail = getenv("BIFOLD_P8_NO_TAIL") ? 1 : 0;

@@ -916,12 +916,21 @@ __device__ __forceinline__ void p8_body(
     // term.  (Until this was split up, every item computed eight offsets with a 64-bit multiply each, and eight more in
     // front of the next item's first DMA: 1 750 cycles per item.)
     unsigned la6[2] = {0, 0}, lb6[2] = {0, 0};
+    [[maybe_unused]] unsigned fbk6[2][2] = {{0, 0}, {0, 0}};             // K-strided B: fragment offsets of tile (g, j)
     if constexpr (BK == 64) {
         const unsigned ch0 = (unsigned)((lane & 7) ^ (lane >> 4));
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             la6[p] = (unsigned)(lane >> 3) * (unsigned)lda * 2u + ((ch0 ^ (unsigned)(p << 2)) << 4);
-            lb6[p] = (unsigned)(lane >> 3) * (unsigned)ldb * 2u + ((ch0 ^ (unsigned)(p << 2)) << 4);
+            if constexpr (!B_KS) {
+                lb6[p] = (unsigned)(lane >> 3) * (unsigned)ldb * 2u + ((ch0 ^ (unsigned)(p << 2)) << 4);
+            } else {
+                // K-strided B (dX = dY W, W stored [K][N]): a piece is 4 k-rows x 256 B of a 128-column sub-tile in the
+                // k-row image of the BK = 32 loop (chunk c of k-row k at c ^ ks_swz(k)); the wave's pieces start at
+                // k-rows ((2 wave) & 7) * 4 + 4 p of a 32-deep half, so ks_swz sees (lane >> 4) and wave & 1 only
+                const unsigned ch = (unsigned)((lane & 15) ^ ((lane >> 4) << 1) ^ ((wave & 1) << 3));
+                lb6[p] = (unsigned)(lane >> 4) * (unsigned)ldb * 2u + (ch << 4);
+            }
         }
         asm volatile("" : "+v"(la6[0]), "+v"(la6[1]), "+v"(lb6[0]), "+v"(lb6[1]));
     }
@@ -929,13 +938,18 @@ __device__ __forceinline__ void p8_body(
     // DMA, where the descriptor's range check sees it: rows past the end of the matrix read as zeros)
     auto a_base6 = [&](const P8Item& it, int rel) { return ((unsigned)(it.m0 + rel) * (unsigned)lda + (unsigned)it.kbeg) * 2u; };
     auto b_base6 = [&](const P8Item& it, int rel) { return ((unsigned)(it.n0 + rel) * (unsigned)ldb + (unsigned)it.kbeg) * 2u; };
+    // K-strided B: first k-row of the wave's piece p of k half h inside a tile, and the wave-uniform part of its offset
+    auto bk_row6 = [&](int h, int p) { return h * 32 + ((2 * wave) & 7) * 4 + 4 * p; };
+    auto bk_base6 = [&](const P8Item& it, int h, int p) {
+        return ((unsigned)(it.kbeg + bk_row6(h, p)) * (unsigned)ldb + (unsigned)(it.n0 + (wave >> 2) * 128)) * 2u;
+    };
     auto set_bases6 = [&](const P8Item& it) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 va6[h][p] = la6[p] + a_base6(it, a_rel6(h, p));
-                vb6[h][p] = lb6[p] + b_base6(it, b_rel6(h, p));
+                vb6[h][p] = lb6[p] + (B_KS ? bk_base6(it, h, p) : b_base6(it, b_rel6(h, p)));
             }
         asm volatile("" : "+v"(va6[0][0]), "+v"(va6[0][1]), "+v"(va6[1][0]), "+v"(va6[1][1]),
                           "+v"(vb6[0][0]), "+v"(vb6[0][1]), "+v"(vb6[1][0]), "+v"(vb6[1][1]));
@@ -943,6 +957,17 @@ __device__ __forceinline__ void p8_body(
     // region (operand, half) of K tile tt of item `it` -> ring buffer tt & 1; `any`: addresses from scratch (item boundary)
     auto issue6 = [&](const P8Item& it, int tt, int is_b, int h, bool any) {
         const int ks = it.rev ? it.nk - 1 - tt : tt;
+        if (B_KS && is_b) {
+            // the K advance of a K-strided operand stays in the VECTOR offset (the descriptor's range check must see it)
+            const unsigned delta = (unsigned)ks * 128u * (unsigned)ldb;
+            char* dst = smem + (tt & 1) * 65536 + 32768 + (wave >> 2) * 16384 + bk_row6(h, 0) * 256;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned v = (any ? lb6[p] + bk_base6(it, h, p) : vb6[h][p]) + delta;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_ptr)(dst + p * 1024), 16, v, 0, 0, 0);
+            }
+            return;
+        }
         const unsigned delta = (unsigned)ks * 128u;
         char* dst = smem + (tt & 1) * 65536 + (is_b ? 32768 + b_rel6(h, 0) * 128 : a_rel6(h, 0) * 128);
 #pragma unroll
@@ -957,13 +982,29 @@ __device__ __forceinline__ void p8_body(
         issue6(it, tt, 1, 0, true); issue6(it, tt, 0, 0, true); issue6(it, tt, 1, 1, true); issue6(it, tt, 0, 1, true);
     };
     if constexpr (BK == 64) {
-        static_assert(BK != 64 || (!A_KS && !B_KS && !GROUPED), "the BK = 64 loop takes K-contiguous operands");
+        static_assert(BK != 64 || (!A_KS && !GROUPED), "the BK = 64 loop takes a K-contiguous A");
         const int sw = (lane >> 1) & 7;                    // (row >> 1) & 7 of the lane's fragment row (bases are multiples of 16)
         fa6[0] = (unsigned)(wm * 16384 + (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4));
         fb6[0] = (unsigned)(32768 + wn * 8192 + (lane & 15) * 128 + (((lane >> 4) ^ sw) << 4));
         fa6[1] = fa6[0] ^ 64u;                             // chunk 4 + c: position bit 2 flipped
         fb6[1] = fb6[0] ^ 64u;
         asm volatile("" : "+v"(fa6[0]), "+v"(fa6[1]), "+v"(fb6[0]), "+v"(fb6[1]));
+        if constexpr (B_KS) {
+            // transposed reads (ds_read_b64_tr_b16) of the k-row image: lane -> k-row gl * 8 + q (+ 4 for the upper half of
+            // the fragment), 8-byte piece p of the 16-column tile; tile (g, j) of the wave's 64 columns XORs its chunk
+            // index (an even number) into bits 5-7, which the k-row term never touches
+            const int gl = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+            const int kk0 = gl * 8 + q;
+            const unsigned lanepart = (unsigned)(kk0 * 256 + ((((pp >> 1)) ^ ks_swz(kk0)) << 4) + ((pp & 1) << 3));
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned c0 = (unsigned)((wn & 1) * 8 + g * 4 + j * 2);
+                    fbk6[g][j] = 32768u + (unsigned)(wn >> 1) * 16384u + (lanepart ^ (c0 << 4));
+                }
+            asm volatile("" : "+v"(fbk6[0][0]), "+v"(fbk6[0][1]), "+v"(fbk6[1][0]), "+v"(fbk6[1][1]));
+        }
     }
 
     P8Item w;
@@ -1063,10 +1104,23 @@ __device__ __forceinline__ void p8_body(
                 const unsigned long long q0 = clock64();
 #endif
                 // ---------------- block 0
+                auto bfrag = [&](int g, int kb, int j) -> F8 {
+                    if constexpr (!B_KS) {
+                        return *(const F8*)(tb + fb6[kb] + g * 4096 + j * 2048);
+                    } else {
+                        typedef typename H16<H>::x4 F4;
+                        const F4 lo = lds_read_tr16<H>(tb + fbk6[g][j] + kb * 8192);
+                        const F4 hi = lds_read_tr16<H>(tb + fbk6[g][j] + kb * 8192 + 1024);
+                        F8 r;
+                        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+                        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+                        return r;
+                    }
+                };
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fb0[kb][j] = *(const F8*)(tb + fb6[kb] + j * 2048);
+                    for (int j = 0; j < 2; ++j) fb0[kb][j] = bfrag(0, kb, j);
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1074,7 +1128,7 @@ __device__ __forceinline__ void p8_body(
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) fb1[kb][j] = *(const F8*)(tb + fb6[kb] + 4096 + j * 2048);
+                    for (int j = 0; j < 2; ++j) fb1[kb][j] = bfrag(1, kb, j);
                 if (n1) {
                     issue6(w, t + 1, 0, 1, false);                       // A1 of tile t + 1
                     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // A1 of this tile landed
@@ -1148,6 +1202,7 @@ __device__ __forceinline__ void p8_body(
 #endif
             }
 #else
+            static_assert(!B_KS, "the four-block variant of the BK = 64 loop was kept for K-contiguous operands only");
             for (int t = 0; t < nk; ++t) {
                 const char* tb = smem + (t & 1) * 65536;
                 const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
@@ -2585,7 +2640,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         bool bk64 = T.p8_bk64 != 0;
         if (variant == 9 || (force_variant == 8 && pipe_env == 9)) { variant = 8; bk64 = true; }
         else if (pipe_env == 8) bk64 = false;
-        bk64 = bk64 && !g->trans_a && !g->b_kn && (g->k % 64) == 0 && (kps % 64) == 0 &&
+        bk64 = bk64 && !g->trans_a && (!g->b_kn || T.p8_bk64_nn) && (g->k % 64) == 0 && (kps % 64) == 0 &&
                a_ext + 512ull * (size_t)g->lda < (1ull << 32) && b_ext + 512ull * (size_t)g->ldb < (1ull << 32);   // 32-bit offsets of the tile rows past M / N
         unsigned* tk8 = variant == 8 ? p8_ticket_set(s) : nullptr;
         if (variant == 8 && !tk8) variant = long_nt ? 0 : 4;
@@ -2649,7 +2704,9 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             if (!g->trans_a && !g->b_kn) {
                 if (bk64) BY_HALF(LAUNCH_P8_H64, false, false); else LAUNCH_P8(false, false);
             }
-            else if (!g->trans_a && g->b_kn) LAUNCH_P8(false, true);
+            else if (!g->trans_a && g->b_kn) {
+                if (bk64) BY_HALF(LAUNCH_P8_H64, false, true); else LAUNCH_P8(false, true);
+            }
             else if (g->trans_a && g->b_kn) LAUNCH_P8(true, true);
             else LAUNCH_P8(true, false);
 #undef LAUNCH_P8E

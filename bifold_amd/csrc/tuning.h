@@ -17,6 +17,7 @@ struct BfTuning {
     int p8_grid;                  // BIFOLD_P8_GRID          cap on the persistent grid (0: every CU)
     int p8_revk;                  // BIFOLD_P8_REVK          alternate the K direction per round of tickets (1)
     int p8_bk64;                  // BIFOLD_P8_BK64          BK = 64 full-line main loop for the persistent NT GEMMs (1)
+    int p8_bk64_nn;               // BIFOLD_P8_BK64_NN       ... and for the NN GEMMs (dX = dY W: K-strided B read transposed) (1)
     int p8_deep;                  // BIFOLD_P8_DEEP          prefetch distance 3: -1 = for TN only, 0 / 1 = never / always
     int p8_nt;                    // BIFOLD_P8_NT            bit mask of non-temporal output stores (5)
     int p8_no_tail;               // BIFOLD_P8_NO_TAIL       1: never cut an under-filled last round off as a split-K tail
