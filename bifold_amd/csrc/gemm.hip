@@ -114,6 +114,60 @@ __device__ __forceinline__ void epilogue_store4(const EpiParams& ep, int m, int 
     if (ep.c2) Vec4<Half2Of<TD>>::store((Half2Of<TD>*)ep.c2 + orow * ep.ldc + n, v);
 }
 
+// epilogue_store4 with the lane's 4 bias values held in registers (see epilogue_store8 on why the bias is not loaded
+// per row) and the persistent kernel's store policy: the fp32 outputs of that kernel leave as ONE 16-byte store per lane,
+// 16 lanes per row -- a store instruction is 4 rows x 256 contiguous bytes.
+template <typename TC, typename TD>
+__device__ __forceinline__ void epilogue_store4b(const EpiParams& ep, int m, int n, float4 v, float4 b) {
+    v.x = fmaf(v.x, ep.alpha, b.x); v.y = fmaf(v.y, ep.alpha, b.y);
+    v.z = fmaf(v.z, ep.alpha, b.z); v.w = fmaf(v.w, ep.alpha, b.w);
+    size_t orow = (size_t)m;
+    if (ep.rows_in > 0) orow = (size_t)(m / ep.rows_in) * ep.rows_out + ep.row_off + (m % ep.rows_in);
+    if (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU || ep.act == BF_ACT_TANH_GELU) {
+        if (ep.pre) Vec4<TD>::store((TD*)ep.pre + orow * ep.ldc + n, v);
+        using AM = ActMath<TD>;
+        if (ep.act == BF_ACT_QUICK_GELU) {
+            v.x = AM::quick(v.x); v.y = AM::quick(v.y); v.z = AM::quick(v.z); v.w = AM::quick(v.w);
+        } else if (ep.act == BF_ACT_TANH_GELU) {
+            v.x = AM::tanh_gelu(v.x); v.y = AM::tanh_gelu(v.y); v.z = AM::tanh_gelu(v.z); v.w = AM::tanh_gelu(v.w);
+        } else {
+            v.x = AM::erf(v.x); v.y = AM::erf(v.y); v.z = AM::erf(v.z); v.w = AM::erf(v.w);
+        }
+    } else if (ep.act == BF_ACT_ERF_GELU_SAVEGRAD) {
+        using AM = ActMath<TD>;
+        float4 gp;
+        AM::erf_both(v.x, v.x, gp.x); AM::erf_both(v.y, v.y, gp.y);
+        AM::erf_both(v.z, v.z, gp.z); AM::erf_both(v.w, v.w, gp.w);
+        Vec4<TD>::store((TD*)ep.pre + orow * ep.ldc + n, gp);
+    } else if (ep.act == BF_ACT_MUL_AUX || ep.act == BF_ACT_ERF_GELU_GRAD || ep.act == BF_ACT_TANH_GELU_GRAD) {
+        using AM = ActMath<TD>;
+        const float4 a = Vec4<TD>::load((const TD*)ep.aux + (size_t)m * ep.ld_aux + n);
+        if (ep.act == BF_ACT_MUL_AUX) { v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w; }
+        else if (ep.act == BF_ACT_ERF_GELU_GRAD) {
+            v.x *= AM::erf_grad(a.x); v.y *= AM::erf_grad(a.y); v.z *= AM::erf_grad(a.z); v.w *= AM::erf_grad(a.w);
+        } else {
+            v.x *= AM::tanh_grad(a.x); v.y *= AM::tanh_grad(a.y); v.z *= AM::tanh_grad(a.z); v.w *= AM::tanh_grad(a.w);
+        }
+    }
+    if (ep.residual) {
+        const size_t rr = ep.resid_mod > 0 ? (size_t)(m % ep.resid_mod) : orow;
+        const float4 r = *(const float4*)(ep.residual + rr * ep.ld_res + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    TC* cp = (TC*)ep.c + orow * ep.ldc + n;
+    if (ep.accumulate) {
+        const float4 o = Vec4<TC>::load(cp);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    if constexpr (std::is_same<TC, float>::value) {
+        const f32x4 q = {v.x, v.y, v.z, v.w};
+        if (ep.store_policy & 2) __builtin_nontemporal_store(q, (f32x4*)cp); else *(f32x4*)cp = q;
+    } else {
+        Vec4<TC>::store(cp, v);
+    }
+    if (ep.c2) Vec4<Half2Of<TD>>::store((Half2Of<TD>*)ep.c2 + orow * ep.ldc + n, v);
+}
+
 // 8 consecutive columns of one output row.  A store instruction costs the issuing wave the
 // same whatever its width (measured on gfx950: ~300 cycles per store and wave when every CU
 // stores at once, 512-byte and 1-KB stores alike), so the epilogue moves 16 bytes per lane per
@@ -286,6 +340,11 @@ struct GemmDims {
     int tiles_m, tiles_n;
     int k_per_split;    // multiple of the K tile
     int group_m;
+    // persistent BK = 64 kernel: the tiles of the under-filled last round, split along K inside the launch
+    int tail_tiles;     // 0: off; else the LAST tail_tiles tiles (in item order) are cut into tail_parts K chunks
+    int tail_parts;     // S: chunks per tail tile (every chunk non-empty)
+    int tail_kt;        // K tiles (of 64) per chunk
+    float* tail_ws;     // [tail_tiles][S][8 waves][32][64 lanes] f32x4: the chunks' accumulators, as the registers hold them
 };
 
 // ---- global -> register tile loads (4 x 16 B per thread per operand) -------------------
@@ -715,7 +774,8 @@ __global__ __launch_bounds__(256, WT == 4 ? 4 : 6) void gemm_bf16_k32_kernel(
 #define P8_ABL_PIECES 2
 #endif
 
-struct P8Item { int m0, n0, kbeg, nk, z, rev, p; };
+#define P8_TAIL_MAX 128            // tail tiles a launch may split (arrival counters in its ticket set)
+struct P8Item { int m0, n0, kbeg, nk, z, rev, p, part, slot; };   // part >= 0: K chunk `part` of tail tile `slot`
 
 // A GROUP of deep dW = dY^T X problems that share K (the four weight gradients of one transformer layer) handed to ONE
 // launch of the persistent kernel: their output tiles are numbered consecutively, an item is (split, tile) over the union,
@@ -799,12 +859,35 @@ __device__ __forceinline__ void p8_body(
     const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
     // ranges proportional to the workgroups a lane has (G need not be a multiple of 8): with exactly one
     // item per workgroup no lane may hold more items than workgroups
-    auto lane_start = [&](int x) { return (int)((long long)n_items * (x * (G / NX) + min(x, G % NX)) / G); };
+    auto lane_share = [&](long long n, int x) { return (int)(n * (x * (G / NX) + min(x, G % NX)) / G); };
+    // Tail split (BK = 64, round 4): the tiles of an under-filled last round -- the last d.tail_tiles in item order -- are
+    // cut into d.tail_parts K chunks, so that round takes 1 / parts of a tile's time; the workgroup whose chunk arrives
+    // last sums the chunks (in chunk order: reproducible) and runs the epilogue.  Every XCD lane gets its share of the
+    // whole tiles first and then its share of the tail tiles, chunk index fastest.
+    const bool tail_on = BK == 64 && !GROUPED && d.tail_tiles > 0;
+    const int n_whole = tail_on ? n_items - d.tail_tiles * d.tail_parts : n_items;
+    auto lane_start = [&](int x) { return lane_share(n_whole, x); };
     const int x_base = lane_start(xl);
-    const int x_cnt = lane_start(xl + 1) - x_base;
+    const int x_whole = lane_start(xl + 1) - x_base;
+    const int t_base = tail_on ? lane_share(d.tail_tiles, xl) : 0;
+    const int x_cnt = x_whole + (tail_on ? (lane_share(d.tail_tiles, xl + 1) - t_base) * d.tail_parts : 0);
     volatile unsigned* bcast = (volatile unsigned*)(smem + 4 * P8_STAGE);
     auto decode = [&](unsigned ticket, P8Item& w) -> bool {
         if (ticket >= (unsigned)x_cnt) return false;
+        w.part = -1; w.slot = 0;
+        if (tail_on && (int)ticket >= x_whole) {
+            const int u = (int)ticket - x_whole;
+            w.slot = t_base + u / d.tail_parts;
+            w.part = u - (u / d.tail_parts) * d.tail_parts;
+            int tm, tn;
+            tile_coords(n_whole + w.slot, d.tiles_m, d.tiles_n, d.group_m, tm, tn);
+            w.z = 0; w.p = 0;
+            w.m0 = tm * 256; w.n0 = tn * 256;
+            w.kbeg = w.part * d.tail_kt * 64;
+            w.nk = min(d.tail_kt, ((d.k + 63) >> 6) - w.part * d.tail_kt);
+            w.rev = 0;
+            return true;
+        }
         const int item = x_base + (int)ticket;
         w.z = item / tiles;
         int tm, tn;
@@ -1031,7 +1114,7 @@ __device__ __forceinline__ void p8_body(
         // the first stages, instead of 16 dependent load -> add -> store rounds in the epilogue
         // (measured: 55k cycles per tile for the epilogue of a residual GEMM).
         const bool res_init = EPI == 0 && ep.residual && !slabs && ep.act == BF_ACT_NONE && ep.alpha == 1.0f &&
-                              ep.resid_mod == 0 && ep.rows_in == 0;
+                              ep.resid_mod == 0 && ep.rows_in == 0 && w.part < 0;     // (a K chunk adds it in its epilogue, once)
         if (res_init) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -1396,6 +1479,57 @@ __device__ __forceinline__ void p8_body(
         const unsigned long long pc2 = clock64();
 #endif
 
+        // ---- K chunk of a tail tile: hand the accumulators over; the LAST chunk to arrive sums them and stores the tile
+        bool run_epilogue = true;
+        if constexpr (BK == 64 && !GROUPED) {
+            if (w.part >= 0) {
+                // The hand-off is the guide's counter form with write-through payload (MI355X_MICROARCH.md, "Valid
+                // forms"): every 16-byte store of the accumulators is `sc1`, every storing wave drains its stores
+                // (vmcnt(0)), a workgroup barrier, then ONE lane's agent-scope add on the tile's arrival counter; the
+                // workgroup whose add returns parts - 1 came last -- it learns so from the returned value -- and reads
+                // every chunk (its own too: a fixed summation order) with `sc1` loads behind a workgroup barrier that
+                // the adding wave joins after its add has returned.  No fence, no poll.  The image is the register
+                // file as it stands ([wave][register][lane] x 16 B): every store instruction writes 1 KB contiguous.
+                const int S = d.tail_parts;
+                const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)d.tail_ws, 0, (unsigned)d.tail_tiles * (unsigned)S * 262144u, 0x00020000);
+                const unsigned own = ((unsigned)(w.slot * S + w.part) * 8u + (unsigned)wave) * 32768u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[j][i]), rw,
+                                                                  (unsigned)lane * 16u, own + (unsigned)(j * 8 + i) * 1024u, 16);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (threadIdx.x == 0)
+                    bcast[1] = __hip_atomic_fetch_add(tk + 16 + w.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_barrier();
+                const unsigned arrived = __builtin_amdgcn_readfirstlane(bcast[1]);
+                run_epilogue = arrived == (unsigned)S - 1u;
+                if (run_epilogue) {
+                    if (threadIdx.x == 0) tk[16 + w.slot] = 0u;          // at rest again for this set's next launch
+#pragma unroll 1
+                    for (int z = 0; z < S; ++z) {
+                        const unsigned src = ((unsigned)(w.slot * S + z) * 8u + (unsigned)wave) * 32768u;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            u32x4_t t8[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                t8[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u,
+                                                                                 src + (unsigned)(j * 8 + i) * 1024u, 16);
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const f32x4 v = __builtin_bit_cast(f32x4, t8[i]);
+                                acc[j][i] = z == 0 ? v : acc[j][i] + v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (run_epilogue) {
         // Epilogue through LDS: in the MFMA layout a wave-instruction's 64 lanes own 16 rows x 4
         // separate 16-byte groups, i.e. 64 scattered requests per store (measured: ~780 cycles per
         // store instruction and wave, the epilogue as long as a K = 768 main loop).  Each wave
@@ -1676,6 +1810,41 @@ __device__ __forceinline__ void p8_body(
                 }
             }
         } else {
+        if constexpr (std::is_same<TC, float>::value) {
+        // fp32 results (and fp32 split-K slabs): 16 bytes per lane are FOUR columns, so 16 lanes cover a row's 64 columns
+        // and a store instruction is 4 rows x 256 contiguous bytes.  (Until round 4 a lane took 8 columns as two
+        // 16-byte stores: every store instruction wrote the even or the odd 16-byte pieces of 8 rows -- half of every
+        // line it touched, twice the write requests per byte.)
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            const int n = w.n0 + wn * 64 + (lane_ep & 15) * 4;
+            if (ep.bias && !slab && n < epn) b4 = *(const float4*)(ep.bias + n);
+        }
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            switch (c) {
+                case 0: stage_chunk(std::integral_constant<int, 0>{}); break;
+                case 1: stage_chunk(std::integral_constant<int, 1>{}); break;
+                case 2: stage_chunk(std::integral_constant<int, 2>{}); break;
+                default: stage_chunk(std::integral_constant<int, 3>{}); break;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int lr = t * 4 + (lane_ep >> 4), cc = lane_ep & 15;
+                const f32x4 q = *(const f32x4*)(stg + lr * 256 + ((cc ^ (lr & 15)) << 4));
+                const int m = w.m0 + wm * 128 + c * 32 + lr;
+                const int n = w.n0 + wn * 64 + cc * 4;
+                if (m < epm && n < epn) {
+                    if (slab) *(f32x4*)(slab + (size_t)m * epn + n) = q;
+                    else epilogue_store4b<TC, H>(epi, m, n, make_float4(q[0], q[1], q[2], q[3]), b4);
+                }
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        } else {
         float b8[8];                   // the lane_ep's 8 columns are the same for every row of the tile
         {
             const int n = w.n0 + wn * 64 + (lane_ep & 7) * 8;
@@ -1716,8 +1885,10 @@ __device__ __forceinline__ void p8_body(
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        }   // 16-bit general outputs
         }
         }   // general epilogue
+        }   // run_epilogue
 #ifdef P8_PROBE
         if (bid == 0 && threadIdx.x == 0 && round == 1) {
             p8_probe[0] = pc1 - pc0; p8_probe[1] = pw1 - pw0; p8_probe[2] = nk;
@@ -2278,7 +2449,7 @@ static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
     if (pipe_env >= 0 && pipe_env != 8 && pipe_env != 9) return false;
     // dX = dY W (NN) runs on the persistent kernel too; its 512-wide outputs are 2.15-round shapes (550 tiles on
     // 256 CUs), but splitting their tails measured neutral, so it is opt-in (BIFOLD_P8_TAIL_K="2048,1536")
-    if (T.p8_no_tail) return false;
+    if (T.p8_no_tail || T.p8_tail_mode != 1) return false;
     const int n_cu = n_cus();
     const long tiles_m = bf_cdiv(g->m, 256), tiles_n = bf_cdiv(g->n, 256);
     const long items = tiles_m * tiles_n;
@@ -2299,9 +2470,45 @@ static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
     return true;
 }
 
+// Round 4: the same idea INSIDE the launch (p8_body's tail split): the last round's tiles are cut into K chunks that
+// are ordinary work items; no extra launches, no slab pass, the tile's last chunk to arrive reduces and stores.
+struct P8InKernelTail { int tiles, parts, kt; size_t bytes; };
+static bool p8_inkernel_tail_plan(const bf_gemm_args* g, P8InKernelTail* plan) {
+    const BfTuning& T = bf_tuning();
+    if (T.p8_tail_mode != 2 || T.p8_no_tail || !T.p8_bk64) return false;
+    if (!bf_is_half(g->cdt) || g->trans_a || (g->b_kn && !T.p8_bk64_nn) || g->split_k > 1 || (g->k % 64) != 0 ||
+        (g->n % 8) != 0 || (g->ldc % 8) != 0 || g->m < T.p8_min_m)
+        return false;
+    const int pipe_env = T.gemm_pipe.load();
+    if (pipe_env >= 0 && pipe_env != 9) return false;
+    const int n_cu = n_cus();
+    const long items = (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256);
+    const int min_tiles = T.p8_min_tiles >= 0 ? T.p8_min_tiles : n_cu / 2;
+    if (items <= n_cu || items < min_tiles) return false;
+    const long rem = items % n_cu;
+    if (rem == 0 || rem > (long)(n_cu * 0.55) || rem > P8_TAIL_MAX) return false;
+    const int nkt = g->k / 64;
+    // A chunk costs a 256 KB write-through hand-off on top of its K tiles (and the last arriver reads them all back): it
+    // pays only when a chunk is deep enough -- measured round 4 (tools/gemm_bench.py, BIFOLD_P8_TAIL_MODE=2 vs 0 with
+    // chunks of any depth): K = 3072 in 3 chunks -5 %, K = 2048 in 6 chunks +-1 %, K = 512 / 768 in 2-8 chunks +12...19 %.
+    int parts = (int)(n_cu / rem);
+    if (parts > 8) parts = 8;
+    if (parts > nkt / T.p8_tail_min_kt) parts = nkt / T.p8_tail_min_kt;
+    if (parts < 2) return false;
+    const int kt = bf_cdiv(nkt, parts);
+    parts = bf_cdiv(nkt, kt);
+    if (parts < 2) return false;
+    plan->tiles = (int)rem; plan->parts = parts; plan->kt = kt;
+    plan->bytes = (size_t)rem * parts * 262144;
+    return plan->bytes < (1ull << 32);
+}
+
 extern "C" size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g) {
+    if (!g) return 0;
+    P8InKernelTail ik;
+    if (p8_inkernel_tail_plan(g, &ik)) return ik.bytes;
     P8TailPlan plan;
-    return (g && p8_tail_plan(g, &plan)) ? plan.bytes : 0;
+    return p8_tail_plan(g, &plan) ? plan.bytes : 0;
 }
 
 static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_variant);
@@ -2311,7 +2518,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
 // ring of sets can never be shared by two running kernels; concurrent streams get rings of their own.
 #define P8_TK_STREAMS 16
 #define P8_TK_RING 64
-__device__ unsigned p8_ticket_sets[P8_TK_STREAMS * P8_TK_RING * 16];
+#define P8_TK_WORDS 160            // per set: 9 ticket / exit counters (padded to 16) + 128 tail-tile arrival counters (+ pad)
+__device__ unsigned p8_ticket_sets[P8_TK_STREAMS * P8_TK_RING * P8_TK_WORDS];
 // One owner table per device (a `__device__` array has one copy per device); a 17th distinct stream on a device takes
 // the least recently used slot after a device synchronise (the old owner's launches may still read their sets).
 #define P8_TK_DEVICES 16
@@ -2346,7 +2554,7 @@ static unsigned* p8_ticket_set(hipStream_t s) {
     }
     t.last_use[slot] = ++clock;
     const unsigned set = t.next[slot]++ % P8_TK_RING;
-    return t.base + ((size_t)slot * P8_TK_RING + set) * 16;
+    return t.base + ((size_t)slot * P8_TK_RING + set) * P8_TK_WORDS;
 }
 
 // Launcher of the persistent e4m3 kernel for bf_gemm_fp8 (gemm_fp8.hip): returns BF_OK when it took the call,
@@ -2487,6 +2695,8 @@ extern "C" int bf_gemm_tn_grouped(const bf_gemm_tn_problem* p, int count, int k,
 extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
     BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
     P8TailPlan plan;
+    P8InKernelTail ik;
+    if (p8_inkernel_tail_plan(g, &ik)) return gemm_impl(g, stream, -1);      // the launch splits its own tail
     if (g->split_k <= 1 && g->workspace && p8_tail_plan(g, &plan) && g->workspace_bytes >= plan.bytes &&
         bf_aligned16(g->workspace)) {
         bf_gemm_args main = *g, tail = *g;
@@ -2661,8 +2871,15 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             GemmDims d8 = d;
             d8.tiles_m = bf_cdiv(g->m, 256); d8.tiles_n = bf_cdiv(g->n, 256);
             d8.group_m = T.p8_group_m;
-            const long items = (long)d8.tiles_m * d8.tiles_n * split;
+            long items = (long)d8.tiles_m * d8.tiles_n * split;
             BF_REQUIRE(items < (1L << 30), BF_EINVAL, "bf_gemm: too many tiles");
+            P8InKernelTail ik;
+            if (bk64 && split == 1 && !slabs && g->workspace && bf_aligned16(g->workspace) && p8_inkernel_tail_plan(g, &ik) &&
+                g->workspace_bytes >= ik.bytes) {
+                d8.tail_tiles = ik.tiles; d8.tail_parts = ik.parts; d8.tail_kt = ik.kt;
+                d8.tail_ws = (float*)g->workspace;
+                items += (long)ik.tiles * (ik.parts - 1);
+            }
             unsigned g8 = (unsigned)(n_cu & ~7);      // every CU draws; workgroups that find no ticket exit
             if (T.p8_grid >= 1 && (unsigned)T.p8_grid < g8) g8 = (unsigned)T.p8_grid;
             // bit 0: alternate the K direction per round of tickets (operand fetches 338 -> 239 MB on the vision QKV

@@ -7,6 +7,7 @@ this file lives in bifold_amd/csrc/*.hip.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -247,7 +248,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         ws = torch.empty(sk * m * n, dtype=torch.float32, device=a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     g.split_k = sk
-    if sk <= 1 and cdt != L.F32 and m >= 16384:
+    if sk <= 1 and cdt != L.F32 and m >= 16384 and not os.environ.get("BIFOLD_TEST_NO_TAIL_WS"):
         tail = lib.bf_gemm_tail_workspace_bytes(C.byref(g))
         if tail:
             ws = torch.empty(tail // 4, dtype=torch.float32, device=a.device)

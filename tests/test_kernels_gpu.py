@@ -7,6 +7,7 @@ bf16-ROUNDED operands, so what is left is accumulation order and the final bf16 
 (2^-8 relative), stated per test.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -257,6 +258,49 @@ def test_gemm_persistent_rounds(ops, L, gpu, layout, k, variant, half):
             assert rel_err(out.float(), ref) < tol
     finally:
         L.lib.bf_gemm_set_variant(-1)
+
+
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("layout", ["nt", "nn"])
+@pytest.mark.parametrize("k", [1536, 1600, 2304])
+def test_gemm_tail_split_inside_the_launch(ops, L, gpu, layout, k, half):
+    """325 tiles on 256 CUs: the 69 tiles of the under-filled second round are cut into K chunks INSIDE the launch
+    (2 chunks of 12 K tiles at K = 1536, 13 + 12 at K = 1600, 3 x 12 at K = 2304), each chunk hands its accumulators
+    over through the workspace and the last to arrive sums them in chunk order and runs the epilogue.  Against the fp64 product:
+    16-bit output with bias + GELU, fp32 output with bias + residual (a chunk must not preload the residual), ragged N;
+    two runs bit for bit equal (fixed summation order); and the same numbers as the unsplit launch."""
+    import ctypes as C
+    b_kn = layout[1] == "n"
+    m, n = 16640, 1096                                # 65 x 5 tiles (ragged N; the persistent kernel takes N % 8 == 0)
+    g = torch.Generator().manual_seed(91 + k)
+    a = round_to(torch.randn(m, k, generator=g), half)
+    b = round_to(torch.randn((k, n) if b_kn else (n, k), generator=g) * k ** -0.5, half)
+    bias, res = torch.randn(n, generator=g), torch.randn(m, n, generator=g)
+    pre = a.double() @ (b.double() if b_kn else b.double().t()) + bias.double()
+    ad, bd = a.to(gpu).to(half), b.to(gpu).to(half)
+    L.lib.bf_gemm_set_variant(9)
+    try:
+        import ctypes as C
+        o16 = ops.gemm(ad, bd, b_kn=b_kn, bias=bias.to(gpu), act=L.ACT_ERF_GELU, out_dtype=half)
+        assert L.lib.bf_gemm_last_variant() == 8
+        probe = L.GemmArgs()
+        probe.m, probe.n, probe.k, probe.lda, probe.ldb, probe.ldc = m, n, k, k, (n if b_kn else k), n
+        probe.cdt = probe.c_dtype = L.F16 if half == torch.float16 else L.BF16
+        probe.b_kn, probe.split_k = int(b_kn), 1
+        assert L.lib.bf_gemm_tail_workspace_bytes(C.byref(probe)) == 69 * (3 if k == 2304 else 2) * 262144
+        o16b = ops.gemm(ad, bd, b_kn=b_kn, bias=bias.to(gpu), act=L.ACT_ERF_GELU, out_dtype=half)
+        o32 = ops.gemm(ad, bd, b_kn=b_kn, bias=bias.to(gpu), residual=res.to(gpu), out_dtype=torch.float32)
+        os.environ["BIFOLD_TEST_NO_TAIL_WS"] = "1"                 # no workspace -> the launch keeps whole tiles
+        try:
+            whole = ops.gemm(ad, bd, b_kn=b_kn, bias=bias.to(gpu), residual=res.to(gpu), out_dtype=torch.float32)
+        finally:
+            del os.environ["BIFOLD_TEST_NO_TAIL_WS"]
+    finally:
+        L.lib.bf_gemm_set_variant(-1)
+    assert torch.equal(o16, o16b)
+    assert rel_err(o16.float(), F.gelu(pre)) < (2 ** -8 if half == torch.bfloat16 else 2 ** -11)
+    assert rel_err(o32, pre + res.double()) < 1e-5
+    assert rel_err(o32, whole.double()) < 2e-6          # fp32 partial sums in another association, nothing else
 
 
 @pytest.mark.parametrize("half", HALF)
