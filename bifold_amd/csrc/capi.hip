@@ -43,6 +43,11 @@ BfTuning& bf_tuning() {
         t.p8_nt = env_int("BIFOLD_P8_NT", 5) & 7;          // plain-16-bit and GELU-grad outputs non-temporal (round 2: 1 -> 5 +0.3 %)
         t.p8_tail_mode = env_int("BIFOLD_P8_TAIL_MODE", 2);
         t.p8_tail_min_kt = env_int("BIFOLD_P8_TAIL_MIN_KT", 12); if (t.p8_tail_min_kt < 1) t.p8_tail_min_kt = 1;
+        t.p8_skew_phases = 0; t.p8_skew_us10 = 0;
+        if (const char* e = getenv("BIFOLD_P8_SKEW")) {
+            int a = 0, b = 0;
+            if (sscanf(e, "%d,%d", &a, &b) == 2 && a > 1 && a < 16 && b > 0 && b < 2000) { t.p8_skew_phases = a; t.p8_skew_us10 = b; }
+        }
         t.p8_no_tail = getenv("BIFOLD_P8_NO_TAIL") ? 1 : 0;
         t.p8_tail_k_nt = 2048; t.p8_tail_k_nn = 1 << 30;   // in-step A/B (round 2): NN tails at K >= 1536 / 512: +-0.1 %; NT at K >= 768: -2 %
         if (const char* e = getenv("BIFOLD_P8_TAIL_K")) {

@@ -1093,6 +1093,17 @@ __device__ __forceinline__ void p8_body(
     P8Item w;
     [[maybe_unused]] int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
     unsigned pend = 0;                 // thread 0: the ticket drawn for the next item
+    // Start skew (round 4, write-heavy epilogues only: fp32 results with a residual, the fc1 + GELU' pair): identical
+    // tiles keep the CUs in lockstep, so every round ends in ONE burst of output stores (67 MB of fp32 at once for the
+    // fusion out-projection) against an HBM that idles through the main loops.  Phase p of P (workgroups of an XCD take
+    // the phases in turn) starts p * delta later, BEFORE it draws its first ticket -- late starters simply draw fewer.
+    {
+        const int phases = (skew_cycles >> 4) & 15, delta = (unsigned)skew_cycles >> 8;       // delta in 10 ns ticks
+        if (phases > 1 && delta > 0) {
+            const unsigned long long t_end = wall_clock64() + (unsigned long long)(((bid / NX) % phases) * delta);
+            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     if (threadIdx.x == 0) bcast[0] = atomicAdd(tk + xl, 1u);
     __syncthreads();
     const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);   // wave-uniform: keeps the item in SGPRs
@@ -2887,7 +2898,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             // pays only where both operands stream from HBM, i.e. the deep dW = dY^T X GEMMs (+5 %; NT / NN -3..5 %)
             const int rev_env = T.p8_revk, deep_env = T.p8_deep;
             const int deep = deep_env >= 0 ? (deep_env ? 1 : 0) : (g->trans_a && g->b_kn ? 1 : 0);
-            const int skew = rev_env | (deep << 1);
+            int skew = rev_env | (deep << 1);
             // which epilogue instantiation (the predicates of the kernel's EPI paths)
             int epi = 0;
             if (!f32out && !slabs && !g->residual && !g->c2 && !g->accumulate && g->rows_in == 0) {
@@ -2895,6 +2906,9 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                 else if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) epi = 1;
                 else if ((g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->pre) epi = 2;
             }
+            // start skew for the write-heavy epilogues (see p8_body): phases << 4 | delta (10 ns ticks) << 8
+            if (T.p8_skew_phases > 1 && T.p8_skew_us10 > 0 && (epi == 3 || (f32out && !slabs && g->residual)))
+                skew |= (T.p8_skew_phases & 15) << 4 | (T.p8_skew_us10 * 10) << 8;
 #define LAUNCH_P8E(AKS, BKS, TC, EPI, H, BKV)                                                       \
     do {                                                                                          \
         static bool lds_ok[P8_TK_DEVICES];  /* > 64 KB of dynamic LDS must be opted into, once per device */ \

@@ -22,6 +22,7 @@ struct BfTuning {
     int p8_nt;                    // BIFOLD_P8_NT            bit mask of non-temporal output stores (5)
     int p8_tail_mode;             // BIFOLD_P8_TAIL_MODE     under-filled last round: 2 = K chunks inside the launch (BK = 64 kernels), 1 = round 2's separate split-K launches, 0 = whole tiles (2)
     int p8_tail_min_kt;           // BIFOLD_P8_TAIL_MIN_KT   ... a K chunk of that split is at least this many K tiles of 64 deep (12)
+    int p8_skew_phases, p8_skew_us10;   // BIFOLD_P8_SKEW     "phases,tenths of a microsecond per phase": start skew of the write-heavy persistent GEMMs (off)
     int p8_no_tail;               // BIFOLD_P8_NO_TAIL       1: never cut an under-filled last round off as a split-K tail
     int p8_tail_k_nt, p8_tail_k_nn;   // BIFOLD_P8_TAIL_K   "nt,nn": K thresholds of that tail split (2048, off)
     int fp8_p8;                   // BIFOLD_FP8_P8           persistent e4m3 kernel (1)
