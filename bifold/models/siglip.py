@@ -32,7 +32,8 @@ _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.flo
 
 class SigLip(BaseModel):
     def __init__(self, patch_size, dim, lora, r, lora_alpha, lora_dropout, automodel_name, target_modules,
-                 pick_place_model, dtype="bf16", siglip_checkpoint=None, loss_scale="auto", **kwargs):
+                 pick_place_model, dtype="bf16", siglip_checkpoint=None, loss_scale="auto", lora_recompute="mlp",
+                 **kwargs):
         super().__init__(**kwargs)
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
@@ -41,7 +42,7 @@ class SigLip(BaseModel):
         self.patch_size = patch_size
         self.lora = bool(lora)
         adapters = (dict(r=r, alpha=lora_alpha, targets=list(target_modules), adapter="siglip_adapter",
-                         dropout=float(lora_dropout)) if lora else None)
+                         dropout=float(lora_dropout), recompute=lora_recompute) if lora else None)
         self.siglip_model = from_pretrained(automodel_name, siglip_checkpoint, lora=adapters)
         self.hidden_size = dim
         assert self.hidden_size == self.siglip_model.vcfg["hidden_size"]

@@ -74,8 +74,11 @@ class SiglipTowers(nn.Module):
             p_drop = float(lora.get("dropout", 0.0))
             if not 0.0 <= p_drop < 1.0:
                 raise ValueError(f"lora_dropout must be in [0, 1), got {p_drop}")
+            recompute = str(lora.get("recompute", "mlp"))
+            if recompute not in ("none", "mlp", "full"):
+                raise ValueError(f"lora_recompute must be none, mlp or full, got {recompute!r}")
             self.lora = dict(r=int(lora["r"]), alpha=float(lora["alpha"]), targets=targets,
-                             adapter=str(lora.get("adapter", "siglip_adapter")), dropout=p_drop)
+                             adapter=str(lora.get("adapter", "siglip_adapter")), dropout=p_drop, recompute=recompute)
             self._prefix = "base_model.model."
         vw, tw = vision["hidden_size"], text["hidden_size"]
         p = vision["patch_size"]
@@ -262,26 +265,18 @@ class SiglipTowers(nn.Module):
             # fold the rank in, so replicas drop different elements like one process over the whole batch would
             if torch.distributed.is_available() and torch.distributed.is_initialized():
                 base_seed ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
-            p_drop, scale = self.lora["dropout"], self.lora["alpha"] / self.lora["r"]
+        policy = self.lora["recompute"] if keep else "none"
         for i in range(cfg["num_hidden_layers"]):
             b = f"{tower}.encoder.layers.{i}."
-            h1, m1, r1 = ops.layernorm_fwd(x, self._f(b + "layer_norm1.weight"), self._f(b + "layer_norm1.bias"), cdt,
-                                           save_stats=keep, eps=LN_EPS)
-            qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
-            drop = None
+            seeds = None
             if unmerged:
-                drop = {}
+                seeds = {}
                 for slot, n in enumerate("qkv"):
-                    if f"{n}_proj" not in self.lora["targets"]:
-                        continue
-                    seed = (base_seed + 16 * i + slot) & (2 ** 63 - 1)
-                    self.last_dropout_seeds[(tower, call, i, f"{n}_proj")] = seed
-                    la, lb = self.lora_params(tower, i, f"{n}_proj")
-                    hd = ops.dropout(h1, p_drop, seed)
-                    u = ops.gemm(hd, la.data.to(cdt))                          # [M, r]
-                    ops.gemm(u, lb.data.to(cdt), alpha=scale, out=qkv[:, slot * w:(slot + 1) * w], accumulate=True)
-                    drop[n] = (u, seed)
-                    del hd
+                    if f"{n}_proj" in self.lora["targets"]:
+                        seeds[n] = (base_seed + 16 * i + slot) & (2 ** 63 - 1)
+                        self.last_dropout_seeds[(tower, call, i, f"{n}_proj")] = seeds[n]
+            h1, m1, r1 = self._ln1(x, b, cdt, keep)
+            qkv, drop = self._qkv(h1, b, i, tower, cdt, w, seeds)
             o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, L.MASK_NONE, need_lse=keep)
             xm = ops.gemm(o, self._w(b + "self_attn.out_proj.weight", cdt), bias=self._f(b + "self_attn.out_proj.bias"),
                           residual=x, out=None if keep else x, out_dtype=torch.float32)
@@ -295,11 +290,69 @@ class SiglipTowers(nn.Module):
                                   act=L.ACT_TANH_GELU), None
             xo = ops.gemm(a, self._w(b + "mlp.fc2.weight", cdt), bias=self._f(b + "mlp.fc2.bias"), residual=xm,
                           out=None if keep else xm, out_dtype=torch.float32)
-            if keep:      # h2 and a feed only frozen weights' gradients: not kept
-                saved.append(dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, xm=xm, m2=m2, r2=r2, pre=pre,
-                                  drop=drop))
+            if keep:      # h2 and a feed only frozen weights' gradients: never kept
+                S = dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, xm=xm, m2=m2, r2=r2, pre=pre, drop=drop,
+                         seeds=seeds)
+                # Activation recomputation (round 4; reference models/siglip.py:85-137 keeps the whole autograd graph of
+                # both towers for every frame -- at B = 128 x 5 frames x 576 tokens x 12 layers that is 88 GB of the
+                # step's 0.2 TB).  "mlp": h1 and the MLP's pre-activation (10 of 26 bytes x width per token and layer)
+                # are re-made in the backward from x / xm -- one LayerNorm each and the fc1 GEMM, 30 % of a block's
+                # forward FLOPs; "full": only the block input x stays, the backward re-runs the block up to fc1
+                # (70 %).  The re-made tensors are bit for bit the forward's (same kernels, same inputs, the same
+                # dropout seeds), so gradients do not depend on the policy.
+                if policy in ("mlp", "full"):
+                    S["h1"] = S["pre"] = None
+                if policy == "full":
+                    S["qkv"] = S["o"] = S["lse"] = S["xm"] = S["m2"] = S["r2"] = S["drop"] = None
+                saved.append(S)
             x = xo
         return x
+
+    def _ln1(self, x, b: str, cdt, keep: bool):
+        return ops.layernorm_fwd(x, self._f(b + "layer_norm1.weight"), self._f(b + "layer_norm1.bias"), cdt,
+                                 save_stats=keep, eps=LN_EPS)
+
+    def _qkv(self, h1, b: str, i: int, tower: str, cdt, w: int, seeds):
+        """Packed QKV projection; with `seeds` (training with lora_dropout > 0) the adapters run unmerged behind their own
+        dropout masks: qkv[:, slot] += s (D h1) A^T B^T.  Returns (qkv, {proj letter: (u, seed)} or None)."""
+        qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
+        if seeds is None:
+            return qkv, None
+        p_drop, scale = self.lora["dropout"], self.lora["alpha"] / self.lora["r"]
+        drop = {}
+        for slot, n in enumerate("qkv"):
+            if n not in seeds:
+                continue
+            la, lb = self.lora_params(tower, i, f"{n}_proj")
+            hd = ops.dropout(h1, p_drop, seeds[n])
+            u = ops.gemm(hd, la.data.to(cdt))                          # [M, r]
+            ops.gemm(u, lb.data.to(cdt), alpha=scale, out=qkv[:, slot * w:(slot + 1) * w], accumulate=True)
+            drop[n] = (u, seeds[n])
+            del hd
+        return qkv, drop
+
+    def _rematerialize(self, S: Dict, b: str, i: int, tower: str, cfg: Dict, batch: int, seq: int, cdt) -> Dict:
+        """Fill in what the forward dropped under the recompute policy, by re-running its kernels on what it kept."""
+        heads, w = cfg["num_attention_heads"], cfg["hidden_size"]
+        d = w // heads
+        if S["h1"] is None:
+            S["h1"], m1, r1 = self._ln1(S["x"], b, cdt, True)
+            if S["m1"] is None:
+                S["m1"], S["r1"] = m1, r1
+        if S["qkv"] is None:
+            S["qkv"], S["drop"] = self._qkv(S["h1"], b, i, tower, cdt, w, S["seeds"])
+        if S["o"] is None:
+            S["o"], S["lse"] = ops.attention_fwd(S["qkv"], batch, seq, heads, d, d ** -0.5, L.MASK_NONE, need_lse=True)
+        if S["xm"] is None:
+            S["xm"] = ops.gemm(S["o"], self._w(b + "self_attn.out_proj.weight", cdt),
+                               bias=self._f(b + "self_attn.out_proj.bias"), residual=S["x"], out_dtype=torch.float32)
+        if S["pre"] is None:
+            h2, m2, r2 = ops.layernorm_fwd(S["xm"], self._f(b + "layer_norm2.weight"), self._f(b + "layer_norm2.bias"),
+                                           cdt, save_stats=True, eps=LN_EPS)
+            if S["m2"] is None:
+                S["m2"], S["r2"] = m2, r2
+            S["pre"] = ops.gemm(h2, self._w(b + "mlp.fc1.weight", cdt), bias=self._f(b + "mlp.fc1.bias"))
+        return S
 
     def _encoder_bwd(self, dx: torch.Tensor, dx_c: Optional[torch.Tensor], saved: List, tower: str, cfg: Dict,
                      batch: int, seq: int, cdt, grad_view) -> None:
@@ -316,7 +369,7 @@ class SiglipTowers(nn.Module):
         dw = torch.empty(3 * w, w, dtype=torch.float32, device=dev)
         for i in reversed(range(cfg["num_hidden_layers"])):
             b = f"{tower}.encoder.layers.{i}."
-            S = saved[i]
+            S = self._rematerialize(saved[i], b, i, tower, cfg, batch, seq, cdt)
             op = dx_c if dx_c is not None else dx
             # MLP:  xo = xm + gelu_tanh(h2 W1^T + b1) W2^T + b2
             dpre = ops.gemm(op, self._w(b + "mlp.fc2.weight", cdt), b_kn=True, act=L.ACT_TANH_GELU_GRAD, aux=S["pre"])

@@ -7,7 +7,7 @@ tag=${1:-r02}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-kernel-timer"
+BENCH="python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_raw -- $BENCH > $out/stats.log 2>&1 || { echo "stats pass failed"; tail -5 $out/stats.log; exit 1; }
 f=$(find $out/stats_raw -name '*kernel_stats.csv' | head -1)
 python3 tools/prof_summary.py "$f" 6 > $out/stats.txt

@@ -7,7 +7,7 @@ tag=${1:-s}; shift
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp BIFOLD_DW_SIDE=0 BIFOLD_TEXT_STREAM=0
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial_raw -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-kernel-timer "$@" > $out/serial.log 2>&1 || { echo "serial stats pass failed"; tail -5 $out/serial.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial_raw -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt "$@" > $out/serial.log 2>&1 || { echo "serial stats pass failed"; tail -5 $out/serial.log; exit 1; }
 f=$(find $out/serial_raw -name '*kernel_stats.csv' | head -1)
 python3 tools/prof_summary.py "$f" 6 > $out/serial_stats.txt
 rm -rf $out/serial_raw
