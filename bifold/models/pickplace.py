@@ -54,14 +54,21 @@ def _dw_stream(device) -> "torch.cuda.Stream":
 
 class _WeightGradSide:
     """Launches `ops.gemm(dY, X, trans_a=True, b_kn=True, out=dW)` on the side stream once the main stream has produced
-    its operands.  Operands allocated on the main stream are pinned to the side stream (`record_stream`), so that the
-    caching allocator does not hand them out again before the side stream has read them."""
+    its operands.  The operands were allocated on the main stream; the side stream must have read them before the
+    caching allocator hands their memory out again.  Rounds 1-3 pinned them with `record_stream`; that makes the
+    allocator re-check an event at every later allocation and take FRESH memory whenever the side stream is not done yet
+    -- at configs[2]'s sizes (2.3 GB operands, ~9 GB per layer) the reserved pool grew to the whole 288 GB while 150-180
+    GB were allocated, and a step then ran into allocator retries (112-196 samples/s from run to run).  Round 4: the
+    object simply HOLDS the operands until the main stream has waited for the event behind their GEMMs (`mark` /
+    `joined`): they are then freed on the stream that allocated them, behind the wait, and reusable at once."""
 
     def __init__(self, device):
         self.on = _DW_SIDE > 0
         self.side = _dw_stream(device) if self.on else None
         self.group = [] if _DW_GROUPED else None       # (dy, x, out) of the layer being walked
         self.group_after = None                         # event behind the producer of the LAST collected operand
+        self.held: List[torch.Tensor] = []              # operands of side-stream GEMMs not yet behind a `mark`
+        self.marked: List = []                          # (event, operands) generations waiting for `joined`
 
     def flush(self):
         """Issue what `gemm` collected (end of a layer: every operand has been produced on the main stream)."""
@@ -80,8 +87,7 @@ class _WeightGradSide:
                     ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
         if self.on:
             for dy, x, _ in todo:
-                dy.record_stream(self.side)
-                x.record_stream(self.side)
+                self.held += [dy, x]
 
     def ready(self):
         """Event on the main stream: everything queued so far (the operands of the next dW GEMM) is produced."""
@@ -105,8 +111,7 @@ class _WeightGradSide:
             self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
-        dy.record_stream(self.side)
-        x.record_stream(self.side)
+        self.held += [dy, x]
 
     def mark(self):
         """Event after which everything launched so far on the side stream is complete."""
@@ -114,7 +119,16 @@ class _WeightGradSide:
             return None
         ev = torch.cuda.Event()
         ev.record(self.side)
+        self.marked.append((ev, self.held))
+        self.held = []
         return ev
+
+    def joined(self, ev) -> None:
+        """The main stream has been told to wait for `ev`: the operands of everything marked up to it may go."""
+        while self.marked:
+            e, _ = self.marked.pop(0)
+            if e is ev:
+                break
 
 
 class _NullCtx:
@@ -379,15 +393,18 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
                 done = []
                 if late is not None:
                     main.wait_event(late[1])
+                    wg.joined(late[1])
                     done = [late[0]]
                 late = (i, ev)
             else:
                 main.wait_event(ev)
+                wg.joined(ev)
         if on_layer_done is not None:
             for j in done:
                 on_layer_done(j)
     if late is not None:
         main.wait_event(late[1])
+        wg.joined(late[1])
         if on_layer_done is not None:
             on_layer_done(late[0])
     return dx

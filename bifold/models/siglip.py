@@ -32,7 +32,7 @@ _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.flo
 
 class SigLip(BaseModel):
     def __init__(self, patch_size, dim, lora, r, lora_alpha, lora_dropout, automodel_name, target_modules,
-                 pick_place_model, dtype="bf16", siglip_checkpoint=None, loss_scale="auto", lora_recompute="mlp",
+                 pick_place_model, dtype="bf16", siglip_checkpoint=None, loss_scale="auto", lora_recompute="none",
                  **kwargs):
         super().__init__(**kwargs)
         if dtype not in _DTYPES:

@@ -74,7 +74,7 @@ class SiglipTowers(nn.Module):
             p_drop = float(lora.get("dropout", 0.0))
             if not 0.0 <= p_drop < 1.0:
                 raise ValueError(f"lora_dropout must be in [0, 1), got {p_drop}")
-            recompute = str(lora.get("recompute", "mlp"))
+            recompute = str(lora.get("recompute", "none"))
             if recompute not in ("none", "mlp", "full"):
                 raise ValueError(f"lora_recompute must be none, mlp or full, got {recompute!r}")
             self.lora = dict(r=int(lora["r"]), alpha=float(lora["alpha"]), targets=targets,
@@ -299,7 +299,10 @@ class SiglipTowers(nn.Module):
                 # are re-made in the backward from x / xm -- one LayerNorm each and the fc1 GEMM, 30 % of a block's
                 # forward FLOPs; "full": only the block input x stays, the backward re-runs the block up to fc1
                 # (70 %).  The re-made tensors are bit for bit the forward's (same kernels, same inputs, the same
-                # dropout seeds), so gradients do not depend on the policy.
+                # dropout seeds), so gradients do not depend on the policy.  Measured at configs[2], B = 128, fp16
+                # (tools/lora_recompute_bench.py, five runs in one process each): none 198 samples/s at 181 GiB peak,
+                # mlp 190 at 147 GiB, full 179 at 109 GiB -- all stable since the dW side stream stopped pinning its
+                # operands with record_stream (pickplace._WeightGradSide).  Default: none (288 GB is there to be used).
                 if policy in ("mlp", "full"):
                     S["h1"] = S["pre"] = None
                 if policy == "full":
