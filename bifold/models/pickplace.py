@@ -67,6 +67,7 @@ class _WeightGradSide:
         self.side = _dw_stream(device) if self.on else None
         self.group = [] if _DW_GROUPED else None       # (dy, x, out) of the layer being walked
         self.group_after = None                         # event behind the producer of the LAST collected operand
+        self.qualifies: Optional[bool] = None           # does the grouped launch take this backward's token count?
         self.held: List[torch.Tensor] = []              # operands of side-stream GEMMs not yet behind a `mark`
         self.marked: List = []                          # (event, operands) generations waiting for `joined`
 
@@ -98,6 +99,12 @@ class _WeightGradSide:
         return ev
 
     def gemm(self, dy, x, out, after=None):
+        if self.group is not None and self.qualifies is None:
+            # decided once per backward (every layer has the same token count): a layer whose weight gradients the
+            # grouped launch would refuse (few tokens, an odd count) keeps the per-GEMM issue order and lifetimes
+            self.qualifies = ops.gemm_tn_grouped_qualifies(dy.shape[0], dy.dtype)
+            if not self.qualifies:
+                self.group = None
         if self.group is not None and dy.dtype in ops.HALF:
             self.group.append((dy, x, out))
             self.group_after = after
@@ -320,7 +327,7 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     d = dx3.shape[1] // heads
     if wg is None:
         wg = _WeightGradSide.__new__(_WeightGradSide)
-        wg.on, wg.side, wg.group, wg.group_after = False, None, None, None
+        wg.on, wg.side, wg.group, wg.group_after, wg.qualifies, wg.held, wg.marked = False, None, None, None, None, [], []
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2

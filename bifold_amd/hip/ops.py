@@ -275,6 +275,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
     return out
 
 
+def gemm_tn_grouped_qualifies(k: int, dtype: torch.dtype) -> bool:
+    """Will a group of dW = dY^T X problems over `k` rows (tokens) be taken by the grouped launch at all?  The library's
+    own answer (bf_gemm_tn_grouped_workspace_bytes on a one-tile probe problem): callers decide ONCE per backward
+    whether to defer a layer's weight gradients to the end of the layer or to issue them as they come."""
+    if dtype not in HALF:
+        return False
+    arr = (L.GemmTnProblem * 1)()
+    arr[0].m, arr[0].n, arr[0].ld_dy, arr[0].ld_x, arr[0].ldc = 256, 256, 256, 256, 256
+    arr[0].dy = arr[0].x = arr[0].c = 4096              # the plan checks alignment only; nothing is dereferenced
+    return lib.bf_gemm_tn_grouped_workspace_bytes(arr, 1, int(k), L.F16 if dtype == torch.float16 else L.BF16) > 0
+
+
 def gemm_tn_grouped(problems, alpha: float = 1.0) -> bool:
     """problems: list of (dy [K, m], x [K, n], out fp32 [m, n]) -- out_p = alpha * dy_p^T x_p for every p in ONE launch of
     the persistent kernel (the weight gradients of a transformer layer).  Returns False, having done nothing, when the
