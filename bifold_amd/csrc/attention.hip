@@ -2487,7 +2487,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             if (grid_pd > batch * heads) grid_pd = batch * heads;
 #define FWD_PD(HT)                                                                                 \
     do {                                                                                          \
-        static size_t lds_set = 0;                                                                \
+        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                                                                \
         if (pd_lds > lds_set) {                                                                   \
             (void)hipFuncSetAttribute((const void*)attn_fwd_pd32_kernel<HT>,                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);   \
@@ -2510,7 +2510,7 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
 #define FWD_RES2(DD, MM) BY_HALF(FWD_RES3, DD, MM)
 #define FWD_RES3(DD, MM, HT)                                                                       \
     do {                                                                                          \
-        static size_t lds_set = 0;                                                                \
+        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                                                                \
         if (res_lds > lds_set) {                                                                  \
             (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 2, HT>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
@@ -2654,7 +2654,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
             dim3 grid(batch * heads), block(256);
 #define BWD_FUSED(HT)                                                                                    \
     do {                                                                                                 \
-        static size_t set_f = 0;                                                                         \
+        static BfPerDevice set_f_dev; size_t& set_f = set_f_dev.cur();                                                                         \
         if (lds_f > set_f) {                                                                             \
             (void)hipFuncSetAttribute((const void*)attn_bwd_fused32_kernel<HT>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);           \
@@ -2688,7 +2688,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
 #define BWD_SPLIT2(DD, MM) BY_HALF(BWD_SPLIT3, DD, MM)
 #define BWD_SPLIT3(DD, MM, HT)                                                                      \
     do {                                                                                            \
-        static size_t set_q = 0, set_kv = 0;                                                        \
+        static BfPerDevice set_q_dev, set_kv_dev; size_t &set_q = set_q_dev.cur(), &set_kv = set_kv_dev.cur();                                                        \
         if (lds_q > set_q) {                                                                        \
             (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DD, MM, HT>,                       \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
@@ -2746,7 +2746,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
 #define BWD_STREAM2(DD, MM) BY_HALF(BWD_STREAM3, DD, MM)
 #define BWD_STREAM3(DD, MM, HT)                                                                         \
     do {                                                                                            \
-        static size_t set_q = 0, set_kv = 0;                                                        \
+        static BfPerDevice set_q_dev, set_kv_dev; size_t &set_q = set_q_dev.cur(), &set_kv = set_kv_dev.cur();                                                        \
         if (lds_q > set_q) {                                                                        \
             (void)hipFuncSetAttribute((const void*)attn_bwd_q_stream_kernel<DD, MM, HT>,                \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
@@ -2795,7 +2795,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
 #define BWD_MFMA2(DD, MM) BY_HALF(BWD_MFMA3, DD, MM)
 #define BWD_MFMA3(DD, MM, HT)                                                                           \
     do {                                                                                            \
-        static size_t lds_set = 0;                                                                  \
+        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                                                                  \
         if (lds > lds_set) {                                                                        \
             (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM, HT>,                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \

@@ -219,3 +219,18 @@ template <> struct ActMath<bf16_t> {
     static __device__ __forceinline__ float tanh_grad(float x) { return tanh_gelu_grad_fast(x); }
 };
 template <> struct ActMath<f16_t> : ActMath<bf16_t> {};          // same fast forms: 1.5e-7 absolute is below 2^-11 too
+
+// "Opt a kernel in to more than 64 KB of dynamic LDS" is a per-DEVICE attribute of the function: the guards that make the
+// call once (and again when a larger size is asked for) are kept per device, so one process may drive several devices
+// (include/bifold_hip.h).  A device index beyond the table simply sets the attribute on every call.
+#define BF_MAX_DEVICES 16
+struct BfPerDevice {
+    size_t v[BF_MAX_DEVICES];
+    size_t spill;
+    size_t& cur() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        if (d < 0 || d >= BF_MAX_DEVICES) { spill = 0; return spill; }
+        return v[d];
+    }
+};

@@ -2586,7 +2586,7 @@ int bf_gemm_fp8_p8_try(const void* a8, const float* sa, const void* b8, const fl
     GemmDims d{m, n, k, lda, ldb, bf_cdiv(m, 256), bf_cdiv(n, 256), k, p8_group};
     Fp8P8Epi ep{(bf16_t*)c, sa, sb, bias, m, n, ldc, act, pol};
     const size_t a_ext = (size_t)(m - 1) * lda + k, b_ext = (size_t)(n - 1) * ldb + k;
-    static bool lds_ok = false;
+    static BfPerDevice lds_ok_dev; size_t& lds_ok = lds_ok_dev.cur();
     if (!lds_ok) {
         (void)hipFuncSetAttribute((const void*)gemm_fp8_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P8_STAGE + 16);
         lds_ok = true;
@@ -2677,7 +2677,7 @@ extern "C" int bf_gemm_tn_grouped(const bf_gemm_tn_problem* p, int count, int k,
     const unsigned g8 = (unsigned)(n_cus() & ~7);
     last_variant = 8;
     if (cdt == BF_F16) {
-        static bool lds_ok = false;
+        static BfPerDevice lds_ok_dev; size_t& lds_ok = lds_ok_dev.cur();
         if (!lds_ok) {
             (void)hipFuncSetAttribute((const void*)gemm_p8_grouped_tn_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       4 * P8_STAGE + 16);
@@ -2686,7 +2686,7 @@ extern "C" int bf_gemm_tn_grouped(const bf_gemm_tn_problem* p, int count, int k,
         hipLaunchKernelGGL(gemm_p8_grouped_tn_kernel<f16_t>, dim3(g8), dim3(512), 4 * P8_STAGE + 16, s, grp, d, ep, (int)items,
                            skew, tk8);
     } else {
-        static bool lds_ok = false;
+        static BfPerDevice lds_ok_dev; size_t& lds_ok = lds_ok_dev.cur();
         if (!lds_ok) {
             (void)hipFuncSetAttribute((const void*)gemm_p8_grouped_tn_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       4 * P8_STAGE + 16);
@@ -2812,7 +2812,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
 #define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
 #define LAUNCH_BF16_T(AKS, BKS, TC, H)                                                             \
     do {                                                                                          \
-        static bool lds_ok = false;  /* > 64 KB of dynamic LDS must be opted into, once */        \
+        static BfPerDevice lds_ok_dev; size_t& lds_ok = lds_ok_dev.cur();  /* > 64 KB of dynamic LDS must be opted into, once */        \
         if (!lds_ok) {                                                                            \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<AKS, BKS, TC, H>,             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
@@ -2982,7 +2982,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
 #define LAUNCH_DMA_T(AKS, BKS, TC, H)                                                                \
     do {                                                                                          \
-        static bool lds_ok = false;                                                               \
+        static BfPerDevice lds_ok_dev; size_t& lds_ok = lds_ok_dev.cur();                                                               \
         if (!lds_ok) {                                                                            \
             (void)hipFuncSetAttribute((const void*)gemm_bf16_dma_kernel<AKS, BKS, TC, H>,         \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);     \
@@ -3015,7 +3015,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         const float* B = (const float*)g->b;
 #define LAUNCH_F32(AKS, BKS)                                                                       \
     do {                                                                                          \
-        static bool lds_ok = false;                                                               \
+        static BfPerDevice lds_ok_dev; size_t& lds_ok = lds_ok_dev.cur();                                                               \
         if (!lds_ok) {                                                                            \
             (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<AKS, BKS>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
