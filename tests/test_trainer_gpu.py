@@ -290,6 +290,33 @@ assert all(flat[i][1] == flat[i + 1][0] for i in range(len(flat) - 1)), flat
 assert len(launched) >= 2                             # at least one bucket left before the end of backward
 got = model.trainable_arena().grad
 assert float((got - plain).abs().max()) <= 1e-6 * float(plain.abs().max()), float((got - plain).abs().max())
+# fp16 mode over RCCL: the overflow flag of the guarded step rides (MAX, int32) behind the last bucket; a clean
+# backward leaves it 0 and the step is applied, a poisoned one (inf target) sets it and the step changes nothing
+from bifold.optim import Optimizers
+cfg16 = dict(cfg, dtype="fp16")
+torch.manual_seed(0)
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    m16 = Models.get_by_name(cfg16, device=dev).to(dev).train()
+opt = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-3, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
+                             params=[p for p in m16.parameters() if p.requires_grad])
+sync16 = bdist.gradient_sync_for(m16)
+assert sync16.flag_getter is not None
+flags = []
+orig_flag = sync16._launch_flag
+sync16._launch_flag = lambda: (flags.append(1), orig_flag())[1]
+def one_step(s):
+    loss_fn(m16(s), s)[0].backward(); sync16.finish(); opt.step(); opt.zero_grad()
+before = opt.arena.flat.clone()
+one_step(sample)
+torch.cuda.synchronize()
+assert len(flags) == 1 and m16._grad_scaler.read()["skipped"] == 0 and not torch.equal(opt.arena.flat, before)
+bad = dict(sample); bad["pick_heatmap"] = sample["pick_heatmap"].clone(); bad["pick_heatmap"][0, 0, 0] = float("inf")
+kept = opt.arena.flat.clone()
+one_step(bad)
+torch.cuda.synchronize()
+seen = m16._grad_scaler.read()
+assert len(flags) == 2 and seen["skipped"] == 1 and torch.equal(opt.arena.flat, kept) and torch.isfinite(opt.arena.flat).all()
 torch.distributed.destroy_process_group()
 print("DDP-HOOKS-OK", len(launched))
 """
@@ -298,7 +325,9 @@ print("DDP-HOOKS-OK", len(launched))
 def test_backward_hooks_drive_rccl_allreduce_world1(gpu, tmp_path):
     """World-size-1 RCCL group (BIFOLD_FORCE_PG=1) in a child process: the REAL fused backward reports layers through
     register_grad_ready_hook, GradSync all-reduces every arena slice exactly once on its side stream while the
-    backward is still running, and the averaged gradients equal the un-synchronised ones."""
+    backward is still running, and the averaged gradients equal the un-synchronised ones.  Then the fp16 mode over the
+    same group: the guarded step's overflow flag travels (int32 MAX over RCCL) behind the last bucket, a clean step is
+    applied, a poisoned one is dropped with the parameters bit for bit unchanged."""
     script = tmp_path / "ddp_world1.py"
     script.write_text(DDP_SCRIPT)
     env = dict(os.environ, BIFOLD_FORCE_PG="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", WORLD_SIZE="1", RANK="0",
