@@ -293,7 +293,7 @@ assert float((got - plain).abs().max()) <= 1e-6 * float(plain.abs().max()), floa
 # fp16 mode over RCCL: the overflow flag of the guarded step rides (MAX, int32) behind the last bucket; a clean
 # backward leaves it 0 and the step is applied, a poisoned one (inf target) sets it and the step changes nothing
 from bifold.optim import Optimizers
-cfg16 = dict(cfg, dtype="fp16")
+cfg16 = dict(cfg, name="rgb_clip", dtype="fp16")     # (the factory deleted cfg["name"], like the reference's)
 torch.manual_seed(0)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
