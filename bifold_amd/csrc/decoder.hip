@@ -215,30 +215,51 @@ __global__ __launch_bounds__(256) void upsample_sigmoid_kernel(const float* __re
     const int S = g * 16;
     float* Us = sm;               // [S][g]
     float* lw = Us + S * g;       // [g][g]
-    float* T = lw + g * g;        // [g][S]   T[i][x] = sum_j low[i][j] U[x][j]
+    float* T = lw + ((g * g + 3) & ~3);   // [g][S]   T[i][x] = sum_j low[i][j] U[x][j]  (16-byte aligned for every g)
     const size_t bh = blockIdx.x;
     for (int i = threadIdx.x; i < S * g; i += 256) Us[i] = U[i];
     for (int i = threadIdx.x; i < g * g; i += 256) lw[i] = low[bh * g * g + i];
     __syncthreads();
+    // U[x][j] is non-zero only for j within one coarse cell of x / 16 (four composed bilinear x2 steps reach less than
+    // one coarse sample either side; the backward kernel below relies on the same band): three terms per sum, not g.
     for (int idx = threadIdx.x; idx < g * S; idx += 256) {
         const int i = idx / S, x = idx - i * S;
+        const int c = x >> 4;
         float a = 0.f;
-        for (int j = 0; j < g; ++j) a = fmaf(lw[i * g + j], Us[x * g + j], a);
+#pragma unroll
+        for (int k = -1; k <= 1; ++k) {                       // fixed trip count: all six LDS reads go out together
+            const int j = c + k, jc = min(max(j, 0), g - 1);
+            float l = lw[i * g + jc], u = Us[x * g + jc];
+            asm volatile("" : "+v"(l), "+v"(u));
+            a = j == jc ? fmaf(l, u, a) : a;
+        }
         T[idx] = a;
     }
     __syncthreads();
     float* dst = heat + bh * (size_t)S * S;
     const int S4 = S >> 2;
-    for (int idx = threadIdx.x; idx < S * S4; idx += 256) {
-        const int y = idx / S4, x4 = (idx - y * S4) * 4;
+    const int yh = S >> 1, y_lo = blockIdx.y * yh;           // two workgroups per map: the upper and the lower half
+    const int step_y = 256 / S4, step_x = 256 - step_y * S4;  // the walk idx += 256 without a division per step
+    int yy = threadIdx.x / S4, xq = threadIdx.x - yy * S4;
+    for (; yy < yh; yy += step_y, xq += step_x) {
+        if (xq >= S4) { xq -= S4; ++yy; if (yy >= yh) break; }
+        const int x4 = xq * 4, y = y_lo + yy;
+        const int c = y >> 4;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < g; ++i) {
-            const float u = Us[y * g + i];
-            const float4 t = *(const float4*)(T + i * S + x4);
-            a.x = fmaf(u, t.x, a.x); a.y = fmaf(u, t.y, a.y); a.z = fmaf(u, t.z, a.z); a.w = fmaf(u, t.w, a.w);
+#pragma unroll
+        for (int k = -1; k <= 1; ++k) {
+            const int i = c + k, ic = min(max(i, 0), g - 1);
+            float u = Us[y * g + ic];
+            float4 t = *(const float4*)(T + ic * S + x4);
+            asm volatile("" : "+v"(u), "+v"(t.x), "+v"(t.y), "+v"(t.z), "+v"(t.w));   // reads unconditional, then selects
+            const bool in = i == ic;
+            a.x = in ? fmaf(u, t.x, a.x) : a.x; a.y = in ? fmaf(u, t.y, a.y) : a.y;
+            a.z = in ? fmaf(u, t.z, a.z) : a.z; a.w = in ? fmaf(u, t.w, a.w) : a.w;
         }
-        a.x = 1.0f / (1.0f + expf(-a.x)); a.y = 1.0f / (1.0f + expf(-a.y));
-        a.z = 1.0f / (1.0f + expf(-a.z)); a.w = 1.0f / (1.0f + expf(-a.w));
+        // v_exp_f32 + v_rcp_f32 (1 ulp each; the argument's rounding adds |logit| * 6e-8 relative): the accurate expf
+        // and the IEEE division were 90 of this loop's 200 instructions per four pixels, and the loop was VALU-bound
+        a.x = __builtin_amdgcn_rcpf(1.0f + __expf(-a.x)); a.y = __builtin_amdgcn_rcpf(1.0f + __expf(-a.y));
+        a.z = __builtin_amdgcn_rcpf(1.0f + __expf(-a.z)); a.w = __builtin_amdgcn_rcpf(1.0f + __expf(-a.w));
         *(float4*)(dst + (size_t)y * S + x4) = a;
     }
 }
@@ -249,8 +270,8 @@ extern "C" int bf_decoder_upsample_sigmoid(const float* low, const float* U, flo
                "bf_decoder_upsample_sigmoid: grid must be in 1..%d (got %d)", DEC_MAXG, grid);
     BF_REQUIRE(bf_aligned16(heat), BF_EALIGN, "bf_decoder_upsample_sigmoid: unaligned heat");
     const int S = grid * 16;
-    const size_t lds = (size_t)(S * grid + grid * grid + grid * S) * sizeof(float);
-    hipLaunchKernelGGL(upsample_sigmoid_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream,
+    const size_t lds = (size_t)(S * grid + ((grid * grid + 3) & ~3) + grid * S) * sizeof(float);
+    hipLaunchKernelGGL(upsample_sigmoid_kernel, dim3(n_maps, 2), dim3(256), lds, (hipStream_t)stream,
                        low, U, heat, grid);
     BF_CHECK_LAUNCH("bf_decoder_upsample_sigmoid");
     return BF_OK;
@@ -271,9 +292,14 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     const int p4n = pixels >> 2;
     const size_t total = (size_t)batch * p4n;
     float acc = 0.f;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int b = (int)(i / p4n);
-        const int p = (int)(i - (size_t)b * p4n) * 4;
+    // the grid-stride walk i += gridDim.x * 256 kept as (sample, quad) with one division up front: a 64-bit division
+    // per step cost more than the two logarithms
+    const size_t first = blockIdx.x * (size_t)256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+    int b = (int)(first / p4n), q = (int)(first - (size_t)b * p4n);
+    const int step_b = (int)(step / p4n), step_q = (int)(step - (size_t)step_b * p4n);
+    for (size_t i = first; i < total; i += step, b += step_b, q += step_q) {
+        if (q >= p4n) { q -= p4n; ++b; }
+        const int p = q * 4;
         const float4 pv = *(const float4*)(heat + b * hb + h * hh + p);
         const float4 tv = *(const float4*)(target + b * tb + h * th + p);
         const float pp[4] = {pv.x, pv.y, pv.z, pv.w};
@@ -359,6 +385,7 @@ extern "C" int bf_bce_bwd(const float* heat, const float* target, const float* g
 // ------------------------------------------------------------------ sigmoid o upsample backward
 // per map: dlogit = d_heat * p (1 - p);  g_low = U^T dlogit U      (adjoint of the separable upsample)
 #define UB_ROWS 16
+#define UB_PF ((UB_ROWS * DEC_MAXG * 4 + 255) / 256)      // float4 per thread and operand of one 16-row chunk
 __global__ __launch_bounds__(256) void upsample_sigmoid_bwd_kernel(const float* __restrict__ heat,
                                                                    const float* __restrict__ d_heat,
                                                                    const float* __restrict__ U,
@@ -366,44 +393,71 @@ __global__ __launch_bounds__(256) void upsample_sigmoid_bwd_kernel(const float* 
     // per map: dl = d_heat * p(1-p);  R = dl U  (S x g);  g_low = U^T R  (g x g).
     // Rows are processed in chunks of 16 staged in LDS; thread (y, j) owns R[y][j] of the chunk
     // and thread (i, j) owns g_low[i][j], so there are no cross-lane reductions at all.
+    // Two workgroups per map (blockIdx.y): each owns half of g_low's rows i and walks only the fine rows y those rows
+    // can see -- U[y][i] is zero outside (i - 1) * 16 <= y < (i + 2) * 16 -- so every entry still has ONE owner that adds
+    // its terms in ascending y (the skipped terms are exact zeros: same bits as the one-workgroup walk over all rows).
+    // The next chunk's heat / d_heat rows are requested before the current chunk is reduced.
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int S = g * 16;
     float* Us = sm;                       // [S][g]
     float* dl = Us + S * g;               // [UB_ROWS][S]
     float* Rc = dl + UB_ROWS * S;         // [UB_ROWS][g]
     const size_t bh = blockIdx.x;
-    for (int i = threadIdx.x; i < S * g; i += 256) Us[i] = U[i];
+    const int gh = (g + 1) >> 1;
+    const int i_lo = blockIdx.y * gh, i_hi = min(g, i_lo + gh);
+    if (i_lo >= i_hi) return;             // g == 1: nothing for the second workgroup (uniform: before any barrier)
+    const int y_beg = max(0, (i_lo - 1) * 16), y_end = min(S, (i_hi + 1) * 16);
     const float* hp = heat + bh * (size_t)S * S;
     const float* dp = d_heat + bh * (size_t)S * S;
-    const int gg = g * g;
-    float gacc[3] = {0.f, 0.f, 0.f};      // g*g <= 576 entries over 256 threads
-    const int S4 = S >> 2;
-    for (int y0 = 0; y0 < S; y0 += UB_ROWS) {
+    const int S4 = S >> 2, chunk4 = UB_ROWS * S4;
+    int off[UB_PF];                       // element offset inside a chunk: the same in LDS and (row stride S) in memory
+#pragma unroll
+    for (int k = 0; k < UB_PF; ++k) {
+        const int idx = threadIdx.x + k * 256;
+        const int y = idx / S4;
+        off[k] = idx < chunk4 ? y * S + (idx - y * S4) * 4 : -1;
+    }
+    float4 pp[UB_PF], dd[UB_PF];
+    auto fetch = [&](int y0) {
+#pragma unroll
+        for (int k = 0; k < UB_PF; ++k)
+            if (off[k] >= 0) {
+                pp[k] = *(const float4*)(hp + (size_t)y0 * S + off[k]);
+                dd[k] = *(const float4*)(dp + (size_t)y0 * S + off[k]);
+            }
+    };
+    fetch(y_beg);
+    for (int i = threadIdx.x; i < S * g; i += 256) Us[i] = U[i];
+    const int n_own = (i_hi - i_lo) * g;  // <= 12 * 24 entries over 256 threads
+    float gacc[2] = {0.f, 0.f};
+    for (int y0 = y_beg; y0 < y_end; y0 += UB_ROWS) {
         __syncthreads();
-        for (int idx = threadIdx.x; idx < UB_ROWS * S4; idx += 256) {
-            const int y = idx / S4, x4 = (idx - y * S4) * 4;
-            const float4 p = *(const float4*)(hp + (size_t)(y0 + y) * S + x4);
-            const float4 d = *(const float4*)(dp + (size_t)(y0 + y) * S + x4);
-            float4 o;
-            o.x = d.x * (p.x * (1.0f - p.x)); o.y = d.y * (p.y * (1.0f - p.y));
-            o.z = d.z * (p.z * (1.0f - p.z)); o.w = d.w * (p.w * (1.0f - p.w));
-            *(float4*)(dl + y * S + x4) = o;
-        }
+#pragma unroll
+        for (int k = 0; k < UB_PF; ++k)
+            if (off[k] >= 0) {
+                const float4 p = pp[k], d = dd[k];
+                float4 o;
+                o.x = d.x * (p.x * (1.0f - p.x)); o.y = d.y * (p.y * (1.0f - p.y));
+                o.z = d.z * (p.z * (1.0f - p.z)); o.w = d.w * (p.w * (1.0f - p.w));
+                *(float4*)(dl + off[k]) = o;
+            }
+        if (y0 + UB_ROWS < y_end) fetch(y0 + UB_ROWS);
         __syncthreads();
         for (int idx = threadIdx.x; idx < UB_ROWS * g; idx += 256) {
             const int y = idx / g, j = idx - y * g;
             // U[x][j] is non-zero only for x within one coarse cell of j (bilinear support)
             const int x_lo = max(0, (j - 1) * 16), x_hi = min(S, (j + 2) * 16);
             float a = 0.f;
+#pragma unroll 8
             for (int x = x_lo; x < x_hi; ++x) a = fmaf(dl[y * S + x], Us[x * g + j], a);
             Rc[idx] = a;
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 3; ++e) {
+        for (int e = 0; e < 2; ++e) {
             const int ij = threadIdx.x + e * 256;
-            if (ij < gg) {
-                const int i = ij / g, j = ij - i * g;
+            if (ij < n_own) {
+                const int i = i_lo + ij / g, j = ij % g;
                 float a = gacc[e];
 #pragma unroll
                 for (int y = 0; y < UB_ROWS; ++y) a = fmaf(Us[(y0 + y) * g + i], Rc[y * g + j], a);
@@ -412,9 +466,9 @@ __global__ __launch_bounds__(256) void upsample_sigmoid_bwd_kernel(const float* 
         }
     }
 #pragma unroll
-    for (int e = 0; e < 3; ++e) {
+    for (int e = 0; e < 2; ++e) {
         const int ij = threadIdx.x + e * 256;
-        if (ij < gg) g_low[bh * gg + ij] = gacc[e];
+        if (ij < n_own) g_low[bh * g * g + i_lo * g + ij] = gacc[e];
     }
 }
 
@@ -424,20 +478,23 @@ extern "C" int bf_decoder_upsample_sigmoid_bwd(const float* heat, const float* d
                "bf_decoder_upsample_sigmoid_bwd: grid must be in 1..%d", DEC_MAXG);
     const int S = grid * 16;
     const size_t lds = (size_t)(S * grid + UB_ROWS * S + UB_ROWS * grid) * sizeof(float);
-    hipLaunchKernelGGL(upsample_sigmoid_bwd_kernel, dim3(n_maps), dim3(256), lds, (hipStream_t)stream, heat,
+    hipLaunchKernelGGL(upsample_sigmoid_bwd_kernel, dim3(n_maps, 2), dim3(256), lds, (hipStream_t)stream, heat,
                        d_heat, U, g_low, grid);
     BF_CHECK_LAUNCH("bf_decoder_upsample_sigmoid_bwd");
     return BF_OK;
 }
 
 // ------------------------------------------------------------------ token projection backward
-#define PB_BLOCKS 256
+#define PB_BLOCKS 1024
 extern "C" size_t bf_decoder_project_bwd_ws(int batch, int n_heads, int dim) {
     (void)batch;
     return (size_t)PB_BLOCKS * n_heads * (dim + 4);
 }
 
 // stage 1: wave per token; d_tok rows written; per-block partial G / gb
+// MH / MC: compile-time bounds on heads and on float4 chunks per lane (2 / 2 at the bench shape: 16 accumulator registers
+// instead of 64, which is what lets four of these workgroups share a CU)
+template <int MH, int MC>
 __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
     const float* __restrict__ tok, const float* __restrict__ w_eff, const float* __restrict__ g_low,
     float* __restrict__ d_tok, float* __restrict__ part, int batch, int n_heads, int n_patch, int dim,
@@ -446,54 +503,76 @@ __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = dim >> 2;
     const int L = n_patch + 1;
-    float4 G[DEC_MAXH][DEC_MAXC];
-    float gb[DEC_MAXH];
+    float4 G[MH][MC];
+    float gb[MH];
 #pragma unroll
-    for (int h = 0; h < DEC_MAXH; ++h) {
+    for (int h = 0; h < MH; ++h) {
         gb[h] = 0.f;
 #pragma unroll
-        for (int i = 0; i < DEC_MAXC; ++i) G[h][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < MC; ++i) G[h][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int rows = batch * L;
-    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const int b = row / L, t = row - b * L;
-        float* dr = d_tok + (size_t)b * dtok_bstride + (size_t)t * dim;
-        if (t == 0) {
-            for (int c = lane; c < nvec; c += 64) *(float4*)(dr + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            continue;
-        }
-        float gl[DEC_MAXH];
+    // two rows of the wave's walk per trip, both rows' loads requested before either is used (the walk's order, and with
+    // it the order of the sums in G / gb, is unchanged)
+    for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += gridDim.x * 8) {
+        float4 x[2][MC];
+        float gl[2][MH];
+        float* dr[2];
+        int kind[2];                       // 0: no row, 1: the class token's row (zeros), 2: a patch row
 #pragma unroll
-        for (int h = 0; h < DEC_MAXH; ++h)
-            gl[h] = h < n_heads ? g_low[((size_t)h * batch + b) * n_patch + (t - 1)] : 0.f;
-        const float* xr = tok + (size_t)b * tok_bstride + (size_t)t * dim;
+        for (int r = 0; r < 2; ++r) {
+            const int row = row0 + r * gridDim.x * 4;
+            kind[r] = 0;
+            if (row >= rows) continue;
+            const int b = row / L, t = row - b * L;
+            dr[r] = d_tok + (size_t)b * dtok_bstride + (size_t)t * dim;
+            kind[r] = t == 0 ? 1 : 2;
+            if (t == 0) continue;
 #pragma unroll
-        for (int i = 0; i < DEC_MAXC; ++i) {
-            const int c = lane + i * 64;
-            if (c < nvec) {
-                const float4 x = *(const float4*)(xr + c * 4);
-                float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int h = 0; h < MH; ++h)
+                gl[r][h] = h < n_heads ? g_low[((size_t)h * batch + b) * n_patch + (t - 1)] : 0.f;
+            const float* xr = tok + (size_t)b * tok_bstride + (size_t)t * dim;
 #pragma unroll
-                for (int h = 0; h < DEC_MAXH; ++h)
-                    if (h < n_heads) {
-                        const float4 w = *(const float4*)(w_eff + (size_t)h * dim + c * 4);
-                        d.x = fmaf(gl[h], w.x, d.x); d.y = fmaf(gl[h], w.y, d.y);
-                        d.z = fmaf(gl[h], w.z, d.z); d.w = fmaf(gl[h], w.w, d.w);
-                        G[h][i].x = fmaf(gl[h], x.x, G[h][i].x); G[h][i].y = fmaf(gl[h], x.y, G[h][i].y);
-                        G[h][i].z = fmaf(gl[h], x.z, G[h][i].z); G[h][i].w = fmaf(gl[h], x.w, G[h][i].w);
-                    }
-                *(float4*)(dr + c * 4) = d;
+            for (int i = 0; i < MC; ++i) {
+                const int c = lane + i * 64;
+                if (c < nvec) x[r][i] = *(const float4*)(xr + c * 4);
             }
         }
 #pragma unroll
-        for (int h = 0; h < DEC_MAXH; ++h) gb[h] += gl[h];
+        for (int r = 0; r < 2; ++r) {
+            if (kind[r] == 1) {
+                for (int c = lane; c < nvec; c += 64) *(float4*)(dr[r] + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if (kind[r] == 2) {
+#pragma unroll
+                for (int i = 0; i < MC; ++i) {
+                    const int c = lane + i * 64;
+                    if (c < nvec) {
+                        const float4 xv = x[r][i];
+                        float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int h = 0; h < MH; ++h)
+                            if (h < n_heads) {
+                                const float4 w = *(const float4*)(w_eff + (size_t)h * dim + c * 4);
+                                const float gh = gl[r][h];
+                                d.x = fmaf(gh, w.x, d.x); d.y = fmaf(gh, w.y, d.y);
+                                d.z = fmaf(gh, w.z, d.z); d.w = fmaf(gh, w.w, d.w);
+                                G[h][i].x = fmaf(gh, xv.x, G[h][i].x); G[h][i].y = fmaf(gh, xv.y, G[h][i].y);
+                                G[h][i].z = fmaf(gh, xv.z, G[h][i].z); G[h][i].w = fmaf(gh, xv.w, G[h][i].w);
+                            }
+                        *(float4*)(dr[r] + c * 4) = d;
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < MH; ++h) gb[h] += gl[r][h];
+            }
+        }
     }
     const int stride = dim + 4;
 #pragma unroll
-    for (int h = 0; h < DEC_MAXH; ++h)
+    for (int h = 0; h < MH; ++h)
         if (h < n_heads) {
 #pragma unroll
-            for (int i = 0; i < DEC_MAXC; ++i) {
+            for (int i = 0; i < MC; ++i) {
                 const int c = lane + i * 64;
                 if (c < nvec) *(float4*)(sm + ((size_t)wave * n_heads + h) * stride + c * 4) = G[h][i];
             }
@@ -507,19 +586,29 @@ __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
             part[(size_t)blockIdx.x * per + i] = (sm[i] + sm[per + i]) + (sm[2 * per + i] + sm[3 * per + i]);
     }
 }
-__global__ __launch_bounds__(256) void decoder_project_bwd2_kernel(const float* __restrict__ part,
-                                                                   float* __restrict__ g_w_eff,
-                                                                   float* __restrict__ g_b_eff, int nblocks,
-                                                                   int n_heads, int dim) {
+// stage 2: 64 outputs x 16 slices of the partials per workgroup; the slices are added in slice order (deterministic)
+__global__ __launch_bounds__(1024) void decoder_project_bwd2_kernel(const float* __restrict__ part,
+                                                                    float* __restrict__ g_w_eff,
+                                                                    float* __restrict__ g_b_eff, int nblocks,
+                                                                    int n_heads, int dim) {
+    __shared__ float red[16][64];
     const int stride = dim + 4, per = n_heads * stride;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= per) return;
-    const int h = i / stride, c = i - h * stride;
-    if (c > dim) return;
+    const int o = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + o;
     float acc = 0.f;
-    for (int k = 0; k < nblocks; ++k) acc += part[(size_t)k * per + i];
-    if (c < dim) g_w_eff[(size_t)h * dim + c] = acc;
-    else g_b_eff[h] = acc;
+    if (i < per) {
+#pragma unroll 4
+        for (int k = ks; k < nblocks; k += 16) acc += part[(size_t)k * per + i];
+    }
+    red[ks][o] = acc;
+    __syncthreads();
+    if (ks != 0 || i >= per) return;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][o];
+    const int h = i / stride, c = i - h * stride;
+    if (c < dim) g_w_eff[(size_t)h * dim + c] = t;
+    else if (c == dim) g_b_eff[h] = t;
 }
 
 extern "C" int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_eff,
@@ -536,10 +625,17 @@ extern "C" int bf_decoder_project_bwd(const float* tok, long tok_bstride, const 
     int nblocks = bf_cdiv(rows, 4);
     if (nblocks > PB_BLOCKS) nblocks = PB_BLOCKS;
     const size_t lds = (size_t)4 * n_heads * (dim + 4) * sizeof(float);
-    hipLaunchKernelGGL(decoder_project_bwd_kernel, dim3(nblocks), dim3(256), lds, s, tok, w_eff, g_low, d_tok,
-                       part_ws, batch, n_heads, n_patch, dim, tok_bstride, dtok_bstride);
+#define PB_LAUNCH(MH, MC)                                                                                       \
+    hipLaunchKernelGGL((decoder_project_bwd_kernel<MH, MC>), dim3(nblocks), dim3(256), lds, s, tok, w_eff, g_low,  \
+                       d_tok, part_ws, batch, n_heads, n_patch, dim, tok_bstride, dtok_bstride)
+    const bool few_heads = n_heads <= 2, narrow = dim <= 512;
+    if (few_heads && narrow) PB_LAUNCH(2, 2);
+    else if (few_heads) PB_LAUNCH(2, DEC_MAXC);
+    else if (narrow) PB_LAUNCH(DEC_MAXH, 2);
+    else PB_LAUNCH(DEC_MAXH, DEC_MAXC);
+#undef PB_LAUNCH
     BF_CHECK_LAUNCH("bf_decoder_project_bwd/1");
-    hipLaunchKernelGGL(decoder_project_bwd2_kernel, dim3(bf_cdiv(n_heads * (dim + 4), 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(decoder_project_bwd2_kernel, dim3(bf_cdiv(n_heads * (dim + 4), 64)), dim3(1024), 0, s,
                        part_ws, g_w_eff, g_b_eff, nblocks, n_heads, dim);
     BF_CHECK_LAUNCH("bf_decoder_project_bwd/2");
     return BF_OK;

@@ -672,7 +672,7 @@ def test_segment_assemble_and_backward(ops, gpu):
 
 
 # ------------------------------------------------------------------ decoder + BCE
-@pytest.mark.parametrize("dim,grid,heads", [(512, 14, 2), (96, 3, 4), (768, 24, 1)])
+@pytest.mark.parametrize("dim,grid,heads", [(512, 14, 2), (96, 3, 4), (768, 24, 1), (640, 2, 4), (512, 1, 2)])
 def test_decoder_collapsed_matches_as_written(ops, gpu, dim, grid, heads):
     from oracle import bifold_oracle as O
     from bifold.models.decoder_math import upsample_operator
