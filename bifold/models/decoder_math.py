@@ -31,4 +31,9 @@ def upsample_operator(grid: int, levels: int = 4) -> torch.Tensor:
     for _ in range(levels):
         u = bilinear_x2_matrix(n) @ u
         n *= 2
+    # the device kernels sum over the band |j - x // 2**levels| <= 1 only (include/bifold_hip.h)
+    x = torch.arange(grid * 2 ** levels).unsqueeze(1) // 2 ** levels
+    j = torch.arange(grid).unsqueeze(0)
+    if bool((u[(x - j).abs() > 1] != 0).any()):
+        raise RuntimeError("upsample operator is not banded: the decoder kernels would drop terms")
     return u.to(torch.float32).contiguous()

@@ -348,7 +348,10 @@ int bf_decoder_collapse_bwd(const float* const* w, const float* const* b, const 
 int bf_decoder_project(const float* tok, long tok_bstride, const float* w_eff, const float* b_eff,
                        float* low, int batch, int n_heads, int n_patch, int dim, bf_stream_t stream);
 /* heat[i, :, :] = sigmoid(U low[i] U^T) for i < n_maps (= n_heads * B, head-major)
- * (models/pickplace.py:108-123), fp32 [n_maps, S, S], S = 16 g;  U fp32 [S, g]. */
+ * (models/pickplace.py:108-123), fp32 [n_maps, S, S], S = 16 g;  U fp32 [S, g].
+ * U is the composition of the decoder's four bilinear x2 steps and therefore BANDED: U[x][j] == 0 unless
+ * |j - x / 16| <= 1.  Both this kernel and its backward sum over that band only (three terms per pixel and axis instead
+ * of g); bifold/models/decoder_math.py:upsample_operator builds U and checks the band. */
 int bf_decoder_upsample_sigmoid(const float* low, const float* U, float* heat, int n_maps, int grid,
                                 bf_stream_t stream);
 /* Backward of sigmoid o upsample: g_low[i] = U^T (d_heat[i] * p (1-p)) U, fp32 [n_maps, g*g]. */
