@@ -20,6 +20,8 @@ step "in-kernel probes of the persistent GEMM (BK 32 loop, BK 64 loop)"
 { BIFOLD_HIP_LIB=$L/libbifold_hip_probe.so timeout -k 5 200 python3 tools/p8_probe3.py 8 fp16 2>&1 | filt; BIFOLD_HIP_LIB=$L/libbifold_hip_probe.so timeout -k 5 200 python3 tools/p8_probe3.py 9 fp16 2>&1 | filt; } > $out/p8_probe.txt
 step "attention kernels, isolated"
 { timeout -k 5 150 python3 tools/attn_bench.py --dtype fp16 2>&1 | filt; timeout -k 5 150 python3 tools/attn_bench.py --bwd --dtype fp16 2>&1 | filt; } > $out/attn_bench.txt
+step "decoder / loss kernels, isolated"
+timeout -k 5 100 python3 tools/decoder_bench.py 2>&1 | filt > $out/decoder_bench.txt
 step "epilogue instruction rates"
 tools/micro/epi_rate > $out/epi_rate.txt 2>&1
 step "write-heavy epilogues with / without start skew"
