@@ -46,6 +46,10 @@ _DW_ORDER = int(os.environ.get("BIFOLD_DW_ORDER", "1"))
 # split 16 / 16 / 64 / 21 ways, a quarter of the fp32 partial slabs, 2 launches instead of 8); groups that do not
 # qualify (fp32 mode, short or ragged token counts) and 0 run the GEMMs one by one as before
 _DW_GROUPED = int(os.environ.get("BIFOLD_DW_GROUPED", "1"))
+# timing experiments only (tools/ab_env.sh): 1 = the fusion layers' weight-gradient GEMMs are NOT launched at all -- the
+# step's time with the side stream's backward work taken away, i.e. the bound on what better scheduling of it could give.
+# The gradients are then wrong; nothing but a stopwatch may set this.
+_DW_SKIP = int(os.environ.get("BIFOLD_DW_SKIP_FOR_TIMING", "0"))
 
 
 def _dw_stream(device) -> "torch.cuda.Stream":
@@ -83,7 +87,9 @@ class _WeightGradSide:
             else:
                 self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side) if self.on else _NullCtx():
-            if not ops.gemm_tn_grouped(todo):
+            if _DW_SKIP:
+                pass
+            elif not ops.gemm_tn_grouped(todo):
                 for dy, x, out in todo:
                     ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
         if self.on:
