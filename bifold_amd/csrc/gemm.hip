@@ -795,9 +795,13 @@ struct P8Group {
 
 #ifdef P8_PROBE
 __device__ unsigned long long p8_probe[16];
+__device__ unsigned long long p8_probe_tail[64 * 8];      // per workgroup < 64 that ran a K chunk: see bf_debug_p8_probe_tail
 __device__ unsigned long long p8_probe_sec[8];      // BK64 loop: load 0 / MFMA 0 / load 1 / MFMA 1 cycles of wave 0 and of wave 4
 extern "C" int bf_debug_p8_probe(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_probe), sizeof(p8_probe)) == hipSuccess ? 0 : 1;
+}
+extern "C" int bf_debug_p8_probe_tail(unsigned long long* out) {   // [64][8]: main loop, dump + drain, arrival, read-back, epilogue (cycles); part, parts, arrived
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_probe_tail), sizeof(p8_probe_tail)) == hipSuccess ? 0 : 1;
 }
 extern "C" int bf_debug_p8_probe_sec(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(p8_probe_sec), sizeof(p8_probe_sec)) == hipSuccess ? 0 : 1;
@@ -1502,6 +1506,9 @@ __device__ __forceinline__ void p8_body(
                 // the adding wave joins after its add has returned.  No fence, no poll.  The image is the register
                 // file as it stands ([wave][register][lane] x 16 B): every store instruction writes 1 KB contiguous.
                 const int S = d.tail_parts;
+#ifdef P8_PROBE
+                const unsigned long long pt0 = clock64();
+#endif
                 const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
                     (void*)d.tail_ws, 0, (unsigned)d.tail_tiles * (unsigned)S * 262144u, 0x00020000);
                 const unsigned own = ((unsigned)(w.slot * S + w.part) * 8u + (unsigned)wave) * 32768u;
@@ -1513,30 +1520,68 @@ __device__ __forceinline__ void p8_body(
                                                                   (unsigned)lane * 16u, own + (unsigned)(j * 8 + i) * 1024u, 16);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
+#ifdef P8_PROBE
+                const unsigned long long pt1 = clock64();
+#endif
                 if (threadIdx.x == 0)
                     bcast[1] = __hip_atomic_fetch_add(tk + 16 + w.slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_s_barrier();
                 const unsigned arrived = __builtin_amdgcn_readfirstlane(bcast[1]);
                 run_epilogue = arrived == (unsigned)S - 1u;
+#ifdef P8_PROBE
+                if (bid < 64 && threadIdx.x == 0) {
+                    unsigned long long* pt = p8_probe_tail + bid * 8;
+                    pt[0] = pc1 - pc0; pt[1] = pt1 - pt0; pt[2] = clock64() - pt1; pt[3] = 0; pt[4] = 0;
+                    pt[5] = (unsigned long long)w.part; pt[6] = (unsigned long long)S; pt[7] = arrived;
+                }
+                const unsigned long long pt2 = clock64();
+#endif
                 if (run_epilogue) {
                     if (threadIdx.x == 0) tk[16 + w.slot] = 0u;          // at rest again for this set's next launch
-#pragma unroll 1
-                    for (int z = 0; z < S; ++z) {
+                    // Read-back, 32 KB per wave and chunk.  This workgroup's own accumulators are in the workspace like
+                    // everyone's, so the registers are free to receive: rows i < 4 first, chunk 0 straight into them and chunk
+                    // 1 into the registers of rows i >= 4 in the same breath (32 loads per lane in flight), then rows i >= 4
+                    // with chunk 0 straight in and the other chunks through eight spare registers.  Eight loads at a time
+                    // for everything made the read-back 4 S dependent trips to memory -- as long as the K tiles the split
+                    // had saved.  Every element is still summed in chunk order (same bits).
+                    auto part_ld = [&](int z, int r) -> f32x4 {
                         const unsigned src = ((unsigned)(w.slot * S + z) * 8u + (unsigned)wave) * 32768u;
+                        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                             rw, (unsigned)lane * 16u, src + (unsigned)r * 1024u, 16));
+                    };
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            u32x4_t t8[8];
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                                t8[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)lane * 16u,
-                                                                                 src + (unsigned)(j * 8 + i) * 1024u, 16);
+                        for (int i = 0; i < 4; ++i) acc[j][i] = part_ld(0, j * 8 + i);
+#pragma unroll 1
+                    for (int z = 1; z < S; ++z) {
 #pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                const f32x4 v = __builtin_bit_cast(f32x4, t8[i]);
-                                acc[j][i] = z == 0 ? v : acc[j][i] + v;
-                            }
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[j][4 + i] = part_ld(z, j * 8 + i);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[j][i] += acc[j][4 + i];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[j][4 + i] = part_ld(0, j * 8 + 4 + i);
+#pragma unroll 1
+                    for (int z = 1; z < S; ++z) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            f32x4 t8[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) t8[q] = part_ld(z, (jj * 2 + (q >> 2)) * 8 + 4 + (q & 3));
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc[jj * 2 + (q >> 2)][4 + (q & 3)] += t8[q];
                         }
                     }
+#ifdef P8_PROBE
+                    if (bid < 64 && threadIdx.x == 0) p8_probe_tail[bid * 8 + 3] = clock64() - pt2;
+#endif
                 }
             }
         }
@@ -1905,6 +1950,8 @@ __device__ __forceinline__ void p8_body(
             p8_probe[0] = pc1 - pc0; p8_probe[1] = pw1 - pw0; p8_probe[2] = nk;
             p8_probe[3] = clock64() - pc1; p8_probe[4] = wall_clock64() - pw1; p8_probe[5] = pc2 - pc1;
         }
+        if constexpr (BK == 64 && !GROUPED)
+            if (w.part >= 0 && bid < 64 && threadIdx.x == 0) p8_probe_tail[bid * 8 + 4] = clock64() - pc1;   // main loop end -> item end
 #endif
         if (!has_next) break;
         w = nx;
