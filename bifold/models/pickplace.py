@@ -306,25 +306,52 @@ def _w2d(t: torch.Tensor) -> torch.Tensor:
     return t.view(t.shape[0], -1)
 
 
-def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, save: bool):
+# 1 (16-bit modes): the residual branches (out-proj, fc2) leave the GEMM as 16-bit tensors and the residual add rides in
+# the NEXT LayerNorm's pass (bf_add_layernorm_fwd, what the towers do) instead of in the GEMM's fp32 epilogue: the
+# fp32-residual epilogue costs a 512-wide GEMM 57 - 61 us per launch (a 256 KB fp32 tile read and written per item), the
+# add inside the LayerNorm pass 40 (tools/decoder_bench.py's neighbour).  0: round 1-4's form.
+_ADD_IN_LN = int(os.environ.get("BIFOLD_FUSION_ADD_IN_LN", "1"))
+
+
+def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, save: bool, pending=None,
+                     last: bool = True):
+    """One pre-LN block on the fp32 residual stream x [B*seq, dim].  `pending` (16-bit, optional) is the previous block's
+    MLP branch, not yet added to x: it is added in this block's first LayerNorm pass.  Returns (x_out, saved, pending_out):
+    with `last` False (and a 16-bit compute dtype) the block's own MLP branch comes back as `pending_out` instead of being
+    added to x_out."""
     d = x.shape[1] // heads
-    h1, m1, r1 = ops.layernorm_fwd(x, P["g1"].data, P["b1"].data, cdt, save_stats=save)
+    defer = bool(_ADD_IN_LN) and cdt in ops.HALF and x.shape[1] in (256, 512, 768, 1024)   # bf_add_layernorm_fwd's widths
+    if pending is None:
+        h1, m1, r1 = ops.layernorm_fwd(x, P["g1"].data, P["b1"].data, cdt, save_stats=save)
+    else:                                    # x <- x + pending, h1 = LN1(x): one pass; a new x (the old one is saved)
+        h1, m1, r1, x = ops.add_layernorm_fwd(x, pending, P["g1"].data, P["b1"].data, cdt, x_out=torch.empty_like(x),
+                                              save_stats=save)
     qkv = ops.gemm(h1, A.operand(P["wqkv"], cdt))
     o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mask_mode, row_mask, need_lse=save)
-    x2 = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, residual=x, out_dtype=torch.float32)
-    h2, m2, r2 = ops.layernorm_fwd(x2, P["g2"].data, P["b2"].data, cdt, save_stats=save)
+    if defer:
+        branch = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data)
+        h2, m2, r2, x2 = ops.add_layernorm_fwd(x, branch, P["g2"].data, P["b2"].data, cdt, x_out=torch.empty_like(x),
+                                               save_stats=save)
+        del branch
+    else:
+        x2 = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, residual=x, out_dtype=torch.float32)
+        h2, m2, r2 = ops.layernorm_fwd(x2, P["g2"].data, P["b2"].data, cdt, save_stats=save)
     if save:       # the forward saves gelu'(pre), not pre: one erf evaluation serves both outputs of the epilogue,
         # and the backward GEMM's epilogue is a multiply instead of an erf + exp per element
         a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data,
                             act=L.ACT_ERF_GELU_SAVEGRAD if _SAVEGRAD else L.ACT_ERF_GELU, want_pre=True)
     else:
         a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data, act=L.ACT_ERF_GELU), None
-    x3 = ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data, residual=x2, out_dtype=torch.float32)
+    pending_out = None
+    if defer and not last:
+        x3, pending_out = x2, ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data)
+    else:
+        x3 = ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data, residual=x2, out_dtype=torch.float32)
     saved = None
     if save:
         saved = dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, x2=x2, m2=m2, r2=r2, h2=h2,
                      a_pre=a_pre, a=a)
-    return x3, saved
+    return x3, saved, pending_out
 
 
 def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, wg=None):
@@ -381,8 +408,10 @@ def fusion_stack_fwd(fus: "ConcatTransformer", A: ParamArena, cdt, x, batch: int
                      row_mask, save: bool):
     """depth x fusion_layer_fwd on x fp32 [B*seq, dim]; returns (x_out, per-layer saved activations)."""
     layers = []
+    pending = None
     for i in range(fus.depth):
-        x, s = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, mask_mode, row_mask, save)
+        x, s, pending = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, mask_mode, row_mask, save,
+                                         pending=pending, last=i == fus.depth - 1)
         layers.append(s)
     return x, layers
 

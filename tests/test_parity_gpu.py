@@ -246,6 +246,42 @@ def test_masked_three_input_component_call_matches_reference(gpu, golden_dir, ob
     assert attn is None and feats.shape == (2, 10, 96)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_fusion_residual_add_inside_the_layernorm_pass_matches_the_epilogue_form(gpu, observed, dtype):
+    """16-bit modes add the residual branches of a fusion block in the NEXT LayerNorm's pass (pickplace._ADD_IN_LN, the
+    towers' form) instead of in the GEMM's fp32 epilogue.  Same function: outputs, input gradients and every parameter
+    gradient of a 3-block stack must agree with the epilogue form to the rounding of ONE 16-bit value per branch
+    (reference: transformer.py:19-28 `x = attn(x) + x; x = ff(x) + x`)."""
+    from bifold.models import Components
+    from bifold.models import pickplace as P
+    cdt = torch.float16 if dtype == "fp16" else torch.bfloat16
+    tol = 2e-3 if dtype == "fp16" else 1.6e-2
+    torch.manual_seed(5)
+    fus = Components.get_by_name("concat_transformer", dim=256, heads=4, depth=3, dropout=0.0, mlp_ratio=4).to(gpu)
+    fus.compute_dtype = cdt
+    x_text = torch.randn(3, 5, 256, device=gpu)
+    x_img = torch.randn(3, 17, 256, device=gpu)
+    w = torch.randn(3, 17, 256, device=gpu)
+    res = {}
+    saved = P._ADD_IN_LN
+    try:
+        for mode in (0, 1):
+            P._ADD_IN_LN = mode
+            ins = [x_text.clone().requires_grad_(True), x_img.clone().requires_grad_(True)]
+            fus.zero_grad(set_to_none=True)
+            feats, _ = fus(ins[0].clone(), ins[1].clone())      # (the type embedding is added to the arguments in place)
+            (feats * w).sum().backward()
+            grads = {n: p.grad.detach().clone() for n, p in fus.named_parameters()}
+            grads.update({f"input {i}": t.grad.detach().clone() for i, t in enumerate(ins)})
+            res[mode] = (feats.detach().clone(), grads)
+    finally:
+        P._ADD_IN_LN = saved
+    worst_out = rel(res[1][0], res[0][0])
+    worst_g = max(rel(res[1][1][n], g) for n, g in res[0][1].items())
+    observed(f"fusion_add_in_ln_{dtype}", out_rel=worst_out, grad_rel=worst_g)
+    assert worst_out < tol and worst_g < 4 * tol
+
+
 def test_fp8_towers_accuracy_gate_on_config_a(gpu, observed):
     """BASELINE configs[4] (fp8 MFMA weights / activations): `dtype: fp8` runs the frozen towers' QKV / fc1 GEMMs in
     OCP e4m3 (per-token and per-channel scales).  There is no reference behaviour for fp8 (the reference is fp32), so
