@@ -311,6 +311,12 @@ def _w2d(t: torch.Tensor) -> torch.Tensor:
 # fp32-residual epilogue costs a 512-wide GEMM 57 - 61 us per launch (a 256 KB fp32 tile read and written per item), the
 # add inside the LayerNorm pass 40 (tools/decoder_bench.py's neighbour).  0: round 1-4's form.
 _ADD_IN_LN = int(os.environ.get("BIFOLD_FUSION_ADD_IN_LN", "1"))
+# 1 (fp16 mode): the gradient of the residual stream travels through the fusion stack's backward as ONE fp16 tensor --
+# it is what the dX GEMMs read anyway -- instead of an fp32 tensor plus its fp16 copy: the two LayerNorm backward passes
+# of a block read 72 instead of 144 MB of it and write 72 instead of 216 (bf_layernorm_bwd without an fp32 dx).  Every
+# add rounds to 11 bits of the running gradient (the loss scale keeps it in range like every other fp16 gradient of the
+# step); bf16's 8 bits would show in the gradient gates, so bf16 and fp32 keep the fp32 stream.  0: round 1-4's form.
+_GRAD_STREAM16 = int(os.environ.get("BIFOLD_GRAD_STREAM16", "1"))
 
 
 def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, save: bool, pending=None,
@@ -355,9 +361,10 @@ def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row
 
 
 def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, wg=None):
-    """dx3 fp32 [M, D] (+ its cdt copy or None in fp32 mode) -> (dx, dx_c) for the layer input.
+    """dx3 fp32 [M, D] (+ its cdt copy or None in fp32 mode) -> (dx, dx_c) for the layer input; dx3 None = the 16-bit
+    gradient stream (_GRAD_STREAM16): dx3_c alone carries the gradient and (None, dx_c) comes back.
     `wg`: the _WeightGradSide that launches the dW GEMMs (default: in line on the current stream)."""
-    d = dx3.shape[1] // heads
+    d = (dx3_c if dx3 is None else dx3).shape[1] // heads
     if wg is None:
         wg = _WeightGradSide.__new__(_WeightGradSide)
         wg.on, wg.side, wg.group, wg.group_after, wg.qualifies, wg.held, wg.marked = False, None, None, None, None, [], []
@@ -383,8 +390,9 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
         wg.gemm(da_pre, S["h2"], g(P["w1"]), e_pre)
     # the LayerNorm backward streams dx3 (in) and dx2 (out): it also emits their column sums,
     # i.e. the bias gradients of net.3 and to_out
-    dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3, cdt, g(P["g2"]), g(P["b2"]),
-                                   dres_sum_out=g(P["bb2"]), dx_sum_out=g(P["bo"]))
+    s16 = dx3 is None                                       # the 16-bit gradient stream (_GRAD_STREAM16): dx3_c is all there is
+    dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3_c if s16 else dx3, cdt,
+                                   g(P["g2"]), g(P["b2"]), dres_sum_out=g(P["bb2"]), dx_sum_out=g(P["bo"]), stream16=s16)
     op2 = dx2_c if dx2_c is not None else dx2
     # attention:  x2 = x + attn(h1 Wqkv^T) Wo^T + bo
     e2 = wg.ready()
@@ -401,7 +409,8 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     if _DW_ORDER:
         wg.gemm(dqkv, S["h1"], g(P["wqkv"]), e_qkv)
     wg.flush()
-    return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2, cdt, g(P["g1"]), g(P["b1"]))
+    return ops.layernorm_bwd(dh1, S["x"], P["g1"].data, S["m1"], S["r1"], dx2_c if s16 else dx2, cdt, g(P["g1"]),
+                             g(P["b1"]), stream16=s16)
 
 
 def fusion_stack_fwd(fus: "ConcatTransformer", A: ParamArena, cdt, x, batch: int, seq: int, mask_mode: int,
@@ -421,7 +430,10 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
     """Backward of fusion_stack_fwd: dx fp32 [B*seq, dim] w.r.t. the stack's output -> w.r.t. its input;
     every layer's parameter gradients go straight into the arena."""
     dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
-    wg = _WeightGradSide(dx.device)
+    s16 = bool(_GRAD_STREAM16) and cdt == torch.float16
+    if s16:
+        dx = None
+    wg = _WeightGradSide(dx_c.device if s16 else dx.device)
     main = torch.cuda.current_stream() if wg.on else None
     late = None                                            # (layer, event) whose join is still owed (_DW_SIDE = 2)
     for i in reversed(range(fus.depth)):
@@ -449,6 +461,8 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
         wg.joined(late[1])
         if on_layer_done is not None:
             on_layer_done(late[0])
+    if s16:
+        dx = ops.cast(dx_c, torch.float32)                 # the callers (token assembly, the towers) take fp32
     return dx
 
 

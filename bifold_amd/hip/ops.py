@@ -142,13 +142,20 @@ def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor,
 def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor,
                   rstd: torch.Tensor, dres: Optional[torch.Tensor], cdt: Optional[torch.dtype],
                   dgamma_out: torch.Tensor, dbeta_out: torch.Tensor,
-                  dres_sum_out: Optional[torch.Tensor] = None, dx_sum_out: Optional[torch.Tensor] = None):
+                  dres_sum_out: Optional[torch.Tensor] = None, dx_sum_out: Optional[torch.Tensor] = None,
+                  stream16: bool = False):
     """Returns (dx fp32, dx_cdt or None); writes dgamma/dbeta (and, when asked, the column sums
-    of dres and of dx) into the given fp32 vectors."""
+    of dres and of dx) into the given fp32 vectors.  `stream16`: the 16-bit gradient stream -- `dres` (if any) is a
+    `cdt` tensor, no fp32 dx is produced (returns (None, dx_cdt))."""
     _dev(dy, "dy"); _dev(x, "x")
     cols = x.shape[-1]
     rows = x.numel() // cols
-    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if stream16:
+        if cdt not in HALF or dy.dtype != cdt or (dres is not None and dres.dtype != cdt):
+            raise TypeError("layernorm_bwd(stream16=True): dy, dres and the result share one 16-bit type")
+    elif dres is not None and dres.dtype != torch.float32:
+        raise TypeError("layernorm_bwd: dres is the fp32 residual gradient (16-bit only with stream16=True)")
+    dx = None if stream16 else torch.empty(x.shape, dtype=torch.float32, device=x.device)
     dx_c = torch.empty(x.shape, dtype=cdt, device=x.device) if (cdt is not None and cdt != torch.float32) else None
     nparts = lib.bf_layernorm_bwd_parts(rows)
     want = dres_sum_out is not None

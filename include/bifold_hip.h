@@ -91,7 +91,10 @@ int bf_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, con
  *   n_part = bf_layernorm_bwd_parts(rows); reduce them with bf_colsum.
  *   dres_sum_part / dx_sum_part (optional, both or neither): partial column sums of dres and
  *   of dx -- the bias gradients of the two residual-branch Linears around this LayerNorm
- *   (FeedForward.net.3 and Attention.to_out), which this kernel streams anyway. */
+ *   (FeedForward.net.3 and Attention.to_out), which this kernel streams anyway.
+ *   dx == NULL: the 16-bit gradient stream (fp16 mode of the fusion stack's backward) -- `dres`, if given, points to a
+ *   cdt_dtype tensor (not fp32), dy is of cdt_dtype too, and the sum leaves ONLY as dx_cdt (required, 16-bit): the
+ *   residual stream's gradient is then one 16-bit tensor per block boundary instead of an fp32 tensor and its copy. */
 int bf_layernorm_bwd_parts(int rows);
 int bf_layernorm_bwd(const void* dy, int dy_dtype, const float* x, const float* gamma,
                      const float* mean, const float* rstd, const float* dres, float* dx,

@@ -246,16 +246,10 @@ def test_masked_three_input_component_call_matches_reference(gpu, golden_dir, ob
     assert attn is None and feats.shape == (2, 10, 96)
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-def test_fusion_residual_add_inside_the_layernorm_pass_matches_the_epilogue_form(gpu, observed, dtype):
-    """16-bit modes add the residual branches of a fusion block in the NEXT LayerNorm's pass (pickplace._ADD_IN_LN, the
-    towers' form) instead of in the GEMM's fp32 epilogue.  Same function: outputs, input gradients and every parameter
-    gradient of a 3-block stack must agree with the epilogue form to the rounding of ONE 16-bit value per branch
-    (reference: transformer.py:19-28 `x = attn(x) + x; x = ff(x) + x`)."""
+def _fusion_stack_both_ways(gpu, knob, cdt):
+    """Outputs and every gradient of a 3-block, 256-wide fusion stack with pickplace.<knob> = 0 and = 1."""
     from bifold.models import Components
     from bifold.models import pickplace as P
-    cdt = torch.float16 if dtype == "fp16" else torch.bfloat16
-    tol = 2e-3 if dtype == "fp16" else 1.6e-2
     torch.manual_seed(5)
     fus = Components.get_by_name("concat_transformer", dim=256, heads=4, depth=3, dropout=0.0, mlp_ratio=4).to(gpu)
     fus.compute_dtype = cdt
@@ -263,10 +257,10 @@ def test_fusion_residual_add_inside_the_layernorm_pass_matches_the_epilogue_form
     x_img = torch.randn(3, 17, 256, device=gpu)
     w = torch.randn(3, 17, 256, device=gpu)
     res = {}
-    saved = P._ADD_IN_LN
+    saved = getattr(P, knob)
     try:
         for mode in (0, 1):
-            P._ADD_IN_LN = mode
+            setattr(P, knob, mode)
             ins = [x_text.clone().requires_grad_(True), x_img.clone().requires_grad_(True)]
             fus.zero_grad(set_to_none=True)
             feats, _ = fus(ins[0].clone(), ins[1].clone())      # (the type embedding is added to the arguments in place)
@@ -275,11 +269,30 @@ def test_fusion_residual_add_inside_the_layernorm_pass_matches_the_epilogue_form
             grads.update({f"input {i}": t.grad.detach().clone() for i, t in enumerate(ins)})
             res[mode] = (feats.detach().clone(), grads)
     finally:
-        P._ADD_IN_LN = saved
-    worst_out = rel(res[1][0], res[0][0])
-    worst_g = max(rel(res[1][1][n], g) for n, g in res[0][1].items())
+        setattr(P, knob, saved)
+    return rel(res[1][0], res[0][0]), max(rel(res[1][1][n], g) for n, g in res[0][1].items())
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_fusion_residual_add_inside_the_layernorm_pass_matches_the_epilogue_form(gpu, observed, dtype):
+    """16-bit modes add the residual branches of a fusion block in the NEXT LayerNorm's pass (pickplace._ADD_IN_LN, the
+    towers' form) instead of in the GEMM's fp32 epilogue.  Same function: outputs, input gradients and every parameter
+    gradient of a 3-block stack must agree with the epilogue form to the rounding of ONE 16-bit value per branch
+    (reference: transformer.py:19-28 `x = attn(x) + x; x = ff(x) + x`)."""
+    tol = 2e-3 if dtype == "fp16" else 1.6e-2
+    worst_out, worst_g = _fusion_stack_both_ways(gpu, "_ADD_IN_LN", torch.float16 if dtype == "fp16" else torch.bfloat16)
     observed(f"fusion_add_in_ln_{dtype}", out_rel=worst_out, grad_rel=worst_g)
     assert worst_out < tol and worst_g < 4 * tol
+
+
+def test_fusion_backward_with_a_16_bit_gradient_stream_matches_the_fp32_stream(gpu, observed):
+    """fp16 mode carries the residual stream's gradient through the fusion backward as one fp16 tensor
+    (pickplace._GRAD_STREAM16: bf_layernorm_bwd without an fp32 dx).  The forward is untouched (identical outputs); every
+    gradient agrees with the fp32 stream's to a few fp16 roundings of the running sum -- the gate the 16-bit gradients are
+    held to everywhere else in this suite is 1e-2."""
+    worst_out, worst_g = _fusion_stack_both_ways(gpu, "_GRAD_STREAM16", torch.float16)
+    observed("fusion_grad_stream16", out_rel=worst_out, grad_rel=worst_g)
+    assert worst_out == 0.0 and worst_g < 4e-3
 
 
 def test_fp8_towers_accuracy_gate_on_config_a(gpu, observed):
