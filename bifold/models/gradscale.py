@@ -9,7 +9,8 @@ Scheme: the gradient ENTERING the trainable tail's backward (the low-resolution 
 fp32) is multiplied by S, so every tensor of the fused backward -- and every parameter gradient it writes into the
 flat arena -- carries a factor S; each arena slice is multiplied by 1 / S as the backward completes it, BEFORE the
 slice is reported to the gradient-ready hooks (data-parallel all-reduce, clipping, the optimiser), so `.grad` never
-shows a scaled value.  S is a power of two (no rounding of its own); it starts at 64 x (elements of one head's
+shows a scaled value to them (with no hook registered -- one process -- the whole arena is un-scaled in one pass at
+the end of the backward).  S is a power of two (no rounding of its own); it starts at 64 x (elements of one head's
 heatmaps) rounded up: measured on config A's gradients that puts the largest 16-bit gradient element at ~1e2 and the
 1 % quantile at ~6e-3 (binary16: max 65 504, smallest normal 6e-5).  `loss_scale: <number>` overrides the start.
 
@@ -25,6 +26,7 @@ The Trainer reads the totals once per epoch, reports dropped steps and raises on
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -103,6 +105,13 @@ class DynamicGradScale:
     def ready(self, layer: int) -> None:
         """The backward's `on_layer_done`: un-scale what layer `layer` completed, then tell the model's hooks."""
         arena = self._plan()
+        if not getattr(self.model, "_grad_hooks", None) and os.environ.get("BIFOLD_UNSCALE_PER_LAYER", "0") != "1":
+            # nobody waits for single layers (one process: no gradient-ready hook is registered): ONE pass over the whole
+            # arena when the backward is complete instead of eleven small launches between the layers of the chain
+            if layer == -1:
+                ops.scale_check_(arena.grad, self.state[_INV:_INV + 1], self.nonfinite)
+            self.model._grad_ready(layer)
+            return
         depth = self._depth
         if layer == -1:
             which = range(depth + 1, len(self._buckets))
