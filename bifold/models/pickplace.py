@@ -429,8 +429,12 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
                      row_mask, on_layer_done=None):
     """Backward of fusion_stack_fwd: dx fp32 [B*seq, dim] w.r.t. the stack's output -> w.r.t. its input;
     every layer's parameter gradients go straight into the arena."""
-    dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
     s16 = bool(_GRAD_STREAM16) and cdt == torch.float16
+    if dx.dtype == cdt and cdt != torch.float32:           # already in the compute dtype (fusion_decoder_bwd, fp16 mode)
+        dx_c = dx
+    else:
+        dx_c = ops.cast(dx, cdt) if cdt != torch.float32 else None
+    keep16 = s16 and dx.dtype == cdt                       # ... and the caller takes the result in it too
     if s16:
         dx = None
     wg = _WeightGradSide(dx_c.device if s16 else dx.device)
@@ -462,7 +466,7 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
         if on_layer_done is not None:
             on_layer_done(late[0])
     if s16:
-        dx = ops.cast(dx_c, torch.float32)                 # the callers (token assembly, the towers) take fp32
+        dx = dx_c if keep16 else ops.cast(dx_c, torch.float32)   # standalone callers hand in and take fp32
     return dx
 
 
@@ -552,7 +556,9 @@ def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heat
     arena and returns d(fusion input) fp32 [B*seq, dim] (all of it times `grad_scale`)."""
     dim = pp.dim
     batch, seq = S["batch"], S["seq"]
-    dx = torch.zeros(batch * seq, dim, dtype=torch.float32, device=S["x_out"].device)
+    # fp16 mode: the stack's backward carries this gradient in fp16 (_GRAD_STREAM16) -- it is born that way
+    s16 = bool(_GRAD_STREAM16) and cdt == torch.float16
+    dx = torch.zeros(batch * seq, dim, dtype=cdt if s16 else torch.float32, device=S["x_out"].device)
     first = seq - (pp.num_patches + 1)
     xv = S["x_out"].view(batch, seq, dim)
     dxv = dx.view(batch, seq, dim)
@@ -778,6 +784,8 @@ class SegmentTailFn(torch.autograd.Function):
         gs = scaler_of(model)                                  # fp16: loss scale (models/gradscale.py)
         ready = gs.ready if gs is not None else model._grad_ready
         dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else None)
+        if dx.dtype != torch.float32:                          # fp16 mode's 16-bit gradient stream: the segment kernels
+            dx = ops.cast(dx, torch.float32)                   # and the towers' backward take fp32
         d_type = g(pp.fusion.token_type_embeddings.weight)
         d_type.zero_()
         leads = {id(sg["lead"]): sg["lead"] for sg in c.segments}

@@ -494,10 +494,10 @@ extern "C" size_t bf_decoder_project_bwd_ws(int batch, int n_heads, int dim) {
 // stage 1: wave per token; d_tok rows written; per-block partial G / gb
 // MH / MC: compile-time bounds on heads and on float4 chunks per lane (2 / 2 at the bench shape: 16 accumulator registers
 // instead of 64, which is what lets four of these workgroups share a CU)
-template <int MH, int MC>
+template <int MH, int MC, typename TD = float>
 __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
     const float* __restrict__ tok, const float* __restrict__ w_eff, const float* __restrict__ g_low,
-    float* __restrict__ d_tok, float* __restrict__ part, int batch, int n_heads, int n_patch, int dim,
+    TD* __restrict__ d_tok, float* __restrict__ part, int batch, int n_heads, int n_patch, int dim,
     long tok_bstride, long dtok_bstride) {
     extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][n_heads][dim+4]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
     for (int row0 = blockIdx.x * 4 + wave; row0 < rows; row0 += gridDim.x * 8) {
         float4 x[2][MC];
         float gl[2][MH];
-        float* dr[2];
+        TD* dr[2];
         int kind[2];                       // 0: no row, 1: the class token's row (zeros), 2: a patch row
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             if (kind[r] == 1) {
-                for (int c = lane; c < nvec; c += 64) *(float4*)(dr[r] + c * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int c = lane; c < nvec; c += 64) Vec4<TD>::store(dr[r] + c * 4, make_float4(0.f, 0.f, 0.f, 0.f));
             } else if (kind[r] == 2) {
 #pragma unroll
                 for (int i = 0; i < MC; ++i) {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256) void decoder_project_bwd_kernel(
                                 G[h][i].x = fmaf(gh, xv.x, G[h][i].x); G[h][i].y = fmaf(gh, xv.y, G[h][i].y);
                                 G[h][i].z = fmaf(gh, xv.z, G[h][i].z); G[h][i].w = fmaf(gh, xv.w, G[h][i].w);
                             }
-                        *(float4*)(dr[r] + c * 4) = d;
+                        Vec4<TD>::store(dr[r] + c * 4, d);
                     }
                 }
 #pragma unroll
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(1024) void decoder_project_bwd2_kernel(const float*
 }
 
 extern "C" int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_eff,
-                                      const float* g_low, float* d_tok, long dtok_bstride, float* g_w_eff,
+                                      const float* g_low, void* d_tok, int dtok_dtype, long dtok_bstride, float* g_w_eff,
                                       float* g_b_eff, float* part_ws, int batch, int n_heads, int n_patch,
                                       int dim, bf_stream_t stream) {
     BF_REQUIRE(batch > 0 && n_heads >= 1 && n_heads <= DEC_MAXH && n_patch > 0 && (dim & 3) == 0 &&
@@ -625,9 +625,17 @@ extern "C" int bf_decoder_project_bwd(const float* tok, long tok_bstride, const 
     int nblocks = bf_cdiv(rows, 4);
     if (nblocks > PB_BLOCKS) nblocks = PB_BLOCKS;
     const size_t lds = (size_t)4 * n_heads * (dim + 4) * sizeof(float);
+    BF_REQUIRE(dtok_dtype == BF_F32 || dtok_dtype == BF_F16, BF_EINVAL,
+               "bf_decoder_project_bwd: d_tok is fp32 or (the fp16 mode's 16-bit gradient stream) fp16, got %d", dtok_dtype);
 #define PB_LAUNCH(MH, MC)                                                                                       \
-    hipLaunchKernelGGL((decoder_project_bwd_kernel<MH, MC>), dim3(nblocks), dim3(256), lds, s, tok, w_eff, g_low,  \
-                       d_tok, part_ws, batch, n_heads, n_patch, dim, tok_bstride, dtok_bstride)
+    do {                                                                                                        \
+        if (dtok_dtype == BF_F16)                                                                               \
+            hipLaunchKernelGGL((decoder_project_bwd_kernel<MH, MC, f16_t>), dim3(nblocks), dim3(256), lds, s, tok, w_eff, \
+                               g_low, (f16_t*)d_tok, part_ws, batch, n_heads, n_patch, dim, tok_bstride, dtok_bstride); \
+        else                                                                                                    \
+            hipLaunchKernelGGL((decoder_project_bwd_kernel<MH, MC>), dim3(nblocks), dim3(256), lds, s, tok, w_eff, g_low, \
+                               (float*)d_tok, part_ws, batch, n_heads, n_patch, dim, tok_bstride, dtok_bstride); \
+    } while (0)
     const bool few_heads = n_heads <= 2, narrow = dim <= 512;
     if (few_heads && narrow) PB_LAUNCH(2, 2);
     else if (few_heads) PB_LAUNCH(2, DEC_MAXC);

@@ -994,9 +994,9 @@ extern "C" int bf_fusion_assemble(const float* text_feat, const float* rgb_feat,
 
 // backward, stage 1: one thread per (token, float4 column): sum dX over the batch, and
 // write the rgb rows out in the compute dtype.
-template <typename TC>
+template <typename TC, typename TI = float>
 __global__ __launch_bounds__(256) void fusion_assemble_bwd_kernel(
-    const float* __restrict__ dx, TC* __restrict__ d_rgb_feat, float* __restrict__ d_text_pos,
+    const TI* __restrict__ dx, TC* __restrict__ d_rgb_feat, float* __restrict__ d_text_pos,
     float* __restrict__ d_rgb_pos, int batch, int n_text, int n_rgb, int dim, int per_chunk) {
     // grid.y cuts the batch into chunks: one workgroup column per chunk, partial sums by fp32 atomics into the
     // zeroed per-token gradients (one thread looping over all 256 samples left 138 workgroups on the chip
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) void fusion_assemble_bwd_kernel(
     const int b0 = blockIdx.y * per_chunk, b1 = min(batch, b0 + per_chunk);
     float4 acc = make_float4(0, 0, 0, 0);
     for (int b = b0; b < b1; ++b) {
-        const float4 v = *(const float4*)(dx + ((size_t)b * L + t) * dim + c * 4);
+        const float4 v = Vec4<TI>::load(dx + ((size_t)b * L + t) * dim + c * 4);
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         if (t > n_text)
             Vec4<TC>::store(d_rgb_feat + ((size_t)b * n_rgb + (t - 1 - n_text)) * dim + c * 4, v);
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(256) void fusion_assemble_bwd2_kernel(
     }
 }
 
-extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt,
+extern "C" int bf_fusion_assemble_bwd(const void* dx, int dx_dtype, void* d_rgb_feat, int cdt,
                                       float* d_text_token, float* d_text_pos, float* d_rgb_pos,
                                       float* d_type, int batch, int n_text, int n_rgb, int dim,
                                       bf_stream_t stream) {
@@ -1060,14 +1060,20 @@ extern "C" int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt
     const int per_chunk = bf_cdiv(batch, chunks);
     chunks = bf_cdiv(batch, per_chunk);
     dim3 grid(bf_cdiv((long)L * (dim / 4), 256), chunks), block(256);
-    if (cdt == BF_F32)
-        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<float>, grid, block, 0, s, dx, (float*)d_rgb_feat,
+    // dx: fp32, or (the 16-bit gradient stream of the fp16 mode) a tensor of the compute dtype
+    BF_REQUIRE(dx_dtype == BF_F32 || (dx_dtype == BF_F16 && cdt == BF_F16), BF_EINVAL,
+               "bf_fusion_assemble_bwd: dx is fp32, or fp16 together with an fp16 d_rgb_feat (got %d / %d)", dx_dtype, cdt);
+    if (dx_dtype == BF_F16)
+        hipLaunchKernelGGL((fusion_assemble_bwd_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)dx,
+                           (f16_t*)d_rgb_feat, d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
+    else if (cdt == BF_F32)
+        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<float>, grid, block, 0, s, (const float*)dx, (float*)d_rgb_feat,
                            d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
     else if (cdt == BF_BF16)
-        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<bf16_t>, grid, block, 0, s, dx, (bf16_t*)d_rgb_feat,
+        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<bf16_t>, grid, block, 0, s, (const float*)dx, (bf16_t*)d_rgb_feat,
                            d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
     else if (cdt == BF_F16)
-        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<f16_t>, grid, block, 0, s, dx, (f16_t*)d_rgb_feat,
+        hipLaunchKernelGGL(fusion_assemble_bwd_kernel<f16_t>, grid, block, 0, s, (const float*)dx, (f16_t*)d_rgb_feat,
                            d_text_pos, d_rgb_pos, batch, n_text, n_rgb, dim, per_chunk);
     else BF_REQUIRE(false, BF_EINVAL, "bf_fusion_assemble_bwd: bad dtype %d", cdt);
     BF_CHECK_LAUNCH("bf_fusion_assemble_bwd/1");

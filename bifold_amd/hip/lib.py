@@ -91,7 +91,7 @@ PROTOTYPES = {
     "bf_embed_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
     "bf_fusion_assemble": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
-    "bf_fusion_assemble_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+    "bf_fusion_assemble_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_segment_assemble": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p]),
@@ -113,7 +113,7 @@ PROTOTYPES = {
     "bf_bce_finish": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "bf_bce_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "bf_decoder_project_bwd_ws": (c_size_t, [c_int, c_int, c_int]),
-    "bf_decoder_project_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_void_p,
+    "bf_decoder_project_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_scale_check": (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "bf_depth_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

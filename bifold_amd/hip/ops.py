@@ -483,7 +483,7 @@ def fusion_assemble_bwd(dx, cdt: torch.dtype, d_text_token, d_text_pos, d_rgb_po
                         n_rgb):
     dim = dx.shape[-1]
     d_rgb = torch.empty(batch * n_rgb, dim, dtype=cdt, device=dx.device)
-    check(lib.bf_fusion_assemble_bwd(_ptr(dx), _ptr(d_rgb), dtype_code(d_rgb), _ptr(d_text_token),
+    check(lib.bf_fusion_assemble_bwd(_ptr(dx), dtype_code(dx), _ptr(d_rgb), dtype_code(d_rgb), _ptr(d_text_token),
                                      _ptr(d_text_pos), _ptr(d_rgb_pos), _ptr(d_type), batch, n_text,
                                      n_rgb, dim, _stream()), "bf_fusion_assemble_bwd")
     return d_rgb
@@ -550,7 +550,7 @@ def decoder_project_bwd(tok, tok_bstride, w_eff, g_low, d_tok, dtok_bstride, g_w
                         n_heads, n_patch, dim):
     ws = torch.empty(lib.bf_decoder_project_bwd_ws(batch, n_heads, dim), dtype=torch.float32,
                      device=w_eff.device)
-    check(lib.bf_decoder_project_bwd(_ptr(tok), tok_bstride, _ptr(w_eff), _ptr(g_low), _ptr(d_tok),
+    check(lib.bf_decoder_project_bwd(_ptr(tok), tok_bstride, _ptr(w_eff), _ptr(g_low), _ptr(d_tok), dtype_code(d_tok),
                                      dtok_bstride, _ptr(g_w_eff), _ptr(g_b_eff), _ptr(ws), batch, n_heads,
                                      n_patch, dim, _stream()), "bf_decoder_project_bwd")
 

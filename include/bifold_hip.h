@@ -306,10 +306,11 @@ int bf_fusion_assemble(const float* text_feat, const float* rgb_feat, const floa
                        const float* text_pos, const float* rgb_pos, const float* type_emb, float* x,
                        int batch, int n_text, int n_rgb, int dim, bf_stream_t stream);
 
-/* Its backward: dX fp32 [B, L, dim] -> d_rgb_feat (cdt, [B*n_rgb, dim]: the dY operand of
+/* Its backward: dX [B, L, dim] (dx_dtype: fp32, or -- the fp16 mode's 16-bit gradient stream -- fp16 together with an
+ * fp16 d_rgb_feat) -> d_rgb_feat (cdt, [B*n_rgb, dim]: the dY operand of
  * project's backward GEMMs) and the batch-reduced parameter gradients (fp32, overwritten):
  * d_text_token [dim], d_text_pos [1+n_text, dim], d_rgb_pos [n_rgb, dim], d_type [2, dim]. */
-int bf_fusion_assemble_bwd(const float* dx, void* d_rgb_feat, int cdt, float* d_text_token,
+int bf_fusion_assemble_bwd(const void* dx, int dx_dtype, void* d_rgb_feat, int cdt, float* d_text_token,
                            float* d_text_pos, float* d_rgb_pos, float* d_type, int batch,
                            int n_text, int n_rgb, int dim, bf_stream_t stream);
 
@@ -377,13 +378,13 @@ int bf_bce_bwd(const float* heat, const float* target, const float* gscale, floa
                size_t count, float inv_count, bf_stream_t stream);
 
 /* Backward of bf_decoder_project:
- *   d_tok[b, 1+p, :] = sum_h g_low[h,b,p] w_eff[h,:], d_tok[b,0,:] = 0   (fp32, overwritten;
- *   batch stride dtok_bstride)
+ *   d_tok[b, 1+p, :] = sum_h g_low[h,b,p] w_eff[h,:], d_tok[b,0,:] = 0   (dtok_dtype: fp32, or fp16 when the
+ *   fusion backward carries its residual gradient in fp16; overwritten; batch stride dtok_bstride elements)
  *   g_w_eff[h,:] = sum_{b,p} g_low[h,b,p] tok[b,1+p,:], g_b_eff[h] = sum g_low[h,:,:]
  *   part_ws: fp32 scratch >= bf_decoder_project_bwd_ws(batch, n_heads, dim) floats. */
 size_t bf_decoder_project_bwd_ws(int batch, int n_heads, int dim);
 int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_eff, const float* g_low,
-                           float* d_tok, long dtok_bstride, float* g_w_eff, float* g_b_eff,
+                           void* d_tok, int dtok_dtype, long dtok_bstride, float* g_w_eff, float* g_b_eff,
                            float* part_ws, int batch, int n_heads, int n_patch, int dim,
                            bf_stream_t stream);
 
