@@ -34,7 +34,10 @@ BfTuning& bf_tuning() {
         t.gemm_bm = env_int("BIFOLD_GEMM_BM", -1);
         t.p8_min_m = env_int("BIFOLD_P8_MIN_M", 16384);
         t.p8_min_tiles = env_int("BIFOLD_P8_MIN_TILES", -1);
-        t.p8_group_m = env_int("BIFOLD_P8_GROUP_M", 4); if (t.p8_group_m < 1) t.p8_group_m = 1;   // in-step A/B (round 2): 4 / 2 +0.5 %, 16 -1.7 % against 8
+        // in-step A/B: round 2 (BK 32 loop): 4 / 2 +0.5 %, 16 -1.7 % against 8; round 4 (BK 64 loop, three runs each on one
+        // box): 5 -> 32.22 ms, 6 -> 32.26, 3 -> 32.29, 7 -> 32.38, 4 -> 32.42 (8 and 1: 33.1 against 32.9 for 4 on another box):
+        // five A panels of 256 rows are 2 - 2.4 MB of a 4 MB L2, and an odd count does not stride the panels by a power of two
+        t.p8_group_m = env_int("BIFOLD_P8_GROUP_M", 5); if (t.p8_group_m < 1) t.p8_group_m = 1;
         t.p8_grid = env_int("BIFOLD_P8_GRID", 0);
         t.p8_revk = env_int("BIFOLD_P8_REVK", 1) ? 1 : 0;
         t.p8_bk64 = env_int("BIFOLD_P8_BK64", 1);         // round 4 same-box A/B of the step: 7 234 / 7 255 -> 7 423 / 7 386 samples/s

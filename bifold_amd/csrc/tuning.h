@@ -13,7 +13,7 @@ struct BfTuning {
     int gemm_bm;                  // BIFOLD_GEMM_BM          64: 64-row tiles in the BK = 32 kernel (opt-in), -1 off
     int p8_min_m;                 // BIFOLD_P8_MIN_M         persistent kernel from this many rows (16384)
     int p8_min_tiles;             // BIFOLD_P8_MIN_TILES     ... and this many 256x256 tiles (-1: half the CUs)
-    int p8_group_m;               // BIFOLD_P8_GROUP_M       row tiles per group of the persistent kernel's item order (4)
+    int p8_group_m;               // BIFOLD_P8_GROUP_M       row tiles per group of the persistent kernel's item order (5)
     int p8_grid;                  // BIFOLD_P8_GRID          cap on the persistent grid (0: every CU)
     int p8_revk;                  // BIFOLD_P8_REVK          alternate the K direction per round of tickets (1)
     int p8_bk64;                  // BIFOLD_P8_BK64          BK = 64 full-line main loop for the persistent NT GEMMs (1)
