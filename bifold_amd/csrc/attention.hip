@@ -510,8 +510,10 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     constexpr int DB = DP / 32;
     constexpr int KROW = D * 2 + 16;          // bytes
     // Every byte of the packed QKV buffer is read exactly once by this launch (232 MB at the vision tower's shape,
-    // about the size of the Infinity Cache): streamed with the non-temporal hint it does not push out the
-    // residual stream the next GEMM's epilogue needs.
+    // about the size of the Infinity Cache).  Round 3 streamed it with the non-temporal hint so that it would not push
+    // out the fp32 residual tile the next GEMM's epilogue re-read; since the residual adds ride in the LayerNorm passes
+    // (round 4) nothing re-reads it, the QKV buffer was written by the GEMM just before and is best found in the caches,
+    // and the hint costs 0.7 % of the step: off by default (BIFOLD_ATTN_NT=1 turns it on).
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
     auto ld16 = [&](const HT* p) -> uint4 {
         if (nt_loads) {
