@@ -76,6 +76,7 @@ BfTuning& bf_tuning() {
         t.attn_kv_tight = env_int("BIFOLD_ATTN_KV_TIGHT", 1);
         t.attn_bwd_stream = env_int("BIFOLD_ATTN_BWD_STREAM", 1);
         t.ln_rows = env_int("BIFOLD_LN_ROWS", 2);
+        t.ln_bwd16_wide = env_int("BIFOLD_LN_BWD16_WIDE", 1);
     });
     return t;
 }

@@ -46,6 +46,7 @@ struct BfTuning {
     int attn_bwd_stream;          // BIFOLD_ATTN_BWD_STREAM  streamed pair for long sequences (1)
     // ---- LayerNorm (norm_elementwise.hip)
     int ln_rows;                  // BIFOLD_LN_ROWS          rows per wave of the exact-width forward (2)
+    int ln_bwd16_wide;            // BIFOLD_LN_BWD16_WIDE    16-bit gradient stream: eight columns per lane in the LayerNorm backward (1)
 };
 
 BfTuning& bf_tuning();
