@@ -27,6 +27,12 @@
 // (PMC: 432 MB read per forward launch for 216 MB of Q / K / V, 885 - 1 015 MB per backward kernel for
 // 360).  Pairing heads 2p and 2p+1 on one XCD, in adjacent dispatch slots, lets the second hit in L2.
 // d = 48: four heads span exactly three lines (384 bytes), so groups of four.  d = 64: a head is a line.
+// Forward kernels: the reference point of the online softmax without a row maximum per block (attn_fwd_res_kernel).  Measured
+// per head width (profiles/r05_attention_forward_diet.txt): it pays at d = 48 (2 373 x 48 masked: 604 - 620 -> 578 us; 262 x 48:
+// 31.2 -> 29.5 us) and COSTS at d = 32 and d = 64 (the branch between the exponentials and the P V products splits the block
+// the compiler schedules across, and the second copy of the score code takes 8 - 22 registers: a workgroup per CU at 576 x 64).
+template <int D> struct FwdNoMax { static constexpr bool value = (D == 48); };
+
 template <int D>
 __device__ __forceinline__ int paired_bh(int i, int n) {
     constexpr int G = D == 32 ? 2 : (D == 48 ? 4 : 1);
@@ -310,6 +316,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
     const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse,
     const int32_t* __restrict__ row_mask, int L, int H, float scale, int waves_per_block) {
     constexpr int mask_mode = MASK;
+    constexpr bool NOMAX = FwdNoMax<D>::value;
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;                // k-steps of Q K^T
     constexpr int DB = DP / 32;               // 32-row blocks of O^T
@@ -374,75 +381,124 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
         }
         __syncthreads();
 
-        // ---- S^T = K Q^T for the two 32-key blocks of this tile -------------------------
-        f32x16 sacc[2];
+        // ---- S^T = K Q^T for the two 32-key blocks of this tile, masks -------------------------
+        auto scores = [&](f32x16 (&sacc)[2]) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
+                for (int e = 0; e < 16; ++e) sacc[kb][e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (kb * 32 + r) * KROW + ks * 32 + hh * 16);
-                sacc[kb] = mfma_32x32x16(kf, qf[ks], sacc[kb]);
-            }
-        }
-        // ---- masks + online softmax (log2 domain; raw scores stay in sacc) --------------
-        // Per score: one max, one FMA (scale and -max folded), one v_exp, one add.  The key-tail
-        // and causal tests run only on tiles that can contain a masked key.
-        const bool edge = (j0 + KT > L) || (mask_mode == BF_MASK_CAUSAL && j0 + KT - 1 > q0);
-        if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[kb][e] = -100000.0f / scale;   // all scores equal
-        }
-        if (edge) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[kb][e] = -INFINITY;
+                for (int ks = 0; ks < KS; ++ks) {
+                    const typename H16<HT>::x8 kf = *(const typename H16<HT>::x8*)(k_lds + (kb * 32 + r) * KROW + ks * 32 + hh * 16);
+                    sacc[kb] = mfma_32x32x16(kf, qf[ks], sacc[kb]);
                 }
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;       // sl2 > 0: max commutes with the scale
-        const float m_new = fmaxf(m, tmax);
-        // lazy reference point (see attn_fwd_res_kernel): m moves, and l / the accumulators are rescaled, only when a
-        // row has risen more than 2^6 above it
-        if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {
-            const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m - m_to);
-            l *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
-            m = m_new;
-        }
-        const float m_use = (m == -INFINITY) ? 0.f : m;
-        // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
-        // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
-        f32x2 psum2 = {0.f, 0.f};
-        const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
-                t = __builtin_elementwise_fma(t, sl2v, mneg);
-                f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                sacc[kb][e] = p2[0];
-                sacc[kb][e + 1] = p2[1];
-                psum2 += p2;
             }
-        float psum = psum2[0] + psum2[1];
-        psum += __shfl_xor(psum, 32, 64);
-        l += psum;
+            // the key-tail and causal tests run only on tiles that can contain a masked key
+            const bool edge = (j0 + KT > L) || (mask_mode == BF_MASK_CAUSAL && j0 + KT - 1 > q0);
+            if (mask_mode == BF_MASK_QUERY_ROW && row_masked) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sacc[kb][e] = -100000.0f / scale;   // all scores equal
+            }
+            if (edge) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = j0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[kb][e] = -INFINITY;
+                    }
+            }
+        };
+        // p = exp2(s * sl2 - mref) in place (log2 domain; one FMA with the scale and the reference folded, one v_exp,
+        // one add per score, in packed pairs); returns this lane's partial row sum
+        auto probs = [&](f32x16 (&sacc)[2], float mref) -> float {
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 sl2v = {sl2, sl2}, mneg = {-mref, -mref};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
+                    t = __builtin_elementwise_fma(t, sl2v, mneg);
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    sacc[kb][e] = p2[0];
+                    sacc[kb][e + 1] = p2[1];
+                    psum2 += p2;
+                }
+            return psum2[0] + psum2[1];
+        };
+        // reference point without a row maximum per tile: see attn_fwd_res_kernel (round 5)
+        f32x16 sacc[2];
+        scores(sacc);
+        if constexpr (NOMAX) {
+            float ps = 0.f;
+            bool classic = j0 == 0;
+            if (!classic) {
+                ps = probs(sacc, (m == -INFINITY) ? 0.f : m);
+                classic = __builtin_amdgcn_ballot_w64(!(ps < 16384.0f)) != 0;
+                if (classic) scores(sacc);
+            }
+            if (classic) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;       // sl2 > 0: max commutes with the scale
+                const float m_new = fmaxf(m, tmax);
+                const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_to);
+                l *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+                m = m_new;
+                ps = probs(sacc, m_to);
+            }
+            l += ps;                      // this lane's half of the row sum: the halves meet after the loop
+        } else {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;       // sl2 > 0: max commutes with the scale
+            const float m_new = fmaxf(m, tmax);
+            // lazy reference point (see attn_fwd_res_kernel): m moves, and l / the accumulators are rescaled, only when a
+            // row has risen more than 2^6 above it
+            if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {
+                const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_to);
+                l *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+                m = m_new;
+            }
+            const float m_use = (m == -INFINITY) ? 0.f : m;
+            // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
+            // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
+                    t = __builtin_elementwise_fma(t, sl2v, mneg);
+                    f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    sacc[kb][e] = p2[0];
+                    sacc[kb][e + 1] = p2[1];
+                    psum2 += p2;
+                }
+            float psum = psum2[0] + psum2[1];
+            psum += __shfl_xor(psum, 32, 64);
+            l += psum;
+        }
 
         // ---- O^T += V^T P^T : P^T accumulator registers are the B operand ---------------
 #pragma unroll
@@ -461,6 +517,7 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
             }
     }
 
+    if constexpr (NOMAX) l += __shfl_xor(l, 32, 64);   // the two half-rows' partial sums
     if (q_live) {
         const float inv = 1.0f / l;
         HT* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D;
@@ -505,6 +562,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse,
     const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp, int nt_loads) {
     constexpr int mask_mode = MASK;
+    constexpr bool NOMAX = FwdNoMax<D>::value;
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;
     constexpr int DB = DP / 32;
@@ -608,10 +666,8 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const int key_end = (mask_mode == BF_MASK_CAUSAL) ? min(L, q0 + 32) : L;
     __syncthreads();
 
-    // NKB 32-key halves per step: 2 (a 64-key tile) or 1 -- a sequence whose last 64-key tile would be more than half
-    // empty (197 = 6 x 32 + 5, 275 = 8 x 32 + 19) walks 32-key steps: 12 % / 10 % fewer exponentials, the kernel's bound
-    for (int j0 = 0; j0 < key_end; j0 += NKB * 32) {
-        f32x16 sacc[NKB];
+    // Masked scores of the NKB blocks at j0 (raw: the scale rides in the exponent's FMA)
+    auto scores = [&](f32x16 (&sacc)[NKB], int j0) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -638,47 +694,112 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
                     if (key >= L || (mask_mode == BF_MASK_CAUSAL && key > qi)) sacc[kb][e] = -INFINITY;
                 }
         }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
-        // LAZY reference point: the running maximum m is moved -- and l / the output accumulators rescaled -- only when
-        // some row of the wave has risen more than 2^6 above it (or has none yet); otherwise the probabilities of this
-        // block are taken against the old m (p <= 64: harmless in fp32 sums and in both 16-bit formats) and the 8-16
-        // packed multiplies of the rescale, its exponential and the bookkeeping are skipped: after the first block
-        // that is almost every block.  The normalisation at the end uses the same m, so the result is unchanged.
-        const float m_new = fmaxf(m, tmax);
-        if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {
-            const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m - m_to);
-            l *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
-            m = m_new;
-        }
-        const float m_use = (m == -INFINITY) ? 0.f : m;
-        // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
-        // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
+    };
+    // p = exp2(s * sl2 - mref) IN PLACE; returns this lane's partial row sum (pairs of scores go through packed fp32 ops)
+    auto probs = [&](f32x16 (&sacc)[NKB], float mref) -> float {
         f32x2 psum2 = {0.f, 0.f};
-        const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
+        const f32x2 sl2v = {sl2, sl2}, mneg = {-mref, -mref};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
                 f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
                 t = __builtin_elementwise_fma(t, sl2v, mneg);
-                f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                 sacc[kb][e] = p2[0];
                 sacc[kb][e + 1] = p2[1];
                 psum2 += p2;
             }
-        float psum = psum2[0] + psum2[1];
-        psum += __shfl_xor(psum, 32, 64);
-        l += psum;
+        return psum2[0] + psum2[1];
+    };
+
+    // NKB 32-key halves per step: 2 (a 64-key tile) or 1 -- a sequence whose last 64-key tile would be more than half
+    // empty (197 = 6 x 32 + 5, 275 = 8 x 32 + 19) walks 32-key steps: 12 % / 10 % fewer exponentials
+    for (int j0 = 0; j0 < key_end; j0 += NKB * 32) {
+        // Reference point WITHOUT a row maximum per block (round 5).  The block's probabilities are taken, in place,
+        // against the reference point m as it stands, p = exp2(s * sl2 - m); the only thing a maximum protects against is
+        // p leaving the 16-bit range, and the lane's own partial row sum (which the kernel needs anyway) bounds every p of
+        // the lane: while it stays below 2^14 nothing can have overflowed (fp16: 65 504).  The first block of a wave, and
+        // any block in which some lane's partial sum reaches 2^14 (or is not a number), takes the classic path: scores
+        // AGAIN (the probabilities overwrote them; two or four MFMAs on fragments still in LDS), row maximum, m moved,
+        // l and the output accumulators rescaled, p recomputed -- after the first block that is rare (a row would have
+        // to rise 14 / log2(e) = 9.7 above its first block's maximum).  Per block this removes 8 v_max3, the half-wave
+        // exchange of the maximum with its LDS round trip and the bookkeeping around the lazy test, a quarter of the
+        // loop's vector instructions, at the register count of before (a second register set for the probabilities cost
+        // a workgroup per CU and 20 % of the kernel: profiles/r05_attention_forward_diet.txt).  l is kept PER LANE (the
+        // lane's 16 of the row's 32 keys per block); the two halves of a row meet once, after the loop.
+        f32x16 sacc[NKB];
+        scores(sacc, j0);
+        if constexpr (NOMAX) {
+            float ps = 0.f;
+            bool classic = j0 == 0;
+            if (!classic) {
+                ps = probs(sacc, (m == -INFINITY) ? 0.f : m);
+                classic = __builtin_amdgcn_ballot_w64(!(ps < 16384.0f)) != 0;
+                if (classic) scores(sacc, j0);
+            }
+            if (classic) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+                const float m_new = fmaxf(m, tmax);
+                const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_to);      // m = -inf (first block): 0, and l / oacc are 0
+                l *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+                m = m_new;
+                ps = probs(sacc, m_to);
+            }
+            l += ps;
+        } else {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[kb][e]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
+            // LAZY reference point: the running maximum m is moved -- and l / the output accumulators rescaled -- only when
+            // some row of the wave has risen more than 2^6 above it (or has none yet); otherwise the probabilities of this
+            // block are taken against the old m (p <= 64: harmless in fp32 sums and in both 16-bit formats) and the 8-16
+            // packed multiplies of the rescale, its exponential and the bookkeeping are skipped: after the first block
+            // that is almost every block.  The normalisation at the end uses the same m, so the result is unchanged.
+            const float m_new = fmaxf(m, tmax);
+            if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {
+                const float m_to = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_to);
+                l *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) oacc[db][e] *= alpha;
+                m = m_new;
+            }
+            const float m_use = (m == -INFINITY) ? 0.f : m;
+            // pairs of scores go through packed fp32 ops (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per
+            // instruction); the softmax, not the MFMA, bounds this kernel (28 VALU instructions per MFMA)
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    f32x2 t = {sacc[kb][e], sacc[kb][e + 1]};
+                    t = __builtin_elementwise_fma(t, sl2v, mneg);
+                    f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    sacc[kb][e] = p2[0];
+                    sacc[kb][e + 1] = p2[1];
+                    psum2 += p2;
+                }
+            float psum = psum2[0] + psum2[1];
+            psum += __shfl_xor(psum, 32, 64);
+            l += psum;
+        }
 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
@@ -703,6 +824,7 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     // instead, so a lane stores 16 bytes and 8 lanes cover a whole row segment.
     __syncthreads();                                   // every wave is done with K
     char* ot = k_lds + (size_t)q0 * KROW;
+    if constexpr (NOMAX) l += __shfl_xor(l, 32, 64);   // the two half-rows' partial sums
     {
         const float inv = q_live ? 1.0f / l : 0.f;
 #pragma unroll

@@ -420,6 +420,28 @@ def test_attention_fwd_many_items_lazy_rescale(ops, gpu, half, B, Lq, H, D):
     assert rel_err(lse, torch.logsumexp(s, -1)) < 1e-5
 
 
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("top", [300.0, 1500.0])
+@pytest.mark.parametrize("B,Lq,H,D", [(3, 275, 2, 32), (2, 197, 2, 64), (1, 700, 2, 48), (2, 77, 2, 64)])
+def test_attention_fwd_rows_that_keep_rising(ops, gpu, half, top, B, Lq, H, D):
+    """Round 5: the forward kernels take a block's probabilities against the reference point as it stands and compute a
+    row maximum only in a wave's first block or when a lane's partial row sum reaches 2^14.  Here every row's scores RISE
+    with the key index, by `top` natural-log units over the sequence: 300 -> each 32-key block lifts the rows far past
+    2^14 (the re-referencing path in every block); 1 500 -> past fp32's exp range (the partial sum is inf).  Against fp64."""
+    g = torch.Generator().manual_seed(Lq + D)
+    qkv = torch.randn(B, Lq, 3, H, D, generator=g) * 0.05
+    qkv[:, :, 0] += 1.0                                                     # q ~ ones
+    ramp = torch.linspace(0.0, top, Lq) / D ** 0.5                          # k_j ~ c_j * ones: s_ij ~ c_j * sqrt(D)
+    qkv[:, :, 1] += ramp[None, :, None, None]
+    qkv[:, :, 2] = torch.randn(B, Lq, H, D, generator=g)
+    qkv = round_to(qkv.reshape(B * Lq, 3 * H * D), half)
+    ref_o, ref_lse = ref_attention(qkv, B, Lq, H, D, D ** -0.5, 0, None)
+    out, lse = ops.attention_fwd(qkv.to(gpu).to(half), B, Lq, H, D, D ** -0.5, 0, None, need_lse=True)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out.float(), ref_o) < 1.5e-2
+    assert rel_err(lse, ref_lse) < 1e-5
+
+
 def ref_attention(qkv, B, Lq, H, D, scale, mode, row_mask):
     q, k, v = qkv.double().reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
     s = q @ k.transpose(-1, -2) * scale
