@@ -2156,6 +2156,527 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_fused32_kernel(
 }
 
 // =====================================================================================
+//   d = 32, unmasked, <= 288 tokens: the one-pass backward as a PERSISTENT kernel (round 5)
+// =====================================================================================
+// attn_bwd_fused32_kernel above is a chain of latencies: a key wave's step is LDS reads -> 4 MFMAs -> 16 exponentials ->
+// LDS write -> transposed reads -> 4 MFMAs -> barrier, 1 200 cycles for 256 cycles of matrix and ~ 270 of vector work,
+// with three key blocks per wave in registers (218 registers: 1.5 waves per SIMD) and a load phase of 6.9 us in front
+// of 17 us of steps; two workgroups per CU take turns.  Measured on the way here (profiles/r05_pipe_overlap.txt): the
+// matrix pipe and the vector ALU of a SIMD DO overlap -- between waves and inside a hand-placed stream -- so what the
+// kernel lacks is waves to overlap, and loads under its compute.  This form (nine-block sequences: 257 - 288 tokens):
+//   * ONE workgroup of TWELVE waves per CU, walking (batch, head) items.  Waves 0 - 8 are KEY waves with ONE key block
+//     each (dK^T / dV^T: 32 accumulator registers instead of 96; K and V fragments of the block in registers for the item):
+//     an item is 9 steps of 9 concurrent blocks instead of 27 steps of 3, 2 - 3 key waves per SIMD to overlap.
+//   * wave 9 sums dQ: after the barrier that ends step j it adds K^T dS^T of the nine images of query block j (18 MFMAs into
+//     one accumulator, key blocks in order: bit-reproducible) while the key waves are in step j + 1.  Its K^T fragments
+//     stay in 72 registers for the item; the image reads go out as assembly in batches ahead of the MFMAs (the compiler
+//     serialised read - wait - multiply per key block: 1.0 us per query block for 0.27 us of MFMAs); the lane is the query,
+//     so a lane stores its own row of dQ.
+//   * waves 10 - 11 are LOADERS: the NEXT item's operands arrive under this item's steps.  A query block's Q / dO rows are
+//     read in exactly one step, so the slot of block j is free after step j: the loaders write the next item's block j
+//     there during step j + 1 (its rows were requested two steps earlier: 21 registers per set, two sets in flight),
+//     together with its row constants -lse / scale and -delta = -rowsum(dO * O) (the O rows go through the loaders'
+//     registers only) into the second constants buffer, the block's K rows into the second K image and its V rows into
+//     the one V image (the key waves take their V fragments at the top of an item).
+//   * the requests are inline-assembly loads with hand-counted waits, in straight-line code: hipcc drains vmcnt(0) at a
+//     loop header for every load it knows to be pending (a full trip to memory per step), and with requests inside
+//     branches it copied the registers of loads in flight (garbage in one test); tools/check_async_loads.py checks the ISA
+//     for any use of such a register before its wait.  No LDS-DMA: the compiler puts vmcnt(0) in front of LDS reads behind one.
+//   * the roles are separate code paths with the SAME barrier sequence (nine per item + one between items): as one loop
+//     with role tests inside, the register allocator kept every role's state alive at once (168 registers, 62 spilled).
+//   * the support waves run at raised priority: as the youngest waves of the workgroup they lost the issue arbitration to
+//     the key waves on their SIMDs, and every barrier waited for them (sum 1.0 -> 0.74 us per step, 0.66 us uncontended).
+// Measured (tools/attn_probe_fusedp.py, B = 256): a step is 0.58 us of key-wave work + 0.48 us at the barrier (the summing
+// wave: one SIMD carries its 18 MFMAs beside two key waves' 16), 2 us between items; 259 - 264 us against 282 - 285 us for
+// the kernel above on the same box.  Splitting the sum over two waves and steps balanced the SIMDs but took the loader to
+// two rows per thread and the kernel to 165 registers with spills in the loader's path: not kept.
+// LDS: Q / dO blocks 36.9 KB + 2 K images 36.9 KB + V image 18.4 KB + 2 x row constants 4.6 KB + 3 x 9 dS images 55.3 KB = 152 KB.
+// Global loads the compiler's wait-count pass does not see (inline assembly): the persistent kernel below keeps requests in
+// flight ACROSS its steps, where hipcc either drains vmcnt(0) at a loop header for every pending load it knows of or, with the
+// steps written out, still waits a full trip to memory per step (2.4 us per step measured).  The caller waits by hand, with an
+// asm statement that names the registers (so that no use can be scheduled before it); the code between request and wait is
+// straight-line (no loop-carried copies of registers whose loads are in flight) -- checked in the ISA.
+__device__ __forceinline__ img_u32x4 gload16_async(const void* p) {
+    img_u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float gload4_async(const void* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+struct Fused32P {
+    static constexpr int ROW = 64, BLK = 2 * 32 * ROW, DO_OFF = 32 * ROW;
+    static constexpr int NKW = 9, NWAVES = 12;                 // key waves; waves
+    static size_t lds_bytes(int nw) {
+        const size_t lp = (size_t)nw * 32;
+        return lp * 2 * ROW + 3 * lp * ROW + 2 * (2 * lp * 4) + 3 * (size_t)nw * 2048;
+    }
+};
+template <typename HT>
+__global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kernel(
+    const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout, const float* __restrict__ lse,
+    HT* __restrict__ dqkv, int L, int H, float scale, int n_items) {
+    constexpr int D = 32, KS = 2, ROW = Fused32P::ROW, BLK = Fused32P::BLK, DO_OFF = Fused32P::DO_OFF;
+    constexpr int NT = Fused32P::NWAVES * 64;
+    using RI = ResImg<32>;
+    using X8 = typename H16<HT>::x8;
+    using X4 = typename H16<HT>::x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nw = (L + 31) >> 5, Lp = nw * 32;
+    char* q_lds = smem;                                    // Q block i, dO block i, Q block i + 1, ...
+    char* k_img0 = q_lds + (size_t)Lp * 2 * ROW;           // two K images (rows swizzled): the current item's, the next one's
+    const int k_img_bytes = Lp * ROW;
+    char* v_img = k_img0 + 2 * (size_t)k_img_bytes;        // ONE V image: the key waves take their fragments at the top of an item
+    float* cst = (float*)(v_img + (size_t)k_img_bytes);    // 2 x { -lse / scale [Lp], -delta [Lp] }
+    char* ds_img = (char*)(cst + 4 * Lp);                  // 3 buffers x nw key blocks: dS^T [key][query], 64-byte rows, 8-byte chunks swizzled
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const float inv_scale = 1.0f / scale;
+    const unsigned row_bytes = 3u * (unsigned)H * D * 2u, orow_bytes = (unsigned)H * D * 2u;
+    const int G = gridDim.x;
+    const img_u32x4 z4 = {0u, 0u, 0u, 0u};
+
+    int v = blockIdx.x;
+    if (v >= n_items) return;
+#ifdef ATTN_PROBE   // stamps of one wave per role (100 MHz wall clock): tools/attn_probe_fusedp.py
+    const bool pr_on = lane == 0 && blockIdx.x < ATTN_PROBE_WGS;
+    unsigned long long* pr = attn_probe + (size_t)blockIdx.x * 8;
+    unsigned long long pr_a = 0, pr_b = 0, pr_c = 0;
+    if (pr_on && w == 0) pr[0] = wall_clock64();
+#endif
+
+    // ---- the first item: everything from memory at once, by all twelve waves -----------------------------------------------
+    {
+        const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
+        const char* q_src = (const char*)(qkv + qkv_off(b, 0, 0, h, L, H, D));
+        const char* k_src = q_src + orow_bytes;
+        const char* do_src = (const char*)(dout + (size_t)b * L * H * D + (size_t)h * D);
+        const char* o_src = (const char*)(out + (size_t)b * L * H * D + (size_t)h * D);
+        const char* v_src = k_src + orow_bytes;
+        constexpr int U = 2;                                  // 288 rows x 4 chunks over 768 threads: 1.5 rounds
+        img_u32x4 vq[U], vd[U], vk[U], vo[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = (int)threadIdx.x + u * NT;
+            const int i = idx >> 2, c = idx & 3;
+            vq[u] = z4; vd[u] = z4; vk[u] = z4; vo[u] = z4; vv[u] = z4;
+            if (i < L) {
+                const unsigned off = (unsigned)i * row_bytes + (unsigned)c * 16u, ooff = (unsigned)i * orow_bytes + (unsigned)c * 16u;
+                vq[u] = *(const img_u32x4*)(q_src + off);
+                vk[u] = *(const img_u32x4*)(k_src + off);
+                vv[u] = *(const img_u32x4*)(v_src + off);
+                vd[u] = *(const img_u32x4*)(do_src + ooff);
+                vo[u] = *(const img_u32x4*)(o_src + ooff);
+            }
+        }
+        const float ls0 = (int)threadIdx.x < L ? lse[((size_t)b * H + h) * L + threadIdx.x] : 1e30f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = (int)threadIdx.x + u * NT;
+            const int i = idx >> 2, c = idx & 3;
+            const X8 gv = *(const X8*)&vd[u], ov = *(const X8*)&vo[u];
+            float dl = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
+            dl += __shfl_xor(dl, 1, 64);
+            dl += __shfl_xor(dl, 2, 64);
+            if (i < Lp) {
+                char* dst = q_lds + (i >> 5) * BLK + RI::at(i & 31, c, ROW);
+                *(img_u32x4*)dst = vq[u];
+                *(img_u32x4*)(dst + DO_OFF) = vd[u];
+                *(img_u32x4*)(k_img0 + RI::at(i, c, ROW)) = vk[u];
+                *(img_u32x4*)(v_img + RI::at(i, c, ROW)) = vv[u];
+                if (c == 0) cst[Lp + i] = -dl;
+            }
+        }
+        if ((int)threadIdx.x < Lp) cst[threadIdx.x] = -ls0 * inv_scale;
+    }
+    __syncthreads();
+
+    if (w < nw) {
+        // =========================== KEY wave: key block w ======================================================================
+        const float sl2 = scale * 1.44269504088896340736f;
+        int a_off[KS], t_off[2], dsw_off[4];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a_off[ks] = RI::at(r, ks * 2 + hh, ROW);
+        {
+            const int cb = (16 * (g16 & 1) + 4 * p4) * 2;
+            t_off[0] = RI::at(4 * hh + q4, cb >> 4, ROW, cb & 15);
+            t_off[1] = RI::at(4 * hh + q4 + 8, cb >> 4, ROW, cb & 15);
+        }
+        // dS^T image: row = key (64 bytes = 32 queries), 8-byte chunk c of row k at chunk c ^ ((k >> 1) & 7)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) dsw_off[g] = r * 64 + (((2 * g + hh) ^ ((r >> 1) & 7)) << 3);
+        const int key = w * 32 + r;
+        const bool last_kb = w * 32 + 32 > L, dead = key >= L;
+        X8 vf[KS], kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            vf[ks] = *(const X8*)(v_img + w * 32 * ROW + a_off[ks]);
+            kf[ks] = *(const X8*)(k_img0 + w * 32 * ROW + a_off[ks]);
+        }
+        int cur = 0;
+        for (;;) {
+            const int vn = v + G;
+            const bool has_next = vn < n_items;
+            const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
+            f32x16 dkacc, dvacc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dkacc[e] = 0.f; dvacc[e] = 0.f; }
+            const float* lse_c = cst + cur * 2 * Lp;
+            const float* del_c = lse_c + Lp;
+            for (int j = 0; j < nw; ++j) {
+#ifdef ATTN_PROBE
+                const unsigned long long pr_t0 = wall_clock64();
+#endif
+                const char* q_blk = q_lds + j * BLK;
+                const float* lrowp = lse_c + j * 32 + 4 * hh;
+                const float* drowp = del_c + j * 32 + 4 * hh;
+                char* my_img = ds_img + ((j % 3) * nw + w) * 2048;
+                f32x16 sacc, pacc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 l4 = *(const float4*)(lrowp + 8 * g);
+                    const float4 d4 = *(const float4*)(drowp + 8 * g);
+                    sacc[4 * g + 0] = l4.x; sacc[4 * g + 1] = l4.y; sacc[4 * g + 2] = l4.z; sacc[4 * g + 3] = l4.w;
+                    pacc[4 * g + 0] = d4.x; pacc[4 * g + 1] = d4.y; pacc[4 * g + 2] = d4.z; pacc[4 * g + 3] = d4.w;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const char* pa = q_blk + a_off[ks];
+                    const X8 qa = *(const X8*)pa;
+                    const X8 da = *(const X8*)(pa + DO_OFF);
+                    sacc = mfma_32x32x16(qa, kf[ks], sacc);
+                    pacc = mfma_32x32x16(da, vf[ks], pacc);
+                }
+                const f32x2 sl2v = {sl2, sl2};
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 t = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    const f32x2 ds2 = p2 * (f32x2){pacc[e], pacc[e + 1]};
+                    sacc[e] = p2[0]; sacc[e + 1] = p2[1];
+                    pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
+                }
+                // a key beyond L has zero K / V rows but exp(-lse) != 0: its dS column would reach dQ (only the last key block)
+                if (last_kb) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) pacc[e] = dead ? 0.f : pacc[e];
+                }
+                X8 pb[2], dsb[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { pb[s][e] = (HT)sacc[8 * s + e]; dsb[s][e] = (HT)pacc[8 * s + e]; }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    X4 v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = dsb[g >> 1][4 * (g & 1) + e];
+                    *(X4*)(my_img + dsw_off[g]) = v4;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char* t0 = q_blk + t_off[0] + s * 16 * ROW;
+                    const char* t1 = q_blk + t_off[1] + s * 16 * ROW;
+                    const X8 dot = tr_pair<HT>(t0 + DO_OFF, t1 + DO_OFF);
+                    const X8 qtt = tr_pair<HT>(t0, t1);
+                    dvacc = mfma_32x32x16(dot, pb[s], dvacc);
+                    dkacc = mfma_32x32x16(qtt, dsb[s], dkacc);
+                }
+#ifdef ATTN_PROBE
+                const unsigned long long pr_t1 = wall_clock64();
+#endif
+                __syncthreads();
+#ifdef ATTN_PROBE
+                pr_a += pr_t1 - pr_t0; pr_b += wall_clock64() - pr_t1;
+#endif
+            }
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t2 = wall_clock64();
+#endif
+            if (!dead) {
+                HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+                HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 8 * g + 4 * hh;
+                    X4 k4, v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { k4[e] = (HT)(dkacc[4 * g + e] * scale); v4[e] = (HT)dvacc[4 * g + e]; }
+                    *(X4*)(dkp + d0) = k4;
+                    *(X4*)(dvp + d0) = v4;
+                }
+            }
+            if (!has_next) break;
+            __syncthreads();                                // between items: the next K image, Q / dO blocks and constants are in place
+            cur ^= 1;
+            v = vn;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                vf[ks] = *(const X8*)(v_img + w * 32 * ROW + a_off[ks]);
+                kf[ks] = *(const X8*)(k_img0 + cur * k_img_bytes + w * 32 * ROW + a_off[ks]);
+            }
+#ifdef ATTN_PROBE
+            pr_c += wall_clock64() - pr_t2;
+#endif
+        }
+#ifdef ATTN_PROBE
+        if (pr_on && w == 0) { pr[2] = pr_a; pr[3] = pr_b; pr[7] = pr_c; pr[4] = wall_clock64(); }
+#endif
+    } else if (w == 9) {
+        // =========================== wave 9: dQ of query block j while the key waves are in step j + 1 ==========================
+        // (Two such waves on alternating query blocks, each spreading a block's eighteen MFMAs over two steps so that no SIMD
+        // carries them all, were built: with the third wave loading two rows per thread the kernel needed 165 registers, the
+        // compiler spilled in the loader's path -- registers with loads in flight -- and one test saw garbage.  One summing wave.)
+        // The youngest waves of the workgroup lose the issue arbitration on their SIMD to the two key waves they share it with
+        // (oldest first), and every step's barrier waits for them: static priority for the three support waves.
+        __builtin_amdgcn_s_setprio(3);
+        int dsr_off[2][2], kb_off[2];       // B operand of dQ^T: a dS^T image read transposed; A operand: K rows read transposed
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int krow = 16 * s2 + 8 * hh + q4 + 4 * u;
+                dsr_off[s2][u] = krow * 64 + (((4 * (g16 & 1) + p4) ^ ((krow >> 1) & 7)) << 3);
+            }
+        {
+            const int cd = (16 * (g16 & 1) + 4 * p4) * 2;
+            kb_off[0] = RI::at(8 * hh + q4, cd >> 4, ROW, cd & 15);
+            kb_off[1] = RI::at(8 * hh + q4 + 4, cd >> 4, ROW, cd & 15);
+        }
+        int cur = 0;
+        for (;;) {
+            const int vn = v + G;
+            const bool has_next = vn < n_items;
+            const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
+            const char* k_img = k_img0 + cur * k_img_bytes;
+            // K^T fragments of ALL key blocks, once per item (72 registers this wave has to spare): half of the sum's LDS reads,
+            // and with the blocks unrolled -- a block beyond the sequence multiplies a ZERO fragment with the last live image --
+            // no branch stands between the reads and the MFMAs, so the compiler requests the images ahead.
+            X8 kfr[Fused32P::NKW][2];
+#pragma unroll
+            for (int wv = 0; wv < Fused32P::NKW; ++wv) {
+                const char* krows = k_img + (wv < nw ? wv : 0) * 32 * ROW;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    kfr[wv][s] = tr_pair<HT>(krows + kb_off[0] + s * 16 * ROW, krows + kb_off[1] + s * 16 * ROW);
+                    if (wv >= nw) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) kfr[wv][s][e] = (HT)0.f;
+                    }
+                }
+            }
+            // dQ^T [d][query] = sum over keys of K^T [d][key] dS^T [key][query]: the lane is the QUERY, so a lane holds 16
+            // columns of one row of dQ and stores them itself (the two half-waves swap 8-byte pieces: two 16-byte stores
+            // per lane, no LDS turn).  Key blocks in order into one accumulator: bit-reproducible.
+            // The image reads go out as inline assembly in batches of three key blocks, the next batch before the MFMAs of the
+            // current one: written with the builtin, the compiler requested a block's four fragments, waited, multiplied and
+            // only then requested the next block's into the SAME registers -- nine LDS round trips per sum, 1.0 us per query
+            // block for 0.27 us of MFMAs (tools/attn_probe_fusedp.py).
+            f32x16 dq;
+            auto issue2 = [&](uint2 (&f)[2][2][2], const char* img_buf, int b2, int nblk) {   // key blocks 2 b2, 2 b2 + 1
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i >= nblk) continue;
+                    const int wv = 2 * b2 + i;
+                    const char* im = img_buf + (wv < nw ? wv : nw - 1) * 2048;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) tr_issue(f[i][s][0], f[i][s][1], im + dsr_off[s][0], im + dsr_off[s][1]);
+                }
+            };
+            auto mul2 = [&](uint2 (&f)[2][2][2], int b2, int nblk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i >= nblk) continue;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const uint4 vq = make_uint4(f[i][s][0].x, f[i][s][0].y, f[i][s][1].x, f[i][s][1].y);
+                        dq = mfma_32x32x16(kfr[2 * b2 + i][s], *(const X8*)&vq, dq);
+                    }
+                }
+            };
+#define BF_LGKM_WAIT2(N, f)                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]), "+v"(f[1][0][0]), \
+                 "+v"(f[1][0][1]), "+v"(f[1][1][0]), "+v"(f[1][1][1]))
+#define BF_LGKM_WAIT1(N, f)                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0][0][0]), "+v"(f[0][0][1]), "+v"(f[0][1][0]), "+v"(f[0][1][1]))
+            static_assert(Fused32P::NKW == 9, "the batches below are written for nine key blocks");
+            auto half1 = [&](int jq) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+                const char* img_buf = ds_img + (size_t)(jq % 3) * nw * 2048;
+                uint2 fa[2][2][2], fb[2][2][2];
+                issue2(fa, img_buf, 0, 2);
+                issue2(fb, img_buf, 1, 2);
+                BF_LGKM_WAIT2(8, fa); mul2(fa, 0, 2); issue2(fa, img_buf, 2, 2);
+                BF_LGKM_WAIT2(8, fb); mul2(fb, 1, 2); issue2(fb, img_buf, 3, 2);
+                BF_LGKM_WAIT2(8, fa); mul2(fa, 2, 2); issue2(fa, img_buf, 4, 1);
+                BF_LGKM_WAIT2(4, fb); mul2(fb, 3, 2);
+                BF_LGKM_WAIT1(0, fa); mul2(fa, 4, 1);
+            };
+#undef BF_LGKM_WAIT2
+#undef BF_LGKM_WAIT1
+            auto half2 = [&](int jq) {
+                const int qi = jq * 32 + r;
+                uint2 own[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    X4 o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (HT)(dq[4 * g + e] * scale);
+                    own[g] = *(const uint2*)&o4;
+                }
+                uint4 st[2];                                // lane (r, 0) owns d 0-7 and 16-23, lane (r, 1) d 8-15 and 24-31
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const unsigned ax = own[2 * k].x, ay = own[2 * k].y, bx = own[2 * k + 1].x, by = own[2 * k + 1].y;
+                    const unsigned gx = (unsigned)__shfl_xor((int)(hh ? ax : bx), 32, 64);
+                    const unsigned gy = (unsigned)__shfl_xor((int)(hh ? ay : by), 32, 64);
+                    st[k].x = hh ? gx : ax; st[k].y = hh ? gy : ay;
+                    st[k].z = hh ? bx : gx; st[k].w = hh ? by : gy;
+                }
+                if (qi < L) {
+                    HT* dst = dqkv + qkv_off(b, qi, 0, h, L, H, D) + hh * 8;
+                    *(uint4*)dst = st[0];
+                    *(uint4*)(dst + 16) = st[1];
+                }
+            };
+            for (int j = 0; j < nw; ++j) {
+#ifdef ATTN_PROBE
+                const unsigned long long pr_t0 = wall_clock64();
+#endif
+                if (j >= 1) { half1(j - 1); half2(j - 1); }
+#ifdef ATTN_PROBE
+                pr_a += wall_clock64() - pr_t0;
+#endif
+                __syncthreads();
+            }
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t3 = wall_clock64();
+#endif
+            half1(nw - 1); half2(nw - 1);
+#ifdef ATTN_PROBE
+            pr_b += wall_clock64() - pr_t3;
+#endif
+            if (!has_next) break;
+            __syncthreads();
+            cur ^= 1;
+            v = vn;
+        }
+#ifdef ATTN_PROBE
+        if (pr_on) { pr[5] = pr_a; pr[6] = pr_b; }
+#endif
+    } else if (w >= 10) {
+        // =========================== waves 10, 11: the next item's rows under this item's steps ================================
+        // Plain loads, and the nine steps written out: hipcc drains vmcnt(0) at a loop header for every load pending at its
+        // entry (the requests would be waited for one step after they are made), and asm loads hidden from its wait-count pass
+        // were copied between registers before they had landed.  Straight-line code gets exact counts.
+        __builtin_amdgcn_s_setprio(3);
+        const int lt = (int)threadIdx.x - 10 * 64, lrow = lt >> 2, lc = lt & 3;     // (row, chunk) of a 32-row block
+        struct LSet { img_u32x4 q[1], d[1], o[1], k[1], vv[1]; float ls[1]; };
+        int cur = 0;
+        for (;;) {
+            const int vn = v + G;
+            const bool has_next = vn < n_items;
+            const int bhn = paired_bh<D>(has_next ? vn : v, n_items), bn = bhn / H, hn = bhn - bn * H;
+            const char* q_src = (const char*)(qkv + qkv_off(bn, 0, 0, hn, L, H, D));
+            const char* k_src = q_src + orow_bytes;
+            const char* v_src = k_src + orow_bytes;
+            const char* do_src = (const char*)(dout + (size_t)bn * L * H * D + (size_t)hn * D);
+            const char* o_src = (const char*)(out + (size_t)bn * L * H * D + (size_t)hn * D);
+            const float* ls_src = lse + ((size_t)bn * H + hn) * L;
+            char* k_next = k_img0 + (cur ^ 1) * k_img_bytes;
+            float* c_next = cst + (cur ^ 1) * 2 * Lp;
+            // rows of the next item's block m (a row beyond the sequence asks for the last live row and is zeroed on deposit):
+            // six requests per set, so that the waits can count
+            auto request = [&](LSet& st, int m) {
+#pragma unroll
+                for (int u = 0; u < 1; ++u) {
+                    const int i = m * 32 + lrow, ic = i < L ? i : L - 1;
+                    const unsigned off = (unsigned)ic * row_bytes + (unsigned)lc * 16u, ooff = (unsigned)ic * orow_bytes + (unsigned)lc * 16u;
+                    st.q[u] = gload16_async(q_src + off);
+                    st.k[u] = gload16_async(k_src + off);
+                    st.vv[u] = gload16_async(v_src + off);
+                    st.d[u] = gload16_async(do_src + ooff);
+                    st.o[u] = gload16_async(o_src + ooff);
+                    st.ls[u] = gload4_async(ls_src + ic);
+                }
+            };
+            // ... into the slot block m of THIS item has left; K and constants into the other buffers; V into the one V image
+            // (the key waves took their fragments at the top of the item)
+            auto deposit = [&](LSet& st, int m, bool newer, bool live) {   // NEWER: the other set's six requests are younger and may stay in flight
+                if (newer) asm volatile("s_waitcnt vmcnt(6)" : "+v"(st.q[0]), "+v"(st.k[0]), "+v"(st.vv[0]), "+v"(st.d[0]), "+v"(st.o[0]), "+v"(st.ls[0]));
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.q[0]), "+v"(st.k[0]), "+v"(st.vv[0]), "+v"(st.d[0]), "+v"(st.o[0]), "+v"(st.ls[0]));
+                if (!live) return;
+#pragma unroll
+                for (int u = 0; u < 1; ++u) {
+                    const int row = lrow, i = m * 32 + row;
+                    if (i >= L) { st.q[u] = z4; st.k[u] = z4; st.vv[u] = z4; st.d[u] = z4; st.o[u] = z4; st.ls[u] = 1e30f; }
+                    const X8 gv = *(const X8*)&st.d[u], ov = *(const X8*)&st.o[u];
+                    float dl = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dl = fmaf((float)ov[e], (float)gv[e], dl);
+                    dl += __shfl_xor(dl, 1, 64);
+                    dl += __shfl_xor(dl, 2, 64);
+                    char* dst = q_lds + m * BLK + RI::at(row, lc, ROW);
+                    *(img_u32x4*)dst = st.q[u];
+                    *(img_u32x4*)(dst + DO_OFF) = st.d[u];
+                    *(img_u32x4*)(k_next + RI::at(i, lc, ROW)) = st.k[u];
+                    *(img_u32x4*)(v_img + RI::at(i, lc, ROW)) = st.vv[u];
+                    if (lc == 0) {
+                        c_next[i] = -st.ls[u] * inv_scale;
+                        c_next[Lp + i] = -dl;
+                    }
+                }
+            };
+            // Straight-line, unconditional requests and waits (the host sends only nine-block sequences here): a request inside
+            // a branch makes the registers of a load in flight the operands of a merge, and the compiler COPIES them right
+            // behind the load (tools/check_async_loads.py looks for exactly that in the ISA).  Without a next item the
+            // requests re-read this item's rows and nothing is deposited.
+            LSet set0, set1;
+            request(set0, 0);
+            // step j: block j - 1 (requested in step j - 2) into its slot, block j + 1 requested; the sets alternate
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t0 = wall_clock64();
+#endif
+#define BF_LOADER_STEP(J, ST)                                        \
+            if ((J) >= 1) deposit(ST, (J) - 1, true, has_next);      \
+            if ((J) + 1 < Fused32P::NKW) request(ST, (J) + 1);       \
+            __syncthreads();
+            BF_LOADER_STEP(0, set1) BF_LOADER_STEP(1, set0) BF_LOADER_STEP(2, set1) BF_LOADER_STEP(3, set0) BF_LOADER_STEP(4, set1)
+            BF_LOADER_STEP(5, set0) BF_LOADER_STEP(6, set1) BF_LOADER_STEP(7, set0) BF_LOADER_STEP(8, set1)
+#undef BF_LOADER_STEP
+            deposit(set0, Fused32P::NKW - 1, false, has_next);
+#ifdef ATTN_PROBE
+            pr_a += wall_clock64() - pr_t0;
+#endif
+            if (!has_next) break;
+            __syncthreads();
+            cur ^= 1;
+            v = vn;
+        }
+#ifdef ATTN_PROBE
+        if (pr_on && w == 10) pr[1] = pr_a;
+#endif
+    } else {
+        // key waves beyond the sequence's blocks (nw < 9): only the barriers
+        for (;;) {
+            const int vn = v + G;
+            for (int j = 0; j < nw; ++j) __syncthreads();
+            if (vn >= n_items) break;
+            __syncthreads();
+            v = vn;
+        }
+    }
+}
+
+// =====================================================================================
 //   The split pair for sequences that do NOT fit LDS (SigLIP towers at 384 px: 576 tokens;
 //   the sequential fusion: 642 - 2 950 tokens): same two kernels, the resident operand streamed
 // =====================================================================================
@@ -2774,6 +3295,32 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
                              nq32 < stream_min_env;
         // d = 32 without a mask, 3 - 9 blocks (the 275-token fusion of config A): the one-pass kernel
         if (half && head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 >= 3 && nq32 <= 9 && bf_tuning().attn_bwd_fused) {
+            // the persistent form (one twelve-wave workgroup per CU walking items) when there are items to walk:
+            // BIFOLD_ATTN_BWD_FUSED_P = 1: from two items per CU; 2: always; 0: never
+            int n_cu = 0, dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+            const int fp_env = bf_tuning().attn_bwd_fused_p;
+            if (nq32 == Fused32P::NKW && (fp_env == 2 || (fp_env == 1 && batch * heads >= 2 * n_cu))) {
+                const size_t lds_p = Fused32P::lds_bytes(nq32);
+                const int grid_p = batch * heads < n_cu ? batch * heads : n_cu;
+#define BWD_FUSED_P(HT)                                                                                  \
+    do {                                                                                                 \
+        static BfPerDevice set_p_dev; size_t& set_p = set_p_dev.cur();                                   \
+        if (lds_p > set_p) {                                                                             \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_fused32p_kernel<HT>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);           \
+            set_p = lds_p;                                                                               \
+        }                                                                                                \
+        hipLaunchKernelGGL((attn_bwd_fused32p_kernel<HT>), dim3(grid_p), dim3(Fused32P::NWAVES * 64), lds_p, s, \
+                           (const HT*)qkv, (const HT*)out, (const HT*)dout, lse, (HT*)dqkv, seq, heads, scale, \
+                           batch * heads);                                                               \
+    } while (0)
+                if (f16) BWD_FUSED_P(f16_t); else BWD_FUSED_P(bf16_t);
+#undef BWD_FUSED_P
+                BF_CHECK_LAUNCH("bf_attention_bwd");
+                return BF_OK;
+            }
             const size_t lds_f = Fused32::lds_bytes(nq32) + lds_pad;
             dim3 grid(batch * heads), block(256);
 #define BWD_FUSED(HT)                                                                                    \

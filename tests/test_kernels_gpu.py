@@ -529,6 +529,53 @@ def test_attention_bwd_one_pass_kernel_over_ragged_lengths(ops, gpu, half, B, Lq
     assert torch.equal(again, dqkv)                         # partial dQ blocks are summed in wave order: bit-reproducible
 
 
+FUSED_P_SCRIPT = """
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from bifold_amd.hip import ops
+gpu = torch.device("cuda:0")
+D = 32
+def ref(qkv, dout, B, Lq, H):
+    leaf = qkv.double().requires_grad_(True)
+    q, k, v = leaf.reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B * Lq, H * D)
+    o.backward(dout.double())
+    return leaf.grad
+for half in (torch.bfloat16, torch.float16):
+    for B, Lq, H in ((2, 65, 2), (3, 96, 4), (5, 197, 3), (2, 257, 2), (75, 275, 16), (2, 288, 4), (130, 100, 8)):
+        g = torch.Generator(device=gpu).manual_seed(Lq * 7 + H)
+        qkv = (torch.randn(B * Lq, 3 * H * D, device=gpu, generator=g) * 1.5).to(half)
+        dout = torch.randn(B * Lq, H * D, device=gpu, generator=g).to(half)
+        want = ref(qkv, dout, B, Lq, H).float().view(B, Lq, 3, H, D)
+        out, lse = ops.attention_fwd(qkv, B, Lq, H, D, D ** -0.5, 0, None, need_lse=True)
+        dqkv = ops.attention_bwd(qkv, out, dout, lse, B, Lq, H, D, D ** -0.5, 0, None)
+        got = dqkv.float().view(B, Lq, 3, H, D)
+        for which, name in enumerate(("dQ", "dK", "dV")):
+            err = ((got[:, :, which] - want[:, :, which]).abs().max() / want[:, :, which].abs().max()).item()
+            assert err < 2e-2, (half, B, Lq, H, name, err)
+        again = ops.attention_bwd(qkv, out, dout, lse, B, Lq, H, D, D ** -0.5, 0, None)
+        assert torch.equal(again, dqkv), (half, B, Lq, H)
+print("FUSED-P-OK")
+"""
+
+
+def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path):
+    """attn_bwd_fused32p_kernel (round 5: one twelve-wave workgroup per CU walking (batch, head) items; the default from two
+    items per CU, forced here with BIFOLD_ATTN_BWD_FUSED_P=2, hence the child process): sequences of 3 - 9 key blocks (idle
+    key waves below 9), a last block of 1 - 32 live keys, fewer items than CUs, and 1 200 items so that every workgroup walks
+    four or five of them through the rolling refill of its images -- against the fp64 formula, twice (bit-reproducible)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "fp.py"
+    script.write_text(FUSED_P_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, BIFOLD_ATTN_BWD_FUSED_P="2"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FUSED-P-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("B,Lq,H,D,spans", [(2, 600, 2, 48, [(64, 256)]), (1, 1290, 1, 64, [(0, 33), (577, 1154)]),
                                             (2, 700, 1, 32, [(100, 420), (650, 700)])])
 def test_attention_bwd_with_whole_masked_segments(ops, gpu, B, Lq, H, D, spans):
