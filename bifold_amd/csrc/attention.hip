@@ -362,6 +362,9 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
     const int q_hi = min(L, (int)(blockIdx.y + 1) * waves_per_block * 32);
     const int key_end = (mask_mode == BF_MASK_CAUSAL) ? q_hi : L;
 
+    // (Round 5: the next tile's K / V rows requested into registers under the current tile's MFMAs -- built, measured, removed:
+    // 16 more registers take the kernel from two eight-wave workgroups per CU to one, and the second workgroup was what hid the
+    // loads: 2 373 x 48 masked 604 -> 773 - 800 us, 576 x 64 177 -> 207 us, profiles/r05_attention_forward_diet.txt.)
     for (int j0 = 0; j0 < key_end; j0 += KT) {
         __syncthreads();
         // ---- stage K (row-major) and V (transposed, permuted) -------------------------
