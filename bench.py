@@ -226,6 +226,21 @@ def parity_vs_oracle(model, sample, n: int = 4, kind: str = "a"):
                        "per head over the checked samples; logits recovered from the heatmaps in fp64"}
 
 
+def train_step(model, loss_fn, opt, sync, sample):
+    """One optimisation step of the benchmark -- the loop body of Trainer.train_epoch (ref:bifold/__main__.py:129-152) plus
+    the data-parallel join: forward, loss, zero_grad, backward (whose hooks hand gradient buckets to `sync` as the
+    layers complete), wait for the last bucket, optimiser step.  A function of its own so that the world-2 gloo test
+    (tests/test_dist_cpu.py) drives exactly this sequence."""
+    out = model(sample)
+    loss, _ = loss_fn(out, sample)
+    opt.zero_grad()
+    loss.backward()
+    if sync is not None:
+        sync.finish()
+    opt.step()
+    return loss
+
+
 def self_launch(args_list, gpus: int) -> int:
     """`python bench.py --gpus N` outside torchrun: start the N ranks as a child `torch.distributed.run`, relay what
     they print, return their exit status.  Called before this process has made any GPU call (a process that has
@@ -275,6 +290,10 @@ def main():
                          "context frames (diagnostic line, run with --batch 128; --lora trains the adapters)")
     ap.add_argument("--lora", action="store_true", help="siglip_seq: LoRA adapters on q/v of both towers (the "
                                                          "reference's default) instead of frozen towers")
+    ap.add_argument("--lora-dropout", type=float, default=0.01,
+                    help="siglip_seq --lora: PEFT's lora_dropout.  Default = the reference's shipped value "
+                         "(ref:bifold/conf/model/siglip_sequential.yaml, models/siglip.py:33-40): the UNMERGED path -- dropout "
+                         "kernels on the adapters' inputs and rank-r side GEMMs; 0 = adapters merged into the weights")
     ap.add_argument("--lora-recompute", default="none", choices=["none", "mlp", "full"],
                     help="siglip_seq --lora: what the towers' backward re-makes instead of keeping (none 198 samples/s at "
                          "181 GiB, mlp 190 at 147 GiB, full 179 at 109 GiB; B = 128)")
@@ -318,7 +337,7 @@ def main():
         if seq:
             cfg = dict(name="siglip_sequential", image_size=384, is_bimanual=True, requires_graph=False, patch_size=16,
                        automodel_name="google/siglip-base-patch16-384", dim=768, emb_dropout=0.0, lora=args.lora, r=8,
-                       lora_alpha=32, lora_dropout=0.0, target_modules=["q_proj", "v_proj"], threshold=0.5,
+                       lora_alpha=32, lora_dropout=(args.lora_dropout if args.lora else 0.0), target_modules=["q_proj", "v_proj"], threshold=0.5,
                        text_encoder=None, pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer",
                        depth=8, heads=16, mlp_ratio=4, dropout=0.0, dtype=dtype, context_length=4,
                        lora_recompute=args.lora_recompute)
@@ -352,7 +371,7 @@ def main():
                 return {k: v.to(dev, non_blocking=True) for k, v in host.items()}
         staged = stage_next()
 
-    def step():
+    def next_sample():
         nonlocal staged, sample
         if args.host_fed:                          # consume the staged batch, start copying the next one
             torch.cuda.current_stream().wait_stream(copy_stream)
@@ -360,14 +379,10 @@ def main():
             for v in sample.values():
                 v.record_stream(torch.cuda.current_stream())
             staged = stage_next()
-        out = model(sample)
-        loss, _ = loss_fn(out, sample)
-        opt.zero_grad()
-        loss.backward()
-        if sync is not None:
-            sync.finish()
-        opt.step()
-        return loss
+        return sample
+
+    def step():
+        return train_step(model, loss_fn, opt, sync, next_sample())
 
     def fence():
         torch.cuda.synchronize()
@@ -400,6 +415,9 @@ def main():
     in_step = timer is not None and (args.per_shape or args.all_kernels or args.timer_stride > 0)
     stride = 1 if (args.per_shape or args.all_kernels) else max(1, args.timer_stride)
     timed_steps = 0
+    if sync is not None:
+        sync.reset_stats()
+        sync.measure = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         if in_step:
@@ -410,6 +428,12 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
+    comm = None
+    if sync is not None:
+        sync.measure = False
+        comm = sync.comm_report()                  # (after the fence: the event pairs are complete)
+        comm["reserved_cus"] = int(os.environ.get("BIFOLD_P8_RESERVE_CUS", "0") or 0)
+        comm["p8_grid_cap"] = int(os.environ.get("BIFOLD_P8_GRID", "0") or 0)
     final_loss = float(loss.item())
     if not (final_loss == final_loss and abs(final_loss) < 1e6):
         raise SystemExit(f"training diverged in the bench: loss = {final_loss}")
@@ -477,9 +501,11 @@ def main():
                        "at random initialisation (operand rounding 2^-9 against fp16's 2^-11)"}
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, (comm or {}).get("exposed_ms_per_step") or 0.0], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if comm is not None:
+            comm["exposed_ms_per_step_max_over_ranks"] = round(float(t[1].item()), 4)
 
     if rank == 0:
         global_batch = args.batch * world
@@ -498,7 +524,9 @@ def main():
             "data": "synthetic (pinned host memory, H2D copy every step)" if args.host_fed else "synthetic",
             "config": {"workload": ("BASELINE configs[2] (diagnostic): siglip_sequential, SigLIP-base/16 @384 (576 patches), "
                                     "4 context frames with a random valid prefix, fusion 8x768 over 2 950 tokens, 4 "
-                                    "decoders; " + ("LoRA r=8 on q/v of both towers" if args.lora else "frozen towers")
+                                    "decoders; " + (f"LoRA r=8 on q/v of both towers, lora_dropout {args.lora_dropout:g} "
+                                                    f"({'merged weights' if args.lora_dropout == 0 else 'unmerged adapters'})"
+                                                    if args.lora else "frozen towers")
                                     if seq else
                                     "BASELINE configs[3] (diagnostic): rgb_clip ViT-L/14@336 (577 tokens, 24 layers, "
                                     "width 1024) + CLIP text + fusion 8x768 (16 heads), 384-px heatmaps"
@@ -518,6 +546,8 @@ def main():
                               "unit": "TFLOP/s", "frac": round(step_tflops / world / PEAK_BF16_TFLOPS, 4),
                               "flops_per_sample": gf * 1e9},
         }
+        if comm is not None:
+            line["comm"] = comm
         if timer is not None:
             summ = timer.summary()
             dom = dom_label

@@ -61,6 +61,7 @@ class SyntheticLoader:
         # fault injection for the fp16 guard's tests (global step indices, counted over epochs): a poisoned batch carries
         # one +inf target pixel -> a non-finite loss gradient -> the step must be dropped on the device; a skipped batch
         # is generated (the random stream advances) but not served -- the clean run the poisoned one must equal.
+        # fault injection for the fp16 guard's tests: keys that only exist when a test adds them (`+train_dataset.poison_steps=[4]`)
         self.poison_steps = {int(x) for x in (dataset_cfg.get("poison_steps", None) or [])}
         self.skip_steps = {int(x) for x in (dataset_cfg.get("skip_steps", None) or [])}
         self.served = 0
@@ -116,15 +117,22 @@ def shard_dataloader(dl, rank: int, world: int, seed: int):
 class _TrackedPixelError:
     """What `best.pth` selection needs when the reference's `bifold.metrics` package (host-side numpy / torchmetrics /
     scipy: out of this build's scope) is not importable: ONE number per evaluation, the mean distance in pixels
-    between the predicted and the annotated pixel over the heads, lower is better, reported under the configured
-    `tracked_metric` name.  It has the call surface `eval_epoch_pixel` uses (`reset`, call, `summary`, `best_eval`);
-    it is not the reference's metric suite -- put the reference checkout behind this build for that."""
+    between the predicted and the annotated pixel over the heads, lower is better.  It is reported under ITS OWN key,
+    `mean_pixel_error` -- never under the configured `tracked_metric` name (`kp_mse` by default): it is not the
+    reference's KeypointMSE (different normalisation), and `eval_<dataset>.yaml` must not carry a number under a name
+    whose definition it does not follow (advisor finding, round 4).  The configured name is only remembered so that the
+    notice can say what was asked for.  Call surface of `eval_epoch_pixel`: `reset`, call, `summary`, `best_eval`; for
+    the reference's metric suite put the reference checkout behind this build."""
+
+    KEY = "mean_pixel_error"
 
     def __init__(self, cfg):
-        self.name = str(cfg["tracked_metric"] if isinstance(cfg, dict) else cfg.tracked_metric)
+        self.asked_for = str(cfg["tracked_metric"] if isinstance(cfg, dict) else cfg.tracked_metric)
+        self.name = self.KEY
         self.best_eval: Optional[float] = None
         self.total, self.count = 0.0, 0
-        print(f"bifold.metrics is not on the path: tracking the mean pixel error as {self.name!r} for best.pth only")
+        print(f"bifold.metrics is not on the path: best.pth follows {self.KEY!r} (lower is better) instead of the "
+              f"configured {self.asked_for!r}; results are written under {self.KEY!r}, none under {self.asked_for!r}")
 
     def reset(self):
         self.total, self.count = 0.0, 0
@@ -294,7 +302,7 @@ class Trainer:
                 dl.set_epoch(epoch)
             elif hasattr(getattr(dl, "sampler", None), "set_epoch"):
                 dl.sampler.set_epoch(epoch)
-        total, t0 = None, time.time()
+        total, counted, t0 = None, None, time.time()
         for i, sample in enumerate(dl):
             sample = self.move_sample_to_device(sample)
             output = self.model(sample)
@@ -315,10 +323,19 @@ class Trainer:
                 self._log_step(epoch, loss, intermediate_losses)
             # the reference calls loss.item() every step (a device sync); keep a device-side running sum
             # instead and read it once per epoch
-            total = loss.detach() if total is None else total + loss.detach()
+            # A non-finite loss (fp16 mode: the batch whose step the device-side guard drops) must not turn the epoch's
+            # mean into inf / NaN while the training state is intact: it is left out of the sum and of the count, on the
+            # device (advisor finding, round 4).  The scheduler still advances on a dropped step, like
+            # torch.cuda.amp.GradScaler users' schedulers do unless they check the scale: the LR trace is a function of
+            # the step index, not of how many steps were applied.
+            lv = loss.detach().float()
+            fin = torch.isfinite(lv)
+            lv = torch.where(fin, lv, torch.zeros_like(lv))
+            total = lv if total is None else total + lv
+            counted = fin.float() if counted is None else counted + fin.float()
         n = len(dl)
         if self.rank == 0:
-            mean = float(total.item()) / n
+            mean = float(total.item()) / max(float(counted.item()), 1.0)
             dt = time.time() - t0
             print(f"epoch {epoch}: mean loss {mean:.6f}  {n * self.cfg.batch_size * self.world / dt:.1f} samples/s "
                   f"lr {self.optimizer.param_groups[0]['lr']:.3e}")

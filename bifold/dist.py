@@ -41,7 +41,24 @@ def init_process_group_from_env(device_backend: Optional[str] = None) -> Tuple[i
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if world > 1 or force:
+        reserve_cus_for_collectives(local_rank)
     return rank, local_rank, world
+
+
+def reserve_cus_for_collectives(local_rank: int = 0) -> Optional[int]:
+    """`BIFOLD_P8_RESERVE_CUS=k`: with a process group alive, the persistent GEMMs run one workgroup on each of (CUs - k) CUs
+    instead of all of them, so that RCCL's reduction kernels find k CUs that no resident GEMM holds (a persistent GEMM
+    takes a whole CU: 225 registers x 2 waves per SIMD and 128 KB of LDS; without the knob the collective's
+    workgroups are time-sliced into GEMM boundaries like any other kernel).  Implemented through the library's own grid cap
+    (`BIFOLD_P8_GRID`, read once at first use): must run before the first GEMM.  Returns the cap it set, or None."""
+    k = int(os.environ.get("BIFOLD_P8_RESERVE_CUS", "0") or 0)
+    if k <= 0 or "BIFOLD_P8_GRID" in os.environ or not torch.cuda.is_available():
+        return None
+    n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    cap = max(8, n_cu - k)
+    os.environ["BIFOLD_P8_GRID"] = str(cap)
+    return cap
 
 
 def layer_buckets(names: List[str], offsets, depth: int, count: int) -> List[Tuple[int, int]]:
@@ -132,6 +149,11 @@ class GradSync:
         self.side = torch.cuda.Stream(device=flat_grad.device) if self.on_gpu else None
         self.pending: List = []
         self.flag_getter = None          # () -> int32 [1] tensor MAX-reduced with the final bucket, or None
+        # read-out for bench.py (`measure = True`): collectives and bytes launched, and the time the COMPUTE stream spends
+        # waiting in finish() -- an event pair around the waits, read after the run (no sync inside the step)
+        self.measure = False
+        self.stats = {"launches": 0, "bytes": 0, "steps": 0}
+        self._wait_events: List = []
         if coalesce is None:
             coalesce = int(os.environ.get("BIFOLD_DDP_COALESCE", "4"))
         self.coalesce = max(1, coalesce)
@@ -176,6 +198,8 @@ class GradSync:
             return
         for a, b in spans:
             view = self.grad[a:b]
+            self.stats["launches"] += 1
+            self.stats["bytes"] += (b - a) * view.element_size()
             if self.on_gpu and self.avg_native:
                 ready = torch.cuda.Event()
                 ready.record(torch.cuda.current_stream())
@@ -220,6 +244,30 @@ class GradSync:
 
     def finish(self) -> None:
         """Make the compute stream wait for every outstanding bucket."""
+        timed = self.measure and self.on_gpu and bool(self.pending)
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         for w in self.pending:
             w.wait()
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            self._wait_events.append((e0, e1))
+        self.stats["steps"] += 1
         self.pending.clear()
+
+    def reset_stats(self) -> None:
+        self.stats = {"launches": 0, "bytes": 0, "steps": 0}
+        self._wait_events.clear()
+
+    def comm_report(self) -> dict:
+        """After a synchronize: what the run launched per step and how long the compute stream stood in finish() per step
+        (the part of the communication that was NOT hidden under the backward)."""
+        steps = max(1, self.stats["steps"])
+        exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) if self._wait_events else None
+        return {"exposed_ms_per_step": None if exposed is None else round(exposed / steps, 4),
+                "buckets": round(self.stats["launches"] / steps, 2), "bytes": int(self.stats["bytes"] / steps),
+                "steps": steps,
+                "note": "exposed = time the compute stream waits in GradSync.finish() for the side stream's collectives "
+                        "(HIP events around the waits); buckets / bytes = all-reduce launches and gradient bytes per step"}

@@ -97,9 +97,18 @@ class DynamicGradScale:
     # ------------------------------------------------------------------ the backward's two ends
     def begin(self, d_heats) -> torch.Tensor:
         """Called at the top of the tail's backward; returns S as a device scalar."""
-        self._plan()
+        arena = self._plan()
         if self.state is None:
-            self._init_state(d_heats)
+            # a checkpoint loaded before the scaler existed left its scale on the arena (FusedAdam.load_state_dict): the
+            # FIRST resumed backward must already run at the saved scale -- applied only inside the first step(), the
+            # backward ran at the default start scale, and a run that had backed off dropped that step and halved the
+            # restored scale again (advisor finding, round 4)
+            pending = getattr(arena, "pending_grad_scaler_sd", None)
+            if pending is not None:
+                self.load_state_dict(pending)
+                arena.pending_grad_scaler_sd = None
+            else:
+                self._init_state(d_heats)
         return self.state[_S:_S + 1]
 
     def ready(self, layer: int) -> None:

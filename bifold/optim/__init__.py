@@ -82,7 +82,9 @@ class FusedAdam:
         # Adam's t: `step_count` counts calls, the device counts drops, the kernel takes the difference.
         gs = getattr(self.arena, "grad_scaler", None)
         if gs is not None and gs.state is not None and self._scaler_sd is not None:
-            gs.load_state_dict(self._scaler_sd)            # a checkpoint loaded before the scaler existed
+            if getattr(self.arena, "pending_grad_scaler_sd", None) is not None:
+                gs.load_state_dict(self._scaler_sd)        # (a scaler whose state was built without passing begin())
+                self.arena.pending_grad_scaler_sd = None
             self._scaler_sd = None
         flag, skipped, known = gs.guard() if gs is not None and gs.state is not None else (None, None, 0.0)
         ops.adam_step(self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.arena.shadow,
@@ -135,6 +137,9 @@ class FusedAdam:
         self.step_count = steps.pop() if steps else 0
         gs = getattr(self.arena, "grad_scaler", None)
         self._scaler_sd = sd.get("bifold_grad_scaler")
+        # (no scaler yet: it is built by the first backward, which takes the saved scale from the arena BEFORE it runs --
+        # DynamicGradScale.begin; the copy kept here only covers a scaler that exists without a state)
+        self.arena.pending_grad_scaler_sd = self._scaler_sd if (gs is None or gs.state is None) else None
         if gs is not None and gs.state is not None:
             if self._scaler_sd is not None:
                 gs.load_state_dict(self._scaler_sd)

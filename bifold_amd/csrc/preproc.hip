@@ -202,7 +202,8 @@ __device__ __forceinline__ float depth_unkey(unsigned k) {
 // mostly exact zeros, so the cuts usually sit inside a run of ties).  Sums in fp64, so the result does not depend on
 // the summation order.
 #define DEPTH_WG 1024
-__global__ __launch_bounds__(DEPTH_WG) void depth_standardize_kernel(const float* __restrict__ x, float* __restrict__ y,
+// (x and y carry no __restrict__: the header documents in-place use, x == y, which is what bifold_amd/hip/ops.py does)
+__global__ __launch_bounds__(DEPTH_WG) void depth_standardize_kernel(const float* x, float* y,
                                                                      float* __restrict__ stats, int n, int lo, int hi) {
     __shared__ unsigned hist[2][256];
     __shared__ unsigned sel_prefix[2], sel_rank[2];

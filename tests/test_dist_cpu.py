@@ -201,6 +201,131 @@ def test_overflow_flag_reaches_every_rank_world2_gloo():
     assert dict(out) == {0: True, 1: True}
 
 
+class _HostModel(torch.nn.Module):
+    """A host stand-in with the data-parallel contract of the real models (bifold/models/__init__.py: `trainable_params`,
+    `trainable_arena`, `register_grad_ready_hook` / `_grad_ready`): a stack of `depth` residual MLP layers named like the
+    fusion transformer's, a decoder behind them and a projection in front; parameters AND gradients are views of flat
+    arenas, and the backward reports layers depth-1 ... 0, then -1, from autograd's post-accumulate hooks -- the order
+    the fused backward reports them in."""
+
+    def __init__(self, depth=3, width=16):
+        super().__init__()
+        g = torch.Generator().manual_seed(3407)
+        shapes = [("project.weight", (width, 8))]
+        for i in range(depth):
+            shapes += [(f"pick_place.fusion.transformer_encoder.layers.{i}.0.w", (width, width)),
+                       (f"pick_place.fusion.transformer_encoder.layers.{i}.1.w", (width, width))]
+        shapes += [("pick_place.pick_decoder.decoder_net.0.weight", (1, width))]
+        self.depth = depth
+        self.offsets, off = {}, 0
+        for n, shp in shapes:
+            cnt = int(torch.tensor(shp).prod())
+            self.offsets[n] = (off, cnt)
+            off += (cnt + 63) // 64 * 64
+        self.count = off
+        self.flat = torch.zeros(off)
+        self.grad = torch.zeros(off)
+        self._named, self._by_id = [], {}
+        for n, shp in shapes:
+            o, cnt = self.offsets[n]
+            p = torch.nn.Parameter(self.flat[o:o + cnt].view(shp))
+            with torch.no_grad():
+                p.copy_(torch.randn(shp, generator=g) * 0.3)
+            p.grad = self.grad[o:o + cnt].view(shp)             # .grad is a view of the arena, as in models/arena.py
+            self._named.append((n, p))
+            self._by_id[id(p)] = n
+            self.register_parameter(n.replace(".", "_"), p)
+        self._grad_hooks = []
+        self._left = {}
+        for n, p in self._named:
+            p.register_post_accumulate_grad_hook(lambda q, n=n: self._param_done(n))
+        import types
+        self.pick_place = types.SimpleNamespace(fusion=types.SimpleNamespace(depth=depth))   # (what gradient_sync_for reads)
+
+    # --- the contract dist.gradient_sync_for uses
+    def trainable_params(self):
+        return list(self._named)
+
+    def trainable_arena(self):
+        return self
+
+    def name_of(self, p):
+        return self._by_id[id(p)]
+
+    def register_grad_ready_hook(self, fn):
+        self._grad_hooks.append(fn)
+
+    def _grad_ready(self, layer):
+        for fn in self._grad_hooks:
+            fn(layer)
+
+    def _param_done(self, name):
+        marker = "transformer_encoder.layers."
+        if marker in name:
+            i = int(name.split(marker)[1].split(".")[0])
+            self._left[i] = self._left.get(i, 2) - 1
+            if self._left[i] == 0:
+                self._left[i] = 2
+                self._grad_ready(i)
+        elif name == "project.weight":                          # the input side is the last thing the backward reaches
+            self._grad_ready(-1)
+
+    def forward(self, sample):
+        p = dict(self._named)
+        x = sample["x"] @ p["project.weight"].t()
+        for i in range(self.depth):
+            pre = f"pick_place.fusion.transformer_encoder.layers.{i}."
+            x = x + torch.tanh(x @ p[pre + "0.w"].t()) @ p[pre + "1.w"].t()
+        return {"pick_heatmap": torch.sigmoid(x @ p["pick_place.pick_decoder.decoder_net.0.weight"].t())}
+
+
+def _bench_loop_worker(rank, world, port, out):
+    """bench.py's OWN step (bench.train_step: forward, loss, zero_grad, backward with the bucket hooks, finish, optimiser
+    step) under world-2 gloo: each rank sees different data, so only the averaged gradients can keep the replicas equal."""
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from bifold import dist as bdist
+    bdist.init_process_group_from_env("gloo")
+    model = _HostModel()
+    start = model.flat.clone()
+    sync = bdist.gradient_sync_for(model)
+    sync.measure = True
+    opt = torch.optim.Adam([p for _, p in model.trainable_params()], lr=1e-2)
+    # (torch's Adam with set_to_none=False keeps .grad the arena view; zero_grad() then zeroes the arena in place)
+    opt_zero = opt.zero_grad
+    opt.zero_grad = lambda: opt_zero(set_to_none=False)
+    g = torch.Generator().manual_seed(100 + rank)               # per-rank data, as bench.py seeds its batches
+    loss_fn = lambda o, s: (torch.nn.functional.binary_cross_entropy(o["pick_heatmap"], s["t"]), {})
+    losses = []
+    for _ in range(3):
+        sample = {"x": torch.randn(32, 8, generator=g), "t": torch.rand(32, 1, generator=g)}
+        losses.append(float(bench.train_step(model, loss_fn, opt, sync, sample)))
+    rep = sync.comm_report()
+    gathered = [torch.zeros_like(model.flat) for _ in range(world)]
+    dist.all_gather(gathered, model.flat)
+    same = all(torch.equal(gathered[0], t) for t in gathered[1:])
+    moved = float((model.flat - start).abs().max()) > 1e-3
+    lg = [None] * world
+    dist.all_gather_object(lg, losses)
+    differ = lg[0] != lg[1]                                     # the ranks really saw different batches
+    out[rank] = bool(same and moved and differ and rep["steps"] == 3 and rep["buckets"] >= 1 and rep["bytes"] > 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_loop_keeps_replicas_identical_world2_gloo():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bench_loop_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
 def test_bench_self_launches_its_ranks(tmp_path):
     """`python bench.py --gpus 2` with no torchrun environment must start its two ranks itself (the driver's
     command).  Without a GPU each rank stops at "needs an MI355X" -- AFTER it has joined the 2-rank rendezvous the

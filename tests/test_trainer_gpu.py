@@ -140,18 +140,18 @@ def test_trainer_default_fp16_mode_trains_and_survives_overflow(gpu, run_home, c
 
 
 def test_fp16_run_with_one_poisoned_batch_equals_the_clean_run_minus_that_step(gpu, run_home, capsys):
-    """One batch of a fp16 training run carries an inf target pixel (`train_dataset.poison_steps`): its backward is
+    """One batch of a fp16 training run carries an inf target pixel (`+train_dataset.poison_steps`: a test-only key, not in the shipped config): its backward is
     non-finite, the device-side guard drops exactly that optimiser step and halves the loss scale, and the run ends
     with finite parameters equal to those of the run that never saw the batch (`train_dataset.skip_steps`) -- same
     weights, same Adam moments, same step count.  No host read happens inside the epoch."""
     base = [o for o in OVERRIDES if not o.startswith(("model.dtype=", "epochs=", "gradient_clip=", "scheduler=",
                                                       "eval_epochs=", "save_epochs="))] + \
            ["epochs=1", "scheduler=none", "eval_epochs=null", "save_epochs=null", "train_dataset.length=96"]
-    tp, _ = _trainer(base + ["train_dataset.poison_steps=[4]"])
+    tp, _ = _trainer(base + ["+train_dataset.poison_steps=[4]"])
     tp.prepare_train()
     tp.train_epoch(0)
     os.chdir(str(run_home))
-    tc, _ = _trainer(base + ["train_dataset.skip_steps=[4]"])
+    tc, _ = _trainer(base + ["+train_dataset.skip_steps=[4]"])
     tc.prepare_train()
     tc.train_epoch(0)
     sp, sc = tp.model._grad_scaler.read(), tc.model._grad_scaler.read()

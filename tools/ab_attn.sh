@@ -8,7 +8,7 @@ for rep in 1 2; do
   done
 done
 [ "$1" = "step" ] || exit 0
-B="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-kernel-timer"
+B="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt"
 for rep in 1 2 3; do
   for v in old new; do
     lib=$PWD/bifold_amd/lib/libbifold_hip.so; [ $v = old ] && lib=$PWD/bifold_amd/lib/libbifold_hip_old.so

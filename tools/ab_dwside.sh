@@ -3,7 +3,7 @@
 set -o pipefail
 out=gpurun_out/ab_dw
 mkdir -p $out
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-kernel-timer"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt"
 for rep in 1 2; do
   for m in 0 1 2; do
     BIFOLD_DW_SIDE=$m timeout -k 10 200 $B > $out/b_${m}_$rep.json 2> $out/b_${m}_$rep.err || { echo "mode $m failed"; tail -5 $out/b_${m}_$rep.err; exit 1; }

@@ -3,7 +3,7 @@
 set -o pipefail
 out=gpurun_out/ab_env
 mkdir -p $out
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-kernel-timer"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt"
 for rep in $(seq 1 ${REPS:-2}); do
   i=0
   for kv in "$@"; do

@@ -3,7 +3,7 @@
 set -o pipefail
 out=gpurun_out/ab_lib
 mkdir -p $out
-B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-kernel-timer"
+B="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt"
 reps=${3:-2}
 for rep in $(seq 1 $reps); do
   for v in "$1" "$2"; do

@@ -20,5 +20,5 @@ filt() { grep -v amdgpu.ids; }
 { echo "# tools/micro/write_bw: streaming 1 GiB, 16 B per lane"; timeout -k 5 100 tools/micro/write_bw; } > $out/hbm_stream_bw.txt || exit 1
 tools/trace_run.sh $tag > /dev/null || exit 1
 cp gpurun_out/trace_$tag/timeline.txt $out/step_timeline.txt
-python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-parity --per-shape 2>&1 | filt > $out/per_shape_in_step.txt || exit 1
+python3 bench.py --no-alt --steps 6 --warmup 3 --no-cpu-baseline --no-parity --per-shape 2>&1 | filt > $out/per_shape_in_step.txt || exit 1
 ls -la $out

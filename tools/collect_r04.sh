@@ -27,13 +27,13 @@ tools/micro/epi_rate > $out/epi_rate.txt 2>&1
 step "write-heavy epilogues with / without start skew"
 { for s in "" "4,80"; do BIFOLD_P8_SKEW=$s timeout -k 5 100 python3 tools/p8_res_bench.py 2>&1 | grep sum; done; } > $out/p8_skew.txt
 step "bench lines: default (with cpu baseline + alt), bf16, vitl14, siglip_seq frozen / lora, fp8"
-timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $out/bench_line_bf16.json 2> /dev/null
-timeout -k 10 400 python3 bench.py --config vitl14 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_line_vitl14.json 2> /dev/null
+timeout -k 10 400 python3 bench.py --no-alt --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
+timeout -k 10 300 python3 bench.py --no-alt --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $out/bench_line_bf16.json 2> /dev/null
+timeout -k 10 400 python3 bench.py --no-alt --config vitl14 --batch 64 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_line_vitl14.json 2> /dev/null
 step "  siglip_seq"
-timeout -k 10 500 python3 bench.py --config siglip_seq --batch 128 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_line_siglip_seq_frozen.json 2> /dev/null
-timeout -k 10 500 python3 bench.py --config siglip_seq --lora --batch 128 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_line_siglip_seq_lora.json 2> /dev/null
-timeout -k 10 300 python3 bench.py --config fp8 --batch 512 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_line_fp8.json 2> /dev/null
+timeout -k 10 500 python3 bench.py --no-alt --config siglip_seq --batch 128 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_line_siglip_seq_frozen.json 2> /dev/null
+timeout -k 10 500 python3 bench.py --no-alt --config siglip_seq --lora --batch 128 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_line_siglip_seq_lora.json 2> /dev/null
+timeout -k 10 300 python3 bench.py --no-alt --config fp8 --batch 512 --steps 10 --warmup 3 --no-cpu-baseline > $out/bench_line_fp8.json 2> /dev/null
 step "LoRA recompute policies (five runs in one process each)"
 timeout -k 10 600 python3 tools/lora_recompute_bench.py none mlp full 2>&1 | grep lora_recompute > $out/lora_recompute.txt
 step "step timeline"

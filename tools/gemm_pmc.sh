@@ -2,7 +2,7 @@
 # instruction counts of the step's kernels (one PMC pass over the bench command): vector / matrix / scalar / LDS / VMEM
 export TMPDIR=/tmp
 out=gpurun_out/gemm_pmc; mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_WAVES -d $out/p1 -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-kernel-timer > $out/p1.log 2>&1 || { echo "pass failed"; tail -3 $out/p1.log; }
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_WAVES -d $out/p1 -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity --no-kernel-timer --no-alt > $out/p1.log 2>&1 || { echo "pass failed"; tail -3 $out/p1.log; }
 python3 - <<'PY'
 import csv, glob, collections, re
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
