@@ -492,10 +492,14 @@ def main():
             aloss = step()
         fence()
         alt_elapsed = time.perf_counter() - ta
+        alt_trained = None
+        if check_parity:       # bf16 misses the logit gate at random init (operand rounding against |logit| <= 0.17) and
+            alt_trained = parity_vs_oracle(model, sample)          # meets it once the logits have grown: show both
+            alt_trained["after_steps"] = opt.step_count
         alt = {"dtype": "bf16", "value": round(args.batch * 10 / alt_elapsed, 2), "unit": "samples/s",
                "ms_per_step": round(1e2 * alt_elapsed, 3), "steps": 10, "warmup": 3,
                "step_roofline_frac": round(args.batch * 10 / alt_elapsed * GF_PER_SAMPLE / 1e3 / PEAK_BF16_TFLOPS, 4),
-               "final_loss": float(aloss.item()), "parity": alt_parity,
+               "final_loss": float(aloss.item()), "parity": alt_parity, "parity_trained": alt_trained,
                "note": "BASELINE configs[1]'s own label; same step, same initial weights and batch; run after the "
                        "headline's timed region.  Not the headline because its logits miss north_star's 1e-3 gate "
                        "at random initialisation (operand rounding 2^-9 against fp16's 2^-11)"}

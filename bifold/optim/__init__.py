@@ -12,6 +12,8 @@ from __future__ import annotations
 import math
 from typing import Dict, Iterable, List, Optional
 
+import os
+
 import torch
 
 from bifold_amd.hip import ops
@@ -188,9 +190,22 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
 
 
 clip_grad_norm_._bifold_original = _torch_clip_grad_norm_
-torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
-if getattr(torch.nn.utils, "clip_grad", None) is not None:
-    torch.nn.utils.clip_grad.clip_grad_norm_ = clip_grad_norm_
+
+
+def wrap_torch_clip_grad_norm(enable: bool = True) -> None:
+    """Install (or remove) the arena-aware `clip_grad_norm_` as `torch.nn.utils.clip_grad_norm_`.  The wrap is process-wide
+    state a host application may not expect from an import; it exists so that the reference trainer's clipping line runs
+    unedited.  Opt out with `BIFOLD_NO_CLIP_WRAP=1` in the environment, or call `wrap_torch_clip_grad_norm(False)` at any
+    time: torch's own function is put back, and `bifold.optim.clip_grad_norm_(params, c)` / `optimizer.clip_grad_norm_(c)`
+    remain available as explicit calls."""
+    fn = clip_grad_norm_ if enable else _torch_clip_grad_norm_
+    torch.nn.utils.clip_grad_norm_ = fn
+    if getattr(torch.nn.utils, "clip_grad", None) is not None:
+        torch.nn.utils.clip_grad.clip_grad_norm_ = fn
+
+
+if os.environ.get("BIFOLD_NO_CLIP_WRAP") != "1":
+    wrap_torch_clip_grad_norm(True)
 
 
 class Optimizers:
