@@ -3076,6 +3076,529 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
     }
 }
 
+// =====================================================================================
+//   One-pass backward for sequences beyond LDS and for d = 48 / 64 (round 5): S, dP and the exponentials ONCE
+// =====================================================================================
+// The streamed pair above computes S, dP and P twice (d = 48: 24 MFMAs and 32 exponentials per 32 x 32 block) because a
+// one-pass kernel has to reduce either dQ over key blocks or dK / dV over query blocks.  This kernel reduces dQ, with the
+// matrix pipe doing the sum, and splits the work of a block over three KINDS of waves so that each SIMD holds one wave
+// with the exponentials and one without (profiles/r05_pipe_overlap.txt: the pipes overlap between waves):
+//   * a workgroup = one (batch, head) x one chunk of EIGHT key blocks (256 keys), walking all query blocks.
+//   * waves 0 - 3, "S waves": two key blocks each.  Per query block: S = Q K^T and dP = dO V^T with the key on the lane and the
+//     row constants as initial accumulators, P = exp2(...), dS = P (dP - delta) scale; dV^T += dO^T P in registers (V
+//     fragments in registers for the kernel); dS leaves, converted, in a 2-KB LDS image [key][query] per key block.
+//   * waves 4 - 5, "dK waves", one step behind: dK^T += Q^T dS for four key blocks each -- the B operand is the very
+//     8-byte pieces the S wave's lanes wrote (same lane, same offsets), the A operand Q^T read transposed from the query
+//     block's slot (a ring of three slots: the S waves are already in the next block).
+//   * waves 6 - 7, "dQ waves", one step behind: dQ^T [d tile][query] = sum over the chunk's key blocks of K^T dS^T -- the K^T
+//     fragments of the whole chunk stay in 64 registers -- the lane is the query, so a lane stores its own row.
+//   MFMAs per step and SIMD (d = 48 / 64): 2 x 14 (S wave: 3 + 3 (4 + 4) + 4 per block... ) beside 16 (dK or dQ wave).
+//   * dQ of a chunk is a partial sum: sequences of one chunk (<= 256 tokens) store it directly; longer ones store fp32 slabs
+//     [chunk][B L][H D] with plain stores (4 - 5 x the rate of float atomics on this part) and attn_dq_reduce_kernel adds
+//     the chunks in order (bit-reproducible) and converts.
+//   * Q / dO rows of the next query block travel in registers (one 16-byte piece per thread), requested a step ahead;
+//     delta = rowsum(dO * O) comes from attn_delta_kernel.
+// Masks: none or the query-row mask (a masked row's scores are the constant -1e5: P = 1 / L, dS = 0; a wholly masked
+// block costs the S waves one product per key block and the others nothing); causal long sequences stay on the pair.
+// LDS (d = 64): K image 36.9 KB + three Q / dO slots 27.6 KB + row constants 1.2 KB + 2 x 8 dS images 32.8 KB = 98 KB.
+#ifndef BF_ONEPASS_S_PRIO
+#define BF_ONEPASS_S_PRIO 0      // static priorities of the S waves / the MFMA-only waves (A/B builds: -DBF_ONEPASS_S_PRIO=3 ...)
+#endif
+#ifndef BF_ONEPASS_M_PRIO
+#define BF_ONEPASS_M_PRIO 2
+#endif
+template <int D>
+struct OnePassCfg {
+    static constexpr int DP = (D + 31) / 32 * 32, KS = D / 16, DB = DP / 32;
+    static constexpr int KROW = DP * 2 + 16;                // K rows padded to DP columns (zero): transposed reads of the d tiles
+    static constexpr int ROW = D * 2 + 16;                  // Q / dO rows
+    static constexpr int NKB = 8, NT = 768, NSLOT = 3;
+    static constexpr int SLOT = 2 * 32 * ROW;               // Q block | dO block
+    static size_t lds_bytes() { return (size_t)NKB * 32 * KROW + NSLOT * SLOT + NSLOT * 3 * 32 * 4 + 2 * NKB * 2048; }
+};
+
+template <typename HT, int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const HT* __restrict__ out, const HT* __restrict__ dout,
+                                                         float* __restrict__ delta, int L, int H, size_t rows) {
+    // one thread per (row, head): delta[b, h, i] = sum_d dO O
+    const size_t total = rows * H;
+    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t row = t / H;
+        const int h = (int)(t - row * H);
+        const HT* o = out + row * (size_t)H * D + (size_t)h * D;
+        const HT* g = dout + row * (size_t)H * D + (size_t)h * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            const typename H16<HT>::x8 ov = *(const typename H16<HT>::x8*)(o + c * 8), gv = *(const typename H16<HT>::x8*)(g + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)ov[e], (float)gv[e], acc);
+        }
+        const size_t b = row / L, i = row - b * L;
+        delta[(b * H + h) * L + i] = acc;
+    }
+}
+
+// slabs [n_chunks][rows][H D] fp32 -> the Q slot of dqkv [rows][3][H D], chunks added in order
+template <typename HT>
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ slabs, HT* __restrict__ dqkv,
+                                                             size_t rows, int hd, int n_chunks) {
+    const int c4n = hd >> 2;
+    const size_t total = rows * c4n, slab = rows * (size_t)hd;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / c4n;
+        const int c = (int)(i - row * c4n) * 4;
+        float4 s = *(const float4*)(slabs + row * hd + c);
+        for (int k = 1; k < n_chunks; ++k) {
+            const float4 v = *(const float4*)(slabs + k * slab + row * hd + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        Vec4<HT>::store(dqkv + row * 3 * hd + c, s);
+    }
+}
+
+template <int D, int MASK, typename HT>
+__global__ __launch_bounds__(OnePassCfg<D>::NT) void attn_bwd_onepass_kernel(
+    const HT* __restrict__ qkv, const HT* __restrict__ dout, const float* __restrict__ lse,
+    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
+    float* __restrict__ dq_slabs, int L, int H, float scale, int n_chunks) {
+    using C = OnePassCfg<D>;
+    constexpr int DP = C::DP, KS = C::KS, DB = C::DB, KROW = C::KROW, ROW = C::ROW, NKB = C::NKB, NT = C::NT;
+    constexpr int CPR = D / 8;                              // 16-byte pieces per Q / dO row
+    using X8 = typename H16<HT>::x8;
+    using X4 = typename H16<HT>::x4;
+    static_assert(DB == 2, "written for d = 48 and d = 64 (two 32-row d tiles: one dQ wave each)");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_img = smem;                                     // [256 keys][KROW]
+    char* slots = k_img + (size_t)NKB * 32 * KROW;          // three slots: Q block [32][ROW] | dO block [32][ROW]
+    float* cst = (float*)(slots + C::NSLOT * C::SLOT);      // three slots: -lse / scale [32] | -delta [32] | masked (int) [32]
+    char* ds_img = (char*)(cst + C::NSLOT * 96);            // 2 buffers x 8 key blocks: dS^T [key][query], 8-byte chunks swizzled
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = lane & 31, hh = lane >> 5;
+    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    // chunks of one (batch, head) are neighbours in dispatch order: they read the same Q / dO rows at about the same time
+    const int chunk = blockIdx.x % n_chunks;
+    const int bh = blockIdx.x / n_chunks, b = bh / H, h = bh - b * H;
+    const int key0 = chunk * NKB * 32;                      // first key of the chunk
+    const int nq = (L + 31) >> 5;                           // query blocks
+    const int nkb = min(NKB, ((L - key0) + 31) >> 5);       // live key blocks of this chunk
+    const float inv_scale = 1.0f / scale;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const float inv_len = 1.0f / (float)L;
+    const size_t tok0 = (size_t)b * L;
+#ifdef ATTN_PROBE   // one wave per role stamps a 100 MHz wall clock: tools/attn_probe_onepass.py
+    const bool pr_on = lane == 0 && blockIdx.x < ATTN_PROBE_WGS;
+    unsigned long long* pr = attn_probe + (size_t)blockIdx.x * 8;
+    unsigned long long pr_a = 0, pr_b = 0, pr_c = 0;
+    if (pr_on && w == 0) pr[0] = wall_clock64();
+#endif
+
+    // ---- the chunk's K rows -> image (zero rows beyond L, zero pad columns) -----------------------------------------------
+    {
+        constexpr int CPK = DP / 8;
+        for (int idx = threadIdx.x; idx < NKB * 32 * CPK; idx += NT) {
+            const int j = idx / CPK, c = idx - j * CPK;
+            uint4 kv = make_uint4(0, 0, 0, 0);
+            if (key0 + j < L && c < CPR) kv = *(const uint4*)(qkv + qkv_off(b, key0 + j, 1, h, L, H, D) + c * 8);
+            *(uint4*)(k_img + j * KROW + c * 16) = kv;
+        }
+    }
+    // ---- the query blocks' rows travel in registers of the eight S waves, TWO steps ahead: one 16-byte piece per thread (Q
+    //      rows, then dO rows) and the row constants by the first 32 threads, in two register sets that alternate.  With one
+    //      set (requested in step j, written to its slot at the top of step j + 1) the step could not be shorter than a trip
+    //      to memory -- every form of this kernel ran 2.0 - 2.5 us per step whatever its waves did (tools/attn_probe_onepass.py).
+    //      Unconditional loads from clamped rows, so that the compiler counts them.
+    static_assert(2 * 32 * CPR <= 512, "one piece per thread of the S waves");
+    struct Pre { uint4 v; float ls, dl; int mk; };
+    const int lt = (int)threadIdx.x;                        // (used by waves 0 - 7 only)
+    const bool p_on = lt < 2 * 32 * CPR, is_do = lt >= 32 * CPR;
+    const int pi = is_do ? lt - 32 * CPR : lt, prow = p_on ? pi / CPR : 0, pc = p_on ? pi - prow * CPR : 0;
+    auto fetch = [&](Pre& pr_, int j) {
+        const int i = min(j * 32 + prow, L - 1);
+        pr_.v = is_do ? *(const uint4*)(dout + (tok0 + i) * (size_t)H * D + (size_t)h * D + pc * 8)
+                      : *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + pc * 8);
+        if (lt < 32) {
+            const int ic = min(j * 32 + lt, L - 1);
+            pr_.ls = lse[((size_t)b * H + h) * L + ic];
+            pr_.dl = delta_ws[((size_t)b * H + h) * L + ic];
+            pr_.mk = MASK == BF_MASK_QUERY_ROW ? (row_mask[tok0 + ic] == 0) : 0;
+        }
+    };
+    auto stash = [&](const Pre& pr_, int j) {
+        const int sl = j % C::NSLOT;
+        if (p_on) {
+            const bool live = j * 32 + prow < L;
+            *(uint4*)(slots + sl * C::SLOT + (is_do ? 32 * ROW : 0) + prow * ROW + pc * 16) = live ? pr_.v : make_uint4(0, 0, 0, 0);
+        }
+        if (lt < 32) {
+            const bool live = j * 32 + lt < L;
+            float* cs = cst + sl * 96;
+            cs[lt] = live ? -pr_.ls * inv_scale : -1e30f * inv_scale;
+            cs[32 + lt] = live ? -pr_.dl : 0.f;
+            ((int*)cs)[64 + lt] = live ? pr_.mk : 1;            // rows beyond L count as masked (their dO rows are zero)
+        }
+    };
+    const bool loader = w < 8;
+    Pre set0, set1;                                         // set (block & 1): block m is requested in step m - 3, written in step m - 1
+    set0.v = make_uint4(0, 0, 0, 0); set0.ls = 0.f; set0.dl = 0.f; set0.mk = 0;
+    set1 = set0;
+    for (int idx = threadIdx.x; idx < 2 * NKB * 2048 / 16; idx += NT) *(uint4*)(ds_img + idx * 16) = make_uint4(0, 0, 0, 0);
+    if (loader) {
+        fetch(set0, 0);
+        stash(set0, 0);
+        if (nq > 1) fetch(set1, 1);
+        if (nq > 2) fetch(set0, 2);
+    }
+    __syncthreads();
+
+    // dS^T image: row = key (64 bytes = 32 queries), 8-byte chunk c of row k at chunk c ^ ((k >> 1) & 7)
+    int dsw_off[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dsw_off[g] = r * 64 + (((2 * g + hh) ^ ((r >> 1) & 7)) << 3);
+
+    if (w < 8) {
+        // =========================== S waves: key block w of the chunk, TWO per SIMD ==========================================
+        // (the vector ALU of a SIMD gives one wave half of what it gives two: 7.6 against 2.9 cycles per instruction,
+        // profiles/r05_pipe_overlap.txt.  A first form had four S waves with two key blocks each, one per SIMD beside a
+        // wave that only multiplies: 1.24 us per step for the S wave alone, 1.78 us beside its partner, slower than the pair.)
+        __builtin_amdgcn_s_setprio(BF_ONEPASS_S_PRIO);
+        const int key = key0 + w * 32 + r;
+        const float lane_on = key < L ? 1.0f : 0.0f;
+        const bool dead_blk = key0 + w * 32 + 32 > L;       // the block holds keys beyond L (only the sequence's last key block can)
+        const bool wave_live = w < nkb;
+        X8 vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (key < L) vf[ks] = *(const X8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vf[ks][e] = (HT)0.f;
+            }
+        }
+        f32x16 dvacc[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dvacc[db][e] = 0.f;
+        const char* krow = k_img + (w * 32 + r) * KROW;
+        auto s_step = [&](int j, Pre& pset) {
+            // block j + 1 (requested two steps ago) into its slot; block j + 3 requested into the same registers
+            if (j + 1 < nq) stash(pset, j + 1);
+            if (j + 3 < nq) fetch(pset, j + 3);
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t1 = wall_clock64();
+#endif
+            const char* q_s = slots + (j % C::NSLOT) * C::SLOT;
+            const char* do_s = q_s + 32 * ROW;
+            const float* cs = cst + (j % C::NSLOT) * 96;
+            const int* mk = (const int*)cs + 64;
+            bool blk_masked = false;
+            if (MASK == BF_MASK_QUERY_ROW) blk_masked = __all(mk[r] != 0);
+            char* my_img = ds_img + ((j & 1) * NKB + w) * 2048;
+            if (!wave_live) {
+            } else if (MASK == BF_MASK_QUERY_ROW && blk_masked) {
+                // all 32 rows masked: P = 1 / L for every (query, key), dS = 0 -> dV^T += dO^T P; the dK / dQ waves skip the block
+                X8 pconst;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pconst[e] = (HT)(inv_len * lane_on);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int row0 = 16 * s + 4 * hh + q4;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                        const X8 dot = tr_pair<HT>(do_s + row0 * ROW + cb, do_s + (row0 + 8) * ROW + cb);
+                        dvacc[db] = mfma_32x32x16(dot, pconst, dvacc[db]);
+                    }
+                }
+            } else {
+                f32x16 sacc, pacc;                          // the row constants -lse / scale and -delta are the initial accumulators
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 l4 = *(const float4*)(cs + 8 * g + 4 * hh);
+                    const float4 d4 = *(const float4*)(cs + 32 + 8 * g + 4 * hh);
+                    sacc[4 * g + 0] = l4.x; sacc[4 * g + 1] = l4.y; sacc[4 * g + 2] = l4.z; sacc[4 * g + 3] = l4.w;
+                    pacc[4 * g + 0] = d4.x; pacc[4 * g + 1] = d4.y; pacc[4 * g + 2] = d4.z; pacc[4 * g + 3] = d4.w;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const X8 qa = *(const X8*)(q_s + r * ROW + ks * 32 + hh * 16);
+                    const X8 da = *(const X8*)(do_s + r * ROW + ks * 32 + hh * 16);
+                    const X8 kfr = *(const X8*)(krow + ks * 32 + hh * 16);
+                    sacc = mfma_32x32x16(qa, kfr, sacc);
+                    pacc = mfma_32x32x16(da, vf[ks], pacc);
+                }
+                // p = exp2(sl2 S'), dS = p dP' (the scale rides in the stores of dK and dQ).  A block with masked rows among
+                // live ones (frame boundaries inside a block: rare) or with keys beyond L (the sequence's last key block)
+                // takes the per-element form; every other block is 8 + 8 packed multiplies and 16 exponentials.
+                bool any_masked = false;
+                if (MASK == BF_MASK_QUERY_ROW) any_masked = __any(mk[r] != 0);
+                const f32x2 sl2v = {sl2, sl2};
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 tt = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
+                    const f32x2 p2 = {__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])};
+                    const f32x2 ds2 = p2 * (f32x2){pacc[e], pacc[e + 1]};
+                    sacc[e] = p2[0]; sacc[e + 1] = p2[1];
+                    pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
+                }
+                if (any_masked || dead_blk) {               // (wave-uniform)
+                    const float pm = inv_len * lane_on;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ql = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        const bool m = MASK == BF_MASK_QUERY_ROW && mk[ql] != 0;
+                        sacc[e] = m ? pm : sacc[e] * lane_on;
+                        pacc[e] = m ? 0.f : pacc[e] * lane_on;
+                    }
+                }
+                X8 pb[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pb[s][e] = (HT)sacc[8 * s + e];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    X4 v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = (HT)pacc[4 * g + e];
+                    *(X4*)(my_img + dsw_off[g]) = v4;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int row0 = 16 * s + 4 * hh + q4;
+#pragma unroll
+                    for (int db = 0; db < DB; ++db) {
+                        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                        const X8 dot = tr_pair<HT>(do_s + row0 * ROW + cb, do_s + (row0 + 8) * ROW + cb);
+                        dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
+                    }
+                }
+            }
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t2 = wall_clock64();
+#endif
+            __syncthreads();
+#ifdef ATTN_PROBE
+            pr_a += pr_t2 - pr_t1; pr_b += wall_clock64() - pr_t2;
+#endif
+        };
+        for (int j = 0; j < nq; j += 2) {                   // (block j + 1 sits in set (j + 1) & 1)
+            s_step(j, set1);
+            if (j + 1 < nq) s_step(j + 1, set0);
+        }
+#ifdef ATTN_PROBE
+        if (pr_on && w == 0) { pr[1] = pr_a; pr[2] = pr_b; pr[6] = pr_c; pr[4] = wall_clock64(); }
+#endif
+        __syncthreads();                                    // (the step the dK / dQ waves run behind)
+        if (key < L) {
+            HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = db * 32 + 8 * g + 4 * hh;
+                    if (d0 < D) {
+                        X4 v4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v4[e] = (HT)dvacc[db][4 * g + e];
+                        *(X4*)(dvp + d0) = v4;
+                    }
+                }
+        }
+    } else if (w < 10) {
+        // =========================== dK waves (8, 9): key blocks 4 (w - 8) .. + 3, one step behind =========================================
+        // (the younger wave of its SIMD loses the issue arbitration to the S wave it shares it with: static priority for the
+        // waves that only multiply, so that their MFMAs go out when their operands are there and the S wave's vector work
+        // fills the gaps)
+        __builtin_amdgcn_s_setprio(BF_ONEPASS_M_PRIO);
+        const int kb0 = 4 * (w - 8);
+        f32x16 dkacc[4][DB];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dkacc[kb][db][e] = 0.f;
+        for (int j = 0; j <= nq; ++j) {
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t0 = wall_clock64();
+#endif
+#ifdef ONEPASS_ABL_NO_PARTNERS
+            if (false) {
+#else
+            if (j >= 1) {
+#endif
+                const int jq = j - 1;
+                const char* q_s = slots + (jq % C::NSLOT) * C::SLOT;
+                const int* mk = (const int*)(cst + (jq % C::NSLOT) * 96) + 64;
+                bool blk_masked = false;
+                if (MASK == BF_MASK_QUERY_ROW) blk_masked = __all(mk[r] != 0);
+                if (!blk_masked) {
+                    // Q^T fragments of the block: two k steps x two d tiles, shared by this wave's four key blocks
+                    X8 qtt[2][DB];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int row0 = 16 * s + 4 * hh + q4;
+#pragma unroll
+                        for (int db = 0; db < DB; ++db) {
+                            const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+                            qtt[s][db] = tr_pair<HT>(q_s + row0 * ROW + cb, q_s + (row0 + 8) * ROW + cb);
+                        }
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {      // (a block beyond the chunk's keys reads a zero / stale image: its dK is never stored)
+                        const char* im = ds_img + ((jq & 1) * NKB + kb0 + kb) * 2048;
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const X4 lo = *(const X4*)(im + dsw_off[2 * s]), hi = *(const X4*)(im + dsw_off[2 * s + 1]);
+                            X8 dsb;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { dsb[e] = lo[e]; dsb[4 + e] = hi[e]; }
+#pragma unroll
+                            for (int db = 0; db < DB; ++db) dkacc[kb][db] = mfma_32x32x16(qtt[s][db], dsb, dkacc[kb][db]);
+                        }
+                    }
+                }
+            }
+#ifdef ATTN_PROBE
+            pr_a += wall_clock64() - pr_t0;
+#endif
+            __syncthreads();
+        }
+#ifdef ATTN_PROBE
+        if (pr_on && w == 8) pr[3] = pr_a;
+#endif
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int key = key0 + (kb0 + kb) * 32 + r;
+            if (key < L) {
+                HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int d0 = db * 32 + 8 * g + 4 * hh;
+                        if (d0 < D) {
+                            X4 k4;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) k4[e] = (HT)(dkacc[kb][db][4 * g + e] * scale);
+                            *(X4*)(dkp + d0) = k4;
+                        }
+                    }
+            }
+        }
+    } else {
+        // =========================== dQ waves (10, 11): d tile w - 10, one step behind ===========================================================
+        __builtin_amdgcn_s_setprio(BF_ONEPASS_M_PRIO);
+        const int db = w - 10;
+        int dsr_off[2][2];                                  // B operand: a dS^T image read transposed
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int krow = 16 * s2 + 8 * hh + q4 + 4 * u;
+                dsr_off[s2][u] = krow * 64 + (((4 * (g16 & 1) + p4) ^ ((krow >> 1) & 7)) << 3);
+            }
+        // K^T fragments of the chunk's key blocks for this d tile (A operand: rows d, k = key), once
+        X8 kfr[NKB][2];
+        {
+            const int cd = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char* k0p = k_img + (kb * 32 + 16 * s + 8 * hh + q4) * KROW + cd;
+                    kfr[kb][s] = tr_pair<HT>(k0p, k0p + 4 * KROW);
+                }
+        }
+        for (int j = 0; j <= nq; ++j) {
+#ifdef ATTN_PROBE
+            const unsigned long long pr_t0 = wall_clock64();
+#endif
+#ifdef ONEPASS_ABL_NO_PARTNERS
+            if (false) {
+#else
+            if (j >= 1) {
+#endif
+                const int jq = j - 1;
+                const int* mk = (const int*)(cst + (jq % C::NSLOT) * 96) + 64;
+                bool blk_masked = false;
+                if (MASK == BF_MASK_QUERY_ROW) blk_masked = __all(mk[r] != 0);
+                f32x16 dq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
+                if (!blk_masked) {
+                    // image reads as assembly in batches of two key blocks, the next batch before the MFMAs of the current one
+                    // (see attn_bwd_fused32p_kernel); a block beyond the chunk's keys multiplies zero K^T fragments with an
+                    // image that is zero or stale-but-finite (the images are cleared at kernel start)
+                    const char* img_buf = ds_img + (size_t)(jq & 1) * NKB * 2048;
+                    auto issue1 = [&](uint2 (&f)[2][2], int kb) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s)
+                            tr_issue(f[s][0], f[s][1], img_buf + kb * 2048 + dsr_off[s][0], img_buf + kb * 2048 + dsr_off[s][1]);
+                    };
+                    auto mul1 = [&](uint2 (&f)[2][2], int kb) {
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const uint4 vq = make_uint4(f[s][0].x, f[s][0].y, f[s][1].x, f[s][1].y);
+                            dq = mfma_32x32x16(kfr[kb][s], *(const X8*)&vq, dq);
+                        }
+                    };
+#define BF_LGKM_WAIT1(N, f) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]))
+                    static_assert(NKB == 8, "eight key blocks, one batch each, two in flight");
+                    uint2 fa[2][2], fb[2][2];
+                    issue1(fa, 0);
+                    issue1(fb, 1);
+                    BF_LGKM_WAIT1(4, fa); mul1(fa, 0); issue1(fa, 2);
+                    BF_LGKM_WAIT1(4, fb); mul1(fb, 1); issue1(fb, 3);
+                    BF_LGKM_WAIT1(4, fa); mul1(fa, 2); issue1(fa, 4);
+                    BF_LGKM_WAIT1(4, fb); mul1(fb, 3); issue1(fb, 5);
+                    BF_LGKM_WAIT1(4, fa); mul1(fa, 4); issue1(fa, 6);
+                    BF_LGKM_WAIT1(4, fb); mul1(fb, 5); issue1(fb, 7);
+                    BF_LGKM_WAIT1(4, fa); mul1(fa, 6);
+                    BF_LGKM_WAIT1(0, fb); mul1(fb, 7);
+#undef BF_LGKM_WAIT1
+                }
+                // lane (query r, half hh) holds d = 32 db + 8 g + 4 hh + {0 .. 3}
+                const int qi = jq * 32 + r;
+                if (qi < L) {
+                    if (n_chunks == 1) {
+                        HT* dst = dqkv + qkv_off(b, qi, 0, h, L, H, D);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int d0 = db * 32 + 8 * g + 4 * hh;
+                            if (d0 < D) {
+                                X4 o4;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o4[e] = (HT)(dq[4 * g + e] * scale);
+                                *(X4*)(dst + d0) = o4;
+                            }
+                        }
+                    } else {
+                        float* dst = dq_slabs + ((size_t)chunk * ((size_t)gridDim.x / n_chunks / H) * L + tok0 + qi) * (size_t)H * D + (size_t)h * D;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int d0 = db * 32 + 8 * g + 4 * hh;
+                            if (d0 < D) *(float4*)(dst + d0) = make_float4(dq[4 * g] * scale, dq[4 * g + 1] * scale, dq[4 * g + 2] * scale, dq[4 * g + 3] * scale);
+                        }
+                    }
+                }
+            }
+#ifdef ATTN_PROBE
+            pr_a += wall_clock64() - pr_t0;
+#endif
+            __syncthreads();
+        }
+#ifdef ATTN_PROBE
+        if (pr_on && w == 10) pr[5] = pr_a;
+#endif
+    }
+}
+
 // dq_ws fp32 [B, L, H*D] -> the Q slot of dqkv [B, L, 3, H, D] (bf16)
 template <typename HT>
 __global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, HT* __restrict__ dqkv,
@@ -3257,6 +3780,21 @@ static int bwd_pick_nw(int seq, int head_dim, bool have_ws) {
     while (nw > 1 && bwd_lds_of(head_dim, nw) > 160 * 1024) --nw;
     return nw;
 }
+// d = 48 / 64, no mask or the query-row mask, sequences the streamed pair used to take: the one-pass kernel
+static bool onepass_takes(int seq, int head_dim, int mask_mode, bool half) {
+    const int nq32 = bf_cdiv(seq, 32);
+    return half && bf_tuning().attn_bwd_onepass && (head_dim == 48 || head_dim == 64) && mask_mode != BF_MASK_CAUSAL &&
+           bf_tuning().attn_bwd_stream && nq32 >= bf_tuning().attn_onepass_min_q32;
+}
+extern "C" long long bf_attention_bwd_ws_elems(int batch, int seq, int heads, int head_dim, int mask_mode, int cdt) {
+    if (batch <= 0 || seq <= 0 || heads <= 0 || !(head_dim == 32 || head_dim == 48 || head_dim == 64)) return 0;
+    const long long one = (long long)batch * seq * heads * head_dim;
+    if (onepass_takes(seq, head_dim, mask_mode, bf_is_half(cdt))) {
+        const int n_chunks = bf_cdiv(bf_cdiv(seq, 32), OnePassCfg<64>::NKB);
+        return n_chunks > 1 ? one * n_chunks : 0;
+    }
+    return (bf_is_half(cdt) && bf_attention_bwd_needs_dq_ws(seq, head_dim)) ? one : 0;
+}
 extern "C" int bf_attention_bwd_needs_dq_ws(int seq, int head_dim) {
     if (!(head_dim == 32 || head_dim == 48 || head_dim == 64) || seq <= 0) return 0;
     const int nw = bwd_pick_nw(seq, head_dim, true);
@@ -3399,6 +3937,50 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
 #undef BWD_SPLIT
 #undef BWD_SPLIT2
 #undef BWD_SPLIT3
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            return BF_OK;
+        }
+    }
+    if (onepass_takes(seq, head_dim, mask_mode, half)) {
+        const int nq32 = bf_cdiv(seq, 32);
+        const int n_chunks = bf_cdiv(nq32, OnePassCfg<64>::NKB);
+        if (n_chunks == 1 || (dq_ws && bf_aligned16(dq_ws))) {     // (no slab workspace: the streamed pair below)
+            const size_t rows = (size_t)batch * seq;
+            BF_REQUIRE((long long)batch * heads * n_chunks < (1ll << 31), BF_EINVAL, "bf_attention_bwd: grid too large");
+            unsigned dblocks = (unsigned)((rows * heads + 255) / 256);
+            if (dblocks > 16384) dblocks = 16384;
+            dim3 grid((unsigned)(batch * heads * n_chunks)), block(OnePassCfg<64>::NT);
+#define BWD_ONEPASS3(DD, MM, HT)                                                                        \
+    do {                                                                                                \
+        const size_t lds_o = OnePassCfg<DD>::lds_bytes();                                               \
+        static BfPerDevice set_o_dev; size_t& set_o = set_o_dev.cur();                                  \
+        if (lds_o > set_o) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_onepass_kernel<DD, MM, HT>,                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o);          \
+            set_o = lds_o;                                                                              \
+        }                                                                                               \
+        hipLaunchKernelGGL((attn_delta_kernel<HT, DD>), dim3(dblocks), dim3(256), 0, s, (const HT*)out, \
+                           (const HT*)dout, delta_ws, seq, heads, rows);                                \
+        hipLaunchKernelGGL((attn_bwd_onepass_kernel<DD, MM, HT>), grid, block, lds_o, s, (const HT*)qkv, \
+                           (const HT*)dout, lse, (const float*)delta_ws, row_mask, (HT*)dqkv, dq_ws,    \
+                           seq, heads, scale, n_chunks);                                                \
+        if (n_chunks > 1) {                                                                             \
+            size_t rb = (rows * (heads * DD / 4) + 255) / 256;                                          \
+            if (rb > 16384) rb = 16384;                                                                 \
+            hipLaunchKernelGGL(attn_dq_reduce_kernel<HT>, dim3((unsigned)rb), dim3(256), 0, s,          \
+                               (const float*)dq_ws, (HT*)dqkv, rows, heads * DD, n_chunks);             \
+        }                                                                                               \
+    } while (0)
+#define BWD_ONEPASS2(DD, MM) BY_HALF(BWD_ONEPASS3, DD, MM)
+#define BWD_ONEPASS(DD)                                                                                 \
+    do {                                                                                                \
+        if (mask_mode == BF_MASK_NONE) BWD_ONEPASS2(DD, BF_MASK_NONE);                                  \
+        else BWD_ONEPASS2(DD, BF_MASK_QUERY_ROW);                                                       \
+    } while (0)
+            if (head_dim == 48) BWD_ONEPASS(48); else BWD_ONEPASS(64);
+#undef BWD_ONEPASS
+#undef BWD_ONEPASS2
+#undef BWD_ONEPASS3
             BF_CHECK_LAUNCH("bf_attention_bwd");
             return BF_OK;
         }

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 7
+#define BF_ABI_VERSION 8
 
 enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
@@ -258,6 +258,11 @@ int bf_attention_fwd(const void* qkv, void* out, float* lse, const int32_t* row_
  * key chunk of the MFMA kernel (L > 512 at D=32, > 192 at D=48, > 128 at D=64): dQ is then
  * accumulated across key chunks with fp32 atomics.  NULL falls back to the VALU kernels. */
 int bf_attention_bwd_needs_dq_ws(int seq, int head_dim);   /* 1 if dq_ws is needed in bf16 mode */
+/* ABI 8: the number of fp32 ELEMENTS dq_ws must hold for this call (0: none).  The one-pass backward of long d = 48 / 64
+ * sequences (transformer.py:28-41 under autograd; query-row mask of models/siglip.py:118-130) writes one partial dQ per
+ * chunk of 256 keys -- [chunks][B, L, H*D] -- and adds them in chunk order; bf_attention_bwd falls back to the two-kernel
+ * streamed pair when handed a smaller / NULL workspace for such a call. */
+long long bf_attention_bwd_ws_elems(int batch, int seq, int heads, int head_dim, int mask_mode, int cdt);
 int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                      const int32_t* row_mask, void* dqkv, float* delta_ws, float* dq_ws, int batch,
                      int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,

@@ -529,6 +529,61 @@ def test_attention_bwd_one_pass_kernel_over_ragged_lengths(ops, gpu, half, B, Lq
     assert torch.equal(again, dqkv)                         # partial dQ blocks are summed in wave order: bit-reproducible
 
 
+ONEPASS_SCRIPT = """
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from bifold_amd.hip import ops
+gpu = torch.device("cuda:0")
+def ref(qkv, dout, B, Lq, H, D, rm):
+    leaf = qkv.double().requires_grad_(True)
+    q, k, v = leaf.reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
+    s = q @ k.transpose(-1, -2) * D ** -0.5
+    if rm is not None:
+        s = s.masked_fill(rm[:, None, :, None] == 0, -100000.0)
+    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Lq, H * D)
+    o.backward(dout.double())
+    return leaf.grad
+for half in (torch.bfloat16, torch.float16):
+    for B, Lq, H, D, mode, spans in ((2, 576, 2, 64, 0, []), (1, 1000, 1, 64, 0, []), (1, 853, 2, 48, 2, []), (2, 600, 2, 48, 2, [(64, 256)]),
+                                     (1, 1290, 1, 64, 2, [(0, 33), (577, 1154)]), (1, 545, 3, 48, 0, [])):
+        g = torch.Generator(device=gpu).manual_seed(Lq * 3 + D)
+        qkv = torch.randn(B * Lq, 3 * H * D, device=gpu, generator=g).to(half)
+        dout = torch.randn(B * Lq, H * D, device=gpu, generator=g).to(half)
+        rm = None
+        if mode == 2:
+            rm = (torch.rand(B, Lq, device=gpu, generator=g) > 0.3).int()
+            for a, b in spans:
+                rm[:, a:b] = 0
+        want = ref(qkv, dout, B, Lq, H, D, rm).float()
+        out, lse = ops.attention_fwd(qkv, B, Lq, H, D, D ** -0.5, mode, rm, need_lse=True)
+        dqkv = ops.attention_bwd(qkv, out, dout, lse, B, Lq, H, D, D ** -0.5, mode, rm)
+        err = ((dqkv.float() - want).abs().max() / want.abs().max()).item()
+        assert err < 2e-2, (half, B, Lq, H, D, mode, err)
+        if rm is not None:
+            dq = dqkv.float().view(B, Lq, 3, H * D)[:, :, 0]
+            assert float(dq[rm == 0].abs().max()) == 0.0, (half, Lq, D)      # masked queries receive exactly no gradient
+        again = ops.attention_bwd(qkv, out, dout, lse, B, Lq, H, D, D ** -0.5, mode, rm)
+        assert torch.equal(again, dqkv), (half, B, Lq, H, D)                 # chunks are added in order: bit-reproducible
+print("ONEPASS-OK")
+"""
+
+
+def test_attention_bwd_one_pass_kernel_for_long_sequences(gpu, tmp_path):
+    """attn_bwd_onepass_kernel (round 5; opt-in, BIFOLD_ATTN_BWD_ONEPASS=1 -- it is correct and slower than the streamed pair, see
+    DESIGN.md -- hence the child process): d = 48 / 64 beyond 512 tokens, no mask and the query-row mask with whole masked
+    frames and lone masked rows, ragged last chunks of 1 - 8 key blocks, partial dQ slabs added in chunk order -- against the
+    fp64 formula, twice (bit-reproducible), masked queries' gradient exactly zero."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "op.py"
+    script.write_text(ONEPASS_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, BIFOLD_ATTN_BWD_ONEPASS="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ONEPASS-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
 FUSED_P_SCRIPT = """
 import sys, torch
 sys.path.insert(0, sys.argv[1])
