@@ -152,6 +152,7 @@ class CLIPEncoder(nn.Module):
         # vision tower's shape).  `final` = the LayerNorm after the last block (ln_post / ln_final), fused the same way.
         fuse_add = (cdt in ops.HALF and not fp8 and width in (256, 512, 768, 1024) and final is not None
                     and os.environ.get("BIFOLD_ADD_LN", "1") != "0")
+        lazy = fuse_add and os.environ.get("BIFOLD_LAZY_STREAM", "1") != "0"
         h = None if fp8 else h0           # ln_1 of block 0, when the caller has already computed it (K1)
         for i in range(layers):
             b = f"{prefix}.{i}."
@@ -166,18 +167,27 @@ class CLIPEncoder(nn.Module):
                 h = None
             o, _ = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mode)
             if fuse_add:
-                delta = ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"))
-                h, _, _, _ = ops.add_layernorm_fwd(x, delta, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt)
+                # The towers are frozen: nothing reads the stream between a block's two branches, so it is written ONCE
+                # per block (round 5).  The pass after the attention branch only produces ln_2(x + attn) (no x_out: 8
+                # bytes per element instead of 12); the pass after the MLP adds BOTH branches to the block's input,
+                # (x + attn) + mlp in that order -- the bits of the two-pass form -- and writes the stream (14 instead
+                # of 12).  BIFOLD_LAZY_STREAM=0 restores the two read-modify-write passes.
+                attn = ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"))
+                h, _, _, _ = ops.add_layernorm_fwd(x, attn, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt,
+                                                   write_x=not lazy)
                 a = ops.gemm(h, self._w(b + "mlp.c_fc.weight", cdt), bias=self._f(b + "mlp.c_fc.bias"),
                              act=L.ACT_QUICK_GELU)
                 delta = ops.gemm(a, self._w(b + "mlp.c_proj.weight", cdt), bias=self._f(b + "mlp.c_proj.bias"))
+                first, second = (attn, delta) if lazy else (delta, None)
                 if i + 1 < layers:
                     nb = f"{prefix}.{i + 1}."
-                    h, _, _, _ = ops.add_layernorm_fwd(x, delta, self._f(nb + "ln_1.weight"), self._f(nb + "ln_1.bias"), cdt)
+                    h, _, _, _ = ops.add_layernorm_fwd(x, first, self._f(nb + "ln_1.weight"), self._f(nb + "ln_1.bias"), cdt,
+                                                       delta2=second)
                 else:
+                    # the last block: nothing reads the stream after the final LayerNorm
                     gname, out_dtype = final
-                    y, _, _, _ = ops.add_layernorm_fwd(x, delta, self._f(gname + ".weight"), self._f(gname + ".bias"),
-                                                       out_dtype)
+                    y, _, _, _ = ops.add_layernorm_fwd(x, first, self._f(gname + ".weight"), self._f(gname + ".bias"),
+                                                       out_dtype, delta2=second, write_x=not lazy)
                     return y
                 continue
             ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"),

@@ -31,6 +31,7 @@ autograd restatement of it (oracle/lora_oracle.py), not against the reference it
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from typing import Dict, List, Optional
 
@@ -245,6 +246,41 @@ class SiglipTowers(nn.Module):
     def _f(self, name: str):
         return self._p(name).data
 
+    def _encoder_frozen(self, x, tower: str, cfg: Dict, batch: int, seq: int, cdt, final: str):
+        """The pre-LN blocks of a FROZEN tower in a 16-bit mode, followed by the tower's last LayerNorm `final` (fp32
+        output).  The form of the CLIP towers (clip_encoder._tower): out-proj and fc2 write their branch as a 16-bit
+        tensor (plain epilogue, no fp32 residual tile), the residual adds ride in the LayerNorm passes, and because
+        nothing reads the stream between a block's two branches it is written once per block
+        (bf_add2_layernorm_fwd): ln_2(x + attn) without an x_out, then ln_1'((x + attn) + mlp) with one."""
+        heads, w = cfg["num_attention_heads"], cfg["hidden_size"]
+        d = w // heads
+        n_layers = cfg["num_hidden_layers"]
+        h1 = None
+        for i in range(n_layers):
+            b = f"{tower}.encoder.layers.{i}."
+            if h1 is None:
+                h1, _, _ = self._ln1(x, b, cdt, False)
+            qkv, _ = self._qkv(h1, b, i, tower, cdt, w, None)
+            o, _ = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, L.MASK_NONE, need_lse=False)
+            attn = ops.gemm(o, self._w(b + "self_attn.out_proj.weight", cdt), bias=self._f(b + "self_attn.out_proj.bias"))
+            h2, _, _, _ = ops.add_layernorm_fwd(x, attn, self._f(b + "layer_norm2.weight"), self._f(b + "layer_norm2.bias"),
+                                                cdt, eps=LN_EPS, write_x=False)
+            a = ops.gemm(h2, self._w(b + "mlp.fc1.weight", cdt), bias=self._f(b + "mlp.fc1.bias"), act=L.ACT_TANH_GELU)
+            mlp = ops.gemm(a, self._w(b + "mlp.fc2.weight", cdt), bias=self._f(b + "mlp.fc2.bias"))
+            if i + 1 < n_layers:
+                nb = f"{tower}.encoder.layers.{i + 1}."
+                h1, _, _, _ = ops.add_layernorm_fwd(x, attn, self._f(nb + "layer_norm1.weight"),
+                                                    self._f(nb + "layer_norm1.bias"), cdt, eps=LN_EPS, delta2=mlp)
+            else:
+                y, _, _, _ = ops.add_layernorm_fwd(x, attn, self._f(final + ".weight"), self._f(final + ".bias"),
+                                                   torch.float32, eps=LN_EPS, delta2=mlp, write_x=False)
+                return y
+        raise RuntimeError("a tower without layers")
+
+    def _frozen_fast(self, keep: bool, cfg: Dict, cdt) -> bool:
+        return (not keep and cdt in ops.HALF and cfg["hidden_size"] in (256, 512, 768, 1024)
+                and cfg["num_hidden_layers"] > 0 and os.environ.get("BIFOLD_SIGLIP_LAZY", "1") != "0")
+
     def _encoder(self, x, tower: str, cfg: Dict, batch: int, seq: int, cdt, saved: Optional[List] = None):
         """The pre-LN blocks.  `saved` (a list) receives per layer what _encoder_bwd needs; without it
         the residual stream is updated in place."""
@@ -449,6 +485,8 @@ class SiglipTowers(nn.Module):
                      residual=self._f("vision_model.embeddings.position_embedding.weight"), resid_mod=n, out=x)
             del cols
             layers: Optional[List] = [] if keep else None
+            if self._frozen_fast(keep, self.vcfg, cdt):
+                return self._encoder_frozen(x, "vision_model", self.vcfg, nimg, n, cdt, "vision_model.post_layernorm")
             x = self._encoder(x, "vision_model", self.vcfg, nimg, n, cdt, layers)
             y, fin = self._final_norm(x, "vision_model.post_layernorm", keep)
             if keep:
@@ -470,6 +508,8 @@ class SiglipTowers(nn.Module):
             x = ops.embed_tokens(ids, self._f("text_model.embeddings.token_embedding.weight"),
                                  self._f("text_model.embeddings.position_embedding.weight"), self._err_flag)
             layers: Optional[List] = [] if keep else None
+            if self._frozen_fast(keep, self.tcfg, cdt):
+                return self._encoder_frozen(x, "text_model", self.tcfg, batch, ctx, cdt, "text_model.final_layer_norm")
             x = self._encoder(x, "text_model", self.tcfg, batch, ctx, cdt, layers)
             y, fin = self._final_norm(x, "text_model.final_layer_norm", keep)
             if keep:

@@ -190,8 +190,9 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 // included): with the add done HERE the GEMM runs its plain-bf16 epilogue (no 256 KB residual tile to wait for at item
 // start, half the store bytes) and this kernel, which reads the residual stream anyway, adds 2 B/element of traffic.
 // Two rows per wave like ln_fwd_rows_kernel; cols == NC * 256.
-template <typename TY, int NC, typename TDL = bf16_t>
+template <typename TY, int NC, typename TDL = bf16_t, bool HAS2 = false>
 __global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restrict__ x, const TDL* __restrict__ delta,
+                                                          const TDL* __restrict__ delta2,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ x_out, TY* __restrict__ y,
                                                           float* __restrict__ mean, float* __restrict__ rstd, int rows,
@@ -208,11 +209,19 @@ __global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restric
         const int row = min(row0 + r, rows - 1);
         const float* xr = x + (size_t)row * cols;
         const TDL* dr = delta + (size_t)row * cols;
+        // second branch (the frozen towers' lazily written stream, bf_add2_layernorm_fwd): (x + delta) + delta2, the
+        // order in which two separate passes would have added them; all three loads of a row go out together
+        const TDL* dr2 = HAS2 ? delta2 + (size_t)row * cols : nullptr;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
             const float4 a = *(const float4*)(xr + (lane + i * 64) * 4);
             const float4 d = Vec4<TDL>::load(dr + (lane + i * 64) * 4);
-            v[r][i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+            if constexpr (HAS2) {
+                const float4 e = Vec4<TDL>::load(dr2 + (lane + i * 64) * 4);
+                v[r][i] = make_float4((a.x + d.x) + e.x, (a.y + d.y) + e.y, (a.z + d.z) + e.z, (a.w + d.w) + e.w);
+            } else {
+                v[r][i] = make_float4(a.x + d.x, a.y + d.y, a.z + d.z, a.w + d.w);
+            }
         }
     }
 #pragma unroll
@@ -252,11 +261,11 @@ __global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restric
     for (int r = 0; r < R; ++r) {
         if (row0 + r >= rows) break;
         const float rs = rsqrtf(q[r] / (float)cols + eps);
-        float* xo = x_out + (size_t)(row0 + r) * cols;
+        float* xo = x_out ? x_out + (size_t)(row0 + r) * cols : nullptr;      // no x_out: only y = LN(x + delta) is wanted
         TY* yr = y + (size_t)(row0 + r) * cols;
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
-            *(float4*)(xo + (lane + i * 64) * 4) = v[r][i];
+            if (xo) *(float4*)(xo + (lane + i * 64) * 4) = v[r][i];
             float4 o;
             o.x = (v[r][i].x - mu[r]) * rs * g[i].x + bt[i].x;
             o.y = (v[r][i].y - mu[r]) * rs * g[i].y + bt[i].y;
@@ -274,18 +283,28 @@ __global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restric
 extern "C" int bf_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, const float* gamma, const float* beta,
                                     float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
                                     float eps, bf_stream_t stream) {
-    BF_REQUIRE(x && delta && gamma && beta && x_out && y, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
+    BF_REQUIRE(x_out, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
+    return bf_add2_layernorm_fwd(x, delta, nullptr, delta_dtype, gamma, beta, x_out, y, y_dtype, mean, rstd, rows, cols, eps,
+                                 stream);
+}
+
+extern "C" int bf_add2_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype,
+                                     const float* gamma, const float* beta, float* x_out, void* y, int y_dtype,
+                                     float* mean, float* rstd, int rows, int cols, float eps, bf_stream_t stream) {
+    BF_REQUIRE(x && delta && gamma && beta && y, BF_EINVAL, "bf_add_layernorm_fwd: null pointer");
+    BF_REQUIRE(!delta2 || bf_aligned16(delta2), BF_EALIGN, "bf_add2_layernorm_fwd: unaligned delta2");
     BF_REQUIRE(rows > 0 && (cols == 256 || cols == 512 || cols == 768 || cols == 1024), BF_EINVAL,
                "bf_add_layernorm_fwd: cols must be 256, 512, 768 or 1024 (got %d)", cols);
     BF_REQUIRE(bf_is_half(y_dtype) || y_dtype == BF_F32, BF_EINVAL, "bf_add_layernorm_fwd: bad y dtype");
     BF_REQUIRE(bf_is_half(delta_dtype) && (y_dtype == BF_F32 || y_dtype == delta_dtype), BF_EINVAL,
                "bf_add_layernorm_fwd: delta is a 16-bit tensor and a 16-bit y has its type (delta %d, y %d)", delta_dtype, y_dtype);
-    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(delta) && bf_aligned16(x_out) && bf_aligned16(y) &&
+    BF_REQUIRE(bf_aligned16(x) && bf_aligned16(delta) && (!x_out || bf_aligned16(x_out)) && bf_aligned16(y) &&
                    bf_aligned16(gamma) && bf_aligned16(beta), BF_EALIGN, "bf_add_layernorm_fwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(bf_cdiv(rows, 8)), block(256);
-#define ADDLN(TY, NCV, TDL) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV, TDL>), grid, block, 0, s, x, (const TDL*)delta, \
-                                               gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
+#define ADDLN2(TY, NCV, TDL, H2) hipLaunchKernelGGL((add_ln_rows_kernel<TY, NCV, TDL, H2>), grid, block, 0, s, x, (const TDL*)delta, \
+                                                   (const TDL*)delta2, gamma, beta, x_out, (TY*)y, mean, rstd, rows, eps)
+#define ADDLN(TY, NCV, TDL) do { if (delta2) ADDLN2(TY, NCV, TDL, true); else ADDLN2(TY, NCV, TDL, false); } while (0)
 #define ADDLN_NC(TY, TDL)                                                              \
     do {                                                                               \
         if (cols == 256) ADDLN(TY, 1, TDL); else if (cols == 512) ADDLN(TY, 2, TDL);   \
@@ -297,6 +316,7 @@ extern "C" int bf_add_layernorm_fwd(const float* x, const void* delta, int delta
     else ADDLN_NC(float, bf16_t);
 #undef ADDLN_NC
 #undef ADDLN
+#undef ADDLN2
     BF_CHECK_LAUNCH("bf_add_layernorm_fwd");
     return BF_OK;
 }

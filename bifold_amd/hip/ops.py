@@ -119,23 +119,30 @@ def layernorm_fwd(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_
 
 def add_layernorm_fwd(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                       out_dtype: torch.dtype, x_out: Optional[torch.Tensor] = None, save_stats: bool = False,
-                      eps: float = 1e-5):
+                      eps: float = 1e-5, delta2: Optional[torch.Tensor] = None, write_x: bool = True):
     """x_out = x + delta (fp32 residual stream + the branch's 16-bit output), y = LN(x_out).  `x_out=None` updates x in
-    place.  Returns (y, mean, rstd, x_out)."""
+    place.  `delta2`: a second branch, x_out = (x + delta) + delta2; `write_x=False`: only y is produced, the stream is
+    left as it is (bf_add2_layernorm_fwd: the frozen towers write their stream once per block).
+    Returns (y, mean, rstd, x_out)."""
     _dev(x, "x"); _dev(delta, "delta"); _dev(gamma, "gamma"); _dev(beta, "beta")
     if (x.dtype != torch.float32 or delta.dtype not in HALF or x.shape != delta.shape
             or (out_dtype in HALF and out_dtype != delta.dtype)):
         raise TypeError("add_layernorm_fwd: x fp32, delta a 16-bit tensor of the same shape, a 16-bit y of delta's type")
+    if delta2 is not None:
+        _dev(delta2, "delta2")
+        if delta2.dtype != delta.dtype or delta2.shape != delta.shape or not delta2.is_contiguous():
+            raise TypeError("add_layernorm_fwd: delta2 has delta's dtype and shape")
     cols = x.shape[-1]
     rows = x.numel() // cols
-    xo = x if x_out is None else x_out
+    xo = (x if x_out is None else x_out) if write_x else None
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     mean = rstd = None
     if save_stats:
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    check(lib.bf_add_layernorm_fwd(_ptr(x), _ptr(delta), dtype_code(delta), _ptr(gamma), _ptr(beta), _ptr(xo), _ptr(y), dtype_code(y),
-                                   _ptr(mean), _ptr(rstd), rows, cols, eps, _stream()), "bf_add_layernorm_fwd")
+    check(lib.bf_add2_layernorm_fwd(_ptr(x), _ptr(delta), _ptr(delta2), dtype_code(delta), _ptr(gamma), _ptr(beta), _ptr(xo),
+                                    _ptr(y), dtype_code(y), _ptr(mean), _ptr(rstd), rows, cols, eps, _stream()),
+          "bf_add2_layernorm_fwd")
     return y, mean, rstd, xo
 
 

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 8
+#define BF_ABI_VERSION 9
 
 enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
@@ -83,6 +83,17 @@ int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, const float
 int bf_add_layernorm_fwd(const float* x, const void* delta, int delta_dtype, const float* gamma, const float* beta,
                          float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows, int cols,
                          float eps, bf_stream_t stream);
+
+/* The same with a SECOND branch and an optional x_out (ABI 9): x_sum = (x + delta) + delta2 ; y = LN(x_sum) ; x_out = x_sum
+ * when x_out is not NULL.  For a FROZEN tower (no backward reads the stream between the two branches of a block,
+ * models/clip/model.py:215-219) the pass after the attention branch then only produces ln_2's output (x_out = NULL:
+ * 8 bytes per element instead of 12) and the pass after the MLP adds both branches to the block's input at once
+ * (delta2 = the MLP's output: 14 bytes per element instead of 12): 22 instead of 24 per block, the fp32 stream written
+ * once.  The sum is taken in the order the two separate passes take it (same bits).  delta2 may be NULL (= the entry
+ * point above). */
+int bf_add2_layernorm_fwd(const float* x, const void* delta, const void* delta2, int delta_dtype, const float* gamma,
+                          const float* beta, float* x_out, void* y, int y_dtype, float* mean, float* rstd, int rows,
+                          int cols, float eps, bf_stream_t stream);
 
 /* Backward of the above fused with the residual branch:
  *   dx = (dres ? dres : 0) + dLN(dy)          fp32 [rows, cols]

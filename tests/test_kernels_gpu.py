@@ -1213,3 +1213,33 @@ def test_add_layernorm_fwd(ops, gpu, rows, cols, out_dtype):
     out = torch.empty_like(x2)
     y2, _, _, xo2 = ops.add_layernorm_fwd(x2, delta.to(gpu), w.to(gpu), b.to(gpu), out_dtype, x_out=out)
     assert xo2 is out and torch.equal(x2.cpu(), x) and torch.equal(out, xd) and torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("rows,cols", [(197 * 3 + 1, 768), (77 * 2, 512), (9, 1024)])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_add_layernorm_fwd_lazy_stream_is_the_two_pass_form(ops, gpu, rows, cols, out_dtype):
+    """The frozen towers write their residual stream once per block (bf_add2_layernorm_fwd): a pass that only produces
+    LN(x + a) and a pass that adds both branches, (x + a) + m.  Same BITS as the two read-modify-write passes
+    (clip/model.py:215-219: x = x + attn; x = x + mlp)."""
+    g = torch.Generator().manual_seed(7 * rows + cols)
+    ddt = out_dtype if out_dtype in HALF else torch.bfloat16
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.5).to(gpu)
+    a = (torch.randn(rows, cols, generator=g) * 0.7).to(ddt).to(gpu)
+    m = (torch.randn(rows, cols, generator=g) * 0.9).to(ddt).to(gpu)
+    w2, b2 = (1 + 0.2 * torch.randn(cols, generator=g)).to(gpu), (0.2 * torch.randn(cols, generator=g)).to(gpu)
+    w1, b1 = (1 + 0.2 * torch.randn(cols, generator=g)).to(gpu), (0.2 * torch.randn(cols, generator=g)).to(gpu)
+    # two passes, the stream updated in place each time
+    xt = x.clone()
+    h2_want, _, _, _ = ops.add_layernorm_fwd(xt, a, w2, b2, out_dtype)
+    h1_want, mean_want, rstd_want, _ = ops.add_layernorm_fwd(xt, m, w1, b1, out_dtype, save_stats=True)
+    # lazy: the first pass leaves the stream alone, the second adds both branches
+    xl = x.clone()
+    h2, _, _, xo = ops.add_layernorm_fwd(xl, a, w2, b2, out_dtype, write_x=False)
+    assert xo is None and torch.equal(xl, x) and torch.equal(h2, h2_want)
+    h1, mean, rstd, xo = ops.add_layernorm_fwd(xl, a, w1, b1, out_dtype, delta2=m, save_stats=True)
+    assert xo is xl and torch.equal(xl, xt) and torch.equal(h1, h1_want)
+    assert torch.equal(mean, mean_want) and torch.equal(rstd, rstd_want)
+    # and without a stream at all (the tower's last block)
+    xn = x.clone()
+    y, _, _, xo = ops.add_layernorm_fwd(xn, a, w1, b1, out_dtype, delta2=m, write_x=False)
+    assert xo is None and torch.equal(xn, x) and torch.equal(y, h1_want)

@@ -19,7 +19,7 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(3407)
 cfg = dict(name="rgb_clip", image_size=224, is_bimanual=False, requires_graph=False, text_encoder="ViT-B/16",
            patch_size=16, depth=8, heads=16, mlp_ratio=4, dropout=0.0, text_dropout=0.0, rgb_dropout=0.0,
-           pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype="bf16")
+           pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer", dtype=os.environ.get("PROBE_DTYPE", "fp16"))
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     model = Models.get_by_name(cfg, device=dev).to(dev)
