@@ -2220,7 +2220,7 @@ struct Fused32P {
 template <typename HT>
 __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kernel(
     const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout, const float* __restrict__ lse,
-    HT* __restrict__ dqkv, int L, int H, float scale, int n_items) {
+    HT* __restrict__ dqkv, int L, int H, float scale, int n_items, int role_map) {
     constexpr int D = 32, KS = 2, ROW = Fused32P::ROW, BLK = Fused32P::BLK, DO_OFF = Fused32P::DO_OFF;
     constexpr int NT = Fused32P::NWAVES * 64;
     using RI = ResImg<32>;
@@ -2236,7 +2236,13 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
     char* ds_img = (char*)(cst + 4 * Lp);                  // 3 buffers x nw key blocks: dS^T [key][query], 64-byte rows, 8-byte chunks swizzled
 
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // ROLE of this wave (w: 0 - 8 key blocks, 9 the dQ sum, 10 - 11 loaders).  Waves p and p + 4 of a workgroup share a SIMD
+    // (tools/micro/pipe_overlap.hip), so with role = wave id the summing wave -- the longest role of a step, 0.83 us against
+    // the key waves' 0.58 (profiles/r05_attn_bwd_fused32p_probe.txt) -- sat on SIMD 1 beside TWO key waves, and every
+    // barrier waited for it.  role_map = 1 (round 5, second session) gives SIMD 1 to the three SUPPORT waves (physical
+    // waves 1, 5, 9: sum, loader, loader) and three key waves to each of the other SIMDs.
+    const int wp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int w = !role_map ? wp : ((wp & 3) == 1 ? 9 + (wp >> 2) : (wp >> 2) * 3 + ((wp & 3) == 0 ? 0 : (wp & 3) - 1));
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const float inv_scale = 1.0f / scale;
@@ -2581,7 +2587,7 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
         // entry (the requests would be waited for one step after they are made), and asm loads hidden from its wait-count pass
         // were copied between registers before they had landed.  Straight-line code gets exact counts.
         __builtin_amdgcn_s_setprio(3);
-        const int lt = (int)threadIdx.x - 10 * 64, lrow = lt >> 2, lc = lt & 3;     // (row, chunk) of a 32-row block
+        const int lt = (w - 10) * 64 + lane, lrow = lt >> 2, lc = lt & 3;           // (row, chunk) of a 32-row block
         struct LSet { img_u32x4 q[1], d[1], o[1], k[1], vv[1]; float ls[1]; };
         int cur = 0;
         for (;;) {
@@ -3855,7 +3861,7 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         }                                                                                                \
         hipLaunchKernelGGL((attn_bwd_fused32p_kernel<HT>), dim3(grid_p), dim3(Fused32P::NWAVES * 64), lds_p, s, \
                            (const HT*)qkv, (const HT*)out, (const HT*)dout, lse, (HT*)dqkv, seq, heads, scale, \
-                           batch * heads);                                                               \
+                           batch * heads, bf_tuning().attn_bwd_fused_p_map);                             \
     } while (0)
                 if (f16) BWD_FUSED_P(f16_t); else BWD_FUSED_P(bf16_t);
 #undef BWD_FUSED_P

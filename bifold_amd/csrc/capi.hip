@@ -72,6 +72,7 @@ BfTuning& bf_tuning() {
         t.attn_bwd_wpb_kv = env_int("BIFOLD_ATTN_BWD_WPB_KV", 4); if (t.attn_bwd_wpb_kv < 1) t.attn_bwd_wpb_kv = 1;
         t.attn_bwd_fused = env_int("BIFOLD_ATTN_BWD_FUSED", 1);
         t.attn_bwd_fused_p = env_int("BIFOLD_ATTN_BWD_FUSED_P", 1);
+        t.attn_bwd_fused_p_map = env_int("BIFOLD_ATTN_BWD_FUSED_P_MAP", 1);
         t.attn_bwd_onepass = env_int("BIFOLD_ATTN_BWD_ONEPASS", 0);
         t.attn_onepass_min_q32 = env_int("BIFOLD_ATTN_ONEPASS_MIN_Q32", 17);
         t.attn_lds_pad = env_int("BIFOLD_ATTN_LDS_PAD", 0); if (t.attn_lds_pad < 0) t.attn_lds_pad = 0;

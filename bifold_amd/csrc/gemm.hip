@@ -1826,23 +1826,29 @@ __device__ __forceinline__ void p8_body(
                     const uint4 raw = apre[C * 4 + t];
                     const typename H16<H>::x8 a8 = *(const typename H16<H>::x8*)&raw;
                     typename H16<H>::x8 o8;
+                    float p8[8];                           // the products in fp32: what the bias-gradient sums add
                     if (ep.act == BF_ACT_MUL_AUX) {        // aux already IS gelu'(pre) (forward: ..._SAVEGRAD)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            o8[e] = (H)(q0[e] * ep.alpha * (float)a8[e]);
-                            o8[4 + e] = (H)(q1[e] * ep.alpha * (float)a8[4 + e]);
+                            p8[e] = q0[e] * ep.alpha * (float)a8[e];
+                            p8[4 + e] = q1[e] * ep.alpha * (float)a8[4 + e];
                         }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            o8[e] = (H)(q0[e] * ep.alpha * AM::erf_grad((float)a8[e]));
-                            o8[4 + e] = (H)(q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]));
+                            p8[e] = q0[e] * ep.alpha * AM::erf_grad((float)a8[e]);
+                            p8[4 + e] = q1[e] * ep.alpha * AM::erf_grad((float)a8[4 + e]);
                         }
                     }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o8[e] = (H)p8[e];
                     if (m < ep.m && n < ep.n) {
                         store16((H*)ep.c + (size_t)m * ep.ldc + n, *(const uint4*)&o8, ep.store_policy & 4);
+                        // Column sums of the fp32 products (round 5; until then of the STORED 16-bit values, converted
+                        // back: eight conversions per row segment, half of what the sums cost this epilogue).  The bias
+                        // gradient is the sum of the unrounded terms -- what an fp32 reduction of the GEMM's result gives.
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) cs[e] += (float)o8[e];      // sums of the STORED values
+                        for (int e = 0; e < 8; ++e) cs[e] += p8[e];
                     }
                 }
                 asm volatile("" ::: "memory");

@@ -41,6 +41,7 @@ struct BfTuning {
     int attn_bwd_wpb_kv;          // BIFOLD_ATTN_BWD_WPB_KV  ... of its kv kernel (4)
     int attn_bwd_fused;           // BIFOLD_ATTN_BWD_FUSED   one-pass backward for d = 32 without a mask, <= 288 tokens (1)
     int attn_bwd_fused_p;         // BIFOLD_ATTN_BWD_FUSED_P 0 / 1 / 2: the persistent twelve-wave form of that kernel never / from two items per CU / always (1)
+    int attn_bwd_fused_p_map;     // BIFOLD_ATTN_BWD_FUSED_P_MAP   1: that kernel's three support waves (dQ sum, two loaders) share ONE SIMD, three key waves on each of the others; 0: roles in wave order (1)
     int attn_bwd_onepass;         // BIFOLD_ATTN_BWD_ONEPASS 1: the one-pass backward for d = 48 / 64 without a causal mask (0: correct, and 10 - 20 % SLOWER than the streamed pair on every shape measured -- attention.hip)
     int attn_onepass_min_q32;     // BIFOLD_ATTN_ONEPASS_MIN_Q32   ... from this many 32-row blocks (17: sequences beyond the resident kernels)
     int attn_lds_pad;             // BIFOLD_ATTN_LDS_PAD     extra dynamic LDS bytes for the resident pair: occupancy experiments (0)

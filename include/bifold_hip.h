@@ -172,10 +172,11 @@ typedef struct bf_gemm_args {
     int split_k;             /* >1: K is split, fp32 partials go through workspace  */
     void* workspace;         /* split_k * m * n * 4 bytes when split_k > 1          */
     size_t workspace_bytes;
-    float* colsum_out;       /* optional fp32 [n]: column sums of the STORED c (the bias gradient of the layer
-                              * that produced c's upstream: d_bias = sum over rows of dY), overwritten.  Fused
-                              * into the epilogue where the kernel can (bf16 GELU-grad path), otherwise computed
-                              * by a bf_colsum launch after the GEMM; needs rows_in == 0 */
+    float* colsum_out;       /* optional fp32 [n]: column sums of c (the bias gradient of the layer that produced
+                              * c's upstream: d_bias = sum over rows of dY), overwritten.  Fused into the epilogue
+                              * where the kernel can (16-bit GELU-grad path: the fp32 values are summed before they
+                              * are rounded for the store), otherwise the stored c is summed by a bf_colsum launch
+                              * after the GEMM; needs rows_in == 0 */
 } bf_gemm_args;
 
 int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
