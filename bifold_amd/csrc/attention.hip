@@ -2217,6 +2217,12 @@ struct Fused32P {
         return lp * 2 * ROW + 3 * lp * ROW + 2 * (2 * lp * 4) + 3 * (size_t)nw * 2048;
     }
 };
+// Workgroup barrier that waits for this wave's LDS traffic ONLY.  __syncthreads() is a workgroup fence: it also drains
+// vmcnt(0), i.e. every global store the wave has issued -- the summing wave's dQ rows of the step before, the key waves'
+// dK / dV rows at the end of an item -- and every other wave of the workgroup then stands at the barrier for the length
+// of a store's round trip although nothing in the workgroup reads those stores.  (The loaders keep __syncthreads: their
+// global loads are inline assembly the compiler does not count, their deposits are LDS writes.)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <typename HT>
 __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kernel(
     const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout, const float* __restrict__ lse,
@@ -2254,7 +2260,7 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
     if (v >= n_items) return;
 #ifdef ATTN_PROBE   // stamps of one wave per role (100 MHz wall clock): tools/attn_probe_fusedp.py
     const bool pr_on = lane == 0 && blockIdx.x < ATTN_PROBE_WGS;
-    unsigned long long* pr = attn_probe + (size_t)blockIdx.x * 8;
+    unsigned long long* pr = attn_probe + (size_t)blockIdx.x * 16;     // 16 slots per workgroup (<= 256 workgroups)
     unsigned long long pr_a = 0, pr_b = 0, pr_c = 0;
     if (pr_on && w == 0) pr[0] = wall_clock64();
 #endif
@@ -2401,7 +2407,7 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
 #ifdef ATTN_PROBE
                 const unsigned long long pr_t1 = wall_clock64();
 #endif
-                __syncthreads();
+                lds_barrier();
 #ifdef ATTN_PROBE
                 pr_a += pr_t1 - pr_t0; pr_b += wall_clock64() - pr_t1;
 #endif
@@ -2423,7 +2429,7 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
                 }
             }
             if (!has_next) break;
-            __syncthreads();                                // between items: the next K image, Q / dO blocks and constants are in place
+            lds_barrier();                                // between items: the next K image, Q / dO blocks and constants are in place
             cur ^= 1;
             v = vn;
 #pragma unroll
@@ -2437,6 +2443,7 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
         }
 #ifdef ATTN_PROBE
         if (pr_on && w == 0) { pr[2] = pr_a; pr[3] = pr_b; pr[7] = pr_c; pr[4] = wall_clock64(); }
+        if (pr_on && w == 8) { pr[11] = pr_a; pr[12] = pr_b; }
 #endif
     } else if (w == 9) {
         // =========================== wave 9: dQ of query block j while the key waves are in step j + 1 ==========================
@@ -2562,9 +2569,13 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
 #endif
                 if (j >= 1) { half1(j - 1); half2(j - 1); }
 #ifdef ATTN_PROBE
-                pr_a += wall_clock64() - pr_t0;
+                const unsigned long long pr_t1 = wall_clock64();
+                pr_a += pr_t1 - pr_t0;
 #endif
-                __syncthreads();
+                lds_barrier();
+#ifdef ATTN_PROBE
+                pr_c += wall_clock64() - pr_t1;
+#endif
             }
 #ifdef ATTN_PROBE
             const unsigned long long pr_t3 = wall_clock64();
@@ -2574,12 +2585,12 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
             pr_b += wall_clock64() - pr_t3;
 #endif
             if (!has_next) break;
-            __syncthreads();
+            lds_barrier();
             cur ^= 1;
             v = vn;
         }
 #ifdef ATTN_PROBE
-        if (pr_on) { pr[5] = pr_a; pr[6] = pr_b; }
+        if (pr_on) { pr[5] = pr_a; pr[6] = pr_b; pr[8] = pr_c; }
 #endif
     } else if (w >= 10) {
         // =========================== waves 10, 11: the next item's rows under this item's steps ================================
@@ -2648,19 +2659,28 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
             // a branch makes the registers of a load in flight the operands of a merge, and the compiler COPIES them right
             // behind the load (tools/check_async_loads.py looks for exactly that in the ISA).  Without a next item the
             // requests re-read this item's rows and nothing is deposited.
+            // (Three sets in flight -- a block requested three steps before its deposit -- measured: 216 - 221 us against
+            // 218 with two: the loader does not hold the barriers up.  profiles/r05_attn_bwd_fused32p_probe.txt: it stands at
+            // them for 590 of a step's 970 ns.)
             LSet set0, set1;
             request(set0, 0);
             // step j: block j - 1 (requested in step j - 2) into its slot, block j + 1 requested; the sets alternate
 #ifdef ATTN_PROBE
             const unsigned long long pr_t0 = wall_clock64();
 #endif
+#ifdef ATTN_PROBE
+#define BF_LOADER_SYNC { const unsigned long long pt_ = wall_clock64(); __syncthreads(); pr_b += wall_clock64() - pt_; }
+#else
+#define BF_LOADER_SYNC __syncthreads();
+#endif
 #define BF_LOADER_STEP(J, ST)                                        \
             if ((J) >= 1) deposit(ST, (J) - 1, true, has_next);      \
             if ((J) + 1 < Fused32P::NKW) request(ST, (J) + 1);       \
-            __syncthreads();
+            BF_LOADER_SYNC
             BF_LOADER_STEP(0, set1) BF_LOADER_STEP(1, set0) BF_LOADER_STEP(2, set1) BF_LOADER_STEP(3, set0) BF_LOADER_STEP(4, set1)
             BF_LOADER_STEP(5, set0) BF_LOADER_STEP(6, set1) BF_LOADER_STEP(7, set0) BF_LOADER_STEP(8, set1)
 #undef BF_LOADER_STEP
+#undef BF_LOADER_SYNC
             deposit(set0, Fused32P::NKW - 1, false, has_next);
 #ifdef ATTN_PROBE
             pr_a += wall_clock64() - pr_t0;
@@ -2671,7 +2691,7 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
             v = vn;
         }
 #ifdef ATTN_PROBE
-        if (pr_on && w == 10) pr[1] = pr_a;
+        if (pr_on && w == 10) { pr[1] = pr_a; pr[10] = pr_b; }
 #endif
     } else {
         // key waves beyond the sequence's blocks (nw < 9): only the barriers
