@@ -622,18 +622,22 @@ print("FUSED-P-OK")
 """
 
 
-def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path):
+@pytest.mark.parametrize("role_map", ["1", "0"])
+def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path, role_map):
     """attn_bwd_fused32p_kernel (round 5: one twelve-wave workgroup per CU walking (batch, head) items; the default from two
-    items per CU, forced here with BIFOLD_ATTN_BWD_FUSED_P=2, hence the child process): sequences of 3 - 9 key blocks (idle
-    key waves below 9), a last block of 1 - 32 live keys, fewer items than CUs, and 1 200 items so that every workgroup walks
-    four or five of them through the rolling refill of its images -- against the fp64 formula, twice (bit-reproducible)."""
+    items per CU, forced here with BIFOLD_ATTN_BWD_FUSED_P=2, hence the child process): sequences of 3 - 9 key blocks (the
+    nine-block ones take this kernel), a last block of 1 - 32 live keys, fewer items than CUs, and 1 200 items so that every
+    workgroup walks four or five of them through the rolling refill of its images -- against the fp64 formula, twice
+    (bit-reproducible).  Both assignments of roles to waves: the support waves on one SIMD (`role_map` 1, the default) and
+    roles in wave order (0)."""
     import os
     import subprocess
     import sys
     script = tmp_path / "fp.py"
     script.write_text(FUSED_P_SCRIPT)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, BIFOLD_ATTN_BWD_FUSED_P="2"),
+    r = subprocess.run([sys.executable, str(script), root],
+                       env=dict(os.environ, BIFOLD_ATTN_BWD_FUSED_P="2", BIFOLD_ATTN_BWD_FUSED_P_MAP=role_map),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FUSED-P-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
