@@ -12,6 +12,7 @@
 #include "common.h"
 #include <type_traits>
 #include "tuning.h"
+#include "attn_common.h"
 
 #include <stdlib.h>
 
@@ -21,25 +22,11 @@
 #endif
 #define IMG_U 5                               // resident kernels: image-load requests a thread keeps in flight (x2 operands)
 
-// Workgroup -> (batch, head).  Consecutive workgroup ids go to consecutive XCDs (8 private L2s).  With
-// d = 32 a head's slice of a token row is 64 bytes, half a 128-byte line: the other half belongs to the
-// neighbouring head, whose workgroup runs on ANOTHER XCD and fetches the same line from HBM again
-// (PMC: 432 MB read per forward launch for 216 MB of Q / K / V, 885 - 1 015 MB per backward kernel for
-// 360).  Pairing heads 2p and 2p+1 on one XCD, in adjacent dispatch slots, lets the second hit in L2.
-// d = 48: four heads span exactly three lines (384 bytes), so groups of four.  d = 64: a head is a line.
 // Forward kernels: the reference point of the online softmax without a row maximum per block (attn_fwd_res_kernel).  Measured
 // per head width (profiles/r05_attention_forward_diet.txt): it pays at d = 48 (2 373 x 48 masked: 604 - 620 -> 578 us; 262 x 48:
 // 31.2 -> 29.5 us) and COSTS at d = 32 and d = 64 (the branch between the exponentials and the P V products splits the block
 // the compiler schedules across, and the second copy of the score code takes 8 - 22 registers: a workgroup per CU at 576 x 64).
 template <int D> struct FwdNoMax { static constexpr bool value = (D == 48); };
-
-template <int D>
-__device__ __forceinline__ int paired_bh(int i, int n) {
-    constexpr int G = D == 32 ? 2 : (D == 48 ? 4 : 1);
-    if (G == 1 || (n % (8 * G))) return i;
-    const int xcd = i & 7, s = i >> 3, t = s % G;
-    return ((s / G) * 8 + xcd) * G + t;
-}
 
 // LDS images of the resident split pair at d = 32: 64-byte rows WITHOUT the 16-byte pad (36.9 KB instead of 46 KB per
 // (batch, head) at 275 tokens: four workgroups per CU instead of three), the 16-byte chunk index XORed with bits 2-3 of
@@ -55,10 +42,6 @@ template <int D> struct ResImg {
         return SWZ ? row * rowb + ((c ^ ((row >> 2) & 3)) << 4) + in : row * rowb + (c << 4) + in;
     }
 };
-
-__device__ __forceinline__ size_t qkv_off(int b, int i, int which, int h, int L, int H, int D) {
-    return (((size_t)b * L + i) * 3 + which) * (size_t)H * D + (size_t)h * D;
-}
 
 // Image load of the resident kernels: `total` (row, 16-byte chunk) items of TWO operands, item idx = row * CH + chunk,
 // thread t takes items t, t + nthreads, ...  All requests of a thread are in flight before its first LDS write (as a
@@ -539,17 +522,6 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
         if (lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
     }
 }
-
-template <typename HT>
-__device__ __forceinline__ typename H16<HT>::x8 tr_pair(const char* p0, const char* p1) {
-    const typename H16<HT>::x4 lo = lds_read_tr16<HT>(p0);
-    const typename H16<HT>::x4 hi = lds_read_tr16<HT>(p1);
-    typename H16<HT>::x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
 
 // =====================================================================================
 //        bf16 MFMA forward, K / V of the whole (batch, head) resident in LDS
@@ -3734,6 +3706,12 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
 #undef FWD_RES
 #undef FWD_RES2
 #undef FWD_RES3
+            BF_CHECK_LAUNCH("bf_attention_fwd");
+            return BF_OK;
+        }
+        // beyond LDS: the software-pipelined kernel (attention_pipe.hip) for d = 48 / 64 without a causal mask
+        if (bf_tuning().attn_fwd_pipe && !bf_tuning().attn_fwd_tiled &&
+            bf_attn_fwd_pipe_launch(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, cdt, s) == BF_OK) {
             BF_CHECK_LAUNCH("bf_attention_fwd");
             return BF_OK;
         }

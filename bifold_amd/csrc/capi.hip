@@ -61,6 +61,7 @@ BfTuning& bf_tuning() {
         t.dw_grouped = env_int("BIFOLD_DW_GROUPED", 1);
         t.attn_fwd_tiled = env_int("BIFOLD_ATTN_FWD_TILED", 0) ? 1 : 0;
         t.attn_fwd_pd = env_int("BIFOLD_ATTN_FWD_PD", 0);
+        t.attn_fwd_pipe = env_int("BIFOLD_ATTN_FWD_PIPE", 1);
         t.attn_nt = env_int("BIFOLD_ATTN_NT", 0);
         t.attn_fwd_kt32 = env_int("BIFOLD_ATTN_FWD_KT32", 2);
         t.attn_bwd_nw = env_int("BIFOLD_ATTN_BWD_NW", 0);

@@ -29,6 +29,7 @@ struct BfTuning {
     int dw_grouped;               // BIFOLD_DW_GROUPED       grouped weight-gradient launch (1)
     // ---- attention (attention.hip)
     int attn_fwd_tiled;           // BIFOLD_ATTN_FWD_TILED   1: always the tiled forward (0)
+    int attn_fwd_pipe;            // BIFOLD_ATTN_FWD_PIPE    software-pipelined forward for sequences beyond LDS, d = 48 / 64, no causal mask (attention_pipe.hip) (1)
     int attn_fwd_pd;              // BIFOLD_ATTN_FWD_PD      persistent double-buffered d = 32 forward (0: measured no faster than the resident kernel)
     int attn_nt;                  // BIFOLD_ATTN_NT          non-temporal QKV loads in the resident forward (0: they paid while the next GEMM's epilogue re-read an fp32 residual tile -- round 3 -- and cost 0.7 % of the step since it does not, round 4)
     int attn_fwd_kt32;            // BIFOLD_ATTN_FWD_KT32    0 / 1 / 2: 64-key tiles / 32-key steps / by the last tile's fill (2)

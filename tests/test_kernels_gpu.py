@@ -429,7 +429,8 @@ def test_attention_fwd_many_items_lazy_rescale(ops, gpu, half, B, Lq, H, D):
 
 @pytest.mark.parametrize("half", HALF)
 @pytest.mark.parametrize("top", [300.0, 1500.0])
-@pytest.mark.parametrize("B,Lq,H,D", [(3, 275, 2, 32), (2, 197, 2, 64), (1, 700, 2, 48), (2, 77, 2, 64)])
+@pytest.mark.parametrize("B,Lq,H,D", [(3, 275, 2, 32), (2, 197, 2, 64), (1, 700, 2, 48), (2, 77, 2, 64), (1, 700, 2, 64),
+                                       (2, 262, 2, 48), (1, 1100, 1, 48)])
 def test_attention_fwd_rows_that_keep_rising(ops, gpu, half, top, B, Lq, H, D):
     """Round 5: the forward kernels take a block's probabilities against the reference point as it stands and compute a
     row maximum only in a wave's first block or when a lane's partial row sum reaches 2^14.  Here every row's scores RISE
@@ -447,6 +448,32 @@ def test_attention_fwd_rows_that_keep_rising(ops, gpu, half, top, B, Lq, H, D):
     assert torch.isfinite(out.float()).all()
     assert rel_err(out.float(), ref_o) < 1.5e-2
     assert rel_err(lse, ref_lse) < 1e-5
+
+
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("B,Lq,H,D,mode", [(2, 576, 3, 64, 0), (1, 577, 2, 64, 0), (2, 1050, 2, 48, 2), (1, 2950, 2, 48, 2),
+                                            (1, 640, 1, 64, 2), (1, 705, 2, 48, 0), (3, 513, 1, 48, 0), (1, 1089, 1, 64, 0)])
+def test_attention_fwd_pipelined_long_sequences(ops, gpu, half, B, Lq, H, D, mode):
+    """attn_fwd_pipe_kernel (round 6, attention_pipe.hip): sequences beyond LDS at d = 48 / 64 -- workgroups of three and of
+    four waves, key tails of 0 / 1 / 6 / 26 / 33 keys, waves with one live query block or none, the query-row mask with
+    whole masked frames, lone masked rows and a masked first row -- output and log-sum-exp against fp64."""
+    g = torch.Generator().manual_seed(B * Lq + D)
+    qkv = round_to(torch.randn(B * Lq, 3 * H * D, generator=g) * 1.3, half)
+    row_mask = None
+    if mode == 2:
+        row_mask = (torch.rand(B, Lq, generator=g) > 0.2).int()
+        row_mask[:, 0] = 0
+        row_mask[:, 65:65 + 300] = 0
+        row_mask[0, Lq - 70:] = 0
+    ref_o, ref_lse = ref_attention(qkv, B, Lq, H, D, D ** -0.5, mode, row_mask)
+    out, lse = ops.attention_fwd(qkv.to(gpu).to(half), B, Lq, H, D, D ** -0.5, mode,
+                                 None if row_mask is None else row_mask.to(gpu), need_lse=True)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out.float(), ref_o) < (2 ** -7 if half == torch.bfloat16 else 2 ** -9)
+    assert rel_err(lse, ref_lse) < 1e-5
+    if mode == 2:                                            # unmasked rows alone (the masked rows' lse is -1e5 + ln L)
+        live = (row_mask == 1)[:, None, :].expand(B, H, Lq)
+        assert float((lse.cpu()[live] - ref_lse[live].float()).abs().max()) < 2e-4
 
 
 def ref_attention(qkv, B, Lq, H, D, scale, mode, row_mask):

@@ -23,8 +23,12 @@ def main():
     ap.add_argument("--only", default="", help="comma-separated shape names")
     ap.add_argument("--family", default="clip", choices=["clip", "siglip"],
                     help="siglip: the long sequences of siglip_sequential at 384 px (B = 16, T = 3)")
+    ap.add_argument("--shape", action="append", default=[],
+                    help="name,B,L,H,D,mode -- a custom shape (repeatable; replaces the family's list)")
     args = ap.parse_args()
     shapes = SHAPES if args.family == "clip" else SIGLIP_SHAPES
+    if args.shape:
+        shapes = [(f[0],) + tuple(int(x) for x in f[1:]) for f in (sh.split(",") for sh in args.shape)]
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     hdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
@@ -36,10 +40,11 @@ def main():
         rm = None
         if mode == 2:       # siglip_sequential's mask: [text | T context frames of 577 rows | current frame], the
             rm = torch.ones(B, L, dtype=torch.int32, device=dev)      # first k ~ U{0..T} context frames valid
-            t = max((L - 65 - 577) // 577, 0)
+            t = max((L - 65 - 577) // 577, 0) if L > 1300 else max((L - 65 - 197) // 197, 0)
             k = torch.randint(0, t + 1, (B,), generator=torch.Generator().manual_seed(1))
             for bi in range(B):
-                rm[bi, 65 + int(k[bi]) * 577: 65 + t * 577] = 0
+                fr = 577 if L > 1300 else 197
+                rm[bi, 65 + int(k[bi]) * fr: 65 + t * fr] = 0
         out, lse = ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, rm, need_lse=True)
         fns = {"fwd": lambda: ops.attention_fwd(qkv, B, L, H, D, D ** -0.5, mode, rm, need_lse=True)}
         if args.bwd:
