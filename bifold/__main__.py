@@ -58,13 +58,6 @@ class SyntheticLoader:
         self.strategy = str(cfg.processor.get("strategy", "gmm"))
         self.siglip = model_name.startswith("siglip")
         self.context = int(model_cfg.get("context_length", 0) or 0) if model_name == "siglip_sequential" else 0
-        # fault injection for the fp16 guard's tests (global step indices, counted over epochs): a poisoned batch carries
-        # one +inf target pixel -> a non-finite loss gradient -> the step must be dropped on the device; a skipped batch
-        # is generated (the random stream advances) but not served -- the clean run the poisoned one must equal.
-        # fault injection for the fp16 guard's tests: keys that only exist when a test adds them (`+train_dataset.poison_steps=[4]`)
-        self.poison_steps = {int(x) for x in (dataset_cfg.get("poison_steps", None) or [])}
-        self.skip_steps = {int(x) for x in (dataset_cfg.get("skip_steps", None) or [])}
-        self.served = 0
 
     def __len__(self):
         return self.steps
@@ -95,11 +88,6 @@ class SyntheticLoader:
             pixels = {n: torch.randint(1, s, (b, 2), generator=g, device=dev).float() for n in names}
             sample.update(pixels)
             sample.update(heatmap_targets(pixels, s, self.sigma, self.strategy))
-            step, self.served = self.served, self.served + 1
-            if step in self.skip_steps:
-                continue
-            if step in self.poison_steps:
-                sample[f"{names[0]}_heatmap"][0, 0, 0] = float("inf")
             yield sample
 
 
@@ -303,6 +291,8 @@ class Trainer:
             elif hasattr(getattr(dl, "sampler", None), "set_epoch"):
                 dl.sampler.set_epoch(epoch)
         total, counted, t0 = None, None, time.time()
+        masking = getattr(self.model, "_grad_scaler", None) is not None or \
+            getattr(self.model, "compute_dtype", None) == torch.float16
         for i, sample in enumerate(dl):
             sample = self.move_sample_to_device(sample)
             output = self.model(sample)
@@ -322,33 +312,50 @@ class Trainer:
             if self.writer:
                 self._log_step(epoch, loss, intermediate_losses)
             # the reference calls loss.item() every step (a device sync); keep a device-side running sum
-            # instead and read it once per epoch
-            # A non-finite loss (fp16 mode: the batch whose step the device-side guard drops) must not turn the epoch's
-            # mean into inf / NaN while the training state is intact: it is left out of the sum and of the count, on the
-            # device (advisor finding, round 4).  The scheduler still advances on a dropped step, like
+            # instead and read it once per epoch.
+            # fp16 mode only: the batch whose backward overflowed binary16 has its step DROPPED by the device-side guard
+            # (training state intact), so its non-finite loss is left out of the sum and of the count, on the device --
+            # but only that many: the count of excluded losses is held against the count of dropped steps below, and
+            # without a scaler (bf16 / fp32) nothing is masked: a diverged run shows NaN like the reference's
+            # loss.item() mean does (advisor finding, round 5).  The scheduler still advances on a dropped step, like
             # torch.cuda.amp.GradScaler users' schedulers do unless they check the scale: the LR trace is a function of
             # the step index, not of how many steps were applied.
             lv = loss.detach().float()
-            fin = torch.isfinite(lv)
-            lv = torch.where(fin, lv, torch.zeros_like(lv))
+            if masking:
+                fin = torch.isfinite(lv)
+                lv = torch.where(fin, lv, torch.zeros_like(lv))
+                counted = fin.float() if counted is None else counted + fin.float()
             total = lv if total is None else total + lv
-            counted = fin.float() if counted is None else counted + fin.float()
         n = len(dl)
-        if self.rank == 0:
-            mean = float(total.item()) / max(float(counted.item()), 1.0)
-            dt = time.time() - t0
-            print(f"epoch {epoch}: mean loss {mean:.6f}  {n * self.cfg.batch_size * self.world / dt:.1f} samples/s "
-                  f"lr {self.optimizer.param_groups[0]['lr']:.3e}")
-        tower = getattr(self.model, "clip_encoder", None) or getattr(self.model, "siglip_model", None)
-        if tower is not None:
-            tower.check_token_ids()
         scaler = getattr(self.model, "_grad_scaler", None)        # fp16 mode: guarded step (models/gradscale.py)
+        seen, dropped = None, 0
         if scaler is not None:
-            # one device read per epoch, like the loss above.  A backward that overflowed binary16 was DROPPED on the
+            # one device read per epoch, like the loss.  A backward that overflowed binary16 was DROPPED on the
             # device (parameters and moments untouched, loss scale halved) -- nothing to repair here; the counters are
             # identical on every rank (the flag is MAX-reduced), so all ranks report / raise together.
             seen = scaler.read()
             dropped = scaler.overflowed()
+        excluded = 0
+        if total is None:
+            mean = float("nan")
+        elif masking:
+            kept = float(counted.item())
+            excluded = int(round(n - kept))
+            # more non-finite losses than dropped steps: some step with a non-finite loss WAS applied -- the run
+            # diverged, and the mean says so
+            mean = float(total.item()) / kept if (kept > 0 and excluded <= dropped) else float("nan")
+        else:
+            mean = float(total.item()) / max(n, 1)
+        self.last_epoch_stats = dict(mean_loss=mean, excluded_losses=excluded, dropped_steps=int(dropped))
+        if self.rank == 0:
+            dt = time.time() - t0
+            note = f"  ({excluded} non-finite losses excluded)" if excluded else ""
+            print(f"epoch {epoch}: mean loss {mean:.6f}{note}  {n * self.cfg.batch_size * self.world / dt:.1f} samples/s "
+                  f"lr {self.optimizer.param_groups[0]['lr']:.3e}")
+        tower = getattr(self.model, "clip_encoder", None) or getattr(self.model, "siglip_model", None)
+        if tower is not None:
+            tower.check_token_ids()
+        if scaler is not None:
             if dropped and self.rank == 0:
                 print(f"epoch {epoch}: model.dtype=fp16 dropped {dropped} optimiser step(s) with non-finite gradients; "
                       f"loss scale now {seen['scale']:g}")

@@ -257,6 +257,26 @@ class GradSync:
         self.stats["steps"] += 1
         self.pending.clear()
 
+    def describe_plan(self) -> dict:
+        """What the first N > 1 record needs to explain itself: the collectives of one step in launch order (trigger =
+        the fusion layer whose completed backward releases the slice, -1 = the end of the backward), their sizes, the
+        backend and the RCCL version the process group initialised."""
+        esz = self.grad.element_size()
+        order = sorted((k for k in self.plan), reverse=True)           # the backward walks the layers downwards
+        launches = [{"after_layer": int(k), "bytes": [int((b - a) * esz) for a, b in self.plan[k]]} for k in order]
+        if self.final:
+            launches.append({"after_layer": -1, "bytes": [int((b - a) * esz) for a, b in self.final]})
+        backend, version = None, None
+        if dist.is_initialized():
+            backend = dist.get_backend(self.group)
+            if backend == "nccl":
+                try:
+                    version = ".".join(str(x) for x in torch.cuda.nccl.version())
+                except Exception:                                          # a build without the binding: say so, do not fail
+                    version = "unknown"
+        return {"launches": launches, "coalesce_layers": self.coalesce, "backend": backend, "rccl_version": version,
+                "world": self.world, "overflow_flag": "int32 MAX-reduced behind the last bucket" if self.flag_getter else None}
+
     def reset_stats(self) -> None:
         self.stats = {"launches": 0, "bytes": 0, "steps": 0}
         self._wait_events.clear()
@@ -268,6 +288,6 @@ class GradSync:
         exposed = sum(a.elapsed_time(b) for a, b in self._wait_events) if self._wait_events else None
         return {"exposed_ms_per_step": None if exposed is None else round(exposed / steps, 4),
                 "buckets": round(self.stats["launches"] / steps, 2), "bytes": int(self.stats["bytes"] / steps),
-                "steps": steps,
+                "steps": steps, "plan": self.describe_plan(),
                 "note": "exposed = time the compute stream waits in GradSync.finish() for the side stream's collectives "
                         "(HIP events around the waits); buckets / bytes = all-reduce launches and gradient bytes per step"}

@@ -139,25 +139,56 @@ def test_trainer_default_fp16_mode_trains_and_survives_overflow(gpu, run_home, c
     assert tb.optimizer.state_dict()["state"] == {}                          # Adam's t is still 0
 
 
+class FaultyLoader:
+    """Fault injection for the fp16 guard's tests, wrapped around the Trainer's loader (global step indices, counted over
+    epochs): a poisoned batch carries one +inf target pixel -> a non-finite loss gradient -> the step must be dropped on
+    the device; a skipped batch is generated (the random stream advances) but not served -- the clean run the poisoned
+    one must equal.  Lives with the tests: the product's loader knows nothing about it."""
+
+    def __init__(self, inner, poison_steps=(), skip_steps=()):
+        self.inner, self.poison, self.skip, self.served = inner, set(poison_steps), set(skip_steps), 0
+
+    def __len__(self):
+        return len(self.inner)
+
+    def set_epoch(self, epoch):
+        self.inner.set_epoch(epoch)
+
+    def __iter__(self):
+        for sample in self.inner:
+            step, self.served = self.served, self.served + 1
+            if step in self.skip:
+                continue
+            if step in self.poison:
+                name = next(k for k in sample if k.endswith("_heatmap"))
+                sample[name][0, 0, 0] = float("inf")
+            yield sample
+
+
 def test_fp16_run_with_one_poisoned_batch_equals_the_clean_run_minus_that_step(gpu, run_home, capsys):
-    """One batch of a fp16 training run carries an inf target pixel (`+train_dataset.poison_steps`: a test-only key, not in the shipped config): its backward is
+    """One batch of a fp16 training run carries an inf target pixel (FaultyLoader above): its backward is
     non-finite, the device-side guard drops exactly that optimiser step and halves the loss scale, and the run ends
-    with finite parameters equal to those of the run that never saw the batch (`train_dataset.skip_steps`) -- same
-    weights, same Adam moments, same step count.  No host read happens inside the epoch."""
+    with finite parameters equal to those of the run that never saw the batch -- same weights, same Adam moments, same
+    step count.  No host read happens inside the epoch.  The epoch's mean loss leaves exactly that batch out and says so."""
     base = [o for o in OVERRIDES if not o.startswith(("model.dtype=", "epochs=", "gradient_clip=", "scheduler=",
                                                       "eval_epochs=", "save_epochs="))] + \
            ["epochs=1", "scheduler=none", "eval_epochs=null", "save_epochs=null", "train_dataset.length=96"]
-    tp, _ = _trainer(base + ["+train_dataset.poison_steps=[4]"])
+    tp, _ = _trainer(base)
+    tp.train_dataloader = FaultyLoader(tp.train_dataloader, poison_steps=[4])
     tp.prepare_train()
     tp.train_epoch(0)
     os.chdir(str(run_home))
-    tc, _ = _trainer(base + ["+train_dataset.skip_steps=[4]"])
+    tc, _ = _trainer(base)
+    tc.train_dataloader = FaultyLoader(tc.train_dataloader, skip_steps=[4])
     tc.prepare_train()
     tc.train_epoch(0)
     sp, sc = tp.model._grad_scaler.read(), tc.model._grad_scaler.read()
     assert sp["skipped"] == 1 and sp["nonfinite"] > 0 and sc["skipped"] == 0
     assert sp["scale"] == sc["scale"] / 2
-    assert "dropped 1 optimiser step" in capsys.readouterr().out
+    printed = capsys.readouterr().out
+    assert "dropped 1 optimiser step" in printed and "(1 non-finite losses excluded)" in printed
+    assert tp.last_epoch_stats["excluded_losses"] == 1 and tp.last_epoch_stats["dropped_steps"] == 1
+    assert np.isfinite(tp.last_epoch_stats["mean_loss"]) and tc.last_epoch_stats["excluded_losses"] == 0
     a, b = tp.optimizer.arena.flat, tc.optimizer.arena.flat
     assert torch.isfinite(a).all() and torch.isfinite(tp.optimizer.exp_avg).all() and torch.isfinite(tp.optimizer.exp_avg_sq).all()
     # the seven later steps ran at half the loss scale: a power of two, so only binary16's subnormal tail can differ
@@ -167,6 +198,21 @@ def test_fp16_run_with_one_poisoned_batch_equals_the_clean_run_minus_that_step(g
     assert tp.optimizer.step_count == n and tc.optimizer.step_count == n - 1
     assert tp.optimizer.state_dict()["state"][0]["step"].item() == n - 1      # a dropped step does not advance Adam's t
     assert tp.optimizer.state_dict()["bifold_grad_scaler"]["scale"] == sp["scale"]
+
+
+def test_a_non_finite_loss_without_a_dropped_step_shows_in_the_epoch_mean(gpu, run_home, capsys):
+    """bf16 has no scaler and no guarded step: a batch with a non-finite loss is APPLIED, so the epoch's mean must show
+    it (the reference's loss.item() mean would), not a finite number over the remaining batches (advisor, round 5)."""
+    base = [o for o in OVERRIDES if not o.startswith(("model.dtype=", "epochs=", "gradient_clip=", "scheduler=",
+                                                      "eval_epochs=", "save_epochs="))] + \
+           ["model.dtype=bf16", "epochs=1", "scheduler=none", "eval_epochs=null", "save_epochs=null",
+            "train_dataset.length=48"]
+    t, _ = _trainer(base)
+    t.train_dataloader = FaultyLoader(t.train_dataloader, poison_steps=[1])
+    t.prepare_train()
+    t.train_epoch(0)
+    assert not np.isfinite(t.last_epoch_stats["mean_loss"]) and t.last_epoch_stats["excluded_losses"] == 0
+    assert "non-finite losses excluded" not in capsys.readouterr().out
 
 
 def test_a_reference_shaped_checkpoint_resumes(gpu, run_home):
