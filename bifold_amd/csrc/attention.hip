@@ -3670,6 +3670,12 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
             BF_CHECK_LAUNCH("bf_attention_fwd");
             return BF_OK;
         }
+        // (A/B: the pipelined kernel for sequences the resident one would take)
+        if (bf_tuning().attn_fwd_pipe && fwd_res_env && seq >= bf_tuning().attn_fwd_pipe_min_seq &&
+            bf_attn_fwd_pipe_launch(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, cdt, s) == BF_OK) {
+            BF_CHECK_LAUNCH("bf_attention_fwd");
+            return BF_OK;
+        }
         if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024 + (size_t)bf_tuning().attn_lds_pad) {
             dim3 rgrid(batch * heads), rblock(nq32 * 64);
             const int nt_env = bf_tuning().attn_nt;
@@ -3992,6 +3998,13 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
     {   // longer sequences: the same pair with the resident operand streamed through LDS in chunks
         const int stream_env = bf_tuning().attn_bwd_stream;
         const int nq32 = bf_cdiv(seq, 32);
+        // round 6: the software-pipelined pair (attention_pipe.hip) for d = 48 / 64 without a causal mask
+        if (half && stream_env && bf_tuning().attn_bwd_pipe && nq32 >= bf_tuning().attn_bwd_pipe_min_q32 &&
+            bf_attn_bwd_pipe_launch(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale,
+                                    mask_mode, cdt, s) == BF_OK) {
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            return BF_OK;
+        }
         const int stream_min_env = bf_tuning().attn_stream_min_q32;
         const int stream_d32_env = bf_tuning().attn_stream_d32;
         if (half && stream_env && nq32 >= ((head_dim == 32 && !stream_d32_env) ? 9 : stream_min_env)) {

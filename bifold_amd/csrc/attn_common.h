@@ -37,3 +37,6 @@ __device__ __forceinline__ typename H16<HT>::x8 tr_pair(const char* p0, const ch
 // Each returns BF_OK, or BF_EUNSUPPORTED-like 1 when the shape is not one it takes (the caller then uses its own kernels).
 int bf_attn_fwd_pipe_launch(const void* qkv, void* out, float* lse, const int32_t* row_mask, int batch, int seq, int heads,
                             int head_dim, float scale, int mask_mode, int cdt, hipStream_t s);
+int bf_attn_bwd_pipe_launch(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* row_mask,
+                            void* dqkv, float* delta_ws, int batch, int seq, int heads, int head_dim, float scale,
+                            int mask_mode, int cdt, hipStream_t s);

@@ -62,6 +62,7 @@ BfTuning& bf_tuning() {
         t.attn_fwd_tiled = env_int("BIFOLD_ATTN_FWD_TILED", 0) ? 1 : 0;
         t.attn_fwd_pd = env_int("BIFOLD_ATTN_FWD_PD", 0);
         t.attn_fwd_pipe = env_int("BIFOLD_ATTN_FWD_PIPE", 1);
+        t.attn_fwd_pipe_min_seq = env_int("BIFOLD_ATTN_FWD_PIPE_MIN_SEQ", 1 << 30);
         t.attn_nt = env_int("BIFOLD_ATTN_NT", 0);
         t.attn_fwd_kt32 = env_int("BIFOLD_ATTN_FWD_KT32", 2);
         t.attn_bwd_nw = env_int("BIFOLD_ATTN_BWD_NW", 0);
@@ -80,6 +81,8 @@ BfTuning& bf_tuning() {
         t.attn_bwd_split = env_int("BIFOLD_ATTN_BWD_SPLIT", 1); if (t.attn_bwd_split < 1) t.attn_bwd_split = 1;
         t.attn_kv_tight = env_int("BIFOLD_ATTN_KV_TIGHT", 1);
         t.attn_bwd_stream = env_int("BIFOLD_ATTN_BWD_STREAM", 1);
+        t.attn_bwd_pipe = env_int("BIFOLD_ATTN_BWD_PIPE", 1);
+        t.attn_bwd_pipe_min_q32 = env_int("BIFOLD_ATTN_BWD_PIPE_MIN_Q32", 17);
         t.ln_rows = env_int("BIFOLD_LN_ROWS", 2);
         t.ln_bwd16_wide = env_int("BIFOLD_LN_BWD16_WIDE", 1);
     });

@@ -191,10 +191,10 @@ extern "C" int bf_layernorm_fwd(const void* x, int x_dtype, const float* gamma, 
 // start, half the store bytes) and this kernel, which reads the residual stream anyway, adds 2 B/element of traffic.
 // Two rows per wave like ln_fwd_rows_kernel; cols == NC * 256.
 template <typename TY, int NC, typename TDL = bf16_t, bool HAS2 = false>
-__global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* __restrict__ x, const TDL* __restrict__ delta,
+__global__ __launch_bounds__(256) void add_ln_rows_kernel(const float* x, const TDL* __restrict__ delta,
                                                           const TDL* __restrict__ delta2,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ x_out, TY* __restrict__ y,
+                                                          float* x_out, TY* __restrict__ y,      // x_out may BE x (the in-place stream update): no restrict on the pair
                                                           float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                           float eps) {
     constexpr int cols = NC * 256;

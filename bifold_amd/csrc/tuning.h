@@ -30,6 +30,7 @@ struct BfTuning {
     // ---- attention (attention.hip)
     int attn_fwd_tiled;           // BIFOLD_ATTN_FWD_TILED   1: always the tiled forward (0)
     int attn_fwd_pipe;            // BIFOLD_ATTN_FWD_PIPE    software-pipelined forward for sequences beyond LDS, d = 48 / 64, no causal mask (attention_pipe.hip) (1)
+    int attn_fwd_pipe_min_seq;    // BIFOLD_ATTN_FWD_PIPE_MIN_SEQ   ... also for sequences that fit LDS, from this length (1 << 30: never)
     int attn_fwd_pd;              // BIFOLD_ATTN_FWD_PD      persistent double-buffered d = 32 forward (0: measured no faster than the resident kernel)
     int attn_nt;                  // BIFOLD_ATTN_NT          non-temporal QKV loads in the resident forward (0: they paid while the next GEMM's epilogue re-read an fp32 residual tile -- round 3 -- and cost 0.7 % of the step since it does not, round 4)
     int attn_fwd_kt32;            // BIFOLD_ATTN_FWD_KT32    0 / 1 / 2: 64-key tiles / 32-key steps / by the last tile's fill (2)
@@ -49,6 +50,8 @@ struct BfTuning {
     int attn_bwd_split;           // BIFOLD_ATTN_BWD_SPLIT   workgroups per (batch, head) of the resident pair (1)
     int attn_kv_tight;            // BIFOLD_ATTN_KV_TIGHT    128-register build of the d = 32 kv kernel (1)
     int attn_bwd_stream;          // BIFOLD_ATTN_BWD_STREAM  streamed pair for long sequences (1)
+    int attn_bwd_pipe;            // BIFOLD_ATTN_BWD_PIPE    software-pipelined pair for d = 48 / 64 without a causal mask, in place of the streamed pair (attention_pipe.hip) (1)
+    int attn_bwd_pipe_min_q32;    // BIFOLD_ATTN_BWD_PIPE_MIN_Q32   ... from this many 32-row blocks (17: sequences beyond the resident kernels)
     // ---- LayerNorm (norm_elementwise.hip)
     int ln_rows;                  // BIFOLD_LN_ROWS          rows per wave of the exact-width forward (2)
     int ln_bwd16_wide;            // BIFOLD_LN_BWD16_WIDE    16-bit gradient stream: eight columns per lane in the LayerNorm backward (1)

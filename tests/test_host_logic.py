@@ -365,3 +365,19 @@ def test_lora_oracle_is_pinned_by_the_reference_at_dropout_0(golden_dir, fixture
         assert close(grads[stem + ".lora_B.siglip_adapter.weight"], (alpha / r) * g @ a.t(), 1e-4), k
         n += 1
     assert n == 8
+
+
+def test_the_build_checked_the_hand_counted_asynchronous_loads():
+    """attn_bwd_fused32p_kernel (config A's attention backward) issues its global loads from inline assembly and waits for
+    them by hand; the compiler may copy or spill a destination register before that wait.  The Makefile therefore runs
+    tools/check_async_loads.py over the ISA of every build of attention.hip and fails the build on a violation; the verdict
+    of the build that produced the library under test must be on file and clean (advisor finding, round 5)."""
+    build = os.path.join(ROOT, "bifold_amd", "csrc", "build")
+    report = os.path.join(build, "async_loads_check.txt")
+    obj = os.path.join(build, "attention.o")
+    if not os.path.isfile(obj):
+        pytest.skip("no object directory beside the library (a prebuilt library travelled alone)")
+    assert os.path.isfile(report), "attention.o was built without the asynchronous-load check"
+    text = open(report).read()
+    assert "violations: 0" in text and "attn_bwd_fused32p" in text, text[-500:]
+    assert os.path.getmtime(report) >= os.path.getmtime(obj) - 1.0

@@ -669,6 +669,42 @@ def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path, role_map):
     assert r.returncode == 0 and "FUSED-P-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("half", HALF)
+@pytest.mark.parametrize("B,Lq,H,D,mode,spans", [
+    (2, 576, 2, 64, 0, []), (1, 577, 3, 64, 0, []), (1, 1089, 1, 64, 0, []), (1, 545, 3, 48, 0, []),
+    (1, 853, 2, 48, 2, []), (2, 600, 2, 48, 2, [(64, 256)]), (1, 1290, 1, 64, 2, [(0, 33), (577, 1154)]),
+    (1, 2950, 2, 48, 2, [(65, 65 + 577), (65 + 2 * 577, 65 + 3 * 577)]), (1, 1050, 2, 48, 2, [(65, 65 + 3 * 197)]),
+    (1, 700, 1, 48, 2, [(0, 700)])])
+def test_attention_bwd_pipelined_long_sequences(ops, gpu, half, B, Lq, H, D, mode, spans):
+    """attn_bwd_q_pipe_kernel + attn_bwd_kv_pipe_kernel (round 6, attention_pipe.hip): d = 48 / 64 beyond 512 tokens, no
+    mask and the query-row mask -- whole masked frames (the blocks they cover entirely are not walked: their dV share is
+    the summed-dO vector, their dQ a zero fill), lone masked rows inside live blocks, an odd number of live blocks, key
+    and query tails, workgroups with idle waves, EVERY row masked -- against the fp64 formula, twice (bit-reproducible:
+    the masked blocks' dO rows are added in a fixed order), masked queries' gradient exactly zero."""
+    g = torch.Generator().manual_seed(Lq * 3 + D)
+    qkv = round_to(torch.randn(B * Lq, 3 * H * D, generator=g), half)
+    dout = round_to(torch.randn(B * Lq, H * D, generator=g), half)
+    row_mask = None
+    if mode == 2:
+        row_mask = (torch.rand(B, Lq, generator=g) > 0.1).int()
+        for a, b in spans:
+            row_mask[:, a:b] = 0
+    leaf = qkv.double().requires_grad_(True)
+    ref_o, _ = ref_attention(leaf, B, Lq, H, D, D ** -0.5, mode, row_mask)
+    ref_o.backward(dout.double())
+    qg, dg = qkv.to(gpu).to(half), dout.to(gpu).to(half)
+    rm = None if row_mask is None else row_mask.to(gpu)
+    out, lse = ops.attention_fwd(qg, B, Lq, H, D, D ** -0.5, mode, rm, need_lse=True)
+    dqkv = ops.attention_bwd(qg, out, dg, lse, B, Lq, H, D, D ** -0.5, mode, rm)
+    got, want = dqkv.float().cpu().view(B, Lq, 3, H, D), leaf.grad.float().view(B, Lq, 3, H, D)
+    for which, name in enumerate(("dQ", "dK", "dV")):
+        assert rel_err(got[:, :, which], want[:, :, which]) < 2e-2, name
+    if row_mask is not None:
+        assert float(got[:, :, 0][row_mask == 0].abs().max()) == 0.0
+    again = ops.attention_bwd(qg, out, dg, lse, B, Lq, H, D, D ** -0.5, mode, rm)
+    assert torch.equal(again, dqkv)
+
+
 @pytest.mark.parametrize("B,Lq,H,D,spans", [(2, 600, 2, 48, [(64, 256)]), (1, 1290, 1, 64, [(0, 33), (577, 1154)]),
                                             (2, 700, 1, 32, [(100, 420), (650, 700)])])
 def test_attention_bwd_with_whole_masked_segments(ops, gpu, B, Lq, H, D, spans):
