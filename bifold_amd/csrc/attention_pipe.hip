@@ -34,6 +34,8 @@
 
 #include <type_traits>
 
+#define PIPE_MAXBLK 1024                                     // 32-row query blocks per sequence (L <= 32 768): the mask lists's capacity
+
 template <int D, int WPB> struct PipeCfg {
     static constexpr int DP = (D + 31) / 32 * 32;
     static constexpr int KS = D / 16, DB = DP / 32;
@@ -44,7 +46,8 @@ template <int D, int WPB> struct PipeCfg {
     static constexpr int PIECES = 64 * CPR;                 // chunks of one 64-row tile of one operand
     static constexpr int NPF = (PIECES + NT - 1) / NT;      // ... per thread
     static constexpr int KTILE = 64 * KROW, VTILE = 64 * VROW, SLOT = KTILE + VTILE;
-    static constexpr int LDS = 3 * SLOT;
+    static constexpr int RING = 3 * SLOT;
+    static constexpr int LDS = RING + 2 * PIPE_MAXBLK * 2;   // + the live / masked query-block lists (query-row mask)
 };
 
 typedef unsigned pipe_u32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's uint4 struct keeps arrays of it in scratch
@@ -68,6 +71,14 @@ typedef unsigned pipe_u32x4 __attribute__((ext_vector_type(4)));   // native vec
 #ifndef PIPE_LEAD_T
 #define PIPE_LEAD_T 4
 #endif
+#ifndef PIPE_BWD_FENCE
+#define PIPE_BWD_FENCE 0    // backward kernels: 1 = scheduling fences between a chunk's four regions; 0 = the chunk body is one scheduling region (measured: 14.3 -> 13.97 ms the pair at 2 950 x 48)
+#endif
+#if PIPE_BWD_FENCE
+#define BWD_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define BWD_FENCE() do {} while (0)
+#endif
 
 // the scheduling pipeline of one region: NDS LDS reads, NM MFMAs
 template <int NM, int NDS>
@@ -86,6 +97,48 @@ __device__ __forceinline__ void region_hints() {
 #endif
 }
 
+
+// Query-row mask: which 32-row query blocks are masked ENTIRELY (every row that exists is masked)?  Every workgroup of a
+// (batch, head) builds the same two lists in LDS, ascending (deterministic): `blist` the blocks with a live row, `mlist` the
+// entirely masked ones.  counts[0 / 1] = their lengths.  NT threads; ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void build_block_lists(const int32_t* __restrict__ mask_b, int L, int nblk, unsigned short* blist,
+                                                  unsigned short* mlist, int* counts, int (*wave_cnt)[NT / 64]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nblk; base += NT) {
+        const int q = base + threadIdx.x;
+        int any_bits = 0;                                    // 32 independent loads (a short-circuit loop is 32 trips to memory)
+        if (q < nblk) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int row = q * 32 + i;
+                const int v = mask_b[min(row, L - 1)];
+                any_bits |= row < L ? v : 0;
+            }
+        }
+        const bool any_live = any_bits != 0;
+        const unsigned long long live_bits = __builtin_amdgcn_ballot_w64(q < nblk && any_live);
+        const unsigned long long mask_bits = __builtin_amdgcn_ballot_w64(q < nblk && !any_live);
+        if (base == 0 && threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; }
+        if (lane == 0) { wave_cnt[0][wave] = __popcll(live_bits); wave_cnt[1][wave] = __popcll(mask_bits); }
+        __syncthreads();
+        int off_l = counts[0], off_m = counts[1];
+        for (int w = 0; w < wave; ++w) { off_l += wave_cnt[0][w]; off_m += wave_cnt[1][w]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (q < nblk) {
+            if (any_live) blist[off_l + __popcll(live_bits & below)] = (unsigned short)q;
+            else mlist[off_m + __popcll(mask_bits & below)] = (unsigned short)q;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tl = 0, tm = 0;
+            for (int w = 0; w < NT / 64; ++w) { tl += wave_cnt[0][w]; tm += wave_cnt[1][w]; }
+            counts[0] += tl; counts[1] += tm;
+        }
+        __syncthreads();
+    }
+}
+
 template <int D, int MASK, int WPB, typename HT>
 __global__ __launch_bounds__(WPB * 64, 2) void attn_fwd_pipe_kernel(
     const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse,
@@ -101,9 +154,32 @@ __global__ __launch_bounds__(WPB * 64, 2) void attn_fwd_pipe_kernel(
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const int bh = paired_bh<D>(blockIdx.x, gridDim.x), b = bh / H, h = bh - b * H;
-    const int q0 = (blockIdx.y * WPB + wave) * 64;             // first query of this wave (block a; block b = q0 + 32)
-    const bool wave_live = q0 < L;
     const int ntiles = (L + 63) >> 6;
+    const int nblk = (L + 31) >> 5;
+    // This wave's two 32-query blocks.  Without a mask: blocks 2 w and 2 w + 1 of the sequence.  Under the query-row mask
+    // the blocks that are masked ENTIRELY all have the same output row (a uniform softmax: the mean of V) -- siglip_sequential
+    // masks whole context frames, two of four on average -- so the waves walk the list of LIVE blocks plus ONE
+    // representative masked block, whose wave copies its row to every other masked block at the end.
+    unsigned short* blist = (unsigned short*)(smem + C::RING);
+    unsigned short* mlist = blist + PIPE_MAXBLK;
+    __shared__ int counts[2];
+    __shared__ int wave_cnt[2][WPB];
+    int n_live = nblk, n_masked = 0;
+    if (MASK == BF_MASK_QUERY_ROW) {
+        build_block_lists<NT>(row_mask + (size_t)b * L, L, nblk, blist, mlist, counts, wave_cnt);
+        n_live = counts[0];
+        n_masked = counts[1];
+    }
+    const int n_work = n_live + (n_masked > 0 ? 1 : 0);
+    if ((int)blockIdx.y * WPB * 2 >= n_work) return;              // nothing for this workgroup (uniform, before any barrier below)
+    const int li0 = (blockIdx.y * WPB + wave) * 2;
+    const bool wave_live = li0 < n_work;
+    auto work_block = [&](int li) __attribute__((always_inline)) -> int {     // list entry -> 32-row block, -1: none
+        if (li >= n_work) return -1;
+        if (MASK != BF_MASK_QUERY_ROW) return li;
+        return li < n_live ? (int)blist[li] : (int)mlist[0];
+    };
+    const int blk_a = work_block(li0), blk_b = work_block(li0 + 1);
     const unsigned row_bytes = 3u * (unsigned)H * D * 2u;       // one token of the packed QKV buffer
     const char* kbase = (const char*)(qkv + qkv_off(b, 0, 1, h, L, H, D));
     const char* vbase = (const char*)(qkv + qkv_off(b, 0, 2, h, L, H, D));
@@ -153,8 +229,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void attn_fwd_pipe_kernel(
     x8 qa[KS], qb[KS];
     bool masked_a = false, masked_b = false;
     {
-        const int ia = q0 + r, ib = q0 + 32 + r;
-        const bool live_a = ia < L, live_b = ib < L;
+        const int ia = blk_a * 32 + r, ib = blk_b * 32 + r;
+        const bool live_a = blk_a >= 0 && ia < L, live_b = blk_b >= 0 && ib < L;
         if (MASK == BF_MASK_QUERY_ROW) {
             masked_a = live_a && row_mask[(size_t)b * L + ia] == 0;
             masked_b = live_b && row_mask[(size_t)b * L + ib] == 0;
@@ -328,7 +404,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void attn_fwd_pipe_kernel(
     // ---- drain: O_b += V_last^T P(b, last); normalise; turn the tile through LDS; store whole row segments --------
     // (the ring is idle: the loop's last barrier is behind every wave)
     char* ot = smem + wave * (64 * KROW);                          // this wave's 64 output rows, KROW-byte rows
-    static_assert(WPB * 64 * KROW <= C::LDS, "output turn fits the ring");
+    static_assert(WPB * 64 * KROW <= C::RING, "output turn fits the ring");
     // The pending P V of block b needs V of the last tile (after the rotation: slot s_prv), which nothing has
     // overwritten (V(t + 1) of the last iteration went to another slot); the output turn below reuses the ring, so the
     // product comes first, then a barrier, then the turn.
@@ -356,16 +432,37 @@ __global__ __launch_bounds__(WPB * 64, 2) void attn_fwd_pipe_kernel(
 #pragma unroll
         for (int idx = lane; idx < 64 * CPR; idx += 64) {
             const int row = idx / CPR, c = idx - row * CPR;
-            if (q0 + row < L)
-                *(uint4*)(out + ((size_t)b * L + q0 + row) * (size_t)H * D + (size_t)h * D + c * 8) =
+            const int blk = row < 32 ? blk_a : blk_b;
+            const int grow = blk * 32 + (row & 31);
+            if (blk >= 0 && grow < L)
+                *(uint4*)(out + ((size_t)b * L + grow) * (size_t)H * D + (size_t)h * D + c * 8) =
                     *(const uint4*)(ot + row * KROW + c * 16);
         }
+        const float ln2 = 0.69314718055994530942f;
+        // masked query rows: the reference's scores are the constant -1e5 for every key
+        const float mask_m = -100000.0f * 1.44269504088896340736f;
+        const float lse_a = ((masked_a ? mask_m : ma) + log2f(la)) * ln2, lse_b = ((masked_b ? mask_m : mb) + log2f(lb)) * ln2;
         if (lse && hh == 0) {
-            const float ln2 = 0.69314718055994530942f;
-            // masked query rows: the reference's scores are the constant -1e5 for every key
-            const float mask_m = -100000.0f * 1.44269504088896340736f;
-            if (q0 + r < L) lse[((size_t)b * H + h) * L + q0 + r] = ((masked_a ? mask_m : ma) + log2f(la)) * ln2;
-            if (q0 + 32 + r < L) lse[((size_t)b * H + h) * L + q0 + 32 + r] = ((masked_b ? mask_m : mb) + log2f(lb)) * ln2;
+            const int ia = blk_a * 32 + r, ib = blk_b * 32 + r;
+            if (blk_a >= 0 && ia < L) lse[((size_t)b * H + h) * L + ia] = lse_a;
+            if (blk_b >= 0 && ib < L) lse[((size_t)b * H + h) * L + ib] = lse_b;
+        }
+        // the representative masked block (list entry n_live): its row goes to every other entirely masked block
+        if (MASK == BF_MASK_QUERY_ROW && n_masked > 1 && (li0 == n_live || li0 + 1 == n_live)) {
+            const int rep = li0 == n_live ? 0 : 32;                    // row of `ot` holding the block's first row (all rows are equal)
+            const float lse_m = __shfl(li0 == n_live ? lse_a : lse_b, 0, 64);
+            for (int m = 1; m < n_masked; ++m) {
+                const int blk = (int)mlist[m];
+#pragma unroll
+                for (int idx = lane; idx < 32 * CPR; idx += 64) {
+                    const int row = idx / CPR, c = idx - row * CPR;
+                    const int grow = blk * 32 + row;
+                    if (grow < L)
+                        *(uint4*)(out + ((size_t)b * L + grow) * (size_t)H * D + (size_t)h * D + c * 8) =
+                            *(const uint4*)(ot + rep * KROW + c * 16);
+                }
+                if (lse && lane < 32 && blk * 32 + lane < L) lse[((size_t)b * H + h) * L + blk * 32 + lane] = lse_m;
+            }
         }
     }
 }
@@ -392,7 +489,7 @@ static void fwd_pipe_launch_one(const void* qkv, void* out, float* lse, const in
 
 int bf_attn_fwd_pipe_launch(const void* qkv, void* out, float* lse, const int32_t* row_mask, int batch, int seq, int heads,
                             int head_dim, float scale, int mask_mode, int cdt, hipStream_t s) {
-    if (!bf_is_half(cdt) || seq < 64 || mask_mode == BF_MASK_CAUSAL) return 1;
+    if (!bf_is_half(cdt) || seq < 64 || seq > 32 * PIPE_MAXBLK || mask_mode == BF_MASK_CAUSAL) return 1;
     if ((size_t)seq * 3u * heads * head_dim * 2u >= (1ull << 32)) return 1;   // 32-bit row offsets inside one batch element
     const int n64 = bf_cdiv(seq, 64);
     // waves per workgroup: 4, or 3 when that leaves fewer idle waves (576 tokens = 9 x 64 = three workgroups of three)
@@ -444,7 +541,7 @@ template <int D> struct KvPipeCfg {
     static constexpr int IMG = CH * ROW + 64;                // one operand's rows (+ the overhang of the last row's transposed reads)
     static constexpr int SLOT = 2 * IMG + 2 * CH * 4;        // Q rows, dO rows, -lse / scale, -delta
     static constexpr int NSLOT = 4;
-    static constexpr int MAXBLK = 1024;                      // 32-row blocks per sequence (L <= 32 768)
+    static constexpr int MAXBLK = PIPE_MAXBLK;                      // 32-row blocks per sequence (L <= 32 768)
     static constexpr int LISTS = 2 * MAXBLK * 2 + 64 * 4;    // live / masked block lists (uint16) + the masked dO sum
     static constexpr int LDS = NSLOT * SLOT + LISTS;
 };
@@ -488,37 +585,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_pipe_kernel(
     int n_live = nblk, n_masked = 0;
     if (MASK == BF_MASK_QUERY_ROW) {
         // block q is "masked" when every row of it that exists is masked; lists in ascending order (deterministic)
-        for (int base = 0; base < nblk; base += NT) {
-            const int q = base + threadIdx.x;
-            int any_bits = 0;                                       // 32 independent loads (a short-circuit loop is 32 trips to memory)
-            if (q < nblk) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int row = q * 32 + i;
-                    const int v = mask_b[min(row, L - 1)];
-                    any_bits |= row < L ? v : 0;
-                }
-            }
-            const bool any_live = any_bits != 0;
-            const unsigned long long live_bits = __builtin_amdgcn_ballot_w64(q < nblk && any_live);
-            const unsigned long long mask_bits = __builtin_amdgcn_ballot_w64(q < nblk && !any_live);
-            if (base == 0 && threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; }
-            if (lane == 0) { wave_cnt[0][wave] = __popcll(live_bits); wave_cnt[1][wave] = __popcll(mask_bits); }
-            __syncthreads();
-            int off_l = counts[0], off_m = counts[1];
-            for (int w = 0; w < wave; ++w) { off_l += wave_cnt[0][w]; off_m += wave_cnt[1][w]; }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (q < nblk) {
-                if (any_live) blist[off_l + __popcll(live_bits & below)] = (unsigned short)q;
-                else mlist[off_m + __popcll(mask_bits & below)] = (unsigned short)q;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                counts[0] += wave_cnt[0][0] + wave_cnt[0][1] + wave_cnt[0][2] + wave_cnt[0][3];
-                counts[1] += wave_cnt[1][0] + wave_cnt[1][1] + wave_cnt[1][2] + wave_cnt[1][3];
-            }
-            __syncthreads();
-        }
+        build_block_lists<NT>(mask_b, L, nblk, blist, mlist, counts, wave_cnt);
         n_live = counts[0];
         n_masked = counts[1];
         // sum of the dO rows of the masked blocks: thread (row-in-block, chunk) adds its chunk over the blocks in list
@@ -728,20 +795,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_pipe_kernel(
             const char* prv = smem + ((c + 3) & 3) * C::SLOT;
             const char* nxt = smem + ((c + 1) & 3) * C::SLOT;
             // ---- block 2c
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sA, pA, ppA0, dsA0);
             b_phase(prv, 32, ppA1, dsA1, ppB, dsB);                // block 2c - 1
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sB0, pB0, ppB, dsB);
             a_phase(cur, 32, sA, pA, sB1, pB1);                    // block 2c + 1
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             // ---- block 2c + 1
             v_phase(sA, pA, ppA1, dsA1);
             b_phase(cur, 0, ppA0, dsA0, ppB, dsB);                 // block 2c
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sB1, pB1, ppB, dsB);
             a_phase(nxt, 0, sA, pA, sB0, pB0);                     // block 2c + 2
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
         }
         stash(nx, smem + ((c + 2) & 3) * C::SLOT);
         __syncthreads();
@@ -818,7 +885,7 @@ template <int D> struct QPipeCfg {
     static constexpr int KIMG = CH * KROW + 64, VIMG = CH * VROW;
     static constexpr int SLOT = KIMG + VIMG;
     static constexpr int NSLOT = 4;
-    static constexpr int MAXBLK = 1024;
+    static constexpr int MAXBLK = PIPE_MAXBLK;
     static constexpr int LISTS = 2 * MAXBLK * 2;
     static constexpr int LDS = NSLOT * SLOT + LISTS;
 };
@@ -857,37 +924,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_pipe_kernel(
 
     int n_live = nblk, n_masked = 0;
     if (MASK == BF_MASK_QUERY_ROW) {                              // the same lists as the kv kernel builds
-        for (int base = 0; base < nblk; base += NT) {
-            const int q = base + threadIdx.x;
-            int any_bits = 0;                                       // 32 independent loads (a short-circuit loop is 32 trips to memory)
-            if (q < nblk) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) {
-                    const int row = q * 32 + i;
-                    const int v = mask_b[min(row, L - 1)];
-                    any_bits |= row < L ? v : 0;
-                }
-            }
-            const bool any_live = any_bits != 0;
-            const unsigned long long live_bits = __builtin_amdgcn_ballot_w64(q < nblk && any_live);
-            const unsigned long long mask_bits = __builtin_amdgcn_ballot_w64(q < nblk && !any_live);
-            if (base == 0 && threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; }
-            if (lane == 0) { wave_cnt[0][wave] = __popcll(live_bits); wave_cnt[1][wave] = __popcll(mask_bits); }
-            __syncthreads();
-            int off_l = counts[0], off_m = counts[1];
-            for (int w = 0; w < wave; ++w) { off_l += wave_cnt[0][w]; off_m += wave_cnt[1][w]; }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (q < nblk) {
-                if (any_live) blist[off_l + __popcll(live_bits & below)] = (unsigned short)q;
-                else mlist[off_m + __popcll(mask_bits & below)] = (unsigned short)q;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                counts[0] += wave_cnt[0][0] + wave_cnt[0][1] + wave_cnt[0][2] + wave_cnt[0][3];
-                counts[1] += wave_cnt[1][0] + wave_cnt[1][1] + wave_cnt[1][2] + wave_cnt[1][3];
-            }
-            __syncthreads();
-        }
+        build_block_lists<NT>(mask_b, L, nblk, blist, mlist, counts, wave_cnt);
         n_live = counts[0];
         n_masked = counts[1];
         // dQ of the entirely masked blocks is zero: the workgroups of this (batch, head) share the list
@@ -1061,19 +1098,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_pipe_kernel(
             const char* cur = smem + (c & 3) * C::SLOT;
             const char* prv = smem + ((c + 3) & 3) * C::SLOT;
             const char* nxt = smem + ((c + 1) & 3) * C::SLOT;
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sA, pA, cla, dsA0);
             c_phase(prv, 32, dsA1, dsB);                           // key block 2c - 1
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sB0, pB0, clb, dsB);
             a_phase(cur, 32, sA, pA, sB1, pB1);                    // key block 2c + 1
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sA, pA, cla, dsA1);
             c_phase(cur, 0, dsA0, dsB);                            // key block 2c
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
             v_phase(sB1, pB1, clb, dsB);
             a_phase(nxt, 0, sA, pA, sB0, pB0);                     // key block 2c + 2
-            __builtin_amdgcn_sched_barrier(0);
+            BWD_FENCE();
         }
         stash(nx, smem + ((c + 2) & 3) * C::SLOT, c + 2);
         __syncthreads();

@@ -82,7 +82,7 @@ BfTuning& bf_tuning() {
         t.attn_kv_tight = env_int("BIFOLD_ATTN_KV_TIGHT", 1);
         t.attn_bwd_stream = env_int("BIFOLD_ATTN_BWD_STREAM", 1);
         t.attn_bwd_pipe = env_int("BIFOLD_ATTN_BWD_PIPE", 1);
-        t.attn_bwd_pipe_min_q32 = env_int("BIFOLD_ATTN_BWD_PIPE_MIN_Q32", 17);
+        t.attn_bwd_pipe_min_q32 = env_int("BIFOLD_ATTN_BWD_PIPE_MIN_Q32", 24);
         t.ln_rows = env_int("BIFOLD_LN_ROWS", 2);
         t.ln_bwd16_wide = env_int("BIFOLD_LN_BWD16_WIDE", 1);
     });

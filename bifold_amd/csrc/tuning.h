@@ -45,13 +45,13 @@ struct BfTuning {
     int attn_bwd_fused_p;         // BIFOLD_ATTN_BWD_FUSED_P 0 / 1 / 2: the persistent twelve-wave form of that kernel never / from two items per CU / always (1)
     int attn_bwd_fused_p_map;     // BIFOLD_ATTN_BWD_FUSED_P_MAP   1: that kernel's three support waves (dQ sum, two loaders) share ONE SIMD, three key waves on each of the others; 0: roles in wave order (1)
     int attn_bwd_onepass;         // BIFOLD_ATTN_BWD_ONEPASS 1: the one-pass backward for d = 48 / 64 without a causal mask (0: correct, and 10 - 20 % SLOWER than the streamed pair on every shape measured -- attention.hip)
-    int attn_onepass_min_q32;     // BIFOLD_ATTN_ONEPASS_MIN_Q32   ... from this many 32-row blocks (17: sequences beyond the resident kernels)
+    int attn_onepass_min_q32;     // BIFOLD_ATTN_ONEPASS_MIN_Q32   ... from this many 32-row blocks (24: at 576 x 64 the streamed pair is faster, 364 vs 523 us: three-workgroup grids with idle waves)
     int attn_lds_pad;             // BIFOLD_ATTN_LDS_PAD     extra dynamic LDS bytes for the resident pair: occupancy experiments (0)
     int attn_bwd_split;           // BIFOLD_ATTN_BWD_SPLIT   workgroups per (batch, head) of the resident pair (1)
     int attn_kv_tight;            // BIFOLD_ATTN_KV_TIGHT    128-register build of the d = 32 kv kernel (1)
     int attn_bwd_stream;          // BIFOLD_ATTN_BWD_STREAM  streamed pair for long sequences (1)
     int attn_bwd_pipe;            // BIFOLD_ATTN_BWD_PIPE    software-pipelined pair for d = 48 / 64 without a causal mask, in place of the streamed pair (attention_pipe.hip) (1)
-    int attn_bwd_pipe_min_q32;    // BIFOLD_ATTN_BWD_PIPE_MIN_Q32   ... from this many 32-row blocks (17: sequences beyond the resident kernels)
+    int attn_bwd_pipe_min_q32;    // BIFOLD_ATTN_BWD_PIPE_MIN_Q32   ... from this many 32-row blocks (24: at 576 x 64 the streamed pair is faster, 364 vs 523 us: three-workgroup grids with idle waves)
     // ---- LayerNorm (norm_elementwise.hip)
     int ln_rows;                  // BIFOLD_LN_ROWS          rows per wave of the exact-width forward (2)
     int ln_bwd16_wide;            // BIFOLD_LN_BWD16_WIDE    16-bit gradient stream: eight columns per lane in the LayerNorm backward (1)

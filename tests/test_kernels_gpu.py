@@ -674,7 +674,7 @@ def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path, role_map):
     (2, 576, 2, 64, 0, []), (1, 577, 3, 64, 0, []), (1, 1089, 1, 64, 0, []), (1, 545, 3, 48, 0, []),
     (1, 853, 2, 48, 2, []), (2, 600, 2, 48, 2, [(64, 256)]), (1, 1290, 1, 64, 2, [(0, 33), (577, 1154)]),
     (1, 2950, 2, 48, 2, [(65, 65 + 577), (65 + 2 * 577, 65 + 3 * 577)]), (1, 1050, 2, 48, 2, [(65, 65 + 3 * 197)]),
-    (1, 700, 1, 48, 2, [(0, 700)])])
+    (1, 800, 1, 48, 2, [(0, 800)])])
 def test_attention_bwd_pipelined_long_sequences(ops, gpu, half, B, Lq, H, D, mode, spans):
     """attn_bwd_q_pipe_kernel + attn_bwd_kv_pipe_kernel (round 6, attention_pipe.hip): d = 48 / 64 beyond 512 tokens, no
     mask and the query-row mask -- whole masked frames (the blocks they cover entirely are not walked: their dV share is
