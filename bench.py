@@ -444,10 +444,8 @@ def main():
         # (text tower, weight-gradient GEMMs), so that a HIP-event pair on the launching stream brackets the dominant
         # kernel ALONE -- in the concurrent step the same pair also spans the time the kernel shares the CUs with the
         # side streams' kernels (157 us in-step against 86 - 130 us in the rocprof summary of round 2).
-        from bifold.models import pickplace as _pp
-        saved = (_pp._DW_SIDE, os.environ.get("BIFOLD_TEXT_STREAM"))
-        _pp._DW_SIDE = 0
-        os.environ["BIFOLD_TEXT_STREAM"] = "0"
+        from bifold.models import streams as _streams
+        was_serial = _streams.set_serial(True)
         try:
             step()
             fence()
@@ -460,11 +458,7 @@ def main():
             serial_ms = 1e3 * (time.perf_counter() - ts) / args.roofline_steps
         finally:
             ops.PROFILER = None
-            _pp._DW_SIDE = saved[0]
-            if saved[1] is None:
-                os.environ.pop("BIFOLD_TEXT_STREAM", None)
-            else:
-                os.environ["BIFOLD_TEXT_STREAM"] = saved[1]
+            _streams.set_serial(was_serial)
     parity_trained = None
     if check_parity:
         # the same check on the weights AFTER the optimisation steps above: logits of a trained model are an order of

@@ -10,7 +10,6 @@ no pooling, no output projections, no logits.  Both towers are frozen in BiFold
 from __future__ import annotations
 
 import math
-import os
 import warnings
 from typing import Dict, Optional
 
@@ -150,9 +149,8 @@ class CLIPEncoder(nn.Module):
         # to fetch before the first MFMA, half the bytes to store -- and the LayerNorm, which streams the residual
         # anyway, adds the branch's bf16 output on the way (in-step: 139 + 43 -> ~170 us for out-proj + ln_2 at the
         # vision tower's shape).  `final` = the LayerNorm after the last block (ln_post / ln_final), fused the same way.
-        fuse_add = (cdt in ops.HALF and not fp8 and width in (256, 512, 768, 1024) and final is not None
-                    and os.environ.get("BIFOLD_ADD_LN", "1") != "0")
-        lazy = fuse_add and os.environ.get("BIFOLD_LAZY_STREAM", "1") != "0"
+        fuse_add = cdt in ops.HALF and not fp8 and width in (256, 512, 768, 1024) and final is not None
+        lazy = fuse_add                   # the frozen tower writes its stream ONCE per block (round 5: +0.8 % on the step, same bits)
         h = None if fp8 else h0           # ln_1 of block 0, when the caller has already computed it (K1)
         for i in range(layers):
             b = f"{prefix}.{i}."
@@ -171,7 +169,7 @@ class CLIPEncoder(nn.Module):
                 # per block (round 5).  The pass after the attention branch only produces ln_2(x + attn) (no x_out: 8
                 # bytes per element instead of 12); the pass after the MLP adds BOTH branches to the block's input,
                 # (x + attn) + mlp in that order -- the bits of the two-pass form -- and writes the stream (14 instead
-                # of 12).  BIFOLD_LAZY_STREAM=0 restores the two read-modify-write passes.
+                # of 12).  (The two read-modify-write passes it replaced: removed in round 6.)
                 attn = ops.gemm(o, self._w(b + "attn.out_proj.weight", cdt), bias=self._f(b + "attn.out_proj.bias"))
                 h, _, _, _ = ops.add_layernorm_fwd(x, attn, self._f(b + "ln_2.weight"), self._f(b + "ln_2.bias"), cdt,
                                                    write_x=not lazy)
@@ -229,7 +227,7 @@ class CLIPEncoder(nn.Module):
         pos = self._f("visual.positional_embedding")
         fp8 = self.fp8 and cdt == torch.bfloat16 and vw % 128 == 0
         h0 = None
-        if not fp8 and os.environ.get("BIFOLD_K1", "1") != "0":
+        if not fp8:
             # K1: the patch-embed GEMM's epilogue adds pos[1 + p] and writes row b*n + p of the
             # [B*n] problem to row b*(n+1) + 1 + p of the token stream; one pass then sets the class rows, applies
             # ln_pre in place and emits block 0's ln_1 -- no [B*n, W] patch buffer, no separate assembly / ln_1 pass

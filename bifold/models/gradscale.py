@@ -26,7 +26,6 @@ The Trainer reads the totals once per epoch, reports dropped steps and raises on
 from __future__ import annotations
 
 import math
-import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -114,7 +113,7 @@ class DynamicGradScale:
     def ready(self, layer: int) -> None:
         """The backward's `on_layer_done`: un-scale what layer `layer` completed, then tell the model's hooks."""
         arena = self._plan()
-        if not getattr(self.model, "_grad_hooks", None) and os.environ.get("BIFOLD_UNSCALE_PER_LAYER", "0") != "1":
+        if not getattr(self.model, "_grad_hooks", None):
             # nobody waits for single layers (one process: no gradient-ready hook is registered): ONE pass over the whole
             # arena when the backward is complete instead of eleven small launches between the layers of the chain
             if layer == -1:

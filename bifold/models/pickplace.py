@@ -26,30 +26,27 @@ from bifold_amd.hip import ops
 from . import Components
 from .arena import ParamArena
 from .gradscale import scaler_of
-from .streams import side_stream
+from .streams import serial, side_stream
 from .decoder_math import upsample_operator
 from .params import add_param, layernorm_init, linear_init
 
 DEC_IDX = (0, 2, 4, 6, 8)
-# the fusion MLP saves gelu'(pre) for the backward (one erf evaluation in the forward epilogue, a multiply in the
-# backward's); BIFOLD_GELU_SAVEGRAD=0 keeps `pre` and evaluates gelu' in the backward (the round-1 form, for A/B)
-_SAVEGRAD = os.environ.get("BIFOLD_GELU_SAVEGRAD", "1") != "0"
+# Module switches below are CONSTANTS since round 6 (they were BIFOLD_* environment variables while their A/Bs ran; the
+# numbers are in DESIGN.md section 6 and docs/).  Tests flip two of them in-process to hold both forms against each other.
+# The fusion MLP saves gelu'(pre) for the backward (one erf evaluation in the forward epilogue, a multiply in the
+# backward's); False keeps `pre` and evaluates gelu' in the backward (the round-1 form)
+_SAVEGRAD = True
 # the weight-gradient GEMMs (dW = dY^T X) have no consumer before the optimiser / the gradient all-reduce: they run on a
 # side stream next to the dX chain, so that one persistent GEMM's under-filled last round is filled by the other's
-# workgroups.  0 = everything on one stream; 1 = the main stream joins the side stream at the end of every layer;
-# 2 = it joins one layer late (layer i's dW GEMMs run beside layer i-1's dX chain)
-_DW_SIDE = int(os.environ.get("BIFOLD_DW_SIDE", "1"))
+# workgroups: the main stream joins the side stream at the end of every layer.  Under streams.serial() (the profiling mode
+# of bench.py's roofline sample and tools/serial_stats.sh) everything runs on one stream.
 # 1 = a dW GEMM is issued AFTER the dX GEMM that becomes runnable at the same moment (see fusion_layer_bwd); 0 = before
-_DW_ORDER = int(os.environ.get("BIFOLD_DW_ORDER", "1"))
+_DW_ORDER = 1
 # 1 = the four dW GEMMs of a layer are collected and issued as ONE grouped launch of the persistent kernel once the last
 # of their operands (dQKV) exists (bf_gemm_tn_grouped: 48 tiles x 5 K-splits for the 8 x 512 layer instead of four GEMMs
 # split 16 / 16 / 64 / 21 ways, a quarter of the fp32 partial slabs, 2 launches instead of 8); groups that do not
 # qualify (fp32 mode, short or ragged token counts) and 0 run the GEMMs one by one as before
-_DW_GROUPED = int(os.environ.get("BIFOLD_DW_GROUPED", "1"))
-# timing experiments only (tools/ab_env.sh): 1 = the fusion layers' weight-gradient GEMMs are NOT launched at all -- the
-# step's time with the side stream's backward work taken away, i.e. the bound on what better scheduling of it could give.
-# The gradients are then wrong; nothing but a stopwatch may set this.
-_DW_SKIP = int(os.environ.get("BIFOLD_DW_SKIP_FOR_TIMING", "0"))
+_DW_GROUPED = 1
 
 
 def _dw_stream(device) -> "torch.cuda.Stream":
@@ -67,7 +64,7 @@ class _WeightGradSide:
     `joined`): they are then freed on the stream that allocated them, behind the wait, and reusable at once."""
 
     def __init__(self, device):
-        self.on = _DW_SIDE > 0
+        self.on = not serial()
         self.side = _dw_stream(device) if self.on else None
         self.group = [] if _DW_GROUPED else None       # (dy, x, out) of the layer being walked
         self.group_after = None                         # event behind the producer of the LAST collected operand
@@ -87,9 +84,7 @@ class _WeightGradSide:
             else:
                 self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side) if self.on else _NullCtx():
-            if _DW_SKIP:
-                pass
-            elif not ops.gemm_tn_grouped(todo):
+            if not ops.gemm_tn_grouped(todo):
                 for dy, x, out in todo:
                     ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
         if self.on:
@@ -310,13 +305,13 @@ def _w2d(t: torch.Tensor) -> torch.Tensor:
 # the NEXT LayerNorm's pass (bf_add_layernorm_fwd, what the towers do) instead of in the GEMM's fp32 epilogue: the
 # fp32-residual epilogue costs a 512-wide GEMM 57 - 61 us per launch (a 256 KB fp32 tile read and written per item), the
 # add inside the LayerNorm pass 40 (tools/decoder_bench.py's neighbour).  0: round 1-4's form.
-_ADD_IN_LN = int(os.environ.get("BIFOLD_FUSION_ADD_IN_LN", "1"))
+_ADD_IN_LN = 1
 # 1 (fp16 mode): the gradient of the residual stream travels through the fusion stack's backward as ONE fp16 tensor --
 # it is what the dX GEMMs read anyway -- instead of an fp32 tensor plus its fp16 copy: the two LayerNorm backward passes
 # of a block read 72 instead of 144 MB of it and write 72 instead of 216 (bf_layernorm_bwd without an fp32 dx).  Every
 # add rounds to 11 bits of the running gradient (the loss scale keeps it in range like every other fp16 gradient of the
 # step); bf16's 8 bits would show in the gradient gates, so bf16 and fp32 keep the fp32 stream.  0: round 1-4's form.
-_GRAD_STREAM16 = int(os.environ.get("BIFOLD_GRAD_STREAM16", "1"))
+_GRAD_STREAM16 = 1
 
 
 def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, save: bool, pending=None,
@@ -439,32 +434,18 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
         dx = None
     wg = _WeightGradSide(dx_c.device if s16 else dx.device)
     main = torch.cuda.current_stream() if wg.on else None
-    late = None                                            # (layer, event) whose join is still owed (_DW_SIDE = 2)
     for i in reversed(range(fus.depth)):
         dx, dx_c = fusion_layer_bwd(dx, dx_c, layers[i], fus.layer_params(i), A, cdt, batch, seq, fus.heads,
                                     mask_mode, row_mask, wg)
         layers[i] = None                                   # free this layer's activations early
         done = [i]
-        if wg.on:
+        if wg.on:                                          # (joining one layer late measured no better: removed in round 6)
             ev = wg.mark()
-            if _DW_SIDE >= 2:
-                done = []
-                if late is not None:
-                    main.wait_event(late[1])
-                    wg.joined(late[1])
-                    done = [late[0]]
-                late = (i, ev)
-            else:
-                main.wait_event(ev)
-                wg.joined(ev)
+            main.wait_event(ev)
+            wg.joined(ev)
         if on_layer_done is not None:
             for j in done:
                 on_layer_done(j)
-    if late is not None:
-        main.wait_event(late[1])
-        wg.joined(late[1])
-        if on_layer_done is not None:
-            on_layer_done(late[0])
     if s16:
         dx = dx_c if keep16 else ops.cast(dx_c, torch.float32)   # standalone callers hand in and take fp32
     return dx

@@ -9,14 +9,13 @@ frozen towers' QKV / fc1 GEMMs in OCP e4m3, per-token and per-channel scales -- 
 """
 from __future__ import annotations
 
-import os
 from typing import Callable, List, Optional
 
 import torch
 from torch import nn
 
 from . import BaseModel, Components
-from .streams import side_stream
+from .streams import serial, side_stream
 from .arena import ParamArena, arena_of
 from .clip_encoder import _MODELS, load
 from .params import add_param, linear_init
@@ -103,7 +102,7 @@ class RGBOnly(BaseModel):
         main = torch.cuda.current_stream()
         side = side_stream(rgb.device, "text")
         self.clip_encoder._runtime(cdt)                   # arenas / bf16 copies ready before the fork
-        if os.environ.get("BIFOLD_TEXT_STREAM", "1") == "0":     # both towers on the main stream
+        if serial():                                      # profiling mode: both towers on the main stream
             text_feat = self.clip_encoder.encode_text_with_embeddings(instr, cdt)
             vis_feat = self.clip_encoder.encode_image_with_embeddings(rgb, cdt)
         else:

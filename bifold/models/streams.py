@@ -11,7 +11,11 @@ section 7).  The step therefore uses as few streams as its concurrency needs:
                             backward
   comm (bifold/dist.py)     the gradient all-reduces (RCCL adds its own internal stream)
 
-BIFOLD_MERGE_STREAMS=0 gives every role its own stream again (A/B).
+(One stream per role measured no better and costs hardware queues: removed in round 6.)
+
+BIFOLD_SERIAL_STREAMS=1 (or `set_serial(True)`) folds the side work into the main stream: the PROFILING mode in which a
+kernel's duration is its own cost instead of its share of a contended machine (bench.py's roofline sample,
+tools/serial_stats.sh).
 """
 from __future__ import annotations
 
@@ -20,15 +24,27 @@ from typing import Dict, Tuple
 
 import torch
 
-_MERGE = os.environ.get("BIFOLD_MERGE_STREAMS", "1") != "0"
+_SERIAL = os.environ.get("BIFOLD_SERIAL_STREAMS", "0") == "1"
 _streams: Dict[Tuple[int, str], "torch.cuda.Stream"] = {}
 
 
 def side_stream(device, role: str) -> "torch.cuda.Stream":
-    """The stream for `role` ("text", "decoder", "dw") on `device`: one shared stream unless BIFOLD_MERGE_STREAMS=0."""
+    """The stream for `role` ("text", "decoder", "dw") on `device`: ONE shared side stream."""
     device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
-    key = (index, "side" if _MERGE else role)
+    key = (index, "side")
     if key not in _streams:
         _streams[key] = torch.cuda.Stream(device=torch.device("cuda", index))
     return _streams[key]
+
+
+def serial() -> bool:
+    """True: towers, decoder collapse and weight-gradient GEMMs all run on the main stream (profiling mode)."""
+    return _SERIAL
+
+
+def set_serial(on: bool) -> bool:
+    """Switch the profiling mode; returns the previous setting."""
+    global _SERIAL
+    old, _SERIAL = _SERIAL, bool(on)
+    return old

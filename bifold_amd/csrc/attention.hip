@@ -535,26 +535,17 @@ __global__ __launch_bounds__(512) void attn_fwd_mfma_kernel(
 template <int D, int MASK, int NKB, typename HT>
 __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse,
-    const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp, int nt_loads) {
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int Lp) {
     constexpr int mask_mode = MASK;
     constexpr bool NOMAX = FwdNoMax<D>::value;
     constexpr int DP = (D + 31) / 32 * 32;
     constexpr int KS = D / 16;
     constexpr int DB = DP / 32;
     constexpr int KROW = D * 2 + 16;          // bytes
-    // Every byte of the packed QKV buffer is read exactly once by this launch (232 MB at the vision tower's shape,
-    // about the size of the Infinity Cache).  Round 3 streamed it with the non-temporal hint so that it would not push
-    // out the fp32 residual tile the next GEMM's epilogue re-read; since the residual adds ride in the LayerNorm passes
-    // (round 4) nothing re-reads it, the QKV buffer was written by the GEMM just before and is best found in the caches,
-    // and the hint costs 0.7 % of the step: off by default (BIFOLD_ATTN_NT=1 turns it on).
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-    auto ld16 = [&](const HT* p) -> uint4 {
-        if (nt_loads) {
-            const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
-            return make_uint4(v[0], v[1], v[2], v[3]);
-        }
-        return *(const uint4*)p;
-    };
+    // (Round 3 streamed the packed QKV buffer with the non-temporal hint; since the residual adds ride in the LayerNorm passes
+    // nothing re-reads what it would have spared, the buffer was written by the GEMM just before and is best found in the
+    // caches, and the hint cost 0.7 % of the step: removed in round 6.)
+    auto ld16 = [&](const HT* p) -> uint4 { return *(const uint4*)p; };
     constexpr int VROW = DP * 2 + 16;         // bytes (pad columns of D = 48 are zero)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -583,8 +574,6 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
         img_load<CH>(threadIdx.x, nthreads, L * CH,
                      [&](int j, int c) -> ImgPair {
                          const unsigned off = (unsigned)j * row_bytes + (unsigned)c * 16u;
-                         if (nt_loads) return ImgPair{__builtin_nontemporal_load((const img_u32x4*)(k_src + off)),
-                                                      __builtin_nontemporal_load((const img_u32x4*)(v_src + off))};
                          return ImgPair{*(const img_u32x4*)(k_src + off), *(const img_u32x4*)(v_src + off)};
                      },
                      [&](int j, int c, img_u32x4 a, img_u32x4 bb) {
@@ -828,202 +817,12 @@ __global__ __launch_bounds__(1024) void attn_fwd_res_kernel(
     if (q_live && lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
 }
 
-// =====================================================================================
-//   d = 32 forward, PERSISTENT and double-buffered: K / V of the next (batch, head) arrive by
-//   LDS-DMA while the current one is consumed
-// =====================================================================================
-// attn_fwd_res_kernel's time is its memory time PLUS its compute time (t = 37 us + bytes / 4.25 TB/s): a
-// workgroup loads its K / V image, then computes.  Here a workgroup keeps TWO images (64-byte rows without padding,
-// XOR-swizzled like ResImg<32>: 2 x 36.9 KB at 275 tokens, two workgroups per CU as before) and walks (batch, head)
-// items: right after the barrier that opens item i it issues `buffer_load ... lds` for item i + 1 into the other image
-// (fire and forget: no registers, no ds_write pass); the only wait for it is the one in front of the next barrier, a
-// whole key loop later (the next item's Q fragments are requested when the key loop ends: 80 registers leave no room
-// to hold them across it).  The output tile leaves straight from
-// the accumulators -- the two half-waves swap 8-byte pieces so that every lane stores 16 bytes -- because the idle K
-// image it used to be turned through is now busy receiving.  Same arithmetic and order as attn_fwd_res_kernel<32, 0, 1>.
-// The transposed V^T fragment reads of the persistent kernel go out as inline assembly: the compiler's wait-count pass
-// puts `s_waitcnt vmcnt(0)` in front of a ds_read_b64_tr_b16 builtin while an LDS-DMA is in flight (it cannot tell
-// that the DMA writes the OTHER image), which is exactly the overlap this kernel exists for.
+// Transposed fragment reads as inline assembly (attn_bwd_fused32p_kernel): the compiler's wait-count pass puts
+// `s_waitcnt vmcnt(0)` in front of a ds_read_b64_tr_b16 builtin while a hand-counted global load is in flight.
 __device__ __forceinline__ void tr_issue(uint2& lo, uint2& hi, const char* p0, const char* p1) {
     typedef __attribute__((address_space(3))) const char* lds_cp;
     const unsigned a0 = (unsigned)(size_t)(lds_cp)p0, a1 = (unsigned)(size_t)(lds_cp)p1;
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1));
-}
-
-template <typename HT>
-__global__ __launch_bounds__(1024, 6) void attn_fwd_pd32_kernel(
-    const HT* __restrict__ qkv, HT* __restrict__ out, float* __restrict__ lse, int L, int H, float scale, int Lp,
-    int n_items, unsigned qkv_bytes) {
-    constexpr int D = 32, KS = 2, ROWB = 64;
-    using RI = ResImg<32>;
-    typedef typename H16<HT>::x8 H8;
-    typedef typename H16<HT>::x4 H4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int img = Lp * ROWB;                          // one K (or V) image; buffer f: K at f * 2 img, V behind it
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nw = blockDim.x >> 6;                     // == Lp / 32: one wave per 32-query block
-    const int q0 = wave * 32;
-    const int G = gridDim.x;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, qkv_bytes, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    // Per-lane values are re-derived from an OPAQUE copy of the lane id in each phase of an item (DMA issue, key loop,
-    // output): hoisted out of the item loop they pushed the kernel past its 80 registers, and a spill reload is a VMEM
-    // instruction -- its s_waitcnt vmcnt(0) sits behind the LDS-DMA just issued (the counter is in order) and
-    // serialises exactly the transfer this kernel wants in flight under the key loop.
-    auto opaque_lane = [&]() { int l = (int)(threadIdx.x & 63); asm volatile("" : "+v"(l)); return l; };
-
-    // 4 nw pieces of 1 KB per item (2 nw of K, then 2 nw of V), four per wave; a piece is 16 rows x 64 B, lane l lands
-    // in slot l & 3 of row l >> 2 and therefore fetches chunk slot ^ swizzle(row).  Rows L .. Lp - 1 read whatever
-    // follows in the buffer (the next sample's tokens, or zeros past its end): their scores are masked to -inf below.
-    auto issue = [&](int v, int f) {
-        const int lane = opaque_lane();
-        const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pc = wave * 4 + i;
-            const int which = pc >= 2 * nw ? 2 : 1;
-            const int lp = pc - (which == 2 ? 2 * nw : 0);
-            const int row = lp * 16 + (lane >> 2);
-            const int c = (lane & 3) ^ ((row >> 2) & 3);
-            const unsigned voff = (unsigned)((qkv_off(b, row, which, h, L, H, D) + (size_t)c * 8) * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)(smem + f * 2 * img + (which == 2 ? img : 0) + lp * 1024), 16,
-                                                     voff, 0, 0, 0);
-        }
-    };
-    auto load_q = [&](int v, uint4 (&q)[KS]) {
-        const int lane = opaque_lane();
-        const int qi = q0 + (lane & 31);
-        const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            q[ks] = qi < L ? *(const uint4*)(qkv + qkv_off(b, qi, 0, h, L, H, D) + ks * 16 + (lane >> 5) * 8)
-                           : make_uint4(0, 0, 0, 0);
-    };
-
-    int v = blockIdx.x, f = 0;
-    if (v >= n_items) return;
-    uint4 qraw[KS];
-    issue(v, 0);
-    load_q(v, qraw);
-    const float sl2 = scale * 1.44269504088896340736f;
-
-    while (true) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this item's image pieces and Q (and the previous item's stores)
-        __syncthreads();                                   // everybody's pieces are in; everybody has left the other image
-        const int vn = v + G;
-        if (vn < n_items) issue(vn, f ^ 1);
-        f32x16 oacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
-        float m = -INFINITY, l = 0.f;
-        {
-            const int lane = opaque_lane();
-            const int r = lane & 31, hh = lane >> 5;
-            const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-            const char* k_lds = smem + f * 2 * img;
-            const char* v_lds = k_lds + img;
-            H8 qf[KS];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const H8*)&qraw[ks];
-            for (int j0 = 0; j0 < L; j0 += 32) {
-                f32x16 sacc;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const H8 kf = *(const H8*)(k_lds + RI::at(j0 + r, ks * 2 + hh, ROWB));
-                    sacc = mfma_32x32x16(kf, qf[ks], sacc);
-                }
-                if (j0 + 32 > L) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = j0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        if (key >= L) sacc[e] = -INFINITY;
-                    }
-                }
-                float tmax = -INFINITY;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, sacc[e]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * sl2;
-                const float m_new = fmaxf(m, tmax);
-                if (__builtin_amdgcn_ballot_w64((m_new - m > 6.0f) || (m == -INFINITY)) != 0) {     // lazy reference point:
-                    const float m_to = (m_new == -INFINITY) ? 0.f : m_new;                        // see attn_fwd_res_kernel
-                    const float alpha = __builtin_amdgcn_exp2f(m - m_to);
-                    l *= alpha;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
-                    m = m_new;
-                }
-                const float m_use = (m == -INFINITY) ? 0.f : m;
-                f32x2 psum2 = {0.f, 0.f};
-                const f32x2 sl2v = {sl2, sl2}, mneg = {-m_use, -m_use};
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    f32x2 t = {sacc[e], sacc[e + 1]};
-                    t = __builtin_elementwise_fma(t, sl2v, mneg);
-                    f32x2 p2 = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                    sacc[e] = p2[0];
-                    sacc[e + 1] = p2[1];
-                    psum2 += p2;
-                }
-                float psum = psum2[0] + psum2[1];
-                psum += __shfl_xor(psum, 32, 64);
-                l += psum;
-                const int cb = (16 * (g16 & 1) + 4 * p4) * 2;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    uint2 vlo, vhi;
-                    const int row0 = j0 + 16 * s2 + 4 * hh + q4;
-                    tr_issue(vlo, vhi, v_lds + RI::at(row0, cb >> 4, ROWB, cb & 15),
-                             v_lds + RI::at(row0 + 8, cb >> 4, ROWB, cb & 15));
-                    H8 pf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[e] = (HT)sacc[8 * s2 + e];
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo), "+v"(vhi));
-                    const uint4 vq = make_uint4(vlo.x, vlo.y, vhi.x, vhi.y);
-                    oacc = mfma_32x32x16(*(const H8*)&vq, pf, oacc);
-                }
-            }
-        }
-
-        // O^T accumulator: lane (r, hh) holds d = 8 g + 4 hh + {0..3} of query row r.  The half-waves swap pieces so
-        // that lane (r, 0) owns d 0-7 and 16-23, lane (r, 1) d 8-15 and 24-31: two 16-byte stores per lane, no LDS.
-        {
-            const int lane = opaque_lane();
-            const int r = lane & 31, hh = lane >> 5;
-            const int qi = q0 + r;
-            const bool q_live = qi < L;
-            const int bh = paired_bh<D>(v, n_items), b = bh / H, h = bh - b * H;
-            const float inv = q_live ? 1.0f / l : 0.f;
-            uint2 own[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                H4 o4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = (HT)(oacc[4 * g + e] * inv);
-                own[g] = *(const uint2*)&o4;
-            }
-            uint4 st[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const unsigned ax = own[2 * k].x, ay = own[2 * k].y, bx = own[2 * k + 1].x, by = own[2 * k + 1].y;
-                const unsigned gx = (unsigned)__shfl_xor((int)(hh ? ax : bx), 32, 64);
-                const unsigned gy = (unsigned)__shfl_xor((int)(hh ? ay : by), 32, 64);
-                st[k].x = hh ? gx : ax; st[k].y = hh ? gy : ay;
-                st[k].z = hh ? bx : gx; st[k].w = hh ? by : gy;
-            }
-            if (q_live) {
-                HT* op = out + ((size_t)b * L + qi) * (size_t)H * D + (size_t)h * D + hh * 8;
-                *(uint4*)op = st[0];
-                *(uint4*)(op + 16) = st[1];
-                if (lse && hh == 0) lse[((size_t)b * H + h) * L + qi] = (m + log2f(l)) * 0.69314718055994530942f;
-            }
-        }
-        if (vn >= n_items) break;
-        load_q(vn, qraw);             // the next item's Q rows: in flight across the stores above and the barrier below
-        v = vn;
-        f ^= 1;
-    }
 }
 
 // =====================================================================================
@@ -2198,7 +1997,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <typename HT>
 __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kernel(
     const HT* __restrict__ qkv, const HT* __restrict__ out, const HT* __restrict__ dout, const float* __restrict__ lse,
-    HT* __restrict__ dqkv, int L, int H, float scale, int n_items, int role_map) {
+    HT* __restrict__ dqkv, int L, int H, float scale, int n_items) {
     constexpr int D = 32, KS = 2, ROW = Fused32P::ROW, BLK = Fused32P::BLK, DO_OFF = Fused32P::DO_OFF;
     constexpr int NT = Fused32P::NWAVES * 64;
     using RI = ResImg<32>;
@@ -2217,10 +2016,10 @@ __global__ __launch_bounds__(Fused32P::NWAVES * 64) void attn_bwd_fused32p_kerne
     // ROLE of this wave (w: 0 - 8 key blocks, 9 the dQ sum, 10 - 11 loaders).  Waves p and p + 4 of a workgroup share a SIMD
     // (tools/micro/pipe_overlap.hip), so with role = wave id the summing wave -- the longest role of a step, 0.83 us against
     // the key waves' 0.58 (profiles/r05_attn_bwd_fused32p_probe.txt) -- sat on SIMD 1 beside TWO key waves, and every
-    // barrier waited for it.  role_map = 1 (round 5, second session) gives SIMD 1 to the three SUPPORT waves (physical
-    // waves 1, 5, 9: sum, loader, loader) and three key waves to each of the other SIMDs.
+    // barrier waited for it.  So SIMD 1 goes to the three SUPPORT waves (physical waves 1, 5, 9: sum, loader, loader) and three
+    // key waves to each of the other SIMDs (222 -> 218 us isolated, step 31.905 -> 31.785 ms; roles in wave order: removed).
     const int wp = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int w = !role_map ? wp : ((wp & 3) == 1 ? 9 + (wp >> 2) : (wp >> 2) * 3 + ((wp & 3) == 0 ? 0 : (wp & 3) - 1));
+    const int w = (wp & 3) == 1 ? 9 + (wp >> 2) : (wp >> 2) * 3 + ((wp & 3) == 0 ? 0 : (wp & 3) - 1);
     const int r = lane & 31, hh = lane >> 5;
     const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
     const float inv_scale = 1.0f / scale;
@@ -3075,542 +2874,6 @@ __global__ __launch_bounds__(StreamCfg<D>::NT, 2) void attn_bwd_kv_stream_kernel
 }
 
 // =====================================================================================
-//   One-pass backward for sequences beyond LDS and for d = 48 / 64 (round 5): S, dP and the exponentials ONCE
-// =====================================================================================
-// The streamed pair above computes S, dP and P twice (d = 48: 24 MFMAs and 32 exponentials per 32 x 32 block) because a
-// one-pass kernel has to reduce either dQ over key blocks or dK / dV over query blocks.  This kernel reduces dQ, with the
-// matrix pipe doing the sum, and splits the work of a block over three KINDS of waves so that each SIMD holds one wave
-// with the exponentials and one without (profiles/r05_pipe_overlap.txt: the pipes overlap between waves):
-//   * a workgroup = one (batch, head) x one chunk of EIGHT key blocks (256 keys), walking all query blocks.
-//   * waves 0 - 3, "S waves": two key blocks each.  Per query block: S = Q K^T and dP = dO V^T with the key on the lane and the
-//     row constants as initial accumulators, P = exp2(...), dS = P (dP - delta) scale; dV^T += dO^T P in registers (V
-//     fragments in registers for the kernel); dS leaves, converted, in a 2-KB LDS image [key][query] per key block.
-//   * waves 4 - 5, "dK waves", one step behind: dK^T += Q^T dS for four key blocks each -- the B operand is the very
-//     8-byte pieces the S wave's lanes wrote (same lane, same offsets), the A operand Q^T read transposed from the query
-//     block's slot (a ring of three slots: the S waves are already in the next block).
-//   * waves 6 - 7, "dQ waves", one step behind: dQ^T [d tile][query] = sum over the chunk's key blocks of K^T dS^T -- the K^T
-//     fragments of the whole chunk stay in 64 registers -- the lane is the query, so a lane stores its own row.
-//   MFMAs per step and SIMD (d = 48 / 64): 2 x 14 (S wave: 3 + 3 (4 + 4) + 4 per block... ) beside 16 (dK or dQ wave).
-//   * dQ of a chunk is a partial sum: sequences of one chunk (<= 256 tokens) store it directly; longer ones store fp32 slabs
-//     [chunk][B L][H D] with plain stores (4 - 5 x the rate of float atomics on this part) and attn_dq_reduce_kernel adds
-//     the chunks in order (bit-reproducible) and converts.
-//   * Q / dO rows of the next query block travel in registers (one 16-byte piece per thread), requested a step ahead;
-//     delta = rowsum(dO * O) comes from attn_delta_kernel.
-// Masks: none or the query-row mask (a masked row's scores are the constant -1e5: P = 1 / L, dS = 0; a wholly masked
-// block costs the S waves one product per key block and the others nothing); causal long sequences stay on the pair.
-// LDS (d = 64): K image 36.9 KB + three Q / dO slots 27.6 KB + row constants 1.2 KB + 2 x 8 dS images 32.8 KB = 98 KB.
-#ifndef BF_ONEPASS_S_PRIO
-#define BF_ONEPASS_S_PRIO 0      // static priorities of the S waves / the MFMA-only waves (A/B builds: -DBF_ONEPASS_S_PRIO=3 ...)
-#endif
-#ifndef BF_ONEPASS_M_PRIO
-#define BF_ONEPASS_M_PRIO 2
-#endif
-template <int D>
-struct OnePassCfg {
-    static constexpr int DP = (D + 31) / 32 * 32, KS = D / 16, DB = DP / 32;
-    static constexpr int KROW = DP * 2 + 16;                // K rows padded to DP columns (zero): transposed reads of the d tiles
-    static constexpr int ROW = D * 2 + 16;                  // Q / dO rows
-    static constexpr int NKB = 8, NT = 768, NSLOT = 3;
-    static constexpr int SLOT = 2 * 32 * ROW;               // Q block | dO block
-    static size_t lds_bytes() { return (size_t)NKB * 32 * KROW + NSLOT * SLOT + NSLOT * 3 * 32 * 4 + 2 * NKB * 2048; }
-};
-
-template <typename HT, int D>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const HT* __restrict__ out, const HT* __restrict__ dout,
-                                                         float* __restrict__ delta, int L, int H, size_t rows) {
-    // one thread per (row, head): delta[b, h, i] = sum_d dO O
-    const size_t total = rows * H;
-    for (size_t t = blockIdx.x * (size_t)256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
-        const size_t row = t / H;
-        const int h = (int)(t - row * H);
-        const HT* o = out + row * (size_t)H * D + (size_t)h * D;
-        const HT* g = dout + row * (size_t)H * D + (size_t)h * D;
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < D / 8; ++c) {
-            const typename H16<HT>::x8 ov = *(const typename H16<HT>::x8*)(o + c * 8), gv = *(const typename H16<HT>::x8*)(g + c * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf((float)ov[e], (float)gv[e], acc);
-        }
-        const size_t b = row / L, i = row - b * L;
-        delta[(b * H + h) * L + i] = acc;
-    }
-}
-
-// slabs [n_chunks][rows][H D] fp32 -> the Q slot of dqkv [rows][3][H D], chunks added in order
-template <typename HT>
-__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(const float* __restrict__ slabs, HT* __restrict__ dqkv,
-                                                             size_t rows, int hd, int n_chunks) {
-    const int c4n = hd >> 2;
-    const size_t total = rows * c4n, slab = rows * (size_t)hd;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / c4n;
-        const int c = (int)(i - row * c4n) * 4;
-        float4 s = *(const float4*)(slabs + row * hd + c);
-        for (int k = 1; k < n_chunks; ++k) {
-            const float4 v = *(const float4*)(slabs + k * slab + row * hd + c);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        Vec4<HT>::store(dqkv + row * 3 * hd + c, s);
-    }
-}
-
-template <int D, int MASK, typename HT>
-__global__ __launch_bounds__(OnePassCfg<D>::NT) void attn_bwd_onepass_kernel(
-    const HT* __restrict__ qkv, const HT* __restrict__ dout, const float* __restrict__ lse,
-    const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, HT* __restrict__ dqkv,
-    float* __restrict__ dq_slabs, int L, int H, float scale, int n_chunks) {
-    using C = OnePassCfg<D>;
-    constexpr int DP = C::DP, KS = C::KS, DB = C::DB, KROW = C::KROW, ROW = C::ROW, NKB = C::NKB, NT = C::NT;
-    constexpr int CPR = D / 8;                              // 16-byte pieces per Q / dO row
-    using X8 = typename H16<HT>::x8;
-    using X4 = typename H16<HT>::x4;
-    static_assert(DB == 2, "written for d = 48 and d = 64 (two 32-row d tiles: one dQ wave each)");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_img = smem;                                     // [256 keys][KROW]
-    char* slots = k_img + (size_t)NKB * 32 * KROW;          // three slots: Q block [32][ROW] | dO block [32][ROW]
-    float* cst = (float*)(slots + C::NSLOT * C::SLOT);      // three slots: -lse / scale [32] | -delta [32] | masked (int) [32]
-    char* ds_img = (char*)(cst + C::NSLOT * 96);            // 2 buffers x 8 key blocks: dS^T [key][query], 8-byte chunks swizzled
-
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int r = lane & 31, hh = lane >> 5;
-    const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-    // chunks of one (batch, head) are neighbours in dispatch order: they read the same Q / dO rows at about the same time
-    const int chunk = blockIdx.x % n_chunks;
-    const int bh = blockIdx.x / n_chunks, b = bh / H, h = bh - b * H;
-    const int key0 = chunk * NKB * 32;                      // first key of the chunk
-    const int nq = (L + 31) >> 5;                           // query blocks
-    const int nkb = min(NKB, ((L - key0) + 31) >> 5);       // live key blocks of this chunk
-    const float inv_scale = 1.0f / scale;
-    const float sl2 = scale * 1.44269504088896340736f;
-    const float inv_len = 1.0f / (float)L;
-    const size_t tok0 = (size_t)b * L;
-#ifdef ATTN_PROBE   // one wave per role stamps a 100 MHz wall clock: tools/attn_probe_onepass.py
-    const bool pr_on = lane == 0 && blockIdx.x < ATTN_PROBE_WGS;
-    unsigned long long* pr = attn_probe + (size_t)blockIdx.x * 8;
-    unsigned long long pr_a = 0, pr_b = 0, pr_c = 0;
-    if (pr_on && w == 0) pr[0] = wall_clock64();
-#endif
-
-    // ---- the chunk's K rows -> image (zero rows beyond L, zero pad columns) -----------------------------------------------
-    {
-        constexpr int CPK = DP / 8;
-        for (int idx = threadIdx.x; idx < NKB * 32 * CPK; idx += NT) {
-            const int j = idx / CPK, c = idx - j * CPK;
-            uint4 kv = make_uint4(0, 0, 0, 0);
-            if (key0 + j < L && c < CPR) kv = *(const uint4*)(qkv + qkv_off(b, key0 + j, 1, h, L, H, D) + c * 8);
-            *(uint4*)(k_img + j * KROW + c * 16) = kv;
-        }
-    }
-    // ---- the query blocks' rows travel in registers of the eight S waves, TWO steps ahead: one 16-byte piece per thread (Q
-    //      rows, then dO rows) and the row constants by the first 32 threads, in two register sets that alternate.  With one
-    //      set (requested in step j, written to its slot at the top of step j + 1) the step could not be shorter than a trip
-    //      to memory -- every form of this kernel ran 2.0 - 2.5 us per step whatever its waves did (tools/attn_probe_onepass.py).
-    //      Unconditional loads from clamped rows, so that the compiler counts them.
-    static_assert(2 * 32 * CPR <= 512, "one piece per thread of the S waves");
-    struct Pre { uint4 v; float ls, dl; int mk; };
-    const int lt = (int)threadIdx.x;                        // (used by waves 0 - 7 only)
-    const bool p_on = lt < 2 * 32 * CPR, is_do = lt >= 32 * CPR;
-    const int pi = is_do ? lt - 32 * CPR : lt, prow = p_on ? pi / CPR : 0, pc = p_on ? pi - prow * CPR : 0;
-    auto fetch = [&](Pre& pr_, int j) {
-        const int i = min(j * 32 + prow, L - 1);
-        pr_.v = is_do ? *(const uint4*)(dout + (tok0 + i) * (size_t)H * D + (size_t)h * D + pc * 8)
-                      : *(const uint4*)(qkv + qkv_off(b, i, 0, h, L, H, D) + pc * 8);
-        if (lt < 32) {
-            const int ic = min(j * 32 + lt, L - 1);
-            pr_.ls = lse[((size_t)b * H + h) * L + ic];
-            pr_.dl = delta_ws[((size_t)b * H + h) * L + ic];
-            pr_.mk = MASK == BF_MASK_QUERY_ROW ? (row_mask[tok0 + ic] == 0) : 0;
-        }
-    };
-    auto stash = [&](const Pre& pr_, int j) {
-        const int sl = j % C::NSLOT;
-        if (p_on) {
-            const bool live = j * 32 + prow < L;
-            *(uint4*)(slots + sl * C::SLOT + (is_do ? 32 * ROW : 0) + prow * ROW + pc * 16) = live ? pr_.v : make_uint4(0, 0, 0, 0);
-        }
-        if (lt < 32) {
-            const bool live = j * 32 + lt < L;
-            float* cs = cst + sl * 96;
-            cs[lt] = live ? -pr_.ls * inv_scale : -1e30f * inv_scale;
-            cs[32 + lt] = live ? -pr_.dl : 0.f;
-            ((int*)cs)[64 + lt] = live ? pr_.mk : 1;            // rows beyond L count as masked (their dO rows are zero)
-        }
-    };
-    const bool loader = w < 8;
-    Pre set0, set1;                                         // set (block & 1): block m is requested in step m - 3, written in step m - 1
-    set0.v = make_uint4(0, 0, 0, 0); set0.ls = 0.f; set0.dl = 0.f; set0.mk = 0;
-    set1 = set0;
-    for (int idx = threadIdx.x; idx < 2 * NKB * 2048 / 16; idx += NT) *(uint4*)(ds_img + idx * 16) = make_uint4(0, 0, 0, 0);
-    if (loader) {
-        fetch(set0, 0);
-        stash(set0, 0);
-        if (nq > 1) fetch(set1, 1);
-        if (nq > 2) fetch(set0, 2);
-    }
-    __syncthreads();
-
-    // dS^T image: row = key (64 bytes = 32 queries), 8-byte chunk c of row k at chunk c ^ ((k >> 1) & 7)
-    int dsw_off[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) dsw_off[g] = r * 64 + (((2 * g + hh) ^ ((r >> 1) & 7)) << 3);
-
-    if (w < 8) {
-        // =========================== S waves: key block w of the chunk, TWO per SIMD ==========================================
-        // (the vector ALU of a SIMD gives one wave half of what it gives two: 7.6 against 2.9 cycles per instruction,
-        // profiles/r05_pipe_overlap.txt.  A first form had four S waves with two key blocks each, one per SIMD beside a
-        // wave that only multiplies: 1.24 us per step for the S wave alone, 1.78 us beside its partner, slower than the pair.)
-        __builtin_amdgcn_s_setprio(BF_ONEPASS_S_PRIO);
-        const int key = key0 + w * 32 + r;
-        const float lane_on = key < L ? 1.0f : 0.0f;
-        const bool dead_blk = key0 + w * 32 + 32 > L;       // the block holds keys beyond L (only the sequence's last key block can)
-        const bool wave_live = w < nkb;
-        X8 vf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (key < L) vf[ks] = *(const X8*)(qkv + qkv_off(b, key, 2, h, L, H, D) + ks * 16 + hh * 8);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vf[ks][e] = (HT)0.f;
-            }
-        }
-        f32x16 dvacc[DB];
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) dvacc[db][e] = 0.f;
-        const char* krow = k_img + (w * 32 + r) * KROW;
-        auto s_step = [&](int j, Pre& pset) {
-            // block j + 1 (requested two steps ago) into its slot; block j + 3 requested into the same registers
-            if (j + 1 < nq) stash(pset, j + 1);
-            if (j + 3 < nq) fetch(pset, j + 3);
-#ifdef ATTN_PROBE
-            const unsigned long long pr_t1 = wall_clock64();
-#endif
-            const char* q_s = slots + (j % C::NSLOT) * C::SLOT;
-            const char* do_s = q_s + 32 * ROW;
-            const float* cs = cst + (j % C::NSLOT) * 96;
-            const int* mk = (const int*)cs + 64;
-            bool blk_masked = false;
-            if (MASK == BF_MASK_QUERY_ROW) blk_masked = __all(mk[r] != 0);
-            char* my_img = ds_img + ((j & 1) * NKB + w) * 2048;
-            if (!wave_live) {
-            } else if (MASK == BF_MASK_QUERY_ROW && blk_masked) {
-                // all 32 rows masked: P = 1 / L for every (query, key), dS = 0 -> dV^T += dO^T P; the dK / dQ waves skip the block
-                X8 pconst;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pconst[e] = (HT)(inv_len * lane_on);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int row0 = 16 * s + 4 * hh + q4;
-#pragma unroll
-                    for (int db = 0; db < DB; ++db) {
-                        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                        const X8 dot = tr_pair<HT>(do_s + row0 * ROW + cb, do_s + (row0 + 8) * ROW + cb);
-                        dvacc[db] = mfma_32x32x16(dot, pconst, dvacc[db]);
-                    }
-                }
-            } else {
-                f32x16 sacc, pacc;                          // the row constants -lse / scale and -delta are the initial accumulators
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 l4 = *(const float4*)(cs + 8 * g + 4 * hh);
-                    const float4 d4 = *(const float4*)(cs + 32 + 8 * g + 4 * hh);
-                    sacc[4 * g + 0] = l4.x; sacc[4 * g + 1] = l4.y; sacc[4 * g + 2] = l4.z; sacc[4 * g + 3] = l4.w;
-                    pacc[4 * g + 0] = d4.x; pacc[4 * g + 1] = d4.y; pacc[4 * g + 2] = d4.z; pacc[4 * g + 3] = d4.w;
-                }
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const X8 qa = *(const X8*)(q_s + r * ROW + ks * 32 + hh * 16);
-                    const X8 da = *(const X8*)(do_s + r * ROW + ks * 32 + hh * 16);
-                    const X8 kfr = *(const X8*)(krow + ks * 32 + hh * 16);
-                    sacc = mfma_32x32x16(qa, kfr, sacc);
-                    pacc = mfma_32x32x16(da, vf[ks], pacc);
-                }
-                // p = exp2(sl2 S'), dS = p dP' (the scale rides in the stores of dK and dQ).  A block with masked rows among
-                // live ones (frame boundaries inside a block: rare) or with keys beyond L (the sequence's last key block)
-                // takes the per-element form; every other block is 8 + 8 packed multiplies and 16 exponentials.
-                bool any_masked = false;
-                if (MASK == BF_MASK_QUERY_ROW) any_masked = __any(mk[r] != 0);
-                const f32x2 sl2v = {sl2, sl2};
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const f32x2 tt = (f32x2){sacc[e], sacc[e + 1]} * sl2v;
-                    const f32x2 p2 = {__builtin_amdgcn_exp2f(tt[0]), __builtin_amdgcn_exp2f(tt[1])};
-                    const f32x2 ds2 = p2 * (f32x2){pacc[e], pacc[e + 1]};
-                    sacc[e] = p2[0]; sacc[e + 1] = p2[1];
-                    pacc[e] = ds2[0]; pacc[e + 1] = ds2[1];
-                }
-                if (any_masked || dead_blk) {               // (wave-uniform)
-                    const float pm = inv_len * lane_on;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int ql = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        const bool m = MASK == BF_MASK_QUERY_ROW && mk[ql] != 0;
-                        sacc[e] = m ? pm : sacc[e] * lane_on;
-                        pacc[e] = m ? 0.f : pacc[e] * lane_on;
-                    }
-                }
-                X8 pb[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pb[s][e] = (HT)sacc[8 * s + e];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    X4 v4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = (HT)pacc[4 * g + e];
-                    *(X4*)(my_img + dsw_off[g]) = v4;
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int row0 = 16 * s + 4 * hh + q4;
-#pragma unroll
-                    for (int db = 0; db < DB; ++db) {
-                        const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                        const X8 dot = tr_pair<HT>(do_s + row0 * ROW + cb, do_s + (row0 + 8) * ROW + cb);
-                        dvacc[db] = mfma_32x32x16(dot, pb[s], dvacc[db]);
-                    }
-                }
-            }
-#ifdef ATTN_PROBE
-            const unsigned long long pr_t2 = wall_clock64();
-#endif
-            __syncthreads();
-#ifdef ATTN_PROBE
-            pr_a += pr_t2 - pr_t1; pr_b += wall_clock64() - pr_t2;
-#endif
-        };
-        for (int j = 0; j < nq; j += 2) {                   // (block j + 1 sits in set (j + 1) & 1)
-            s_step(j, set1);
-            if (j + 1 < nq) s_step(j + 1, set0);
-        }
-#ifdef ATTN_PROBE
-        if (pr_on && w == 0) { pr[1] = pr_a; pr[2] = pr_b; pr[6] = pr_c; pr[4] = wall_clock64(); }
-#endif
-        __syncthreads();                                    // (the step the dK / dQ waves run behind)
-        if (key < L) {
-            HT* dvp = dqkv + qkv_off(b, key, 2, h, L, H, D);
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = db * 32 + 8 * g + 4 * hh;
-                    if (d0 < D) {
-                        X4 v4;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v4[e] = (HT)dvacc[db][4 * g + e];
-                        *(X4*)(dvp + d0) = v4;
-                    }
-                }
-        }
-    } else if (w < 10) {
-        // =========================== dK waves (8, 9): key blocks 4 (w - 8) .. + 3, one step behind =========================================
-        // (the younger wave of its SIMD loses the issue arbitration to the S wave it shares it with: static priority for the
-        // waves that only multiply, so that their MFMAs go out when their operands are there and the S wave's vector work
-        // fills the gaps)
-        __builtin_amdgcn_s_setprio(BF_ONEPASS_M_PRIO);
-        const int kb0 = 4 * (w - 8);
-        f32x16 dkacc[4][DB];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dkacc[kb][db][e] = 0.f;
-        for (int j = 0; j <= nq; ++j) {
-#ifdef ATTN_PROBE
-            const unsigned long long pr_t0 = wall_clock64();
-#endif
-#ifdef ONEPASS_ABL_NO_PARTNERS
-            if (false) {
-#else
-            if (j >= 1) {
-#endif
-                const int jq = j - 1;
-                const char* q_s = slots + (jq % C::NSLOT) * C::SLOT;
-                const int* mk = (const int*)(cst + (jq % C::NSLOT) * 96) + 64;
-                bool blk_masked = false;
-                if (MASK == BF_MASK_QUERY_ROW) blk_masked = __all(mk[r] != 0);
-                if (!blk_masked) {
-                    // Q^T fragments of the block: two k steps x two d tiles, shared by this wave's four key blocks
-                    X8 qtt[2][DB];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int row0 = 16 * s + 4 * hh + q4;
-#pragma unroll
-                        for (int db = 0; db < DB; ++db) {
-                            const int cb = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-                            qtt[s][db] = tr_pair<HT>(q_s + row0 * ROW + cb, q_s + (row0 + 8) * ROW + cb);
-                        }
-                    }
-#pragma unroll
-                    for (int kb = 0; kb < 4; ++kb) {      // (a block beyond the chunk's keys reads a zero / stale image: its dK is never stored)
-                        const char* im = ds_img + ((jq & 1) * NKB + kb0 + kb) * 2048;
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const X4 lo = *(const X4*)(im + dsw_off[2 * s]), hi = *(const X4*)(im + dsw_off[2 * s + 1]);
-                            X8 dsb;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { dsb[e] = lo[e]; dsb[4 + e] = hi[e]; }
-#pragma unroll
-                            for (int db = 0; db < DB; ++db) dkacc[kb][db] = mfma_32x32x16(qtt[s][db], dsb, dkacc[kb][db]);
-                        }
-                    }
-                }
-            }
-#ifdef ATTN_PROBE
-            pr_a += wall_clock64() - pr_t0;
-#endif
-            __syncthreads();
-        }
-#ifdef ATTN_PROBE
-        if (pr_on && w == 8) pr[3] = pr_a;
-#endif
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int key = key0 + (kb0 + kb) * 32 + r;
-            if (key < L) {
-                HT* dkp = dqkv + qkv_off(b, key, 1, h, L, H, D);
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int d0 = db * 32 + 8 * g + 4 * hh;
-                        if (d0 < D) {
-                            X4 k4;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) k4[e] = (HT)(dkacc[kb][db][4 * g + e] * scale);
-                            *(X4*)(dkp + d0) = k4;
-                        }
-                    }
-            }
-        }
-    } else {
-        // =========================== dQ waves (10, 11): d tile w - 10, one step behind ===========================================================
-        __builtin_amdgcn_s_setprio(BF_ONEPASS_M_PRIO);
-        const int db = w - 10;
-        int dsr_off[2][2];                                  // B operand: a dS^T image read transposed
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int krow = 16 * s2 + 8 * hh + q4 + 4 * u;
-                dsr_off[s2][u] = krow * 64 + (((4 * (g16 & 1) + p4) ^ ((krow >> 1) & 7)) << 3);
-            }
-        // K^T fragments of the chunk's key blocks for this d tile (A operand: rows d, k = key), once
-        X8 kfr[NKB][2];
-        {
-            const int cd = (db * 32 + 16 * (g16 & 1) + 4 * p4) * 2;
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const char* k0p = k_img + (kb * 32 + 16 * s + 8 * hh + q4) * KROW + cd;
-                    kfr[kb][s] = tr_pair<HT>(k0p, k0p + 4 * KROW);
-                }
-        }
-        for (int j = 0; j <= nq; ++j) {
-#ifdef ATTN_PROBE
-            const unsigned long long pr_t0 = wall_clock64();
-#endif
-#ifdef ONEPASS_ABL_NO_PARTNERS
-            if (false) {
-#else
-            if (j >= 1) {
-#endif
-                const int jq = j - 1;
-                const int* mk = (const int*)(cst + (jq % C::NSLOT) * 96) + 64;
-                bool blk_masked = false;
-                if (MASK == BF_MASK_QUERY_ROW) blk_masked = __all(mk[r] != 0);
-                f32x16 dq;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) dq[e] = 0.f;
-                if (!blk_masked) {
-                    // image reads as assembly in batches of two key blocks, the next batch before the MFMAs of the current one
-                    // (see attn_bwd_fused32p_kernel); a block beyond the chunk's keys multiplies zero K^T fragments with an
-                    // image that is zero or stale-but-finite (the images are cleared at kernel start)
-                    const char* img_buf = ds_img + (size_t)(jq & 1) * NKB * 2048;
-                    auto issue1 = [&](uint2 (&f)[2][2], int kb) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s)
-                            tr_issue(f[s][0], f[s][1], img_buf + kb * 2048 + dsr_off[s][0], img_buf + kb * 2048 + dsr_off[s][1]);
-                    };
-                    auto mul1 = [&](uint2 (&f)[2][2], int kb) {
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const uint4 vq = make_uint4(f[s][0].x, f[s][0].y, f[s][1].x, f[s][1].y);
-                            dq = mfma_32x32x16(kfr[kb][s], *(const X8*)&vq, dq);
-                        }
-                    };
-#define BF_LGKM_WAIT1(N, f) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]))
-                    static_assert(NKB == 8, "eight key blocks, one batch each, two in flight");
-                    uint2 fa[2][2], fb[2][2];
-                    issue1(fa, 0);
-                    issue1(fb, 1);
-                    BF_LGKM_WAIT1(4, fa); mul1(fa, 0); issue1(fa, 2);
-                    BF_LGKM_WAIT1(4, fb); mul1(fb, 1); issue1(fb, 3);
-                    BF_LGKM_WAIT1(4, fa); mul1(fa, 2); issue1(fa, 4);
-                    BF_LGKM_WAIT1(4, fb); mul1(fb, 3); issue1(fb, 5);
-                    BF_LGKM_WAIT1(4, fa); mul1(fa, 4); issue1(fa, 6);
-                    BF_LGKM_WAIT1(4, fb); mul1(fb, 5); issue1(fb, 7);
-                    BF_LGKM_WAIT1(4, fa); mul1(fa, 6);
-                    BF_LGKM_WAIT1(0, fb); mul1(fb, 7);
-#undef BF_LGKM_WAIT1
-                }
-                // lane (query r, half hh) holds d = 32 db + 8 g + 4 hh + {0 .. 3}
-                const int qi = jq * 32 + r;
-                if (qi < L) {
-                    if (n_chunks == 1) {
-                        HT* dst = dqkv + qkv_off(b, qi, 0, h, L, H, D);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int d0 = db * 32 + 8 * g + 4 * hh;
-                            if (d0 < D) {
-                                X4 o4;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) o4[e] = (HT)(dq[4 * g + e] * scale);
-                                *(X4*)(dst + d0) = o4;
-                            }
-                        }
-                    } else {
-                        float* dst = dq_slabs + ((size_t)chunk * ((size_t)gridDim.x / n_chunks / H) * L + tok0 + qi) * (size_t)H * D + (size_t)h * D;
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int d0 = db * 32 + 8 * g + 4 * hh;
-                            if (d0 < D) *(float4*)(dst + d0) = make_float4(dq[4 * g] * scale, dq[4 * g + 1] * scale, dq[4 * g + 2] * scale, dq[4 * g + 3] * scale);
-                        }
-                    }
-                }
-            }
-#ifdef ATTN_PROBE
-            pr_a += wall_clock64() - pr_t0;
-#endif
-            __syncthreads();
-        }
-#ifdef ATTN_PROBE
-        if (pr_on && w == 10) pr[5] = pr_a;
-#endif
-    }
-}
-
-// dq_ws fp32 [B, L, H*D] -> the Q slot of dqkv [B, L, 3, H, D] (bf16)
-template <typename HT>
-__global__ __launch_bounds__(256) void attn_dq_cast_kernel(const float* __restrict__ dq_ws, HT* __restrict__ dqkv,
-                                                           size_t rows, int hd) {
-    const int c4n = hd >> 2;
-    const size_t total = rows * c4n;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t row = i / c4n;
-        const int c = (int)(i - row * c4n) * 4;
-        Vec4<HT>::store(dqkv + row * 3 * hd + c, *(const float4*)(dq_ws + row * hd + c));
-    }
-}
-
-// =====================================================================================
 //                                        host
 // =====================================================================================
 static int attn_check(const char* who, const void* qkv, int batch, int seq, int heads, int head_dim,
@@ -3626,6 +2889,18 @@ static int attn_check(const char* who, const void* qkv, int batch, int seq, int 
     return BF_OK;
 }
 
+// Which kernel takes which call (16-bit modes; every choice below is the winner of a measured A/B, DESIGN.md section 6 and
+// docs/ -- the losing variants and their knobs were removed in round 6):
+//   forward   K + V of the sequence fit 80 KB of LDS (<= 512 tokens)      attn_fwd_res_kernel (32-key steps when the last 64-key tile
+//                                                                          would be more than half empty)
+//             longer, no causal mask                                       attn_fwd_pipe_kernel (attention_pipe.hip)
+//             longer, causal                                               attn_fwd_mfma_kernel
+//   backward  d = 32, no mask, 3 - 9 blocks                                attn_bwd_fused32p_kernel (nine blocks, >= 2 items per CU) / attn_bwd_fused32_kernel
+//             d = 32 / 48 whose images fit LDS, not causal under 128 tokens  attn_bwd_q_kernel + attn_bwd_kv_kernel
+//             d = 48 / 64, >= 24 blocks, no causal mask                    attn_bwd_q_pipe_kernel + attn_bwd_kv_pipe_kernel (attention_pipe.hip)
+//             everything else beyond one workgroup                         attn_bwd_q_stream_kernel + attn_bwd_kv_stream_kernel
+//             short causal sequences (the CLIP text tower would, were it trained)   attn_bwd_mfma_kernel, one chunk
+// fp32 (the exact mode): the VALU kernels.
 extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const int32_t* row_mask,
                                 int batch, int seq, int heads, int head_dim, float scale, int mask_mode,
                                 int cdt, bf_stream_t stream) {
@@ -3635,88 +2910,41 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
     hipStream_t s = (hipStream_t)stream;
     const bool f16 = cdt == BF_F16;
 #define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
+#define BY_MASK(M, DD) do { if (mask_mode == BF_MASK_NONE) BY_HALF(M, DD, BF_MASK_NONE); else if (mask_mode == BF_MASK_CAUSAL) BY_HALF(M, DD, BF_MASK_CAUSAL); else BY_HALF(M, DD, BF_MASK_QUERY_ROW); } while (0)
+#define BY_DIM(M) do { if (head_dim == 32) BY_MASK(M, 32); else if (head_dim == 48) BY_MASK(M, 48); else BY_MASK(M, 64); } while (0)
     if (bf_is_half(cdt)) {
         const int nq32 = bf_cdiv(seq, 32);
-        // whole-sequence K / V resident in LDS when they fit and one workgroup can hold every
-        // 32-query wave (the sequences of this model family); otherwise the tiled kernel
         const int lp = bf_cdiv(seq, 64) * 64;
         const int dp = (head_dim + 31) / 32 * 32;
-        const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16)) + (size_t)bf_tuning().attn_lds_pad;   // (+ occupancy experiments)
-        const int fwd_res_env = bf_tuning().attn_fwd_tiled ? 0 : 1;
-        // d = 32 without a mask (the fusion transformer of rgb_clip): the persistent, double-buffered kernel
-        const size_t pd_lds = (size_t)2 * (nq32 * 32) * 128;
-        const size_t qkv_ext = (size_t)batch * seq * 3 * heads * head_dim * 2;
-        if (fwd_res_env && bf_tuning().attn_fwd_pd && head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 <= 16 &&
-            pd_lds <= 80 * 1024 && qkv_ext < (1ull << 32)) {
-            int n_cu = 0, dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
-            const int per_cu = (int)((160 * 1024) / pd_lds) < 2 ? 1 : 2;
-            int grid_pd = n_cu * per_cu;
-            if (grid_pd > batch * heads) grid_pd = batch * heads;
-#define FWD_PD(HT)                                                                                 \
-    do {                                                                                          \
-        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                                                                \
-        if (pd_lds > lds_set) {                                                                   \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_pd32_kernel<HT>,                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pd_lds);   \
-            lds_set = pd_lds;                                                                     \
-        }                                                                                         \
-        hipLaunchKernelGGL((attn_fwd_pd32_kernel<HT>), dim3(grid_pd), dim3(nq32 * 64), pd_lds, s, (const HT*)qkv, \
-                           (HT*)out, lse, seq, heads, scale, nq32 * 32, batch * heads, (unsigned)qkv_ext); \
-    } while (0)
-            if (f16) FWD_PD(f16_t); else FWD_PD(bf16_t);
-#undef FWD_PD
-            BF_CHECK_LAUNCH("bf_attention_fwd");
-            return BF_OK;
-        }
-        // (A/B: the pipelined kernel for sequences the resident one would take)
-        if (bf_tuning().attn_fwd_pipe && fwd_res_env && seq >= bf_tuning().attn_fwd_pipe_min_seq &&
-            bf_attn_fwd_pipe_launch(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, cdt, s) == BF_OK) {
-            BF_CHECK_LAUNCH("bf_attention_fwd");
-            return BF_OK;
-        }
-        if (fwd_res_env && nq32 <= 16 && res_lds <= 80 * 1024 + (size_t)bf_tuning().attn_lds_pad) {
+        const size_t res_lds = (size_t)lp * ((head_dim * 2 + 16) + (dp * 2 + 16));
+        if (nq32 <= 16 && res_lds <= 80 * 1024) {
             dim3 rgrid(batch * heads), rblock(nq32 * 64);
-            const int nt_env = bf_tuning().attn_nt;
-            const int nt_loads = nt_env & 1;
-            const int kt_env = bf_tuning().attn_fwd_kt32;      // 0: 64-key tiles always; 1: 32-key steps always; default: by the last tile's fill
-            const bool half_steps = kt_env == 1 || (kt_env == 2 && mask_mode != BF_MASK_CAUSAL && (seq % 64) != 0 && (seq % 64) <= 32);
-#define FWD_RES2(DD, MM) BY_HALF(FWD_RES3, DD, MM)
-#define FWD_RES3(DD, MM, HT)                                                                       \
+            // a sequence whose last 64-key tile would be more than half empty walks 32-key steps
+            const bool half_steps = mask_mode != BF_MASK_CAUSAL && (seq % 64) != 0 && (seq % 64) <= 32;
+#define FWD_RES(DD, MM, HT)                                                                        \
     do {                                                                                          \
-        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                                                                \
+        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                      \
         if (res_lds > lds_set) {                                                                  \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 2, HT>,                \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 2, HT>,            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
-            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 1, HT>,                \
+            (void)hipFuncSetAttribute((const void*)attn_fwd_res_kernel<DD, MM, 1, HT>,            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)res_lds);  \
             lds_set = res_lds;                                                                    \
         }                                                                                         \
         if (half_steps)                                                                           \
             hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 1, HT>), rgrid, rblock, res_lds, s, (const HT*)qkv, \
-                               (HT*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
+                               (HT*)out, lse, row_mask, seq, heads, scale, lp);                \
         else                                                                                      \
             hipLaunchKernelGGL((attn_fwd_res_kernel<DD, MM, 2, HT>), rgrid, rblock, res_lds, s, (const HT*)qkv, \
-                               (HT*)out, lse, row_mask, seq, heads, scale, lp, nt_loads);     \
+                               (HT*)out, lse, row_mask, seq, heads, scale, lp);                \
     } while (0)
-#define FWD_RES(DD)                                                                               \
-    do {                                                                                          \
-        if (mask_mode == BF_MASK_NONE) FWD_RES2(DD, BF_MASK_NONE);                                \
-        else if (mask_mode == BF_MASK_CAUSAL) FWD_RES2(DD, BF_MASK_CAUSAL);                       \
-        else FWD_RES2(DD, BF_MASK_QUERY_ROW);                                                     \
-    } while (0)
-            if (head_dim == 32) FWD_RES(32);
-            else if (head_dim == 48) FWD_RES(48);
-            else FWD_RES(64);
+            BY_DIM(FWD_RES);
 #undef FWD_RES
-#undef FWD_RES2
-#undef FWD_RES3
             BF_CHECK_LAUNCH("bf_attention_fwd");
             return BF_OK;
         }
-        // beyond LDS: the software-pipelined kernel (attention_pipe.hip) for d = 48 / 64 without a causal mask
-        if (bf_tuning().attn_fwd_pipe && !bf_tuning().attn_fwd_tiled &&
+        // beyond LDS: the software-pipelined kernel (attention_pipe.hip) unless the mask is causal
+        if (bf_tuning().attn_pipe &&
             bf_attn_fwd_pipe_launch(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, cdt, s) == BF_OK) {
             BF_CHECK_LAUNCH("bf_attention_fwd");
             return BF_OK;
@@ -3724,22 +2952,11 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         const int chunks = bf_cdiv(nq32, 8);
         const int wpb = bf_cdiv(nq32, chunks);
         dim3 grid(batch * heads, chunks), block(wpb * 64);
-#define FWD_MFMA2(DD, MM) BY_HALF(FWD_MFMA3, DD, MM)
-#define FWD_MFMA3(DD, MM, HT)                                                                     \
+#define FWD_MFMA(DD, MM, HT)                                                                      \
     hipLaunchKernelGGL((attn_fwd_mfma_kernel<DD, MM, HT>), grid, block, 0, s, (const HT*)qkv,     \
                        (HT*)out, lse, row_mask, seq, heads, scale, wpb)
-#define FWD_MFMA(DD)                                                                              \
-    do {                                                                                          \
-        if (mask_mode == BF_MASK_NONE) FWD_MFMA2(DD, BF_MASK_NONE);                               \
-        else if (mask_mode == BF_MASK_CAUSAL) FWD_MFMA2(DD, BF_MASK_CAUSAL);                      \
-        else FWD_MFMA2(DD, BF_MASK_QUERY_ROW);                                                    \
-    } while (0)
-        if (head_dim == 32) FWD_MFMA(32);
-        else if (head_dim == 48) FWD_MFMA(48);
-        else FWD_MFMA(64);
+        BY_DIM(FWD_MFMA);
 #undef FWD_MFMA
-#undef FWD_MFMA2
-#undef FWD_MFMA3
     } else {
         dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
 #define FWD_SIMPLE(DD)                                                                            \
@@ -3750,7 +2967,6 @@ extern "C" int bf_attention_fwd(const void* qkv, void* out, float* lse, const in
         else FWD_SIMPLE(64);
 #undef FWD_SIMPLE
     }
-#undef BY_HALF
     BF_CHECK_LAUNCH("bf_attention_fwd");
     return BF_OK;
 }
@@ -3778,41 +2994,9 @@ static size_t bwd_lds_of(int head_dim, int nw) {
     return head_dim == 32 ? BwdCfg<32>::lds_bytes(nw) : head_dim == 48 ? BwdCfg<48>::lds_bytes(nw)
                                                                       : BwdCfg<64>::lds_bytes(nw);
 }
-// waves (32-key blocks) per workgroup of the MFMA backward for this sequence; 0 = not applicable
-static int bwd_pick_nw(int seq, int head_dim, bool have_ws) {
-    const int nw_all = bf_cdiv(seq, 32);
-    int maxw = head_dim == 32 ? 16 : 8;
-    const int cap = bf_tuning().attn_bwd_nw;
-    if (cap > 0 && cap < maxw && have_ws) maxw = cap;
-    if (nw_all <= maxw && bwd_lds_of(head_dim, nw_all) <= 160 * 1024) return nw_all;
-    if (!have_ws) return 0;
-    int nw = maxw;
-    while (nw > 1 && bwd_lds_of(head_dim, nw) > 160 * 1024) --nw;
-    return nw;
-}
-// d = 48 / 64, no mask or the query-row mask, sequences the streamed pair used to take: the one-pass kernel
-static bool onepass_takes(int seq, int head_dim, int mask_mode, bool half) {
-    const int nq32 = bf_cdiv(seq, 32);
-    return half && bf_tuning().attn_bwd_onepass && (head_dim == 48 || head_dim == 64) && mask_mode != BF_MASK_CAUSAL &&
-           bf_tuning().attn_bwd_stream && nq32 >= bf_tuning().attn_onepass_min_q32;
-}
-extern "C" long long bf_attention_bwd_ws_elems(int batch, int seq, int heads, int head_dim, int mask_mode, int cdt) {
-    if (batch <= 0 || seq <= 0 || heads <= 0 || !(head_dim == 32 || head_dim == 48 || head_dim == 64)) return 0;
-    const long long one = (long long)batch * seq * heads * head_dim;
-    if (onepass_takes(seq, head_dim, mask_mode, bf_is_half(cdt))) {
-        const int n_chunks = bf_cdiv(bf_cdiv(seq, 32), OnePassCfg<64>::NKB);
-        return n_chunks > 1 ? one * n_chunks : 0;
-    }
-    return (bf_is_half(cdt) && bf_attention_bwd_needs_dq_ws(seq, head_dim)) ? one : 0;
-}
-extern "C" int bf_attention_bwd_needs_dq_ws(int seq, int head_dim) {
-    if (!(head_dim == 32 || head_dim == 48 || head_dim == 64) || seq <= 0) return 0;
-    const int nw = bwd_pick_nw(seq, head_dim, true);
-    return bf_cdiv(seq, nw * 32) > 1 ? 1 : 0;
-}
 
 extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                                const int32_t* row_mask, void* dqkv, float* delta_ws, float* dq_ws, int batch,
+                                const int32_t* row_mask, void* dqkv, float* delta_ws, int batch,
                                 int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                                 bf_stream_t stream) {
     int rc = attn_check("bf_attention_bwd", qkv, batch, seq, heads, head_dim, mask_mode, row_mask, cdt);
@@ -3822,39 +3006,25 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
                "bf_attention_bwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     const bool f16 = cdt == BF_F16, half = bf_is_half(cdt);
-#define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
-    // MFMA kernel geometry: one chunk of 32*nw keys per workgroup.  Short sequences run as ONE chunk
-    // (whole sequence in LDS, dQ stored directly); longer ones use the largest nw whose LDS image
-    // fits 160 KB and accumulate dQ across key chunks through dq_ws.
-    // Sequences whose K+V / Q+dO fit LDS: two barrier-free kernels (dQ with the query on the lane,
-    // then dK/dV with the key on the lane); longer ones: the single tiled kernel below.
-    {
-        const int nq32 = bf_cdiv(seq, 32), lp = nq32 * 32;
-        const int dp = (head_dim + 31) / 32 * 32;
-        const int pad = head_dim == 32 ? 0 : 16, row = head_dim * 2 + pad;          // ResImg<D>: d = 32 rows are unpadded
-        const size_t lds_pad = (size_t)bf_tuning().attn_lds_pad;      // occupancy experiments only
-        const size_t lds_q = (size_t)lp * ((dp * 2 + pad) + row) + lds_pad;
-        const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4 + lds_pad;
-        const int split_env = bf_tuning().attn_bwd_single ? 0 : 1;
-        // (short causal sequences stay on the single kernel: 72 vs 116 us at L = 77)
-        const int res_wide_env = bf_tuning().attn_bwd_resident_wide;   // which head widths take the resident pair: 1: also d = 64; -1: d = 32 only
-        const int stream_min_env = bf_tuning().attn_stream_min_q32;
-        const int stream_d32_env = bf_tuning().attn_stream_d32;
-        // d = 48 joins d = 32 on the resident pair since its kernels are bounded at 512 threads (148-174 registers, no
-        // scratch: 80.8 vs 92.9 us at 262 x 48); d = 64 stays on the streamed pair (300 x 64: 99 vs 134 us resident)
-        const bool wide_ok = (head_dim == 32 && !stream_d32_env) || (head_dim == 48 && res_wide_env != -1) || res_wide_env > 0 ||
-                             nq32 < stream_min_env;
-        // d = 32 without a mask, 3 - 9 blocks (the 275-token fusion of config A): the one-pass kernel
-        if (half && head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 >= 3 && nq32 <= 9 && bf_tuning().attn_bwd_fused) {
-            // the persistent form (one twelve-wave workgroup per CU walking items) when there are items to walk:
-            // BIFOLD_ATTN_BWD_FUSED_P = 1: from two items per CU; 2: always; 0: never
-            int n_cu = 0, dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
-            const int fp_env = bf_tuning().attn_bwd_fused_p;
-            if (nq32 == Fused32P::NKW && (fp_env == 2 || (fp_env == 1 && batch * heads >= 2 * n_cu))) {
-                const size_t lds_p = Fused32P::lds_bytes(nq32);
-                const int grid_p = batch * heads < n_cu ? batch * heads : n_cu;
+    if (!half) {
+        if (cdt == BF_F32)
+            attn_bwd_launch<float>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale, mask_mode, s);
+        BF_CHECK_LAUNCH("bf_attention_bwd");
+        return BF_OK;
+    }
+    const int nq32 = bf_cdiv(seq, 32), lp = nq32 * 32;
+    const int dp = (head_dim + 31) / 32 * 32;
+    // ---- d = 32 without a mask, 3 - 9 blocks (the 275-token fusion of config A): the one-pass kernels
+    if (head_dim == 32 && mask_mode == BF_MASK_NONE && nq32 >= 3 && nq32 <= 9) {
+        // the persistent form (one twelve-wave workgroup per CU walking items) for nine-block sequences when there are items to
+        // walk: BIFOLD_ATTN_BWD_FUSED_P = 1: from two items per CU (the default); 2: always (tests); 0: never
+        int n_cu = 0, dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+        const int fp_env = bf_tuning().attn_bwd_fused_p;
+        if (nq32 == Fused32P::NKW && (fp_env == 2 || (fp_env == 1 && batch * heads >= 2 * n_cu))) {
+            const size_t lds_p = Fused32P::lds_bytes(nq32);
+            const int grid_p = batch * heads < n_cu ? batch * heads : n_cu;
 #define BWD_FUSED_P(HT)                                                                                  \
     do {                                                                                                 \
         static BfPerDevice set_p_dev; size_t& set_p = set_p_dev.cur();                                   \
@@ -3865,18 +3035,18 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         }                                                                                                \
         hipLaunchKernelGGL((attn_bwd_fused32p_kernel<HT>), dim3(grid_p), dim3(Fused32P::NWAVES * 64), lds_p, s, \
                            (const HT*)qkv, (const HT*)out, (const HT*)dout, lse, (HT*)dqkv, seq, heads, scale, \
-                           batch * heads, bf_tuning().attn_bwd_fused_p_map);                             \
+                           batch * heads);                                                               \
     } while (0)
-                if (f16) BWD_FUSED_P(f16_t); else BWD_FUSED_P(bf16_t);
+            if (f16) BWD_FUSED_P(f16_t); else BWD_FUSED_P(bf16_t);
 #undef BWD_FUSED_P
-                BF_CHECK_LAUNCH("bf_attention_bwd");
-                return BF_OK;
-            }
-            const size_t lds_f = Fused32::lds_bytes(nq32) + lds_pad;
-            dim3 grid(batch * heads), block(256);
+            BF_CHECK_LAUNCH("bf_attention_bwd");
+            return BF_OK;
+        }
+        const size_t lds_f = Fused32::lds_bytes(nq32);
+        dim3 grid(batch * heads), block(256);
 #define BWD_FUSED(HT)                                                                                    \
     do {                                                                                                 \
-        static BfPerDevice set_f_dev; size_t& set_f = set_f_dev.cur();                                                                         \
+        static BfPerDevice set_f_dev; size_t& set_f = set_f_dev.cur();                                   \
         if (lds_f > set_f) {                                                                             \
             (void)hipFuncSetAttribute((const void*)attn_bwd_fused32_kernel<HT>,                          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f);           \
@@ -3885,232 +3055,120 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
         hipLaunchKernelGGL((attn_bwd_fused32_kernel<HT>), grid, block, lds_f, s, (const HT*)qkv,         \
                            (const HT*)out, (const HT*)dout, lse, (HT*)dqkv, seq, heads, scale);          \
     } while (0)
-            if (f16) BWD_FUSED(f16_t); else BWD_FUSED(bf16_t);
+        if (f16) BWD_FUSED(f16_t); else BWD_FUSED(bf16_t);
 #undef BWD_FUSED
-            BF_CHECK_LAUNCH("bf_attention_bwd");
-            return BF_OK;
-        }
-        if (half && split_env && wide_ok && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
+        BF_CHECK_LAUNCH("bf_attention_bwd");
+        return BF_OK;
+    }
+#define BY_HALF(M, ...) do { if (f16) M(__VA_ARGS__, f16_t); else M(__VA_ARGS__, bf16_t); } while (0)
+#define BY_MASK(M, DD) do { if (mask_mode == BF_MASK_NONE) BY_HALF(M, DD, BF_MASK_NONE); else if (mask_mode == BF_MASK_CAUSAL) BY_HALF(M, DD, BF_MASK_CAUSAL); else BY_HALF(M, DD, BF_MASK_QUERY_ROW); } while (0)
+#define BY_DIM(M) do { if (head_dim == 32) BY_MASK(M, 32); else if (head_dim == 48) BY_MASK(M, 48); else BY_MASK(M, 64); } while (0)
+    // ---- sequences whose K + V / Q + dO fit LDS, d = 32 / 48: two barrier-free kernels (dQ with the query on the lane, then
+    // dK / dV with the key on the lane), ONE workgroup per (batch, head): three waves x three blocks in the q kernel, four
+    // waves in the kv kernel (d = 32: its 128-register build, four workgroups per CU).  d = 64 goes to the streamed pair
+    // (300 x 64: 99 vs 134 us resident); short causal sequences to the single kernel (72 vs 116 us at 77 tokens).
+    {
+        const int pad = head_dim == 32 ? 0 : 16, row = head_dim * 2 + pad;          // ResImg<D>: d = 32 rows are unpadded
+        const size_t lds_q = (size_t)lp * ((dp * 2 + pad) + row);
+        const size_t lds_kv = 2 * ((size_t)lp * row + 64) + 3 * (size_t)lp * 4;
+        if (head_dim != 64 && nq32 <= 16 && lds_q <= 96 * 1024 && lds_kv <= 96 * 1024 &&
             !(mask_mode == BF_MASK_CAUSAL && seq < 128)) {
-            // ~5-wave workgroups when three of them fit a CU's LDS (d = 32: 15 waves per CU instead of 9);
-            // with larger images (d = 64: two workgroups per CU either way) one workgroup per (batch, head)
-            // Workgroup shape of the split pair: `wpb` waves, `n_split` workgroups per (batch, head); a wave walks the
-            // 32-row blocks slot, slot + n_split * wpb, ...  Default: ONE four-wave workgroup per (batch, head) -- one wave
-            // per SIMD, three workgroups per CU by LDS, one K / V (Q / dO) image load per (batch, head).  (Five-wave
-            // workgroups, one block per wave, measured 1.5 workgroups alive per CU: tools/attn_probe.py.)
-            const int wpb_env = bf_tuning().attn_bwd_wpb, split_env2 = bf_tuning().attn_bwd_split;
-            const int wpb = (wpb_env < nq32 ? wpb_env : nq32) < 8 ? (wpb_env < nq32 ? wpb_env : nq32) : 8;   // launch bound: 512 threads
-            const int n_split = bf_cdiv(nq32, wpb) < split_env2 ? bf_cdiv(nq32, wpb) : split_env2;
-            dim3 grid(batch * heads, n_split), block(wpb * 64);
-            const int wkv_env = bf_tuning().attn_bwd_wpb_kv;
-            const int wpb_kv = (wkv_env < nq32 ? wkv_env : nq32) < 8 ? (wkv_env < nq32 ? wkv_env : nq32) : 8;
-            const int n_split_kv = bf_cdiv(nq32, wpb_kv) < split_env2 ? bf_cdiv(nq32, wpb_kv) : split_env2;
-            dim3 grid_kv(batch * heads, n_split_kv), block_kv(wpb_kv * 64);
-            const int kv_tight = bf_tuning().attn_kv_tight;   // d = 32: the 128-register build of the kv kernel (four workgroups per CU)
-#define BWD_SPLIT2(DD, MM) BY_HALF(BWD_SPLIT3, DD, MM)
-#define BWD_SPLIT3(DD, MM, HT)                                                                      \
+            const int wpb = nq32 < 3 ? nq32 : 3, wpb_kv = nq32 < 4 ? nq32 : 4;
+            dim3 grid(batch * heads, 1), block(wpb * 64);
+            dim3 grid_kv(batch * heads, 1), block_kv(wpb_kv * 64);
+#define BWD_SPLIT(DD, MM, HT)                                                                       \
     do {                                                                                            \
-        static BfPerDevice set_q_dev, set_kv_dev; size_t &set_q = set_q_dev.cur(), &set_kv = set_kv_dev.cur();                                                        \
+        static BfPerDevice set_q_dev, set_kv_dev; size_t &set_q = set_q_dev.cur(), &set_kv = set_kv_dev.cur(); \
         if (lds_q > set_q) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DD, MM, HT>,                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_kernel<DD, MM, HT>,                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);      \
             set_q = lds_q;                                                                          \
         }                                                                                           \
         if (lds_kv > set_kv) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM, HT>,                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
             (void)hipFuncSetAttribute((const void*)attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>, \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);     \
             set_kv = lds_kv;                                                                        \
         }                                                                                           \
         hipLaunchKernelGGL((attn_bwd_q_kernel<DD, MM, HT>), grid, block, lds_q, s, (const HT*)qkv,  \
-                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,   \
+                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,               \
                            delta_ws, seq, heads, scale, lp);                                        \
-        if (kv_tight)                                                                               \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>), grid_kv, block_kv, lds_kv, s, (const HT*)qkv, \
-                               (const HT*)dout, lse, (const float*)delta_ws, row_mask,             \
-                               (HT*)dqkv, seq, heads, scale);                                      \
-        else                                                                                        \
-            hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT>), grid_kv, block_kv, lds_kv, s, (const HT*)qkv, \
-                               (const HT*)dout, lse, (const float*)delta_ws, row_mask,             \
-                               (HT*)dqkv, seq, heads, scale);                                      \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<DD, MM, HT, (DD == 32 ? 4 : 1)>), grid_kv, block_kv, lds_kv, s, (const HT*)qkv, \
+                           (const HT*)dout, lse, (const float*)delta_ws, row_mask,                  \
+                           (HT*)dqkv, seq, heads, scale);                                           \
     } while (0)
-#define BWD_SPLIT(DD)                                                                               \
-    do {                                                                                            \
-        if (mask_mode == BF_MASK_NONE) BWD_SPLIT2(DD, BF_MASK_NONE);                                \
-        else if (mask_mode == BF_MASK_CAUSAL) BWD_SPLIT2(DD, BF_MASK_CAUSAL);                       \
-        else BWD_SPLIT2(DD, BF_MASK_QUERY_ROW);                                                     \
-    } while (0)
-            if (head_dim == 32) BWD_SPLIT(32);
-            else if (head_dim == 48) BWD_SPLIT(48);
-            else BWD_SPLIT(64);
+            BY_DIM(BWD_SPLIT);
 #undef BWD_SPLIT
-#undef BWD_SPLIT2
-#undef BWD_SPLIT3
             BF_CHECK_LAUNCH("bf_attention_bwd");
             return BF_OK;
         }
     }
-    if (onepass_takes(seq, head_dim, mask_mode, half)) {
-        const int nq32 = bf_cdiv(seq, 32);
-        const int n_chunks = bf_cdiv(nq32, OnePassCfg<64>::NKB);
-        if (n_chunks == 1 || (dq_ws && bf_aligned16(dq_ws))) {     // (no slab workspace: the streamed pair below)
-            const size_t rows = (size_t)batch * seq;
-            BF_REQUIRE((long long)batch * heads * n_chunks < (1ll << 31), BF_EINVAL, "bf_attention_bwd: grid too large");
-            unsigned dblocks = (unsigned)((rows * heads + 255) / 256);
-            if (dblocks > 16384) dblocks = 16384;
-            dim3 grid((unsigned)(batch * heads * n_chunks)), block(OnePassCfg<64>::NT);
-#define BWD_ONEPASS3(DD, MM, HT)                                                                        \
-    do {                                                                                                \
-        const size_t lds_o = OnePassCfg<DD>::lds_bytes();                                               \
-        static BfPerDevice set_o_dev; size_t& set_o = set_o_dev.cur();                                  \
-        if (lds_o > set_o) {                                                                            \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_onepass_kernel<DD, MM, HT>,                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_o);          \
-            set_o = lds_o;                                                                              \
-        }                                                                                               \
-        hipLaunchKernelGGL((attn_delta_kernel<HT, DD>), dim3(dblocks), dim3(256), 0, s, (const HT*)out, \
-                           (const HT*)dout, delta_ws, seq, heads, rows);                                \
-        hipLaunchKernelGGL((attn_bwd_onepass_kernel<DD, MM, HT>), grid, block, lds_o, s, (const HT*)qkv, \
-                           (const HT*)dout, lse, (const float*)delta_ws, row_mask, (HT*)dqkv, dq_ws,    \
-                           seq, heads, scale, n_chunks);                                                \
-        if (n_chunks > 1) {                                                                             \
-            size_t rb = (rows * (heads * DD / 4) + 255) / 256;                                          \
-            if (rb > 16384) rb = 16384;                                                                 \
-            hipLaunchKernelGGL(attn_dq_reduce_kernel<HT>, dim3((unsigned)rb), dim3(256), 0, s,          \
-                               (const float*)dq_ws, (HT*)dqkv, rows, heads * DD, n_chunks);             \
-        }                                                                                               \
-    } while (0)
-#define BWD_ONEPASS2(DD, MM) BY_HALF(BWD_ONEPASS3, DD, MM)
-#define BWD_ONEPASS(DD)                                                                                 \
-    do {                                                                                                \
-        if (mask_mode == BF_MASK_NONE) BWD_ONEPASS2(DD, BF_MASK_NONE);                                  \
-        else BWD_ONEPASS2(DD, BF_MASK_QUERY_ROW);                                                       \
-    } while (0)
-            if (head_dim == 48) BWD_ONEPASS(48); else BWD_ONEPASS(64);
-#undef BWD_ONEPASS
-#undef BWD_ONEPASS2
-#undef BWD_ONEPASS3
-            BF_CHECK_LAUNCH("bf_attention_bwd");
-            return BF_OK;
-        }
+    // ---- d = 48 / 64 without a causal mask from 24 blocks: the software-pipelined pair (attention_pipe.hip); at 576 x 64 the
+    // streamed pair below is faster (364 vs 523 us: three-workgroup grids with idle waves)
+    if (bf_tuning().attn_pipe && nq32 >= 24 &&
+        bf_attn_bwd_pipe_launch(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale,
+                                mask_mode, cdt, s) == BF_OK) {
+        BF_CHECK_LAUNCH("bf_attention_bwd");
+        return BF_OK;
     }
-    {   // longer sequences: the same pair with the resident operand streamed through LDS in chunks
-        const int stream_env = bf_tuning().attn_bwd_stream;
-        const int nq32 = bf_cdiv(seq, 32);
-        // round 6: the software-pipelined pair (attention_pipe.hip) for d = 48 / 64 without a causal mask
-        if (half && stream_env && bf_tuning().attn_bwd_pipe && nq32 >= bf_tuning().attn_bwd_pipe_min_q32 &&
-            bf_attn_bwd_pipe_launch(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale,
-                                    mask_mode, cdt, s) == BF_OK) {
-            BF_CHECK_LAUNCH("bf_attention_bwd");
-            return BF_OK;
-        }
-        const int stream_min_env = bf_tuning().attn_stream_min_q32;
-        const int stream_d32_env = bf_tuning().attn_stream_d32;
-        if (half && stream_env && nq32 >= ((head_dim == 32 && !stream_d32_env) ? 9 : stream_min_env)) {
-            // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
-            // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)
-            const int CH = head_dim == 32 ? StreamCfg<32>::CH : StreamCfg<64>::CH;       // see StreamCfg
-            const int wpb = head_dim == 32 ? StreamCfg<32>::WPB : StreamCfg<64>::WPB;
-            const int dp = (head_dim + 31) / 32 * 32, row = head_dim * 2 + 16;
-            const size_t lds_q = (size_t)CH * ((dp * 2 + 16) + row);
-            const size_t lds_kv = 2 * ((size_t)CH * row + 64) + 3 * (size_t)CH * 4;
-            dim3 grid(batch * heads, bf_cdiv(nq32, wpb)), block(wpb * 64);
-#define BWD_STREAM2(DD, MM) BY_HALF(BWD_STREAM3, DD, MM)
-#define BWD_STREAM3(DD, MM, HT)                                                                         \
+    // ---- everything else beyond one workgroup: the same pair with the resident operand streamed through LDS in chunks
+    if (head_dim != 32 || nq32 >= 9) {
+        // rows per chunk, waves per workgroup: d = 32 fits 128 registers (16 waves per CU as 2 x 8);
+        // d = 48 / 64 needs ~190, so 8 waves per CU as 2 workgroups x 4 (one stages while one computes)
+        const int CH = head_dim == 32 ? StreamCfg<32>::CH : StreamCfg<64>::CH;       // see StreamCfg
+        const int wpb = head_dim == 32 ? StreamCfg<32>::WPB : StreamCfg<64>::WPB;
+        const int row = head_dim * 2 + 16;
+        const size_t lds_q = (size_t)CH * ((dp * 2 + 16) + row);
+        const size_t lds_kv = 2 * ((size_t)CH * row + 64) + 3 * (size_t)CH * 4;
+        dim3 grid(batch * heads, bf_cdiv(nq32, wpb)), block(wpb * 64);
+#define BWD_STREAM(DD, MM, HT)                                                                      \
     do {                                                                                            \
-        static BfPerDevice set_q_dev, set_kv_dev; size_t &set_q = set_q_dev.cur(), &set_kv = set_kv_dev.cur();                                                        \
+        static BfPerDevice set_q_dev, set_kv_dev; size_t &set_q = set_q_dev.cur(), &set_kv = set_kv_dev.cur(); \
         if (lds_q > set_q) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_q_stream_kernel<DD, MM, HT>,                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);     \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_q_stream_kernel<DD, MM, HT>,            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);      \
             set_q = lds_q;                                                                          \
         }                                                                                           \
         if (lds_kv > set_kv) {                                                                      \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_stream_kernel<DD, MM, HT>,               \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);    \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_kv_stream_kernel<DD, MM, HT>,           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);     \
             set_kv = lds_kv;                                                                        \
         }                                                                                           \
         hipLaunchKernelGGL((attn_bwd_q_stream_kernel<DD, MM, HT>), grid, block, lds_q, s, (const HT*)qkv, \
-                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,   \
+                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,               \
                            delta_ws, seq, heads, scale);                                            \
         hipLaunchKernelGGL((attn_bwd_kv_stream_kernel<DD, MM, HT>), grid, block, lds_kv, s, (const HT*)qkv, \
-                           (const HT*)dout, lse, (const float*)delta_ws, row_mask,              \
-                           (HT*)dqkv, seq, heads, scale);                                       \
+                           (const HT*)dout, lse, (const float*)delta_ws, row_mask,                  \
+                           (HT*)dqkv, seq, heads, scale);                                           \
     } while (0)
-#define BWD_STREAM(DD)                                                                              \
-    do {                                                                                            \
-        if (mask_mode == BF_MASK_NONE) BWD_STREAM2(DD, BF_MASK_NONE);                               \
-        else if (mask_mode == BF_MASK_CAUSAL) BWD_STREAM2(DD, BF_MASK_CAUSAL);                      \
-        else BWD_STREAM2(DD, BF_MASK_QUERY_ROW);                                                    \
-    } while (0)
-            if (head_dim == 32) BWD_STREAM(32);
-            else if (head_dim == 48) BWD_STREAM(48);
-            else BWD_STREAM(64);
+        BY_DIM(BWD_STREAM);
 #undef BWD_STREAM
-#undef BWD_STREAM2
-#undef BWD_STREAM3
-            BF_CHECK_LAUNCH("bf_attention_bwd");
-            return BF_OK;
-        }
+        BF_CHECK_LAUNCH("bf_attention_bwd");
+        return BF_OK;
     }
-    const int nw = bwd_pick_nw(seq, head_dim, dq_ws != nullptr);
-    auto lds_of = [&](int n) { return bwd_lds_of(head_dim, n); };
-    if (half && nw > 0) {
-        const int chunks = bf_cdiv(seq, nw * 32);
-        BF_REQUIRE(chunks == 1 || (dq_ws && bf_aligned16(dq_ws)), BF_EINVAL,
-                   "bf_attention_bwd: dq_ws is required for sequences longer than one key chunk");
-        if (chunks > 1) {
-            hipError_t e = hipMemsetAsync(dq_ws, 0, (size_t)batch * seq * heads * head_dim * sizeof(float), s);
-            BF_REQUIRE(e == hipSuccess, BF_ELAUNCH, "bf_attention_bwd: memset failed");
-        }
-        dim3 grid(batch * heads, chunks), block(nw * 64);
-        const size_t lds = lds_of(nw);
-#define BWD_MFMA2(DD, MM) BY_HALF(BWD_MFMA3, DD, MM)
-#define BWD_MFMA3(DD, MM, HT)                                                                           \
+    // ---- what is left is d = 32 under 9 blocks that the resident pair did not take (causal, under 128 tokens): the single
+    // kernel, whole sequence in one workgroup
+    {
+        const int nw = nq32;
+        const size_t lds = bwd_lds_of(head_dim, nw);
+        BF_REQUIRE(nw <= 16 && lds <= 160 * 1024, BF_EINVAL, "bf_attention_bwd: no kernel for this shape");
+        dim3 grid(batch * heads, 1), block(nw * 64);
+#define BWD_MFMA(DD, MM, HT)                                                                        \
     do {                                                                                            \
-        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                                                                  \
+        static BfPerDevice lds_set_dev; size_t& lds_set = lds_set_dev.cur();                        \
         if (lds > lds_set) {                                                                        \
-            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM, HT>,                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<DD, MM, HT>,                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);        \
             lds_set = lds;                                                                          \
         }                                                                                           \
         hipLaunchKernelGGL((attn_bwd_mfma_kernel<DD, MM, HT>), grid, block, lds, s, (const HT*)qkv, \
-                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,  \
-                           dq_ws, seq, heads, scale);                                               \
+                           (const HT*)out, (const HT*)dout, lse, row_mask, (HT*)dqkv,               \
+                           (float*)nullptr, seq, heads, scale);                                     \
     } while (0)
-#define BWD_MFMA(DD)                                                                                \
-    do {                                                                                            \
-        if (mask_mode == BF_MASK_NONE) BWD_MFMA2(DD, BF_MASK_NONE);                                 \
-        else if (mask_mode == BF_MASK_CAUSAL) BWD_MFMA2(DD, BF_MASK_CAUSAL);                        \
-        else BWD_MFMA2(DD, BF_MASK_QUERY_ROW);                                                      \
-    } while (0)
-        if (head_dim == 32) BWD_MFMA(32);
-        else if (head_dim == 48) BWD_MFMA(48);
-        else BWD_MFMA(64);
+        BY_DIM(BWD_MFMA);
 #undef BWD_MFMA
-#undef BWD_MFMA2
-#undef BWD_MFMA3
-        if (chunks > 1) {
-            BF_CHECK_LAUNCH("bf_attention_bwd");
-            const size_t rows = (size_t)batch * seq;
-            size_t blocks = (rows * (heads * head_dim / 4) + 255) / 256;
-            if (blocks > 8192) blocks = 8192;
-            if (f16)
-                hipLaunchKernelGGL(attn_dq_cast_kernel<f16_t>, dim3((unsigned)blocks), dim3(256), 0, s, dq_ws, (f16_t*)dqkv,
-                                   rows, heads * head_dim);
-            else
-                hipLaunchKernelGGL(attn_dq_cast_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, s, dq_ws, (bf16_t*)dqkv,
-                                   rows, heads * head_dim);
-        }
-    } else if (cdt == BF_F16)
-        attn_bwd_launch<f16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
-                               head_dim, scale, mask_mode, s);
-    else if (cdt == BF_BF16)
-        attn_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
-                                head_dim, scale, mask_mode, s);
-    else
-        attn_bwd_launch<float>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads,
-                               head_dim, scale, mask_mode, s);
+    }
+#undef BY_DIM
+#undef BY_MASK
 #undef BY_HALF
     BF_CHECK_LAUNCH("bf_attention_bwd");
     return BF_OK;

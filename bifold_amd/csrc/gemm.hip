@@ -812,11 +812,6 @@ extern "C" int bf_debug_p8_probe_sec(unsigned long long* out) {
 // (any output type, residual / aux / copies / row remap / split-K slabs), 1 = plain bf16 (alpha, bias,
 // activation, optional pre-activation copy), 2 = bf16 GELU-grad.  One kernel with all three paths sat at
 // the 256-register limit and spilled differently with every edit.
-#ifndef P8_EPI_DIRECT
-#define P8_EPI_DIRECT 0               // 1: plain 16-bit epilogue with 16-byte stores straight from the accumulators (v_permlane16_swap), no LDS turn.
-                                      // Measured round 4 (tools/ab_gemm_libs.sh, twelve NT shapes): 3.17-3.20 ms against 3.09 through LDS -- a store
-                                      // instruction of 16 rows x 64 B costs more than the LDS turn that makes it 8 rows x 128 B saves.  Kept for A/B.
-#endif
 #ifndef P9_PHASES
 #define P9_PHASES 2                   // BK = 64 main loop: MFMA blocks per K tile (4 x 16 MFMAs, or 2 x 32 with half the barriers)
 #endif
@@ -826,7 +821,7 @@ extern "C" int bf_debug_p8_probe_sec(unsigned long long* out) {
 template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, bool GROUPED = false, int BK = 32>
 __device__ __forceinline__ void p8_body(
     const H* __restrict__ A, const H* __restrict__ B, const GemmDims& d, const EpiParams& ep,
-    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
+    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int mode_bits,
     unsigned* __restrict__ tk, const P8Group* __restrict__ grp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x (A 16 KB | B 16 KB) + 16 B
     const int lane = threadIdx.x & 63;
@@ -859,8 +854,8 @@ __device__ __forceinline__ void p8_body(
     const int NX = G < 8 ? G : 8;
     const int xl = bid % NX;
     const int per_xcd = max(1, G / NX);
-    const int rev_rounds = skew_cycles & 1;            // `skew_cycles` carries mode bits now (the start-skew experiment is retired)
-    const bool deep = (skew_cycles & 2) != 0;          // prefetch distance 3 stages instead of 2 (see the main loop)
+    const int rev_rounds = mode_bits & 1;              // bit 0: alternate the K direction per round of tickets
+    const bool deep = (mode_bits & 2) != 0;            // bit 1: prefetch distance 3 stages instead of 2 (see the main loop)
     // ranges proportional to the workgroups a lane has (G need not be a multiple of 8): with exactly one
     // item per workgroup no lane may hold more items than workgroups
     auto lane_share = [&](long long n, int x) { return (int)(n * (x * (G / NX) + min(x, G % NX)) / G); };
@@ -1097,17 +1092,9 @@ __device__ __forceinline__ void p8_body(
     P8Item w;
     [[maybe_unused]] int round = 0;                     // items this workgroup has started (probe / bookkeeping only)
     unsigned pend = 0;                 // thread 0: the ticket drawn for the next item
-    // Start skew (round 4, write-heavy epilogues only: fp32 results with a residual, the fc1 + GELU' pair): identical
-    // tiles keep the CUs in lockstep, so every round ends in ONE burst of output stores (67 MB of fp32 at once for the
-    // fusion out-projection) against an HBM that idles through the main loops.  Phase p of P (workgroups of an XCD take
-    // the phases in turn) starts p * delta later, BEFORE it draws its first ticket -- late starters simply draw fewer.
-    {
-        const int phases = (skew_cycles >> 4) & 15, delta = (unsigned)skew_cycles >> 8;       // delta in 10 ns ticks
-        if (phases > 1 && delta > 0) {
-            const unsigned long long t_end = wall_clock64() + (unsigned long long)(((bid / NX) % phases) * delta);
-            while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(32);
-        }
-    }
+    // (A start skew for the write-heavy epilogues -- workgroups of an XCD starting in phases so that a round's output
+    // stores do not leave in one burst -- measured slower on every shape, 3.12 -> 3.15 - 3.27 ms: late starters cost more
+    // than the spread-out bursts give back at 7 rounds per launch.  Removed in round 6.)
     if (threadIdx.x == 0) bcast[0] = atomicAdd(tk + xl, 1u);
     __syncthreads();
     const unsigned first = __builtin_amdgcn_readfirstlane(bcast[0]);   // wave-uniform: keeps the item in SGPRs
@@ -1675,57 +1662,9 @@ __device__ __forceinline__ void p8_body(
                 }
 #endif
             };
-            // Round 4: the same stores WITHOUT the trip through LDS.  In the (swapped-role) MFMA layout a lane holds 4
-            // consecutive columns of one row per 16-column tile j, i.e. 8 bytes after conversion; v_permlane16_swap
-            // trades the j+1 half of the even 16-lane rows against the j half of the odd ones, after which every lane
-            // holds 8 CONSECUTIVE columns (16 bytes) of its row: one store instruction = 16 rows x 64 contiguous
-            // bytes, 16 store instructions per wave and pass as before, no ds_write / ds_read / lgkmcnt wait between
-            // the accumulators and the stores.
-            auto direct_pass = [&](auto pass_) {
-                constexpr int PASS = decltype(pass_)::value;
-                H* dst = PASS == 0 ? (H*)ep.pre : (H*)ep.c;
-                const int g = lane_ep >> 4;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = w.m0 + wm * 128 + i * 16 + (lane_ep & 15);
-#pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) {
-                        unsigned pk[2][2];
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const int j = jp * 2 + jj;
-                            const f32x4 a = acc[j][i];
-                            float v[4] = {fmaf(a[0], ep.alpha, bj[j].x), fmaf(a[1], ep.alpha, bj[j].y),
-                                          fmaf(a[2], ep.alpha, bj[j].z), fmaf(a[3], ep.alpha, bj[j].w)};
-                            if (PASS == 1) {
-                                if (ep.act == BF_ACT_QUICK_GELU) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = AM::quick(v[e]);
-                                } else if (ep.act == BF_ACT_TANH_GELU) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = AM::tanh_gelu(v[e]);
-                                } else if (ep.act == BF_ACT_ERF_GELU) {
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] = AM::erf(v[e]);
-                                }
-                            }
-                            typename H16<H>::x4 h4;
-                            h4[0] = (H)v[0]; h4[1] = (H)v[1]; h4[2] = (H)v[2]; h4[3] = (H)v[3];
-                            const uint2 u = *(const uint2*)&h4;
-                            pk[jj][0] = u.x; pk[jj][1] = u.y;
-                        }
-#pragma unroll
-                        for (int d = 0; d < 2; ++d) {       // odd rows of tile j <-> even rows of tile j + 1
-                            const auto r = __builtin_amdgcn_permlane16_swap(pk[0][d], pk[1][d], false, false);
-                            pk[0][d] = r[0]; pk[1][d] = r[1];
-                        }
-                        const int n = w.n0 + wn * 64 + (jp * 2 + (g & 1)) * 16 + (g >> 1) * 8;
-                        if (m < ep.m && n < ep.n)
-                            store16(dst + (size_t)m * ep.ldc + n, make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]),
-                                    ep.store_policy & 1);
-                    }
-                }
-            };
+            // (Round 4 also built these stores WITHOUT the trip through LDS -- v_permlane16_swap pairs, 16 rows x 64 bytes
+            // per store instruction -- and measured 3.17 - 3.20 ms against 3.09 through LDS over the twelve NT shapes: a store
+            // of 16 rows x 64 B costs more than the LDS turn that makes it 8 rows x 128 B saves.  Removed in round 6.)
             const bool want_pre = ep.pre && (ep.act == BF_ACT_QUICK_GELU || ep.act == BF_ACT_ERF_GELU ||
                                              ep.act == BF_ACT_TANH_GELU);
             if constexpr (EPI == 3) {
@@ -1775,9 +1714,6 @@ __device__ __forceinline__ void p8_body(
                 quarter_pair(std::integral_constant<int, 1>{});
                 quarter_pair(std::integral_constant<int, 2>{});
                 quarter_pair(std::integral_constant<int, 3>{});
-            } else if constexpr (P8_EPI_DIRECT != 0) {
-                if (want_pre) direct_pass(std::integral_constant<int, 0>{});
-                direct_pass(std::integral_constant<int, 1>{});
             } else {
             if (want_pre) {
                 half_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -1973,17 +1909,17 @@ __device__ __forceinline__ void p8_body(
 template <bool A_KS, bool B_KS, typename TC, int EPI, typename H, int BK = 32>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(
     const H* __restrict__ A, const H* __restrict__ B, GemmDims d, EpiParams ep,
-    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int skew_cycles,
+    float* __restrict__ slabs, unsigned a_bytes, unsigned b_bytes, int n_items, int mode_bits,
     unsigned* __restrict__ tk) {
-    p8_body<A_KS, B_KS, TC, EPI, H, false, BK>(A, B, d, ep, slabs, a_bytes, b_bytes, n_items, skew_cycles, tk, nullptr);
+    p8_body<A_KS, B_KS, TC, EPI, H, false, BK>(A, B, d, ep, slabs, a_bytes, b_bytes, n_items, mode_bits, tk, nullptr);
 }
 
 // The grouped dW launch: TN layout, fp32 partial slabs (general epilogue), every problem's geometry in `grp`.
 template <typename H>
 __global__ __launch_bounds__(512, 1) void gemm_p8_grouped_tn_kernel(P8Group grp, GemmDims d, EpiParams ep, int n_items,
-                                                                    int skew_cycles, unsigned* __restrict__ tk) {
+                                                                    int mode_bits, unsigned* __restrict__ tk) {
     p8_body<true, true, float, 0, H, true>((const H*)grp.a[0], (const H*)grp.b[0], d, ep, grp.slab[0], grp.a_bytes[0],
-                                           grp.b_bytes[0], n_items, skew_cycles, tk, &grp);
+                                           grp.b_bytes[0], n_items, mode_bits, tk, &grp);
 }
 
 // =====================================================================================
@@ -2502,49 +2438,14 @@ static int n_cus() {
     return n_cu;
 }
 
-// The persistent 256x256 kernel hands out whole tiles; when the last round of tiles fills less
-// than ~half of the CUs (N = 768: 591 tiles = 2.3 rounds), the rows of that last round are cut
-// off and run as a split-K problem of their own (tail tiles x sub <= CUs, reduced with the
-// epilogue by splitk_reduce), so the job takes ~2.3 rounds instead of 3.
-struct P8TailPlan { int rows_main; int sub; size_t bytes; };
-static bool p8_tail_plan(const bf_gemm_args* g, P8TailPlan* plan) {
-    const BfTuning& T = bf_tuning();
-    const int min_k_nt = T.p8_tail_k_nt, min_k_nn = T.p8_tail_k_nn;
-    if (!bf_is_half(g->cdt) || g->trans_a || g->split_k > 1 || g->rows_in != 0 || g->resid_mod != 0 ||
-        g->accumulate || g->m < 16384 || (g->k % 64) != 0 || (g->n % 8) != 0 ||
-        g->k < (g->b_kn ? min_k_nn : min_k_nt) || g->colsum_out)
-        return false;   // measured: pays only for deep K (the extra launches + slab pass cost ~20 us)
-    const int pipe_env = T.gemm_pipe.load();
-    if (pipe_env >= 0 && pipe_env != 8 && pipe_env != 9) return false;
-    // dX = dY W (NN) runs on the persistent kernel too; its 512-wide outputs are 2.15-round shapes (550 tiles on
-    // 256 CUs), but splitting their tails measured neutral, so it is opt-in (BIFOLD_P8_TAIL_K="2048,1536")
-    if (T.p8_no_tail || T.p8_tail_mode != 1) return false;
-    const int n_cu = n_cus();
-    const long tiles_m = bf_cdiv(g->m, 256), tiles_n = bf_cdiv(g->n, 256);
-    const long items = tiles_m * tiles_n;
-    if (items <= n_cu) return false;
-    const long rem = items % n_cu;
-    if (rem == 0 || rem > (long)(n_cu * 0.55)) return false;
-    const long tm1 = (items - rem) / tiles_n;
-    const long tail_tiles = (tiles_m - tm1) * tiles_n;
-    if (tm1 <= 0 || tail_tiles <= 0 || tail_tiles > n_cu / 2) return false;
-    int sub = (int)(n_cu / tail_tiles);
-    if (sub > 8) sub = 8;
-    const int kps = ((bf_cdiv(g->k, sub) + 63) / 64) * 64;
-    sub = bf_cdiv(g->k, kps);
-    if (sub < 2) return false;
-    plan->rows_main = (int)(tm1 * 256);
-    plan->sub = sub;
-    plan->bytes = (size_t)sub * (size_t)(g->m - plan->rows_main) * g->n * sizeof(float);
-    return true;
-}
-
-// Round 4: the same idea INSIDE the launch (p8_body's tail split): the last round's tiles are cut into K chunks that
-// are ordinary work items; no extra launches, no slab pass, the tile's last chunk to arrive reduces and stores.
+// The persistent 256x256 kernel hands out whole tiles; when the last round of tiles fills less than ~half of the CUs
+// (N = 768: 591 tiles = 2.3 rounds) and K is deep, the tiles of that round are cut into K chunks that are ordinary work
+// items of the SAME launch (p8_body's tail split): no extra launches, no slab pass, the tile's last chunk to arrive
+// reduces and stores.  (Round 2's form -- the tail rows as a split-K launch of their own -- was removed in round 6.)
 struct P8InKernelTail { int tiles, parts, kt; size_t bytes; };
 static bool p8_inkernel_tail_plan(const bf_gemm_args* g, P8InKernelTail* plan) {
     const BfTuning& T = bf_tuning();
-    if (T.p8_tail_mode != 2 || T.p8_no_tail || !T.p8_bk64) return false;
+    if (!T.p8_bk64) return false;
     if (!bf_is_half(g->cdt) || g->trans_a || (g->b_kn && !T.p8_bk64_nn) || g->split_k > 1 || (g->k % 64) != 0 ||
         (g->n % 8) != 0 || (g->ldc % 8) != 0 || g->m < T.p8_min_m)
         return false;
@@ -2558,7 +2459,7 @@ static bool p8_inkernel_tail_plan(const bf_gemm_args* g, P8InKernelTail* plan) {
     if (rem == 0 || rem > (long)(n_cu * 0.55) || rem > P8_TAIL_MAX) return false;
     const int nkt = g->k / 64;
     // A chunk costs a 256 KB write-through hand-off on top of its K tiles (and the last arriver reads them all back): it
-    // pays only when a chunk is deep enough -- measured round 4 (tools/gemm_bench.py, BIFOLD_P8_TAIL_MODE=2 vs 0 with
+    // pays only when a chunk is deep enough -- measured round 4 (tools/gemm_bench.py, the split against whole tiles with
     // chunks of any depth): K = 3072 in 3 chunks -5 %, K = 2048 in 6 chunks +-1 %, K = 512 / 768 in 2-8 chunks +12...19 %.
     int parts = (int)(n_cu / rem);
     if (parts > 8) parts = 8;
@@ -2575,9 +2476,7 @@ static bool p8_inkernel_tail_plan(const bf_gemm_args* g, P8InKernelTail* plan) {
 extern "C" size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g) {
     if (!g) return 0;
     P8InKernelTail ik;
-    if (p8_inkernel_tail_plan(g, &ik)) return ik.bytes;
-    P8TailPlan plan;
-    return p8_tail_plan(g, &plan) ? plan.bytes : 0;
+    return p8_inkernel_tail_plan(g, &ik) ? ik.bytes : 0;
 }
 
 static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_variant);
@@ -2763,27 +2662,6 @@ extern "C" int bf_gemm_tn_grouped(const bf_gemm_tn_problem* p, int count, int k,
 
 extern "C" int bf_gemm(const bf_gemm_args* g, bf_stream_t stream) {
     BF_REQUIRE(g != nullptr, BF_EINVAL, "bf_gemm: null args");
-    P8TailPlan plan;
-    P8InKernelTail ik;
-    if (p8_inkernel_tail_plan(g, &ik)) return gemm_impl(g, stream, -1);      // the launch splits its own tail
-    if (g->split_k <= 1 && g->workspace && p8_tail_plan(g, &plan) && g->workspace_bytes >= plan.bytes &&
-        bf_aligned16(g->workspace)) {
-        bf_gemm_args main = *g, tail = *g;
-        main.m = plan.rows_main; main.workspace = nullptr; main.workspace_bytes = 0; main.split_k = 1;
-        int rc = gemm_impl(&main, stream, 8);
-        if (rc) return rc;
-        const size_t r0 = (size_t)plan.rows_main;
-        const size_t csz = g->c_dtype == BF_F32 ? 4 : 2;
-        tail.m = g->m - plan.rows_main;
-        tail.a = (const char*)g->a + r0 * g->lda * 2;
-        tail.c = (char*)g->c + r0 * g->ldc * csz;
-        if (g->c2) tail.c2 = (char*)g->c2 + r0 * g->ldc * 2;
-        if (g->pre) tail.pre = (char*)g->pre + r0 * g->ldc * 2;
-        if (g->aux) tail.aux = (const char*)g->aux + r0 * g->ld_aux * 2;
-        if (g->residual) tail.residual = g->residual + r0 * g->ld_res;
-        tail.split_k = plan.sub;
-        return gemm_impl(&tail, stream, 8);
-    }
     return gemm_impl(g, stream, -1);
 }
 
@@ -2886,7 +2764,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         const size_t a_ext = ((size_t)((g->trans_a ? g->k : g->m) - 1) * g->lda + (g->trans_a ? g->m : g->k)) * 2;
         const size_t b_ext = ((size_t)((g->b_kn ? g->k : g->n) - 1) * g->ldb + (g->b_kn ? g->n : g->k)) * 2;
         const bool dma_ok = ((g->trans_a && g->b_kn) || (g->k % 64) == 0) && a_ext < (1ull << 32) &&
-                            b_ext < (1ull << 32) && !T.gemm_no_dma;
+                            b_ext < (1ull << 32);
         const int pipe_env = T.gemm_pipe.load();
         // Kernel choice (measured in-step at B = 256): the BK = 32 kernel runs 4
         // workgroups per CU, which overlaps the epilogue traffic of one tile with the MFMAs of the
@@ -2915,7 +2793,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         // the persistent kernel draws its items from a per-stream ring of ticket sets; a process that uses
         // more streams than there are rings runs the extra streams' GEMMs on the other kernels
         // variant 9 = the persistent kernel with the BK = 64 full-line main loop for NT (K-contiguous operands, K a
-        // multiple of 64); BIFOLD_P8_BK64 makes it the automatic choice for those shapes
+        // multiple of 64): the automatic choice for those shapes
         bool bk64 = T.p8_bk64 != 0;
         if (variant == 9 || (force_variant == 8 && pipe_env == 9)) { variant = 8; bk64 = true; }
         else if (pipe_env == 8) bk64 = false;
@@ -2964,9 +2842,6 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                 else if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) epi = 1;
                 else if ((g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->pre) epi = 2;
             }
-            // start skew for the write-heavy epilogues (see p8_body): phases << 4 | delta (10 ns ticks) << 8
-            if (T.p8_skew_phases > 1 && T.p8_skew_us10 > 0 && (epi == 3 || (f32out && !slabs && g->residual)))
-                skew |= (T.p8_skew_phases & 15) << 4 | (T.p8_skew_us10 * 10) << 8;
 #define LAUNCH_P8E(AKS, BKS, TC, EPI, H, BKV)                                                       \
     do {                                                                                          \
         static bool lds_ok[P8_TK_DEVICES];  /* > 64 KB of dynamic LDS must be opted into, once per device */ \
@@ -3006,25 +2881,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
         } else if (dma_ok && (variant == 4 || (variant == 8 && !long_nt))) {
             last_variant = 4;
             const unsigned ab = (unsigned)a_ext, bb = (unsigned)b_ext;
-            // 64-row tiles when they fill the chip's workgroup slots better (256 CUs x 4 vs x 6)
-            const long t128 = (long)tiles_m * tiles_n * split;
-            const long t64 = (long)bf_cdiv(g->m, 64) * tiles_n * split;
-            const double e128 = (double)t128 / ((double)((t128 + 1023) / 1024) * 1024.0);
-            const double e64 = (double)t64 / ((double)((t64 + 1535) / 1536) * 1536.0);
-            const int bm_env = T.gemm_bm;
-            // measured: the 64-row tile does not pay even where it fills the slots better (more
-            // L2 -> LDS bytes per FLOP), so it is opt-in (BIFOLD_GEMM_BM=64), K-contiguous A only
-            (void)e128; (void)e64;
-            const bool small = bm_env == 64 && !g->trans_a;
+            // (64-row tiles fill the chip's workgroup slots better on some shapes and still lost -- more L2 -> LDS bytes per
+            // FLOP -- removed in round 6)
 #define LAUNCH_K32_T(AKS, BKS, TC, H)                                                                \
-    do {                                                                                          \
-        if (small) {                                                                              \
-            GemmDims d64 = d; d64.tiles_m = bf_cdiv(g->m, 64);                                    \
-            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 2, H>), dim3((unsigned)t64), block, 24576, s, (const H*)g->a, (const H*)g->b, d64, ep, slabs, ab, bb); \
-        } else {                                                                                  \
-            hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 4, H>), grid, block, 32768, s, (const H*)g->a, (const H*)g->b, d, ep, slabs, ab, bb); \
-        }                                                                                         \
-    } while (0)
+    hipLaunchKernelGGL((gemm_bf16_k32_kernel<AKS, BKS, TC, 4, H>), grid, block, 32768, s, (const H*)g->a, (const H*)g->b, d, ep, slabs, ab, bb)
 #define LAUNCH_K32_H(AKS, BKS, H) do { if (f32out) LAUNCH_K32_T(AKS, BKS, float, H); else LAUNCH_K32_T(AKS, BKS, H, H); } while (0)
 #define LAUNCH_K32(AKS, BKS) BY_HALF(LAUNCH_K32_H, AKS, BKS)
             if (!g->trans_a && !g->b_kn) LAUNCH_K32(false, false);

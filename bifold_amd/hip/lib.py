@@ -19,7 +19,7 @@ ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TA
 ACT_ERF_GELU_SAVEGRAD, ACT_MUL_AUX = 6, 7
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, TARGETS_FIT, MAX_TARGET_POINTS = 0, 1, 2, 16
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
@@ -81,10 +81,8 @@ PROTOTYPES = {
     "bf_colsum_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bf_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_float, c_int, c_int, c_void_p]),
-    "bf_attention_bwd_needs_dq_ws": (c_int, [c_int, c_int]),
-    "bf_attention_bwd_ws_elems": (C.c_longlong, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "bf_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+                                 c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "bf_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_patchify_ld": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_vision_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -403,15 +403,12 @@ def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_
     _dev(qkv, "qkv"); _dev(out, "out"); _dev(dout, "dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
-    # long sequences (16-bit modes): partial dQ per key chunk in an fp32 scratch (the library says how many elements)
-    ws = int(lib.bf_attention_bwd_ws_elems(batch, seq, heads, head_dim, mask_mode, dtype_code(qkv)))
-    dq_ws = torch.empty(ws, dtype=torch.float32, device=qkv.device) if ws > 0 else None
     span = None
     if PROFILER is not None and PROFILER.wants("attn_bwd"):
         span = _Span(f"attn_bwd_{_TAG[dtype_code(qkv)]}_d{head_dim}",
                      10.0 * batch * heads * seq * seq * head_dim)
     check(lib.bf_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
-                               _ptr(delta), _ptr(dq_ws), batch, seq, heads, head_dim, scale, mask_mode,
+                               _ptr(delta), batch, seq, heads, head_dim, scale, mask_mode,
                                dtype_code(qkv), _stream()), "bf_attention_bwd")
     if span is not None:
         span.close()

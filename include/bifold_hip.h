@@ -13,8 +13,8 @@
  *    name ends in _host; the caller owns all memory: the library never allocates, frees
  *    or synchronises;
  *  - process-wide state, all of it internal and none of it data: a thread-local error
- *    string; ONE table of tuning knobs (csrc/tuning.h: kernel selection and geometry only, results are the same up to
- *    summation order) filled from the BIFOLD_* environment variables exactly once per process under std::call_once,
+ *    string; ONE table of four knobs (csrc/tuning.h: kernel selection only, results are the same up to
+ *    summation order) filled from BIFOLD_GEMM_PIPE / BIFOLD_P8_GRID / BIFOLD_ATTN_PIPE / BIFOLD_ATTN_BWD_FUSED_P exactly once per process under std::call_once,
  *    plus the bf_gemm_set_variant hook, which stores into an atomic of that table and may be called at any time from
  *    any thread; and, for the persistent
  *    GEMM, a __device__ array of work-ticket counters (one copy per device) with a host-side table per
@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 9
+#define BF_ABI_VERSION 10
 
 enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
@@ -265,18 +265,13 @@ int bf_attention_fwd(const void* qkv, void* out, float* lse, const int32_t* row_
                      int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                      bf_stream_t stream);
 
-/* dqkv [B, L, 3, H, D] cdt from dout [B, L, H*D] cdt; delta_ws fp32 [B, H, L] scratch;
- * dq_ws fp32 [B, L, H*D] scratch, needed (bf16 mode) only when the sequence does not fit one
- * key chunk of the MFMA kernel (L > 512 at D=32, > 192 at D=48, > 128 at D=64): dQ is then
- * accumulated across key chunks with fp32 atomics.  NULL falls back to the VALU kernels. */
-int bf_attention_bwd_needs_dq_ws(int seq, int head_dim);   /* 1 if dq_ws is needed in bf16 mode */
-/* ABI 8: the number of fp32 ELEMENTS dq_ws must hold for this call (0: none).  The one-pass backward of long d = 48 / 64
- * sequences (transformer.py:28-41 under autograd; query-row mask of models/siglip.py:118-130) writes one partial dQ per
- * chunk of 256 keys -- [chunks][B, L, H*D] -- and adds them in chunk order; bf_attention_bwd falls back to the two-kernel
- * streamed pair when handed a smaller / NULL workspace for such a call. */
-long long bf_attention_bwd_ws_elems(int batch, int seq, int heads, int head_dim, int mask_mode, int cdt);
+/* dqkv [B, L, 3, H, D] cdt from dout [B, L, H*D] cdt; delta_ws fp32 [B, H, L] scratch (rowsum(dO . O), written by the
+ * dQ kernel, read by the dK / dV kernel).  ABI 10: no other workspace -- the chunked kernel that summed dQ across key
+ * chunks with fp32 atomics (dq_ws, bf_attention_bwd_needs_dq_ws) and round 5's opt-in one-pass kernel
+ * (bf_attention_bwd_ws_elems) are gone; every sequence beyond one workgroup runs a dQ / dK+dV kernel pair that needs
+ * neither.  Replaces the autograd of models/transformer.py:28-41 and of the towers' attention under LoRA. */
 int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
-                     const int32_t* row_mask, void* dqkv, float* delta_ws, float* dq_ws, int batch,
+                     const int32_t* row_mask, void* dqkv, float* delta_ws, int batch,
                      int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                      bf_stream_t stream);
 

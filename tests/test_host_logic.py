@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
     for name in declared:
         assert hasattr(L.lib, name)
-    assert L.lib.bf_abi_version() == L.ABI_VERSION == 9
+    assert L.lib.bf_abi_version() == L.ABI_VERSION == 10
 
 
 def test_c_abi_rejects_bad_arguments_before_launching():
@@ -50,11 +50,6 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     g.m = g.n = g.k = 64; g.lda = g.ldb = g.ldc = 64; g.cdt, g.c_dtype = L.F16, L.BF16      # 16-bit output of another type
     assert L.lib.bf_gemm(C.byref(g), None) == -1 and b"c_dtype" in L.lib.bf_last_error()
     assert L.lib.bf_bce_parts(256) == 1024 and L.lib.bf_layernorm_bwd_parts(70400) > 0
-    assert L.lib.bf_attention_bwd_needs_dq_ws(275, 32) == 0 and L.lib.bf_attention_bwd_needs_dq_ws(2950, 48) == 1
-    # ABI 8: the workspace size is the library's to say (one fp32 slab for the chunked kernel; one per key chunk with the
-    # opt-in one-pass kernel); config A's resident sequences need none
-    assert L.lib.bf_attention_bwd_ws_elems(2, 275, 16, 32, 0, 2) == 0
-    assert L.lib.bf_attention_bwd_ws_elems(2, 2950, 16, 48, 2, 2) in (2 * 2950 * 16 * 48, 12 * 2 * 2950 * 16 * 48)
 
 
 def test_missing_library_fails_loudly(tmp_path):

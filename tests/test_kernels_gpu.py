@@ -376,42 +376,6 @@ def test_colsum_and_cast(ops, gpu):
 
 
 # ------------------------------------------------------------------ attention
-PD_SCRIPT = """
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from bifold_amd.hip import ops
-gpu = torch.device("cuda:0")
-D = 32
-for half in (torch.bfloat16, torch.float16):
-    for B, Lq, H in ((40, 275, 16), (70, 100, 8), (33, 64, 16)):
-        g = torch.Generator(device=gpu).manual_seed(B * 1000 + Lq)
-        qkv = torch.randn(B * Lq, 3 * H * D, device=gpu, generator=g).to(half)
-        out, lse = ops.attention_fwd(qkv, B, Lq, H, D, D ** -0.5, 0, None, need_lse=True)
-        q, k, v = qkv.double().reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
-        s = q @ k.transpose(-1, -2) * D ** -0.5
-        ref = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Lq, H * D)
-        err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
-        lerr = ((lse.double() - torch.logsumexp(s, -1)).abs().max() / torch.logsumexp(s, -1).abs().max()).item()
-        assert err < (2 ** -7 if half == torch.bfloat16 else 2 ** -9) and lerr < 1e-5, (half, B, Lq, H, err, lerr)
-print("PD-OK")
-"""
-
-
-def test_attention_fwd_persistent_walks_many_items(gpu, tmp_path):
-    """attn_fwd_pd32_kernel (d = 32, no mask; opt-in: BIFOLD_ATTN_FWD_PD=1, hence the child process -- the knobs are read
-    once per process): more (batch, head) items than resident workgroups (2 per CU), so every workgroup walks several
-    items through its two LDS images -- checked against the fp64 formula evaluated by torch on the GPU."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / "pd.py"
-    script.write_text(PD_SCRIPT)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, BIFOLD_ATTN_FWD_PD="1"),
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "PD-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
-
-
 @pytest.mark.parametrize("half", HALF)
 @pytest.mark.parametrize("B,Lq,H,D", [(40, 275, 16, 32), (24, 197, 12, 64), (3, 700, 4, 48)])
 def test_attention_fwd_many_items_lazy_rescale(ops, gpu, half, B, Lq, H, D):
@@ -563,61 +527,6 @@ def test_attention_bwd_one_pass_kernel_over_ragged_lengths(ops, gpu, half, B, Lq
     assert torch.equal(again, dqkv)                         # partial dQ blocks are summed in wave order: bit-reproducible
 
 
-ONEPASS_SCRIPT = """
-import sys, torch
-sys.path.insert(0, sys.argv[1])
-from bifold_amd.hip import ops
-gpu = torch.device("cuda:0")
-def ref(qkv, dout, B, Lq, H, D, rm):
-    leaf = qkv.double().requires_grad_(True)
-    q, k, v = leaf.reshape(B, Lq, 3, H, D).permute(2, 0, 3, 1, 4)
-    s = q @ k.transpose(-1, -2) * D ** -0.5
-    if rm is not None:
-        s = s.masked_fill(rm[:, None, :, None] == 0, -100000.0)
-    o = (torch.softmax(s, -1) @ v).permute(0, 2, 1, 3).reshape(B * Lq, H * D)
-    o.backward(dout.double())
-    return leaf.grad
-for half in (torch.bfloat16, torch.float16):
-    for B, Lq, H, D, mode, spans in ((2, 576, 2, 64, 0, []), (1, 1000, 1, 64, 0, []), (1, 853, 2, 48, 2, []), (2, 600, 2, 48, 2, [(64, 256)]),
-                                     (1, 1290, 1, 64, 2, [(0, 33), (577, 1154)]), (1, 545, 3, 48, 0, [])):
-        g = torch.Generator(device=gpu).manual_seed(Lq * 3 + D)
-        qkv = torch.randn(B * Lq, 3 * H * D, device=gpu, generator=g).to(half)
-        dout = torch.randn(B * Lq, H * D, device=gpu, generator=g).to(half)
-        rm = None
-        if mode == 2:
-            rm = (torch.rand(B, Lq, device=gpu, generator=g) > 0.3).int()
-            for a, b in spans:
-                rm[:, a:b] = 0
-        want = ref(qkv, dout, B, Lq, H, D, rm).float()
-        out, lse = ops.attention_fwd(qkv, B, Lq, H, D, D ** -0.5, mode, rm, need_lse=True)
-        dqkv = ops.attention_bwd(qkv, out, dout, lse, B, Lq, H, D, D ** -0.5, mode, rm)
-        err = ((dqkv.float() - want).abs().max() / want.abs().max()).item()
-        assert err < 2e-2, (half, B, Lq, H, D, mode, err)
-        if rm is not None:
-            dq = dqkv.float().view(B, Lq, 3, H * D)[:, :, 0]
-            assert float(dq[rm == 0].abs().max()) == 0.0, (half, Lq, D)      # masked queries receive exactly no gradient
-        again = ops.attention_bwd(qkv, out, dout, lse, B, Lq, H, D, D ** -0.5, mode, rm)
-        assert torch.equal(again, dqkv), (half, B, Lq, H, D)                 # chunks are added in order: bit-reproducible
-print("ONEPASS-OK")
-"""
-
-
-def test_attention_bwd_one_pass_kernel_for_long_sequences(gpu, tmp_path):
-    """attn_bwd_onepass_kernel (round 5; opt-in, BIFOLD_ATTN_BWD_ONEPASS=1 -- it is correct and slower than the streamed pair, see
-    DESIGN.md -- hence the child process): d = 48 / 64 beyond 512 tokens, no mask and the query-row mask with whole masked
-    frames and lone masked rows, ragged last chunks of 1 - 8 key blocks, partial dQ slabs added in chunk order -- against the
-    fp64 formula, twice (bit-reproducible), masked queries' gradient exactly zero."""
-    import os
-    import subprocess
-    import sys
-    script = tmp_path / "op.py"
-    script.write_text(ONEPASS_SCRIPT)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, str(script), root], env=dict(os.environ, BIFOLD_ATTN_BWD_ONEPASS="1"),
-                       capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ONEPASS-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
-
-
 FUSED_P_SCRIPT = """
 import sys, torch
 sys.path.insert(0, sys.argv[1])
@@ -649,14 +558,12 @@ print("FUSED-P-OK")
 """
 
 
-@pytest.mark.parametrize("role_map", ["1", "0"])
-def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path, role_map):
+def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path):
     """attn_bwd_fused32p_kernel (round 5: one twelve-wave workgroup per CU walking (batch, head) items; the default from two
     items per CU, forced here with BIFOLD_ATTN_BWD_FUSED_P=2, hence the child process): sequences of 3 - 9 key blocks (the
     nine-block ones take this kernel), a last block of 1 - 32 live keys, fewer items than CUs, and 1 200 items so that every
     workgroup walks four or five of them through the rolling refill of its images -- against the fp64 formula, twice
-    (bit-reproducible).  Both assignments of roles to waves: the support waves on one SIMD (`role_map` 1, the default) and
-    roles in wave order (0)."""
+    (bit-reproducible)."""
     import os
     import subprocess
     import sys
@@ -664,7 +571,7 @@ def test_attention_bwd_persistent_one_pass_kernel(gpu, tmp_path, role_map):
     script.write_text(FUSED_P_SCRIPT)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, str(script), root],
-                       env=dict(os.environ, BIFOLD_ATTN_BWD_FUSED_P="2", BIFOLD_ATTN_BWD_FUSED_P_MAP=role_map),
+                       env=dict(os.environ, BIFOLD_ATTN_BWD_FUSED_P="2"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FUSED-P-OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
 
