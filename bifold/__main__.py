@@ -290,11 +290,12 @@ class Trainer:
                 dl.set_epoch(epoch)
             elif hasattr(getattr(dl, "sampler", None), "set_epoch"):
                 dl.sampler.set_epoch(epoch)
-        total, counted, t0 = None, None, time.time()
+        total, counted, t0, seen_batches = None, None, time.time(), 0
         masking = getattr(self.model, "_grad_scaler", None) is not None or \
             getattr(self.model, "compute_dtype", None) == torch.float16
         for i, sample in enumerate(dl):
             sample = self.move_sample_to_device(sample)
+            seen_batches += 1
             output = self.model(sample)
             loss, intermediate_losses = self.loss_fn(output, sample)
             self.optimizer.zero_grad()
@@ -340,12 +341,12 @@ class Trainer:
             mean = float("nan")
         elif masking:
             kept = float(counted.item())
-            excluded = int(round(n - kept))
+            excluded = int(round(seen_batches - kept))
             # more non-finite losses than dropped steps: some step with a non-finite loss WAS applied -- the run
             # diverged, and the mean says so
             mean = float(total.item()) / kept if (kept > 0 and excluded <= dropped) else float("nan")
         else:
-            mean = float(total.item()) / max(n, 1)
+            mean = float(total.item()) / max(seen_batches, 1)
         self.last_epoch_stats = dict(mean_loss=mean, excluded_losses=excluded, dropped_steps=int(dropped))
         if self.rank == 0:
             dt = time.time() - t0

@@ -157,8 +157,14 @@ class ConcatTransformer(nn.Module):
 
     def __init__(self, dim, heads, depth, dropout, mlp_ratio, num_modalities=2, num_registers=0, **kwargs):
         super().__init__()
-        if dropout != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path (all shipped configs use 0)")
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"dropout must be in [0, 1), got {dropout}")
+        # nn.Dropout(dropout) sits in four places of every block (ref:bifold/models/transformer.py:18-24,36,
+        # ref:bifold/models/modules.py:21-27): on the attention probabilities, behind to_out, behind the GELU and behind the
+        # MLP's second Linear.  Active in training only; masks are functions of (seed, element index) (bf_dropout), the
+        # backward regenerates them, `last_dropout_seeds` lets a checker replay them.  All shipped configs say 0.0.
+        self.dropout = float(dropout)
+        self.last_dropout_seeds: Dict = {}
         if num_registers:
             raise NotImplementedError("register tokens are not used by any shipped config")
         if dim % heads:
@@ -315,7 +321,7 @@ _GRAD_STREAM16 = 1
 
 
 def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row_mask, save: bool, pending=None,
-                     last: bool = True):
+                     last: bool = True, drop=None):
     """One pre-LN block on the fp32 residual stream x [B*seq, dim].  `pending` (16-bit, optional) is the previous block's
     MLP branch, not yet added to x: it is added in this block's first LayerNorm pass.  Returns (x_out, saved, pending_out):
     with `last` False (and a 16-bit compute dtype) the block's own MLP branch comes back as `pending_out` instead of being
@@ -328,14 +334,25 @@ def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row
         h1, m1, r1, x = ops.add_layernorm_fwd(x, pending, P["g1"].data, P["b1"].data, cdt, x_out=torch.empty_like(x),
                                               save_stats=save)
     qkv = ops.gemm(h1, A.operand(P["wqkv"], cdt))
-    o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mask_mode, row_mask, need_lse=save)
+    # `drop` = (p, seeds) in a training forward with dropout > 0: the four nn.Dropout sites of the block
+    pd, sd = drop if drop is not None else (0.0, {})
+    o, lse = ops.attention_fwd(qkv, batch, seq, heads, d, d ** -0.5, mask_mode, row_mask, need_lse=save,
+                               dropout=pd, seed=sd.get("attn", 0))
     if defer:
         branch = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data)
+        if drop is not None:
+            ops.dropout(branch, pd, sd["out"], out=branch)
         h2, m2, r2, x2 = ops.add_layernorm_fwd(x, branch, P["g2"].data, P["b2"].data, cdt, x_out=torch.empty_like(x),
                                                save_stats=save)
         del branch
     else:
-        x2 = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, residual=x, out_dtype=torch.float32)
+        if drop is not None:                       # x2 = x + dropout(o Wo^T + bo): the branch in fp32, masked into a copy of x
+            branch = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, out_dtype=torch.float32)
+            x2 = x.clone()
+            ops.dropout(branch, pd, sd["out"], out=x2, accumulate=True)
+            del branch
+        else:
+            x2 = ops.gemm(o, A.operand(P["wo"], cdt), bias=P["bo"].data, residual=x, out_dtype=torch.float32)
         h2, m2, r2 = ops.layernorm_fwd(x2, P["g2"].data, P["b2"].data, cdt, save_stats=save)
     if save:       # the forward saves gelu'(pre), not pre: one erf evaluation serves both outputs of the epilogue,
         # and the backward GEMM's epilogue is a multiply instead of an erf + exp per element
@@ -343,15 +360,30 @@ def fusion_layer_fwd(x, P, A: ParamArena, cdt, batch, seq, heads, mask_mode, row
                             act=L.ACT_ERF_GELU_SAVEGRAD if _SAVEGRAD else L.ACT_ERF_GELU, want_pre=True)
     else:
         a, a_pre = ops.gemm(h2, A.operand(P["w1"], cdt), bias=P["bb1"].data, act=L.ACT_ERF_GELU), None
+    if drop is not None:
+        # behind the GELU: the SAME mask goes onto the activation and onto the saved gelu' (the backward's multiplier then
+        # carries D / (1 - p) with it)
+        ops.dropout(a, pd, sd["act"], out=a)
+        if a_pre is not None:
+            if not _SAVEGRAD:
+                raise RuntimeError("dropout > 0 needs the saved-gelu' form of the MLP backward")
+            ops.dropout(a_pre, pd, sd["act"], out=a_pre)
     pending_out = None
     if defer and not last:
         x3, pending_out = x2, ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data)
+        if drop is not None:
+            ops.dropout(pending_out, pd, sd["ff"], out=pending_out)
+    elif drop is not None:                         # x3 = x2 + dropout(a W2^T + b2)
+        branch = ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data, out_dtype=torch.float32)
+        x3 = x2.clone()
+        ops.dropout(branch, pd, sd["ff"], out=x3, accumulate=True)
+        del branch
     else:
         x3 = ops.gemm(a, A.operand(P["w2"], cdt), bias=P["bb2"].data, residual=x2, out_dtype=torch.float32)
     saved = None
     if save:
         saved = dict(x=x, m1=m1, r1=r1, h1=h1, qkv=qkv, o=o, lse=lse, x2=x2, m2=m2, r2=r2, h2=h2,
-                     a_pre=a_pre, a=a)
+                     a_pre=a_pre, a=a, drop=drop)
     return x3, saved, pending_out
 
 
@@ -365,6 +397,10 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
         wg.on, wg.side, wg.group, wg.group_after, wg.qualifies, wg.held, wg.marked = False, None, None, None, None, [], []
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
+    drop = S.get("drop")
+    pd, sd = drop if drop is not None else (0.0, {})
+    if drop is not None:
+        op3 = ops.dropout(op3, pd, sd["ff"])       # through dropout(a W2^T + b2): the mask of the forward, regenerated
     # FF:  x3 = x2 + gelu(h2 W1^T + b1) W2^T + b2
     # Every dW GEMM waits only for the producer of its operands (an event recorded right behind it) but is ISSUED after the
     # next dX GEMM of the chain (_DW_ORDER = 1): both become runnable at the same moment, and the one the hardware sees
@@ -389,6 +425,11 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     dx2, dx2_c = ops.layernorm_bwd(dh2, S["x2"], P["g2"].data, S["m2"], S["r2"], dx3_c if s16 else dx3, cdt,
                                    g(P["g2"]), g(P["b2"]), dres_sum_out=g(P["bb2"]), dx_sum_out=g(P["bo"]), stream16=s16)
     op2 = dx2_c if dx2_c is not None else dx2
+    if drop is not None:
+        # the two bias gradients the LayerNorm pass just summed are those of the UNMASKED gradients: redo them on the masked ones
+        ops.colsum(op3, out=g(P["bb2"]))
+        op2 = ops.dropout(op2, pd, sd["out"])      # through dropout(o Wo^T + bo)
+        ops.colsum(op2, out=g(P["bo"]))
     # attention:  x2 = x + attn(h1 Wqkv^T) Wo^T + bo
     e2 = wg.ready()
     if not _DW_ORDER:
@@ -396,7 +437,8 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
     do = ops.gemm(op2, A.operand(P["wo"], cdt), b_kn=True)
     if _DW_ORDER:
         wg.gemm(op2, S["o"], g(P["wo"]), e2)
-    dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask)
+    dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask,
+                             dropout=pd, seed=sd.get("attn", 0))
     e_qkv = wg.ready()
     if not _DW_ORDER:
         wg.gemm(dqkv, S["h1"], g(P["wqkv"]), e_qkv)
@@ -413,9 +455,23 @@ def fusion_stack_fwd(fus: "ConcatTransformer", A: ParamArena, cdt, x, batch: int
     """depth x fusion_layer_fwd on x fp32 [B*seq, dim]; returns (x_out, per-layer saved activations)."""
     layers = []
     pending = None
+    p_drop = float(getattr(fus, "dropout", 0.0))
+    active = p_drop > 0.0 and fus.training and save
+    if active:
+        # one host-side draw per forward from torch's CPU generator (seeded by cfg.seed): no device sync; the rank is
+        # folded in so that data-parallel replicas drop different elements
+        base = int(torch.empty((), dtype=torch.int64).random_().item())
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            base ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+        fus.last_dropout_seeds = {}
     for i in range(fus.depth):
+        drop = None
+        if active:
+            seeds = {n: (base + 8 * i + j) & (2 ** 63 - 1) for j, n in enumerate(("attn", "out", "act", "ff"))}
+            fus.last_dropout_seeds[i] = seeds
+            drop = (p_drop, seeds)
         x, s, pending = fusion_layer_fwd(x, fus.layer_params(i), A, cdt, batch, seq, fus.heads, mask_mode, row_mask, save,
-                                         pending=pending, last=i == fus.depth - 1)
+                                         pending=pending, last=i == fus.depth - 1, drop=drop)
         layers.append(s)
     return x, layers
 
@@ -672,17 +728,33 @@ class RGBTailFn(torch.autograd.Function):
         # (models/rgb_clip.py:52-66 + models/fusion.py:45-56).
         type_w = fus.token_type_embeddings.weight.data
         x = torch.empty(batch * seq, dim, dtype=torch.float32, device=vis_feat.device)
+        # nn.Dropout on the embeddings (rgb_clip.py:56,65; training, p > 0): the mask sits BETWEEN the position add and the
+        # type-embedding add, so the two are separated -- the rows are assembled without the type vector, masked in place
+        # (bf_dropout_rows), and the type vector is added behind the mask by the same kernel
+        p_t, p_r = float(getattr(model, "text_dropout", 0.0)), float(getattr(model, "rgb_dropout", 0.0))
+        emb_drop = None
+        if save and model.training and (p_t > 0.0 or p_r > 0.0):
+            base = int(torch.empty((), dtype=torch.int64).random_().item())
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                base ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+            emb_drop = dict(p_text=p_t, p_rgb=p_r, text=base & (2 ** 63 - 1), rgb=(base + 1) & (2 ** 63 - 1))
+            model.last_dropout_seeds = dict(emb_drop)
+        zero = torch.zeros(dim, dtype=torch.float32, device=vis_feat.device) if emb_drop is not None else None
         ops.segment_assemble(text_feat, n_text * dim, model.text_token.data.view(-1),
-                             model.text_pos_embedding.data.view(-1, dim)[:1 + n_text], type_w[0], x, batch,
-                             n_text, seq, 0)
-        rgb_table = model.rgb_pos_embedding.data.view(-1, dim) + type_w[1]          # [n_rgb, dim], 400 KB of glue
+                             model.text_pos_embedding.data.view(-1, dim)[:1 + n_text],
+                             type_w[0] if emb_drop is None else zero, x, batch, n_text, seq, 0)
+        rgb_table = model.rgb_pos_embedding.data.view(-1, dim) + (type_w[1] if emb_drop is None else zero)   # [n_rgb, dim], 400 KB of glue
         ops.gemm(vis_feat, A.operand(model.project.weight, cdt), bias=model.project.bias.data,
                  residual=rgb_table, resid_mod=n_rgb, out=x, rows_in=n_rgb, rows_out=seq, row_off=1 + n_text)
+        if emb_drop is not None:
+            ops.dropout_rows(x, type_w[0].contiguous(), batch, seq, 0, 1 + n_text, p_t, emb_drop["text"])
+            ops.dropout_rows(x, type_w[1].contiguous(), batch, seq, 1 + n_text, n_rgb, p_r, emb_drop["rgb"])
         heat, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, L.MASK_NONE, None, save)
         if save:
             c = _Ctx()
             c.model, c.saved, c.vis_feat = model, saved, vis_feat
             c.batch, c.n_text, c.n_rgb = batch, n_text, n_rgb
+            c.emb_drop = emb_drop
             ctx.c = c
         return tuple(heat[h] for h in range(nh))
 
@@ -699,14 +771,27 @@ class RGBTailFn(torch.autograd.Function):
         gs = scaler_of(model)                                  # fp16: loss scale (models/gradscale.py)
         ready = gs.ready if gs is not None else model._grad_ready
         dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else None)
+        g_type = g(pp.fusion.token_type_embeddings.weight)
+        type_true = None
+        if c.emb_drop is not None:
+            # the type embeddings were added BEHIND the masks: their gradient sums the gradient as it is; everything in
+            # front of the masks (tokens, positions, project) takes the masked, rescaled gradient
+            ops.fusion_assemble_bwd(dx, cdt, g(model.text_token).view(-1), g(model.text_pos_embedding).view(-1, dim),
+                                    g(model.rgb_pos_embedding).view(-1, dim), g_type, c.batch, c.n_text, c.n_rgb)
+            type_true = g_type.clone()
+            dx = dx.clone()
+            seq = 1 + c.n_text + c.n_rgb
+            ops.dropout_rows(dx, None, c.batch, seq, 0, 1 + c.n_text, c.emb_drop["p_text"], c.emb_drop["text"])
+            ops.dropout_rows(dx, None, c.batch, seq, 1 + c.n_text, c.n_rgb, c.emb_drop["p_rgb"], c.emb_drop["rgb"])
         d_rgb = ops.fusion_assemble_bwd(dx, cdt, g(model.text_token).view(-1),
                                         g(model.text_pos_embedding).view(-1, dim),
-                                        g(model.rgb_pos_embedding).view(-1, dim),
-                                        g(pp.fusion.token_type_embeddings.weight), c.batch, c.n_text, c.n_rgb)
+                                        g(model.rgb_pos_embedding).view(-1, dim), g_type, c.batch, c.n_text, c.n_rgb)
         ops.gemm(d_rgb, c.vis_feat, trans_a=True, b_kn=True, out=g(model.project.weight))
         # d project.bias = the sum of d rgb_feat over every image token of the batch = the gradient of the image
         # modality's type embedding, which the assembly backward has just reduced in fp32
-        g(model.project.bias).copy_(g(pp.fusion.token_type_embeddings.weight)[1])
+        g(model.project.bias).copy_(g_type[1])
+        if type_true is not None:
+            g_type.copy_(type_true)
         ready(-1)
         ctx.c = None
         # gradients were written into the arena (and attached as .grad) by the kernels

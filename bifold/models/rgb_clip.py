@@ -30,8 +30,13 @@ class RGBOnly(BaseModel):
     def __init__(self, patch_size, text_dropout, rgb_dropout, text_encoder, pick_place_model,
                  dtype="bf16", clip_checkpoint=None, loss_scale="auto", **kwargs):
         super().__init__(**kwargs)
-        if text_dropout != 0.0 or rgb_dropout != 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented on the HIP path")
+        for name, v in (("text_dropout", text_dropout), ("rgb_dropout", rgb_dropout)):
+            if not 0.0 <= float(v) < 1.0:
+                raise ValueError(f"{name} must be in [0, 1), got {v}")
+        # nn.Dropout on the two modalities' embeddings (ref:bifold/models/rgb_clip.py:39-42,56,65), active in training; the
+        # fused tail applies the replayable masks (RGBTailFn) and records their seeds in `last_dropout_seeds`
+        self.text_dropout, self.rgb_dropout = float(text_dropout), float(rgb_dropout)
+        self.last_dropout_seeds = {}
         if dtype not in _DTYPES:
             raise ValueError(f"dtype must be one of {sorted(_DTYPES)}, got {dtype!r}")
         self.compute_dtype = _DTYPES[dtype]

@@ -109,10 +109,13 @@ __device__ __forceinline__ void stage_rows(float* lds, const T* __restrict__ bas
     }
 }
 
-template <typename T, int D>
+// DROP: nn.Dropout on the probabilities (ref:bifold/models/transformer.py:36, `attn = self.dropout(attn)` AFTER the softmax):
+// the normaliser l sums the probabilities as they are, the P V product takes keep(seed, ((b H + h) L + i) L + j) ? p / (1 - rate) : 0.
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(
     const T* __restrict__ qkv, T* __restrict__ out, float* __restrict__ lse,
-    const int32_t* __restrict__ row_mask, int L, int H, float scale, int mask_mode) {
+    const int32_t* __restrict__ row_mask, int L, int H, float scale, int mask_mode,
+    unsigned drop_thr = 0, float inv_keep = 1.f, unsigned long long seed = 0) {
     __shared__ __attribute__((aligned(16))) float ks[KT * D];
     __shared__ __attribute__((aligned(16))) float vs[KT * D];
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -146,8 +149,10 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(
             }
             const float p = expf(s - m);
             l += p;
+            float pd = p;
+            if (DROP) pd = dropout_keep((((unsigned long long)bh * L + i) * L) + (unsigned)(j0 + j), seed, drop_thr) ? p * inv_keep : 0.f;
 #pragma unroll
-            for (int d = 0; d < D; ++d) o[d] = fmaf(p, vs[j * D + d], o[d]);
+            for (int d = 0; d < D; ++d) o[d] = fmaf(pd, vs[j * D + d], o[d]);
         }
     }
     if (live) {
@@ -161,11 +166,12 @@ __global__ __launch_bounds__(256) void attn_fwd_simple_kernel(
 }
 
 // dQ (thread per query) + delta = rowsum(dO * O)
-template <typename T, int D>
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const T* __restrict__ qkv, const T* __restrict__ out, const T* __restrict__ dout,
     const float* __restrict__ lse, const int32_t* __restrict__ row_mask, T* __restrict__ dqkv,
-    float* __restrict__ delta_ws, int L, int H, float scale, int mask_mode) {
+    float* __restrict__ delta_ws, int L, int H, float scale, int mask_mode,
+    unsigned drop_thr = 0, float inv_keep = 1.f, unsigned long long seed = 0) {
     __shared__ __attribute__((aligned(16))) float ks[KT * D];
     __shared__ __attribute__((aligned(16))) float vs[KT * D];
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
@@ -203,6 +209,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
                 dp = fmaf(dO[d], vs[j * D + d], dp);
             }
             const float p = expf(s * scale - lse_i);
+            // with dropout the gradient w.r.t. the probability is the masked, rescaled dP; delta = rowsum(dO . O) is unchanged
+            if (DROP) dp = dropout_keep((((unsigned long long)bh * L + i) * L) + (unsigned)(j0 + j), seed, drop_thr) ? dp * inv_keep : 0.f;
             const float ds = p * (dp - delta) * scale;
 #pragma unroll
             for (int d = 0; d < D; ++d) dq[d] = fmaf(ds, ks[j * D + d], dq[d]);
@@ -217,11 +225,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 }
 
 // dK, dV (thread per key)
-template <typename T, int D>
+template <typename T, int D, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
     const T* __restrict__ qkv, const T* __restrict__ dout, const float* __restrict__ lse,
     const float* __restrict__ delta_ws, const int32_t* __restrict__ row_mask, T* __restrict__ dqkv,
-    int L, int H, float scale, int mask_mode) {
+    int L, int H, float scale, int mask_mode,
+    unsigned drop_thr = 0, float inv_keep = 1.f, unsigned long long seed = 0) {
     __shared__ __attribute__((aligned(16))) float qs[KT * D];
     __shared__ __attribute__((aligned(16))) float dos[KT * D];
     __shared__ float lses[KT], dels[KT];
@@ -268,10 +277,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(
             // a masked query row is exactly uniform over the L keys (all scores equal -1e5);
             // exp(-1e5 - lse) would lose ~2^-7 absolute precision at that magnitude
             const float p = rm ? inv_len : expf(s * scale - lses[r]);
+            float pd = p;
+            if (DROP) {
+                const bool keep = dropout_keep((((unsigned long long)bh * L + (unsigned)(i0 + r)) * L) + (unsigned)j, seed, drop_thr);
+                pd = keep ? p * inv_keep : 0.f;
+                dp = keep ? dp * inv_keep : 0.f;
+            }
             const float ds = rm ? 0.f : p * (dp - dels[r]) * scale;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                dv[d] = fmaf(p, dos[r * D + d], dv[d]);
+                dv[d] = fmaf(pd, dos[r * D + d], dv[d]);
                 dk[d] = fmaf(ds, qs[r * D + d], dk[d]);
             }
         }
@@ -3171,5 +3186,76 @@ extern "C" int bf_attention_bwd(const void* qkv, const void* out, const void* do
 #undef BY_MASK
 #undef BY_HALF
     BF_CHECK_LAUNCH("bf_attention_bwd");
+    return BF_OK;
+}
+
+// =====================================================================================
+//   nn.Dropout on the attention probabilities (ref:bifold/models/transformer.py:18,36; p > 0 only in training)
+// =====================================================================================
+// No shipped configuration sets `dropout` above 0 (ref:bifold/conf/model/*.yaml), so this is the correct-first form: the
+// VALU kernels (fp32 math, any storage type) with the replayable mask of common.h on P.  The flash kernels above have no
+// dropout; callers reach these entry points only when p > 0.
+template <typename T>
+static void attn_dropout_fwd_launch(const void* qkv, void* out, float* lse, const int32_t* row_mask, int batch, int seq,
+                                    int heads, int head_dim, float scale, int mask_mode, unsigned thr, float inv_keep,
+                                    unsigned long long seed, hipStream_t s) {
+    dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
+#define FWD_DROP(DD)                                                                                       \
+    hipLaunchKernelGGL((attn_fwd_simple_kernel<T, DD, true>), grid, block, 0, s, (const T*)qkv, (T*)out, lse, row_mask, \
+                       seq, heads, scale, mask_mode, thr, inv_keep, seed)
+    if (head_dim == 32) FWD_DROP(32); else if (head_dim == 48) FWD_DROP(48); else FWD_DROP(64);
+#undef FWD_DROP
+}
+template <typename T>
+static void attn_dropout_bwd_launch(const void* qkv, const void* out, const void* dout, const float* lse,
+                                    const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq, int heads,
+                                    int head_dim, float scale, int mask_mode, unsigned thr, float inv_keep,
+                                    unsigned long long seed, hipStream_t s) {
+    dim3 grid(batch * heads, bf_cdiv(seq, 256)), block(256);
+#define BWD_DROP(DD)                                                                                        \
+    do {                                                                                                    \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD, true>), grid, block, 0, s, (const T*)qkv, (const T*)out, \
+                           (const T*)dout, lse, row_mask, (T*)dqkv, delta_ws, seq, heads, scale, mask_mode, thr, inv_keep, seed); \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD, true>), grid, block, 0, s, (const T*)qkv, (const T*)dout, \
+                           lse, delta_ws, row_mask, (T*)dqkv, seq, heads, scale, mask_mode, thr, inv_keep, seed); \
+    } while (0)
+    if (head_dim == 32) BWD_DROP(32); else if (head_dim == 48) BWD_DROP(48); else BWD_DROP(64);
+#undef BWD_DROP
+}
+
+extern "C" int bf_attention_dropout_fwd(const void* qkv, void* out, float* lse, const int32_t* row_mask, int batch, int seq,
+                                        int heads, int head_dim, float scale, int mask_mode, int cdt, float p,
+                                        unsigned long long seed, bf_stream_t stream) {
+    int rc = attn_check("bf_attention_dropout_fwd", qkv, batch, seq, heads, head_dim, mask_mode, row_mask, cdt);
+    if (rc) return rc;
+    BF_REQUIRE(bf_aligned16(out), BF_EALIGN, "bf_attention_dropout_fwd: unaligned out");
+    BF_REQUIRE(p > 0.f && p < 1.f, BF_EINVAL, "bf_attention_dropout_fwd: p must be in (0, 1) (got %f)", (double)p);
+    BF_REQUIRE((unsigned long long)batch * heads * seq * seq < (1ull << 62), BF_EINVAL, "bf_attention_dropout_fwd: too many scores");
+    const unsigned thr = dropout_threshold(p);
+    const float inv_keep = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+    if (cdt == BF_F32) attn_dropout_fwd_launch<float>(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, thr, inv_keep, seed, s);
+    else if (cdt == BF_F16) attn_dropout_fwd_launch<f16_t>(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, thr, inv_keep, seed, s);
+    else attn_dropout_fwd_launch<bf16_t>(qkv, out, lse, row_mask, batch, seq, heads, head_dim, scale, mask_mode, thr, inv_keep, seed, s);
+    BF_CHECK_LAUNCH("bf_attention_dropout_fwd");
+    return BF_OK;
+}
+
+extern "C" int bf_attention_dropout_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                                        const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq, int heads,
+                                        int head_dim, float scale, int mask_mode, int cdt, float p, unsigned long long seed,
+                                        bf_stream_t stream) {
+    int rc = attn_check("bf_attention_dropout_bwd", qkv, batch, seq, heads, head_dim, mask_mode, row_mask, cdt);
+    if (rc) return rc;
+    BF_REQUIRE(lse && delta_ws, BF_EINVAL, "bf_attention_dropout_bwd: lse and delta_ws are required");
+    BF_REQUIRE(bf_aligned16(out) && bf_aligned16(dout) && bf_aligned16(dqkv), BF_EALIGN, "bf_attention_dropout_bwd: unaligned pointer");
+    BF_REQUIRE(p > 0.f && p < 1.f, BF_EINVAL, "bf_attention_dropout_bwd: p must be in (0, 1) (got %f)", (double)p);
+    const unsigned thr = dropout_threshold(p);
+    const float inv_keep = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+    if (cdt == BF_F32) attn_dropout_bwd_launch<float>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale, mask_mode, thr, inv_keep, seed, s);
+    else if (cdt == BF_F16) attn_dropout_bwd_launch<f16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale, mask_mode, thr, inv_keep, seed, s);
+    else attn_dropout_bwd_launch<bf16_t>(qkv, out, dout, lse, row_mask, dqkv, delta_ws, batch, seq, heads, head_dim, scale, mask_mode, thr, inv_keep, seed, s);
+    BF_CHECK_LAUNCH("bf_attention_dropout_bwd");
     return BF_OK;
 }

@@ -234,3 +234,17 @@ struct BfPerDevice {
         return v[d];
     }
 };
+
+// ---- replayable dropout masks ---------------------------------------------------------------------------------------
+// The keep decision of element i of a tensor is a pure function of (seed, i): splitmix64 -> 24 bits >= p * 2^24.  The
+// backward (and a CPU checker, through bf_dropout_mask) regenerates the mask instead of storing it.  Used by bf_dropout
+// (LoRA's lora_dropout, the fusion blocks' and the embeddings' nn.Dropout) and by bf_attention_dropout_fwd / _bwd
+// (nn.Dropout on the attention probabilities: element index ((b H + h) L + i) L + j).
+__device__ __forceinline__ bool dropout_keep(unsigned long long idx, unsigned long long seed, unsigned thr) {
+    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 40) >= thr;
+}
+static inline unsigned dropout_threshold(float p) { return (unsigned)((double)p * 16777216.0); }

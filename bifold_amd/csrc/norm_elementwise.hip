@@ -1308,14 +1308,7 @@ extern "C" int bf_segment_assemble_bwd(const float* dx, float* d_lead, float* d_
 // element i is a pure function of (seed, i): splitmix64 -> 24 bits >= p * 2^24, so the backward pass
 // (and a CPU oracle, through bf_dropout_mask) regenerates the mask instead of storing it.
 // ----------------------------------------------------------------------------------------
-__device__ __forceinline__ bool dropout_keep(unsigned long long idx, unsigned long long seed, unsigned thr) {
-    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 40) >= thr;
-}
-
+// (dropout_keep / dropout_threshold: common.h -- the attention kernels with dropout on the probabilities share them)
 template <typename T, bool ACC>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, size_t n4,
                                                       unsigned thr, float inv_keep, unsigned long long seed) {
@@ -1337,7 +1330,6 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__
         mask[i] = dropout_keep(i, seed, thr) ? 1 : 0;
 }
 
-static inline unsigned dropout_threshold(float p) { return (unsigned)((double)p * 16777216.0); }
 
 extern "C" int bf_dropout(const void* x, void* y, int dtype, size_t count, float p, unsigned long long seed,
                           int accumulate, bf_stream_t stream) {
@@ -1368,5 +1360,52 @@ extern "C" int bf_dropout_mask(uint8_t* mask, size_t count, float p, unsigned lo
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, mask, count,
                        dropout_threshold(p), seed);
     BF_CHECK_LAUNCH("bf_dropout_mask");
+    return BF_OK;
+}
+
+// Dropout on a ROW RANGE of every group of a [batch, group_rows, cols] tensor, in place, plus an optional per-column
+// vector added AFTER the mask: the embeddings' nn.Dropout of RGBOnly (ref:bifold/models/rgb_clip.py:39-42,56,65:
+// `x = dropout(x + pos)`) applied to the text / image rows of the assembled fusion input, followed by fusion.py:52's
+// `inp += token_type_embeddings(mod)`.  Mask index of element (b, r, c) of the range: (b * nrows + r) * cols + c, i.e. the
+// flat index of the modality's own [batch, nrows, cols] tensor (what bf_dropout_mask replays).  p = 0: only the add.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_rows_kernel(T* __restrict__ x, const float* __restrict__ add, int group_rows,
+                                                           int row0, int nrows, int cols, size_t total4, unsigned thr,
+                                                           float inv_keep, unsigned long long seed) {
+    const int c4n = cols >> 2;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / c4n;                            // row of the [batch * nrows] range
+        const int c = (int)(i - row * c4n) * 4;
+        const size_t b = row / nrows, r = row - b * nrows;
+        T* p = x + ((b * group_rows + row0 + r) * (size_t)cols + c);
+        float4 v = Vec4<T>::load(p);
+        float* vp = &v.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (thr) vp[e] = dropout_keep(row * cols + c + e, seed, thr) ? vp[e] * inv_keep : 0.f;
+            if (add) vp[e] += add[c + e];
+        }
+        Vec4<T>::store(p, v);
+    }
+}
+
+extern "C" int bf_dropout_rows(void* x, int dtype, const float* add, int batch, int group_rows, int row0, int nrows, int cols,
+                               float p, unsigned long long seed, bf_stream_t stream) {
+    BF_REQUIRE(x && batch > 0 && group_rows > 0 && row0 >= 0 && nrows > 0 && row0 + nrows <= group_rows && cols > 0 &&
+               (cols & 3) == 0, BF_EINVAL, "bf_dropout_rows: bad shape");
+    BF_REQUIRE(p >= 0.f && p < 1.f, BF_EINVAL, "bf_dropout_rows: p must be in [0, 1) (got %f)", (double)p);
+    BF_REQUIRE(dtype == BF_F32 || bf_is_half(dtype), BF_EINVAL, "bf_dropout_rows: bad dtype");
+    BF_REQUIRE(bf_aligned16(x), BF_EALIGN, "bf_dropout_rows: unaligned pointer");
+    const size_t total4 = (size_t)batch * nrows * (cols >> 2);
+    size_t blocks = (total4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const unsigned thr = dropout_threshold(p);
+    const float inv_keep = 1.0f / (1.0f - p);
+    hipStream_t s = (hipStream_t)stream;
+#define DROWS(T) hipLaunchKernelGGL((dropout_rows_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, (T*)x, add, group_rows, \
+                                    row0, nrows, cols, total4, thr, inv_keep, seed)
+    if (dtype == BF_F32) DROWS(float); else if (dtype == BF_F16) DROWS(f16_t); else DROWS(bf16_t);
+#undef DROWS
+    BF_CHECK_LAUNCH("bf_dropout_rows");
     return BF_OK;
 }

@@ -83,6 +83,11 @@ PROTOTYPES = {
                                  c_float, c_int, c_int, c_void_p]),
     "bf_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "bf_attention_dropout_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                         c_int, c_int, c_float, C.c_ulonglong, c_void_p]),
+    "bf_attention_dropout_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_float, C.c_ulonglong,
+                                         c_void_p]),
     "bf_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_patchify_ld": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bf_vision_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -134,6 +139,8 @@ PROTOTYPES = {
     "bf_cast": (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_void_p]),
     "bf_dropout": (c_int, [c_void_p, c_void_p, c_int, c_size_t, c_float, C.c_ulonglong, c_int, c_void_p]),
     "bf_dropout_mask": (c_int, [c_void_p, c_size_t, c_float, C.c_ulonglong, c_void_p]),
+    "bf_dropout_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, C.c_ulonglong,
+                                c_void_p]),
     "bf_preprocess_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p]),
     "bf_resize_normalize_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

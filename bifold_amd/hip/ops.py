@@ -367,6 +367,21 @@ def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = 
     return y
 
 
+def dropout_rows(x: torch.Tensor, add: Optional[torch.Tensor], batch: int, group_rows: int, row0: int, nrows: int,
+                 p: float, seed: int) -> torch.Tensor:
+    """In place on rows [row0, row0 + nrows) of every group of x [batch * group_rows, cols]: dropout with the mask of the
+    range's own [batch, nrows, cols] tensor, then += add (fp32 [cols] or None)."""
+    _dev(x, "x")
+    cols = x.shape[-1]
+    if x.numel() != batch * group_rows * cols or not x.is_contiguous():
+        raise RuntimeError("dropout_rows: x must be a contiguous [batch * group_rows, cols] tensor")
+    if add is not None and (add.dtype != torch.float32 or add.numel() != cols or not add.is_contiguous()):
+        raise RuntimeError("dropout_rows: add must be a contiguous float32 [cols] vector")
+    check(lib.bf_dropout_rows(_ptr(x), dtype_code(x), _ptr(add), batch, group_rows, row0, nrows, cols, float(p),
+                              int(seed) & (2 ** 64 - 1), _stream()), "bf_dropout_rows")
+    return x
+
+
 def dropout_mask(shape, p: float, seed: int, device) -> torch.Tensor:
     """The keep decisions of ops.dropout(x, p, seed) for a tensor of `shape`, as uint8 (1 = kept)."""
     mask = torch.empty(shape, dtype=torch.uint8, device=device)
@@ -378,7 +393,8 @@ def dropout_mask(shape, p: float, seed: int, device) -> torch.Tensor:
 # ----------------------------------------------------------------------------- attention
 def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim: int, scale: float,
                   mask_mode: int = L.MASK_NONE, row_mask: Optional[torch.Tensor] = None,
-                  need_lse: bool = False):
+                  need_lse: bool = False, dropout: float = 0.0, seed: int = 0):
+    """`dropout` > 0: nn.Dropout on the probabilities with the replayable mask of `seed` (bf_attention_dropout_fwd)."""
     _dev(qkv, "qkv")
     if qkv.numel() != batch * seq * 3 * heads * head_dim:
         raise RuntimeError("qkv has the wrong number of elements")
@@ -386,6 +402,11 @@ def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim:
     lse = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device) if need_lse else None
     if row_mask is not None and row_mask.dtype != torch.int32:
         raise TypeError("row_mask must be int32")
+    if dropout > 0.0:
+        check(lib.bf_attention_dropout_fwd(_ptr(qkv), _ptr(out), _ptr(lse), _ptr(row_mask), batch, seq, heads, head_dim,
+                                           scale, mask_mode, dtype_code(qkv), float(dropout), int(seed), _stream()),
+              "bf_attention_dropout_fwd")
+        return out, lse
     span = None
     if PROFILER is not None and PROFILER.wants("attn_fwd"):
         causal = 0.5 if mask_mode == L.MASK_CAUSAL else 1.0
@@ -399,10 +420,15 @@ def attention_fwd(qkv: torch.Tensor, batch: int, seq: int, heads: int, head_dim:
 
 
 def attention_bwd(qkv, out, dout, lse, batch, seq, heads, head_dim, scale, mask_mode=L.MASK_NONE,
-                  row_mask=None):
+                  row_mask=None, dropout: float = 0.0, seed: int = 0):
     _dev(qkv, "qkv"); _dev(out, "out"); _dev(dout, "dout")
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(batch, heads, seq, dtype=torch.float32, device=qkv.device)
+    if dropout > 0.0:
+        check(lib.bf_attention_dropout_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(row_mask), _ptr(dqkv),
+                                           _ptr(delta), batch, seq, heads, head_dim, scale, mask_mode, dtype_code(qkv),
+                                           float(dropout), int(seed), _stream()), "bf_attention_dropout_bwd")
+        return dqkv
     span = None
     if PROFILER is not None and PROFILER.wants("attn_bwd"):
         span = _Span(f"attn_bwd_{_TAG[dtype_code(qkv)]}_d{head_dim}",

@@ -275,6 +275,20 @@ int bf_attention_bwd(const void* qkv, const void* out, const void* dout, const f
                      int seq, int heads, int head_dim, float scale, int mask_mode, int cdt,
                      bf_stream_t stream);
 
+/* ABI 10: nn.Dropout on the attention PROBABILITIES (models/transformer.py:18,36: `attn = self.dropout(attn)` after the
+ * softmax, active in training when the model's `dropout` > 0; every shipped YAML says 0).  Same tensors as
+ * bf_attention_fwd / _bwd; element (b, h, i, j) of P is kept iff bf_dropout_mask's function keeps index
+ * ((b H + h) L + i) L + j under `seed`, kept probabilities are scaled by 1 / (1 - p) into P V while the softmax normaliser
+ * sums them as they are; the backward regenerates the mask.  Correct-first: fp32 math on the vector units for every
+ * storage type (the MFMA kernels carry no dropout). */
+int bf_attention_dropout_fwd(const void* qkv, void* out, float* lse, const int32_t* row_mask, int batch, int seq,
+                             int heads, int head_dim, float scale, int mask_mode, int cdt, float p,
+                             unsigned long long seed, bf_stream_t stream);
+int bf_attention_dropout_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                             const int32_t* row_mask, void* dqkv, float* delta_ws, int batch, int seq, int heads,
+                             int head_dim, float scale, int mask_mode, int cdt, float p, unsigned long long seed,
+                             bf_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Token / patch plumbing.
  * ---------------------------------------------------------------------- */
@@ -463,6 +477,12 @@ int bf_gradscale_update(float* state, unsigned* nonfinite_flag, float backoff, f
 int bf_dropout(const void* x, void* y, int dtype, size_t count, float p, unsigned long long seed, int accumulate,
                bf_stream_t stream);
 int bf_dropout_mask(uint8_t* mask, size_t count, float p, unsigned long long seed, bf_stream_t stream);
+/* ABI 10: dropout on rows [row0, row0 + nrows) of every group of x [batch, group_rows, cols], IN PLACE, then += add[cols]
+ * (NULL: nothing added): the embeddings' nn.Dropout of RGBOnly (models/rgb_clip.py:39-42,56,65) on the text / image rows of
+ * the assembled fusion input, followed by the modality's type embedding (models/fusion.py:52).  The mask is that of the
+ * range's own [batch, nrows, cols] tensor under bf_dropout_mask.  p = 0: only the add. */
+int bf_dropout_rows(void* x, int dtype, const float* add, int batch, int group_rows, int row0, int nrows, int cols,
+                    float p, unsigned long long seed, bf_stream_t stream);
 
 /* Elementwise cast between fp32 and bf16 (count elements). */
 int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,

@@ -55,8 +55,17 @@ def merge_heads(t: torch.Tensor):
     return t.permute(0, 2, 1, 3).reshape(b, l, h * d)
 
 
+def _drop(x: torch.Tensor, spec):
+    """nn.Dropout with a GIVEN mask: spec = (p, keep mask broadcastable to x) or None.  The reference draws its masks from
+    torch's generator; a checker feeds the masks the device generated (bf_dropout_mask) instead."""
+    if spec is None:
+        return x
+    p, keep = spec
+    return x * keep.to(x.dtype).reshape(x.shape) / (1.0 - p)
+
+
 def attention_core(q, k, v, scale: float, causal: bool = False,
-                   query_row_mask: Optional[torch.Tensor] = None):
+                   query_row_mask: Optional[torch.Tensor] = None, p_drop=None):
     """softmax(q k^T * scale [+mask]) v on [B,h,L,d] tensors.
 
     * causal: additive -inf above the diagonal (models/clip/model.py:414-420).
@@ -71,7 +80,7 @@ def attention_core(q, k, v, scale: float, causal: bool = False,
         s = s.masked_fill(upper, float("-inf"))
     if query_row_mask is not None:
         s = s.masked_fill(query_row_mask[:, None, :, None] == 0, -100000.0)
-    p = torch.softmax(s, dim=-1)
+    p = _drop(torch.softmax(s, dim=-1), p_drop)              # models/transformer.py:36: dropout AFTER the softmax
     return torch.matmul(p, v)
 
 
@@ -190,28 +199,30 @@ def siglip_text_tokens(state: State, ids: torch.Tensor, heads: int,
 # trainable tail: fusion transformer + heatmap decoders
 # --------------------------------------------------------------------------
 def fusion_layer(state: State, pfx: str, x: torch.Tensor, heads: int,
-                 query_row_mask: Optional[torch.Tensor] = None):
+                 query_row_mask: Optional[torch.Tensor] = None, drop=None):
     """One Transformer layer (models/transformer.py:44-64, modules.py:8-30):
     x = Attn(LN x) + x ; x = FF(LN x) + x.  to_qkv has NO bias, scale = d_h^-0.5,
-    FF = Linear -> erf-GELU -> Linear, dropout p = 0."""
+    FF = Linear -> erf-GELU -> Linear.  `drop` = (p, {"attn", "out", "act", "ff": keep masks}) applies the block's four
+    nn.Dropout sites (transformer.py:18,20-24,36; modules.py:24,26) with GIVEN masks; None = the shipped p = 0."""
+    dp = (lambda n: (drop[0], drop[1][n])) if drop is not None else (lambda n: None)
     w = x.shape[-1]
     h = layer_norm(x, state[pfx + "0.norm.weight"], state[pfx + "0.norm.bias"])
     qkv = F.linear(h, state[pfx + "0.fn.to_qkv.weight"])
     q, k, v = (split_heads(t, heads) for t in qkv.chunk(3, dim=-1))
-    o = attention_core(q, k, v, scale=(w // heads) ** -0.5, query_row_mask=query_row_mask)
-    o = F.linear(merge_heads(o), state[pfx + "0.fn.to_out.0.weight"],
-                 state[pfx + "0.fn.to_out.0.bias"])
+    o = attention_core(q, k, v, scale=(w // heads) ** -0.5, query_row_mask=query_row_mask, p_drop=dp("attn"))
+    o = _drop(F.linear(merge_heads(o), state[pfx + "0.fn.to_out.0.weight"],
+                       state[pfx + "0.fn.to_out.0.bias"]), dp("out"))
     x = o + x
     h = layer_norm(x, state[pfx + "1.norm.weight"], state[pfx + "1.norm.bias"])
-    h = erf_gelu(F.linear(h, state[pfx + "1.fn.net.0.weight"], state[pfx + "1.fn.net.0.bias"]))
-    h = F.linear(h, state[pfx + "1.fn.net.3.weight"], state[pfx + "1.fn.net.3.bias"])
+    h = _drop(erf_gelu(F.linear(h, state[pfx + "1.fn.net.0.weight"], state[pfx + "1.fn.net.0.bias"])), dp("act"))
+    h = _drop(F.linear(h, state[pfx + "1.fn.net.3.weight"], state[pfx + "1.fn.net.3.bias"]), dp("ff"))
     return h + x
 
 
 def concat_transformer(state: State, inputs: Sequence[torch.Tensor], heads: int,
                        modalities: Optional[Sequence[int]] = None,
                        attention_masks: Optional[torch.Tensor] = None,
-                       pfx: str = "pick_place.fusion."):
+                       pfx: str = "pick_place.fusion.", layer_drop=None):
     """ConcatTransformer.forward (models/fusion.py:35-64): add the modality's
     type embedding to each input, concatenate along the sequence, run the
     pre-norm transformer (no final norm), return the last input's tokens."""
@@ -222,7 +233,7 @@ def concat_transformer(state: State, inputs: Sequence[torch.Tensor], heads: int,
     depth = 0
     while f"{pfx}transformer_encoder.layers.{depth}.0.norm.weight" in state:
         x = fusion_layer(state, f"{pfx}transformer_encoder.layers.{depth}.", x, heads,
-                         attention_masks)
+                         attention_masks, drop=None if layer_drop is None else layer_drop[depth])
         depth += 1
     return x[:, -inputs[-1].shape[1]:, :]
 
@@ -293,15 +304,18 @@ def collapse_decoder(state: State, pfx: str):
 # model, loss, optimiser
 # --------------------------------------------------------------------------
 def rgb_clip_forward(state: State, sample: Mapping[str, torch.Tensor], heads: int,
-                     is_bimanual: bool = False):
-    """RGBOnly.forward (models/rgb_clip.py:52-73)."""
+                     is_bimanual: bool = False, dropout=None):
+    """RGBOnly.forward (models/rgb_clip.py:52-73).  `dropout` (training with p > 0, GIVEN masks):
+    dict(text=(p, keep [B,78,D]), rgb=(p, keep [B,n+1,D]), layers=[(p, {attn, out, act, ff})...])."""
     t = clip_text_tokens(state, sample["instruction"])
     b = t.shape[0]
     t = torch.cat([state["text_token"].expand(b, 1, -1), t], dim=1)
-    x_text = t + state["text_pos_embedding"][:, : t.shape[1]]
+    dr = dropout or {}
+    x_text = _drop(t + state["text_pos_embedding"][:, : t.shape[1]], dr.get("text"))
     v = clip_vision_tokens(state, sample["rgb"])
-    x_rgb = F.linear(v, state["project.weight"], state["project.bias"]) + state["rgb_pos_embedding"]
-    return pick_place_convdecoder(state, [x_text, x_rgb], heads, is_bimanual)
+    x_rgb = _drop(F.linear(v, state["project.weight"], state["project.bias"]) + state["rgb_pos_embedding"], dr.get("rgb"))
+    kw = dict(layer_drop=dr["layers"]) if dr.get("layers") is not None else {}
+    return pick_place_convdecoder(state, [x_text, x_rgb], heads, is_bimanual, **kw)
 
 
 def _prepend(token: torch.Tensor, feats: torch.Tensor):

@@ -14,7 +14,7 @@ def _round16(t):
     return t.half().float()
 
 
-def _fusion_layer_16(state, pfx, x, heads, query_row_mask=None):      # O.fusion_layer with the stream rounded after each add
+def _fusion_layer_16(state, pfx, x, heads, query_row_mask=None, drop=None):      # O.fusion_layer with the stream rounded after each add
     w = x.shape[-1]
     h = O.layer_norm(x, state[pfx + "0.norm.weight"], state[pfx + "0.norm.bias"])
     qkv = F.linear(h, state[pfx + "0.fn.to_qkv.weight"])

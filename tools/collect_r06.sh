@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-5 evidence, in three GPU calls (each under gpurun's 20-minute limit; run on the GPU box from the repo root):
-#   tools/collect_r05.sh a   config A: serial kernel stats, concurrent stats + PMC passes, attention kernels, timeline, bench line
-#   tools/collect_r05.sh b   the other configurations' bench lines + a kernel profile of --config siglip_seq
-#   tools/collect_r05.sh c   GEMM against the vendor library, the whole GPU test suite with the observed-parity record
-# Everything lands in gpurun_out/r05/; tools/publish_r05.sh copies what is judged into profiles/r05_*.
+# Round-6 evidence, in three GPU calls (each under gpurun's 20-minute limit; run on the GPU box from the repo root):
+#   tools/collect_r06.sh a   config A: serial kernel stats, concurrent stats + PMC passes, attention kernels, timeline, bench line
+#   tools/collect_r06.sh b   the other configurations' bench lines + a kernel profile of --config siglip_seq
+#   tools/collect_r06.sh c   GEMM against the vendor library, the whole GPU test suite with the observed-parity record
+# Everything lands in gpurun_out/r06/; tools/publish_r06.sh copies what is judged into profiles/r06_*.
 # Every step writes its own file as it goes (a long silent call is taken for hung).
 set -o pipefail
 part=${1:-a}
-out=gpurun_out/r05
+out=gpurun_out/r06
 mkdir -p $out
 export TMPDIR=/tmp
 filt() { grep -v amdgpu.ids; }
@@ -15,15 +15,15 @@ step() { echo "[$(date +%H:%M:%S)] $*"; }
 case $part in
 a)
   step "serial kernel stats fp16"
-  tools/serial_stats.sh r05s_fp16 > $out/serial_fp16.log 2>&1 && cp gpurun_out/prof_r05s_fp16/serial_stats.txt $out/serial_kernel_stats_fp16.txt || { echo FAILED serial fp16; tail -3 $out/serial_fp16.log; }
+  tools/serial_stats.sh r06s_fp16 > $out/serial_fp16.log 2>&1 && cp gpurun_out/prof_r06s_fp16/serial_stats.txt $out/serial_kernel_stats_fp16.txt || { echo FAILED serial fp16; tail -3 $out/serial_fp16.log; }
   step "concurrent kernel stats + PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy)"
-  tools/collect_profiles.sh r05p > $out/collect.log 2>&1 && cp gpurun_out/prof_r05p/stats.txt $out/bench_kernel_stats.txt && cp gpurun_out/prof_r05p/hbm_traffic.txt $out/hbm_traffic_pmc.txt && cp gpurun_out/prof_r05p/mfma.txt $out/mfma_busy_pmc.txt || { echo FAILED collect_profiles; tail -3 $out/collect.log; }
+  tools/collect_profiles.sh r06p > $out/collect.log 2>&1 && cp gpurun_out/prof_r06p/stats.txt $out/bench_kernel_stats.txt && cp gpurun_out/prof_r06p/hbm_traffic.txt $out/hbm_traffic_pmc.txt && cp gpurun_out/prof_r06p/mfma.txt $out/mfma_busy_pmc.txt || { echo FAILED collect_profiles; tail -3 $out/collect.log; }
   step "attention kernels, isolated"
   { timeout -k 5 150 python3 tools/attn_bench.py --dtype fp16 2>&1 | filt; timeout -k 5 150 python3 tools/attn_bench.py --bwd --dtype fp16 2>&1 | filt; } > $out/attn_bench.txt
   step "LayerNorm passes, isolated (the frozen towers' stream written once per block)"
   timeout -k 5 150 python3 tools/add_ln_bench.py 2>&1 | filt > $out/add_ln_bench.txt
   step "step timeline"
-  tools/trace_run.sh r05t > /dev/null 2>&1 && cp gpurun_out/trace_r05t/timeline.txt $out/step_timeline.txt
+  tools/trace_run.sh r06t > /dev/null 2>&1 && cp gpurun_out/trace_r06t/timeline.txt $out/step_timeline.txt
   step "bench line: default (cpu baseline + alt)"
   timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench_line.err
   python3 tools/benchline.py $out/bench_line.json
@@ -39,7 +39,7 @@ b)
   timeout -k 10 500 python3 bench.py --no-alt --config siglip_seq --lora --lora-dropout 0 --batch 128 --steps 6 --warmup 2 --no-cpu-baseline > $out/bench_line_siglip_seq_lora_merged.json 2> /dev/null
   for f in bench_line_bf16 bench_line_vitl14 bench_line_fp8 bench_line_siglip_seq_frozen bench_line_siglip_seq_lora bench_line_siglip_seq_lora_merged; do python3 tools/benchline.py $out/$f.json; done
   step "kernel profile of --config siglip_seq (frozen towers, B = 128), side streams folded in"
-  tools/serial_stats.sh r05s_siglip --config siglip_seq --batch 128 > $out/serial_siglip.log 2>&1 && cp gpurun_out/prof_r05s_siglip/serial_stats.txt $out/siglip_seq_frozen_b128_kernel_stats.txt || { echo FAILED serial siglip; tail -3 $out/serial_siglip.log; }
+  tools/serial_stats.sh r06s_siglip --config siglip_seq --batch 128 > $out/serial_siglip.log 2>&1 && cp gpurun_out/prof_r06s_siglip/serial_stats.txt $out/siglip_seq_frozen_b128_kernel_stats.txt || { echo FAILED serial siglip; tail -3 $out/serial_siglip.log; }
   ;;
 c)
   step "GEMM vs the vendor library, fp16 (same buffers, rotated order)"
