@@ -89,8 +89,10 @@ def test_factories_and_error_behaviour():
         m({"rgb": torch.zeros(1, 3, 64, 64), "instruction": torch.zeros(1, 77, dtype=torch.int32)})
     with pytest.raises(AssertionError):
         Models.get_by_name(tiny_cfg(image_size=70), device=torch.device("cpu"))
-    with pytest.raises(NotImplementedError):
-        Models.get_by_name(tiny_cfg(dropout=0.1), device=torch.device("cpu"))
+    md = Models.get_by_name(tiny_cfg(dropout=0.1, text_dropout=0.2), device=torch.device("cpu"))   # round 6: dropout > 0 is built
+    assert md.pick_place.fusion.dropout == 0.1 and md.text_dropout == 0.2 and md.rgb_dropout == 0.0
+    with pytest.raises(ValueError, match="dropout"):
+        Models.get_by_name(tiny_cfg(dropout=1.0), device=torch.device("cpu"))
     loss = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=True, mask_pick_heatmap=False))
     assert loss.heads() == ["left_pick", "left_place", "right_pick", "right_place"]
 

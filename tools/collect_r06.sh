@@ -19,7 +19,9 @@ a)
   step "concurrent kernel stats + PMC passes (FETCH_SIZE, WRITE_SIZE, MFMA busy)"
   tools/collect_profiles.sh r06p > $out/collect.log 2>&1 && cp gpurun_out/prof_r06p/stats.txt $out/bench_kernel_stats.txt && cp gpurun_out/prof_r06p/hbm_traffic.txt $out/hbm_traffic_pmc.txt && cp gpurun_out/prof_r06p/mfma.txt $out/mfma_busy_pmc.txt || { echo FAILED collect_profiles; tail -3 $out/collect.log; }
   step "attention kernels, isolated"
-  { timeout -k 5 150 python3 tools/attn_bench.py --dtype fp16 2>&1 | filt; timeout -k 5 150 python3 tools/attn_bench.py --bwd --dtype fp16 2>&1 | filt; } > $out/attn_bench.txt
+  { timeout -k 5 150 python3 tools/attn_bench.py --bwd --dtype fp16 2>&1 | filt;
+    echo "# long sequences (configs[2] at B = 128: 2 950 tokens, query-row mask; the 224-px form; SigLIP / ViT-L towers), BIFOLD_ATTN_PIPE=1 (default) then 0 (rounds 1 - 5's kernels)";
+    for pipe in 1 0; do echo "== BIFOLD_ATTN_PIPE=$pipe"; BIFOLD_ATTN_PIPE=$pipe timeout -k 5 200 python3 tools/attn_bench.py --bwd --dtype fp16 --shape fusion128,128,2950,16,48,2 --shape fus224,32,1050,16,48,2 --shape vision384,64,576,12,64,0 --shape vitl,64,577,16,64,0 2>&1 | filt; done; } > $out/attn_bench.txt
   step "LayerNorm passes, isolated (the frozen towers' stream written once per block)"
   timeout -k 5 150 python3 tools/add_ln_bench.py 2>&1 | filt > $out/add_ln_bench.txt
   step "step timeline"
@@ -40,6 +42,10 @@ b)
   for f in bench_line_bf16 bench_line_vitl14 bench_line_fp8 bench_line_siglip_seq_frozen bench_line_siglip_seq_lora bench_line_siglip_seq_lora_merged; do python3 tools/benchline.py $out/$f.json; done
   step "kernel profile of --config siglip_seq (frozen towers, B = 128), side streams folded in"
   tools/serial_stats.sh r06s_siglip --config siglip_seq --batch 128 > $out/serial_siglip.log 2>&1 && cp gpurun_out/prof_r06s_siglip/serial_stats.txt $out/siglip_seq_frozen_b128_kernel_stats.txt || { echo FAILED serial siglip; tail -3 $out/serial_siglip.log; }
+  step "  ... and with LoRA as shipped"
+  tools/serial_stats.sh r06s_siglip_lora --config siglip_seq --lora --batch 128 > $out/serial_siglip_lora.log 2>&1 && cp gpurun_out/prof_r06s_siglip_lora/serial_stats.txt $out/siglip_seq_lora_b128_kernel_stats.txt || { echo FAILED serial siglip lora; tail -3 $out/serial_siglip_lora.log; }
+  step "PMC counters of the long-sequence attention kernels (wave life, instruction mix, LDS conflicts)"
+  bash tools/r06_attn_prof.sh pipe --shape fusion128,128,2950,16,48,2 --shape vision384,64,576,12,64,0 > $out/attn_pipe_pmc.txt 2>&1 || echo FAILED attn pmc
   ;;
 c)
   step "GEMM vs the vendor library, fp16 (same buffers, rotated order)"

@@ -11,6 +11,8 @@ cp_if attn_bench.txt r06_attn_bench.txt
 cp_if add_ln_bench.txt r06_add_ln_bench.txt
 cp_if step_timeline.txt r06_step_timeline.txt
 cp_if siglip_seq_frozen_b128_kernel_stats.txt r06_siglip_seq_frozen_b128_kernel_stats.txt
+cp_if siglip_seq_lora_b128_kernel_stats.txt r06_siglip_seq_lora_b128_kernel_stats.txt
+cp_if attn_pipe_pmc.txt r06_attn_pipe_pmc.txt
 cp_if gemm_vs_hipblaslt_fp16.txt r06_gemm_vs_hipblaslt_fp16.txt
 cp_if observed_parity.jsonl r06_observed_parity.jsonl
 for f in bench_line bench_line_bf16 bench_line_vitl14 bench_line_fp8 bench_line_siglip_seq_frozen bench_line_siglip_seq_lora bench_line_siglip_seq_lora_merged; do
