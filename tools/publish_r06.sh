@@ -2,7 +2,7 @@
 # Copies what tools/collect_r06.sh left in gpurun_out/r06/ (scratch) into profiles/r06_* (tracked, judged).
 set -e
 src=gpurun_out/r06
-cp_if() { [ -s "$src/$1" ] && cp "$src/$1" "profiles/$2" && echo "profiles/$2"; }
+cp_if() { if [ -s "$src/$1" ]; then cp "$src/$1" "profiles/$2" && echo "profiles/$2"; fi; }
 cp_if serial_kernel_stats_fp16.txt r06_serial_kernel_stats_fp16.txt
 cp_if bench_kernel_stats.txt r06_bench_kernel_stats_v1.txt
 cp_if hbm_traffic_pmc.txt r06_hbm_traffic_pmc_v1.txt
@@ -16,5 +16,5 @@ cp_if attn_pipe_pmc.txt r06_attn_pipe_pmc.txt
 cp_if gemm_vs_hipblaslt_fp16.txt r06_gemm_vs_hipblaslt_fp16.txt
 cp_if observed_parity.jsonl r06_observed_parity.jsonl
 for f in bench_line bench_line_bf16 bench_line_vitl14 bench_line_fp8 bench_line_siglip_seq_frozen bench_line_siglip_seq_lora bench_line_siglip_seq_lora_merged; do
-  [ -s "$src/$f.json" ] && tail -1 "$src/$f.json" > "profiles/r06_$f.json" && echo "profiles/r06_$f.json"
+  if [ -s "$src/$f.json" ]; then tail -1 "$src/$f.json" > "profiles/r06_$f.json"; echo "profiles/r06_$f.json"; fi
 done
