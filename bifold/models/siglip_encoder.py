@@ -121,6 +121,7 @@ class SiglipTowers(nn.Module):
         self._saved: Dict[str, Dict] = {}             # per tower: what backward() needs
         self._packed_merged = False
         self._unmerged_now = False
+        self._lora_packed = {}                    # tower -> operands of the bf_lora_* kernels (None: GEMM form)
         # (tower, call index within the step, layer, projection) -> seed of that Linear's dropout mask in the
         # most recent training forward; bf_dropout_mask(seed) replays it
         self.last_dropout_seeds: Dict = {}
@@ -305,6 +306,7 @@ class SiglipTowers(nn.Module):
             # fold the rank in, so replicas drop different elements like one process over the whole batch would
             if torch.distributed.is_available() and torch.distributed.is_initialized():
                 base_seed ^= (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+            self._lora_pack(tower, cfg, cdt)
         policy = self.lora["recompute"] if keep else "none"
         for i in range(cfg["num_hidden_layers"]):
             b = f"{tower}.encoder.layers.{i}."
@@ -362,6 +364,14 @@ class SiglipTowers(nn.Module):
         if seeds is None:
             return qkv, None
         p_drop, scale = self.lora["dropout"], self.lora["alpha"] / self.lora["r"]
+        pk = self._lora_packed.get(tower)
+        if pk is not None:
+            # the adapter branch of every adapted projection in two launches (csrc/lora.hip): u = (D . h1) A^T / (1 - p)
+            # from ONE read of h1, then qkv[:, slot] += scaling u B^T
+            sd = [seeds[n] for n in pk["names"]]
+            u = ops.lora_down(h1, [0] * len(sd), pk["a"][i], pk["r"], w, p_drop, sd, alpha=1.0 / (1.0 - p_drop))
+            ops.lora_up(u, pk["bt"][i], qkv, pk["offs"], pk["r"], w)
+            return qkv, dict(u=u, seeds=sd)
         drop = {}
         for slot, n in enumerate("qkv"):
             if n not in seeds:
@@ -373,6 +383,22 @@ class SiglipTowers(nn.Module):
             drop[n] = (u, seeds[n])
             del hd
         return qkv, drop
+
+    def _lora_pack(self, tower: str, cfg: Dict, cdt) -> None:
+        """Operands of the bf_lora_* kernels for one tower call: every layer's lora_A rows stacked ([layers, S r, width])
+        and scaling * lora_B^T in the same layout, in the compute dtype -- three launches per tower call instead of a cast
+        per use.  None for shapes the kernels do not take (fp32 mode, other ranks): those run dropout + GEMMs."""
+        w, r = cfg["hidden_size"], self.lora["r"]
+        names = [n for n in "qkv" if f"{n}_proj" in self.lora["targets"]]
+        self._lora_packed[tower] = None
+        if os.environ.get("BIFOLD_LORA_FUSED", "1") == "0" or not ops.lora_supported(cdt, w, r, len(names)):
+            return
+        scale = self.lora["alpha"] / r
+        n_layers = cfg["num_hidden_layers"]
+        pairs = [self.lora_params(tower, i, f"{n}_proj") for i in range(n_layers) for n in names]
+        a = torch.cat([la.data for la, _ in pairs]).to(cdt).view(n_layers, len(names) * r, w)
+        bt = (torch.cat([lb.data.t() for _, lb in pairs]) * scale).to(cdt).view(n_layers, len(names) * r, w)
+        self._lora_packed[tower] = dict(a=a, bt=bt, names=names, r=r, offs=["qkv".index(n) * w for n in names])
 
     def _rematerialize(self, S: Dict, b: str, i: int, tower: str, cfg: Dict, batch: int, seq: int, cdt) -> Dict:
         """Fill in what the forward dropped under the recompute policy, by re-running its kernels on what it kept."""
@@ -443,8 +469,20 @@ class SiglipTowers(nn.Module):
                 #   dh1 += D (du A)
                 dh1 = ops.gemm(dqkv, self._packed[b + "self_attn.w"], b_kn=True)      # base rows
                 p_drop = self.lora["dropout"]
+                pk = self._lora_packed.get(tower) if "u" in S["drop"] else None
+                if pk is not None:
+                    # csrc/lora.hip: every adapted projection of the layer per launch, each wide tensor read once per pass
+                    u, sd = S["drop"]["u"], S["drop"]["seeds"]
+                    r, offs, zero = pk["r"], pk["offs"], [0] * len(sd)
+                    keep_inv = 1.0 / (1.0 - p_drop)
+                    grads = [self.lora_params(tower, i, f"{n}_proj") for n in pk["names"]]
+                    du = ops.lora_down(dqkv, offs, pk["bt"][i], r, w)                                # scaling dy B
+                    ops.lora_tn(dqkv, offs, u, [grad_view(lb) for _, lb in grads], r, w, True, alpha=scale)
+                    ops.lora_tn(S["h1"], zero, du, [grad_view(la) for la, _ in grads], r, w, False, p_drop, sd,
+                                alpha=keep_inv)
+                    ops.lora_up(du, pk["a"][i], dh1, zero, r, w, p_drop, sd, alpha=keep_inv)
                 for slot, n in enumerate("qkv"):
-                    if n not in S["drop"]:
+                    if pk is not None or n not in S["drop"]:
                         continue
                     u, seed = S["drop"][n]
                     la, lb = self.lora_params(tower, i, f"{n}_proj")

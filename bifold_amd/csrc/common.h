@@ -236,15 +236,41 @@ struct BfPerDevice {
 };
 
 // ---- replayable dropout masks ---------------------------------------------------------------------------------------
-// The keep decision of element i of a tensor is a pure function of (seed, i): splitmix64 -> 24 bits >= p * 2^24.  The
-// backward (and a CPU checker, through bf_dropout_mask) regenerates the mask instead of storing it.  Used by bf_dropout
-// (LoRA's lora_dropout, the fusion blocks' and the embeddings' nn.Dropout) and by bf_attention_dropout_fwd / _bwd
-// (nn.Dropout on the attention probabilities: element index ((b H + h) L + i) L + j).
-__device__ __forceinline__ bool dropout_keep(unsigned long long idx, unsigned long long seed, unsigned thr) {
-    unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
+// The keep decision of element i of a tensor is a pure function of (seed, i).  One splitmix64 value serves FOUR consecutive
+// elements (i >> 2 is hashed; element i & 3 takes 15 of its bits from the 16-bit field i & 3): keep iff those 15 bits
+// >= p * 2^15.  A lane that holds four (or eight) consecutive 16-bit elements therefore pays one (two) hashes and turns
+// them into AND-masks with packed 16-bit arithmetic (dropout_mask4): the adapters' dropout inside the LoRA kernels
+// (lora.hip) costs a quarter of what one hash per element did (round 6; the hash, not HBM, bounded bf_dropout: 225 us for
+// 283 M elements).  The backward (and a CPU checker, through bf_dropout_mask) regenerates the mask instead of storing it.
+// Used by bf_dropout / bf_dropout_rows (the fusion blocks' and the embeddings' nn.Dropout), the bf_lora_* kernels (PEFT's
+// lora_dropout) and bf_attention_dropout_fwd / _bwd (nn.Dropout on the attention probabilities: element index
+// ((b H + h) L + i) L + j).
+__device__ __forceinline__ unsigned long long dropout_hash(unsigned long long q, unsigned long long seed) {
+    unsigned long long z = q + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 40) >= thr;
+    return z ^ (z >> 31);
 }
-static inline unsigned dropout_threshold(float p) { return (unsigned)((double)p * 16777216.0); }
+__device__ __forceinline__ bool dropout_keep(unsigned long long idx, unsigned long long seed, unsigned thr) {
+    const unsigned long long z = dropout_hash(idx >> 2, seed);
+    return (((unsigned)(z >> (16 * (unsigned)(idx & 3))) & 0xFFFFu) >> 1) >= thr;
+}
+// AND-masks (0xFFFF per kept element) for the four 16-bit elements idx .. idx + 3 (idx % 4 == 0) as two packed words;
+// thr_m1 = dropout_threshold_packed(p).  field >> 1 >= thr  <=>  (thr - 1) - (field >> 1) < 0.
+typedef short bf_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 dropout_mask4(unsigned long long idx, unsigned long long seed, unsigned thr_m1) {
+    const unsigned long long z = dropout_hash(idx >> 2, seed);
+    const bf_i16x2 t = __builtin_bit_cast(bf_i16x2, thr_m1);
+    const bf_i16x2 f0 = __builtin_bit_cast(bf_i16x2, ((unsigned)z >> 1) & 0x7FFF7FFFu);
+    const bf_i16x2 f1 = __builtin_bit_cast(bf_i16x2, ((unsigned)(z >> 32) >> 1) & 0x7FFF7FFFu);
+    uint2 m;
+    m.x = __builtin_bit_cast(unsigned, (bf_i16x2)((t - f0) >> 15));
+    m.y = __builtin_bit_cast(unsigned, (bf_i16x2)((t - f1) >> 15));
+    return m;
+}
+static inline unsigned dropout_threshold(float p) { return (unsigned)((double)p * 32768.0 + 0.5); }
+// (thr - 1) in both halves of a word, for dropout_mask4; thr = 0 (p < 2^-16) keeps everything.
+static inline unsigned dropout_threshold_packed(float p) {
+    const unsigned t = (dropout_threshold(p) - 1u) & 0xFFFFu;
+    return t | (t << 16);
+}

@@ -1305,7 +1305,7 @@ extern "C" int bf_segment_assemble_bwd(const float* dx, float* d_lead, float* d_
 // ----------------------------------------------------------------------------------------
 // Dropout with a REPLAYABLE mask (LoRA's `lora_dropout` on the adapter input, reference
 // bifold/models/siglip.py:33-40 -> peft LoraLayer: lora_B(lora_A(dropout(x)))).  The keep decision of
-// element i is a pure function of (seed, i): splitmix64 -> 24 bits >= p * 2^24, so the backward pass
+// element i is a pure function of (seed, i) (common.h: splitmix64 of i >> 2, 15 bits >= p * 2^15), so the backward pass
 // (and a CPU oracle, through bf_dropout_mask) regenerates the mask instead of storing it.
 // ----------------------------------------------------------------------------------------
 // (dropout_keep / dropout_threshold: common.h -- the attention kernels with dropout on the probabilities share them)

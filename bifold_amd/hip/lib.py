@@ -19,11 +19,17 @@ ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TA
 ACT_ERF_GELU_SAVEGRAD, ACT_MUL_AUX = 6, 7
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, TARGETS_FIT, MAX_TARGET_POINTS = 0, 1, 2, 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
     "BIFOLD_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libbifold_hip.so"))
+
+
+class LoraSlots(C.Structure):
+    """Mirror of `struct bf_lora_slots` (include/bifold_hip.h)."""
+    _fields_ = [("n_slots", c_int), ("rank", c_int), ("col_off", c_int * 3), ("p", c_float),
+                ("seed", C.c_ulonglong * 3)]
 
 
 class GemmArgs(C.Structure):
@@ -141,6 +147,11 @@ PROTOTYPES = {
     "bf_dropout_mask": (c_int, [c_void_p, c_size_t, c_float, C.c_ulonglong, c_void_p]),
     "bf_dropout_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, C.c_ulonglong,
                                 c_void_p]),
+    "bf_lora_down": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, POINTER(LoraSlots), c_float, c_int, c_void_p]),
+    "bf_lora_up": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(LoraSlots), c_float, c_int, c_void_p]),
+    "bf_lora_tn_workspace_elems": (c_size_t, [c_int, c_int, POINTER(LoraSlots)]),
+    "bf_lora_tn": (c_int, [c_void_p, c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_int,
+                           POINTER(LoraSlots), c_float, c_int, c_void_p]),
     "bf_preprocess_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p]),
     "bf_resize_normalize_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -367,6 +367,76 @@ def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = 
     return y
 
 
+def _lora_slots(n_slots: int, rank: int, col_off, p: float, seeds) -> "L.LoraSlots":
+    sl = L.LoraSlots()
+    sl.n_slots, sl.rank, sl.p = int(n_slots), int(rank), float(p)
+    for s in range(n_slots):
+        sl.col_off[s] = int(col_off[s])
+        sl.seed[s] = (int(seeds[s]) & (2 ** 64 - 1)) if seeds is not None else 0
+    return sl
+
+
+def lora_supported(dtype: torch.dtype, width: int, rank: int, n_slots: int) -> bool:
+    """Shapes the bf_lora_* kernels take (the others run the adapter branch as dropout + GEMMs)."""
+    return dtype in HALF and rank in (8, 16) and n_slots * rank <= 32 and 1 <= n_slots <= 3 and width % 16 == 0 \
+        and (n_slots * rank + 1) * (2 * width + 16) <= 65536          # bf_lora_down keeps the stacked A rows in LDS
+
+
+def lora_down(x: torch.Tensor, col_off, wt: torch.Tensor, rank: int, width: int, p: float = 0.0, seeds=None,
+              alpha: float = 1.0) -> torch.Tensor:
+    """u fp32 [rows, S * rank]: u[:, slot s] = alpha (mask_s . x[:, col_off[s] : col_off[s] + width]) wt[slot s rows]^T.
+    x: 16-bit [rows, ld] (ld = x.shape[1]); wt: same dtype [S * rank, width]."""
+    _dev(x, "x"), _dev(wt, "wt")
+    n = len(col_off)
+    if x.dim() != 2 or wt.dtype != x.dtype or tuple(wt.shape) != (n * rank, width) or not wt.is_contiguous() \
+            or x.stride(1) != 1:
+        raise RuntimeError("lora_down: x [rows, ld] and wt [S * rank, width] of one 16-bit type expected")
+    rows = x.shape[0]
+    u = torch.empty(rows, n * rank, dtype=torch.float32, device=x.device)
+    sl = _lora_slots(n, rank, col_off, p, seeds)
+    check(lib.bf_lora_down(_ptr(x), x.stride(0), _ptr(wt), _ptr(u), rows, width, C.byref(sl), float(alpha),
+                           dtype_code(x), _stream()), "bf_lora_down")
+    return u
+
+
+def lora_up(u: torch.Tensor, wt: torch.Tensor, y: torch.Tensor, col_off, rank: int, width: int, p: float = 0.0, seeds=None,
+            alpha: float = 1.0) -> torch.Tensor:
+    """y[:, col_off[s] + c] += alpha mask_s . (u[:, slot s] wt[slot s rows, c]), in place; y: 16-bit [rows, ld]."""
+    _dev(u, "u"), _dev(wt, "wt"), _dev(y, "y")
+    n = len(col_off)
+    rows = y.shape[0]
+    if y.dim() != 2 or wt.dtype != y.dtype or tuple(wt.shape) != (n * rank, width) or not wt.is_contiguous() \
+            or y.stride(1) != 1 or u.dtype != torch.float32 or tuple(u.shape) != (rows, n * rank) or not u.is_contiguous():
+        raise RuntimeError("lora_up: u fp32 [rows, S * rank], wt [S * rank, width], y [rows, ld] expected")
+    sl = _lora_slots(n, rank, col_off, p, seeds)
+    check(lib.bf_lora_up(_ptr(u), _ptr(wt), _ptr(y), y.stride(0), rows, width, C.byref(sl), float(alpha), dtype_code(y),
+                         _stream()), "bf_lora_up")
+    return y
+
+
+def lora_tn(x: torch.Tensor, col_off, u: torch.Tensor, outs, rank: int, width: int, transposed: bool, p: float = 0.0,
+            seeds=None, alpha: float = 1.0) -> None:
+    """outs[s] (fp32 [rank, width], or [width, rank] when transposed) = alpha u[:, slot s]^T (mask_s . x[:, col_off[s] : + width])."""
+    _dev(x, "x"), _dev(u, "u")
+    n = len(col_off)
+    rows = x.shape[0]
+    if x.dim() != 2 or x.stride(1) != 1 or u.dtype != torch.float32 or tuple(u.shape) != (rows, n * rank) \
+            or not u.is_contiguous() or len(outs) != n:
+        raise RuntimeError("lora_tn: x [rows, ld], u fp32 [rows, S * rank] and S outputs expected")
+    want = (width, rank) if transposed else (rank, width)
+    ptrs = (C.c_void_p * n)()
+    for s, o in enumerate(outs):
+        _dev(o, "out")
+        if o.dtype != torch.float32 or tuple(o.shape) != want or not o.is_contiguous():
+            raise RuntimeError(f"lora_tn: out[{s}] must be a contiguous float32 {want} tensor")
+        ptrs[s] = o.data_ptr()
+    sl = _lora_slots(n, rank, col_off, p, seeds)
+    elems = int(lib.bf_lora_tn_workspace_elems(rows, width, C.byref(sl)))
+    ws = torch.empty(max(elems, 1), dtype=torch.float32, device=x.device)
+    check(lib.bf_lora_tn(_ptr(x), x.stride(0), _ptr(u), ptrs, int(transposed), _ptr(ws), elems, rows, width, C.byref(sl),
+                         float(alpha), dtype_code(x), _stream()), "bf_lora_tn")
+
+
 def dropout_rows(x: torch.Tensor, add: Optional[torch.Tensor], batch: int, group_rows: int, row0: int, nrows: int,
                  p: float, seed: int) -> torch.Tensor:
     """In place on rows [row0, row0 + nrows) of every group of x [batch * group_rows, cols]: dropout with the mask of the

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 10
+#define BF_ABI_VERSION 11
 
 enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
@@ -469,7 +469,7 @@ int bf_gradscale_update(float* state, unsigned* nonfinite_flag, float backoff, f
                         float min_scale, float max_scale, bf_stream_t stream);
 
 /* Inverted dropout with a replayable mask: y[i] (+)= keep(seed, i) ? x[i] / (1 - p) : 0, keep = a pure function
- * of (seed, element index) (splitmix64, 24 bits against p * 2^24), so the backward pass regenerates the mask from
+ * of (seed, element index) (splitmix64 of index / 4, 15 of its bits per element against p * 2^15), so the backward pass regenerates the mask from
  * the seed instead of storing it.  Replaces the nn.Dropout(lora_dropout) PEFT puts in front of lora_A
  * (models/siglip.py:33-40 -> LoraConfig(lora_dropout=...)).  x, y: dtype BF_F32 / BF_BF16, count % 4 == 0;
  * accumulate != 0 adds into y (the backward: dX += mask * dT / (1 - p)).  bf_dropout_mask writes the same
@@ -483,6 +483,39 @@ int bf_dropout_mask(uint8_t* mask, size_t count, float p, unsigned long long see
  * range's own [batch, nrows, cols] tensor under bf_dropout_mask.  p = 0: only the add. */
 int bf_dropout_rows(void* x, int dtype, const float* add, int batch, int group_rows, int row0, int nrows, int cols,
                     float p, unsigned long long seed, bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * ABI 11: the LoRA adapter branch of the adapted projections of one layer, UNMERGED (training with lora_dropout > 0:
+ * models/siglip.py:33-40 -> peft LoraLayer.forward, `result + lora_B(lora_A(dropout(x))) * scaling`;
+ * conf/model/siglip_sequential.yaml:10-14).  One launch serves every adapted projection ("slot") of the layer; each wide
+ * [rows, width] tensor is read once per pass; masks are regenerated from (seed, element index) like bf_dropout's.
+ * 16-bit storage only (the fp32 mode composes the branch from bf_dropout + bf_gemm); rank 8 or 16, n_slots * rank <= 32,
+ * width % 16 == 0.  u tensors are fp32 [rows, n_slots * rank], slot s in columns [s rank, (s + 1) rank).
+ * ---------------------------------------------------------------------- */
+typedef struct bf_lora_slots {
+    int n_slots;                  /* adapted projections handled by the launch: 1..3 */
+    int rank;                     /* r */
+    int col_off[3];               /* element offset of slot s inside a row of the wide tensor (multiple of 8) */
+    float p;                      /* lora_dropout of the masks; 0: no mask */
+    unsigned long long seed[3];   /* p > 0: element (row, c) of slot s is element row * width + c of bf_dropout_mask(seed[s]) */
+} bf_lora_slots;
+/* u[:, slot s] = alpha (mask_s . x[:, col_off[s] : col_off[s] + width]) wt[s rank : (s + 1) rank, :]^T
+ * forward: x = LayerNorm output, wt = lora_A rows stacked, alpha = 1 / (1 - p);
+ * backward: x = d(packed projection output), col_off = the slot's column block, wt = scaling * lora_B^T, p = 0. */
+int bf_lora_down(const void* x, int ldx, const void* wt, float* u, int rows, int width, const bf_lora_slots* slots,
+                 float alpha, int cdt, bf_stream_t stream);
+/* y[:, col_off[s] + c] += alpha mask_s . (u[:, slot s] wt[slot s rows, c]); slots either share col_off (one
+ * read-modify-write for all: the backward's d(LayerNorm output), wt = lora_A, alpha = 1 / (1 - p)) or name disjoint column
+ * blocks (the forward: y = packed projection output, wt = scaling * lora_B^T, p = 0). */
+int bf_lora_up(const float* u, const void* wt, void* y, int ldy, int rows, int width, const bf_lora_slots* slots,
+               float alpha, int cdt, bf_stream_t stream);
+/* out[s] (fp32, [rank, width]; transposed != 0: [width, rank]) = alpha u[:, slot s]^T (mask_s . x[:, col_off[s] : + width]),
+ * WRITTEN.  lora_A's gradient (x = LayerNorm output, u = du, masks) and lora_B's (x = d(projection output), u = the forward's
+ * u, transposed, alpha = scaling).  ws: fp32 scratch of bf_lora_tn_workspace_elems elements (partial sums of row chunks,
+ * added in a fixed order: results are reproducible bit for bit). */
+size_t bf_lora_tn_workspace_elems(int rows, int width, const bf_lora_slots* slots);
+int bf_lora_tn(const void* x, int ldx, const float* u, float* const* out, int transposed, float* ws, size_t ws_elems,
+               int rows, int width, const bf_lora_slots* slots, float alpha, int cdt, bf_stream_t stream);
 
 /* Elementwise cast between fp32 and bf16 (count elements). */
 int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,

@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
     for name in declared:
         assert hasattr(L.lib, name)
-    assert L.lib.bf_abi_version() == L.ABI_VERSION == 10
+    assert L.lib.bf_abi_version() == L.ABI_VERSION == 11
 
 
 def test_c_abi_rejects_bad_arguments_before_launching():

@@ -1228,3 +1228,95 @@ def test_add_layernorm_fwd_lazy_stream_is_the_two_pass_form(ops, gpu, rows, cols
     xn = x.clone()
     y, _, _, xo = ops.add_layernorm_fwd(xn, a, w1, b1, out_dtype, delta2=m, write_x=False)
     assert xo is None and torch.equal(xn, x) and torch.equal(y, h1_want)
+
+
+# ---- replayable dropout masks and the LoRA adapter-branch kernels (csrc/lora.hip, ABI 11) --------------------------------
+@pytest.mark.parametrize("cdt", [torch.float32, torch.float16, torch.bfloat16])
+def test_dropout_applies_the_mask_bf_dropout_mask_replays(ops, gpu, cdt):
+    """bf_dropout / bf_dropout_mask share one keep function (common.h: one hash per four elements, 15 bits each): the
+    output is x / (1 - p) exactly where the replayed mask says 1, the kept fraction is 1 - p within sampling error, the
+    four elements of a hash group are not tied to each other, and another seed gives another mask."""
+    torch.manual_seed(3)
+    n, p = 1 << 20, 0.25
+    x = (torch.randn(n, device=gpu) + 3.0).to(cdt)
+    y = ops.dropout(x, p, 1234)
+    m = ops.dropout_mask((n,), p, 1234, gpu).bool()
+    want = torch.where(m, (x.float() / (1.0 - p)), torch.zeros((), device=gpu)).to(cdt)
+    assert torch.equal(y, want)
+    frac = m.float().mean().item()
+    assert abs(frac - (1.0 - p)) < 4.0 * math.sqrt(p * (1.0 - p) / n)
+    g = m.view(-1, 4).float()
+    for a in range(4):
+        for b in range(a + 1, 4):                         # independent fields of one hash: joint keep rate = (1 - p)^2
+            joint = (g[:, a] * g[:, b]).mean().item()
+            assert abs(joint - (1.0 - p) ** 2) < 5e-3
+    m2 = ops.dropout_mask((n,), p, 1235, gpu).bool()
+    assert 0.3 < (m ^ m2).float().mean().item() < 0.45     # 2 p (1 - p) = 0.375
+    acc = torch.ones_like(x)
+    ops.dropout(x, p, 1234, out=acc, accumulate=True)
+    assert torch.equal(acc, (1.0 + torch.where(m, x.float() / (1.0 - p), torch.zeros((), device=gpu))).to(cdt))   # one rounding
+
+
+def _lora_case(gpu, cdt, rows, width, n_slots, rank, ld_extra):
+    g = torch.Generator().manual_seed(rows * 7 + width + n_slots)
+    ld = n_slots * width + ld_extra
+    wide = torch.randn(rows, ld, generator=g).to(cdt).to(gpu)
+    wt = (torch.randn(n_slots * rank, width, generator=g) / math.sqrt(width)).to(cdt).to(gpu)
+    u = torch.randn(rows, n_slots * rank, generator=g).to(gpu)
+    return wide, wt, u
+
+
+@pytest.mark.parametrize("cdt", HALF)
+@pytest.mark.parametrize("rows,width,n_slots,rank", [(7, 64, 2, 8), (1000, 768, 2, 8), (333, 256, 3, 8), (130, 512, 1, 16),
+                                                     (257, 128, 2, 16), (4096, 768, 1, 8)])
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_lora_kernels_against_the_masked_matrix_products(ops, gpu, cdt, rows, width, n_slots, rank, p):
+    """bf_lora_down / bf_lora_up / bf_lora_tn against float64 products of the same 16-bit operands, masks replayed with
+    bf_dropout_mask; both addressing forms (all slots on the same columns: the forward's h1 and the backward's dh1; one
+    column block per slot: the packed projection output and its gradient), ragged row counts, a row stride beyond the
+    columns used.  fp32 accumulation: 2e-5 relative (down / tn); up rounds once to the storage type."""
+    wide, wt, u = _lora_case(gpu, cdt, rows, width, n_slots, rank, 8)
+    seeds = [11 + 5 * s for s in range(n_slots)]
+    keep = 1.0 / (1.0 - p)
+    masks = [ops.dropout_mask((rows, width), p, sd, gpu).double() if p > 0 else torch.ones(rows, width, device=gpu).double()
+             for sd in seeds]
+    W = wt.double()
+    for offs in ([0] * n_slots, [s * width for s in range(n_slots)]):
+        xs = [wide[:, o:o + width].double() * m for o, m in zip(offs, masks)]
+        # down
+        got = ops.lora_down(wide, offs, wt, rank, width, p, seeds, alpha=keep)
+        want = torch.cat([keep * x @ W[s * rank:(s + 1) * rank].t() for s, x in enumerate(xs)], dim=1)
+        assert rel_err(got, want) < 2e-5, ("down", offs)
+        # tn, both output layouts
+        for transposed in (False, True):
+            outs = [torch.full((width, rank) if transposed else (rank, width), float("nan"), device=gpu) for _ in xs]
+            ops.lora_tn(wide, offs, u, outs, rank, width, transposed, p, seeds, alpha=0.5)
+            for s, x in enumerate(xs):
+                ref = 0.5 * u[:, s * rank:(s + 1) * rank].double().t() @ x
+                assert rel_err(outs[s], ref.t() if transposed else ref) < 2e-5, ("tn", offs, transposed, s)
+            again = [torch.empty_like(o) for o in outs]
+            ops.lora_tn(wide, offs, u, again, rank, width, transposed, p, seeds, alpha=0.5)
+            assert all(torch.equal(a, b) for a, b in zip(outs, again))          # fixed summation order
+        # up: in place, nothing outside the slots' columns touched
+        y = wide.clone()
+        ops.lora_up(u, wt, y, offs, rank, width, p, seeds, alpha=keep)
+        ref = wide.double().clone()
+        for s, (o, m) in enumerate(zip(offs, masks)):
+            ref[:, o:o + width] += keep * m * (u[:, s * rank:(s + 1) * rank].double() @ W[s * rank:(s + 1) * rank])
+        assert torch.equal(y.float(), ref.to(cdt).float()) or rel_err(y, ref) < (2 ** -7 if cdt == torch.bfloat16 else 2 ** -10)
+        untouched = torch.ones(wide.shape[1], dtype=torch.bool)
+        for o in set(offs):
+            untouched[o:o + width] = False
+        assert torch.equal(y[:, untouched.to(gpu)], wide[:, untouched.to(gpu)])
+
+
+def test_lora_kernels_refuse_what_they_do_not_take(ops, gpu):
+    wide, wt, u = _lora_case(gpu, torch.float16, 64, 64, 2, 8, 0)
+    with pytest.raises(RuntimeError):                     # fp32 storage: the GEMM form serves it
+        ops.lora_down(wide.float(), [0, 0], wt.float(), 8, 64)
+    with pytest.raises(RuntimeError):                     # rank 4
+        ops.lora_down(wide, [0, 0, 0], wt[:12].contiguous(), 4, 64)
+    with pytest.raises(RuntimeError):                     # overlapping, unequal column blocks
+        ops.lora_up(u, wt, wide.clone(), [0, 32], 8, 64)
+    assert not ops.lora_supported(torch.float32, 768, 8, 2) and ops.lora_supported(torch.float16, 768, 8, 2)
+    assert not ops.lora_supported(torch.float16, 768, 4, 2) and not ops.lora_supported(torch.float16, 776, 8, 2)
