@@ -478,9 +478,12 @@ class SiglipTowers(nn.Module):
                     grads = [self.lora_params(tower, i, f"{n}_proj") for n in pk["names"]]
                     du = ops.lora_down(dqkv, offs, pk["bt"][i], r, w)                                # scaling dy B
                     ops.lora_tn(dqkv, offs, u, [grad_view(lb) for _, lb in grads], r, w, True, alpha=scale)
-                    ops.lora_tn(S["h1"], zero, du, [grad_view(la) for la, _ in grads], r, w, False, p_drop, sd,
-                                alpha=keep_inv)
-                    ops.lora_up(du, pk["a"][i], dh1, zero, r, w, p_drop, sd, alpha=keep_inv)
+                    d_a = [grad_view(la) for la, _ in grads]
+                    if len(sd) * r <= 16:      # dA = du^T (D . h1) and dh1 += D . (du A): one walk, one mask evaluation
+                        ops.lora_bwd_input(S["h1"], du, pk["a"][i], dh1, d_a, r, w, p_drop, sd, alpha=keep_inv)
+                    else:
+                        ops.lora_tn(S["h1"], zero, du, d_a, r, w, False, p_drop, sd, alpha=keep_inv)
+                        ops.lora_up(du, pk["a"][i], dh1, zero, r, w, p_drop, sd, alpha=keep_inv)
                 for slot, n in enumerate("qkv"):
                     if pk is not None or n not in S["drop"]:
                         continue

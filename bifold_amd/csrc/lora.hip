@@ -25,6 +25,13 @@
 // are bounded by HBM or by the mask hash, not by the FMA count.
 #include "common.h"
 
+#ifndef LORA_KU
+#define LORA_KU 2            // bf_lora_down: k-steps (16 columns each) fetched before the first is used
+#endif
+#ifndef LORA_UN
+#define LORA_UN 2            // bf_lora_up / bf_lora_tn: rows fetched before the first is used
+#endif
+
 namespace {
 
 struct LoraDev {                       // device copy of bf_lora_slots' per-slot fields
@@ -41,6 +48,24 @@ template <> __device__ __forceinline__ float4 half4_to_f32<f16_t>(uint2 w) {
     const f16x4 h = __builtin_bit_cast(f16x4, w);
     return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
 }
+// four columns of a lane as two packed pairs (v_pk_fma_f32: two FMAs per issue slot)
+struct Quad { f32x2 lo, hi; };
+__device__ __forceinline__ Quad quad_zero() { Quad q; q.lo = (f32x2){0.f, 0.f}; q.hi = (f32x2){0.f, 0.f}; return q; }
+__device__ __forceinline__ Quad quad_of(float4 v, float a) { Quad q; q.lo = (f32x2){v.x * a, v.y * a}; q.hi = (f32x2){v.z * a, v.w * a}; return q; }
+__device__ __forceinline__ void quad_fma(Quad& acc, float u, const Quad& x) {
+    const f32x2 u2 = {u, u};
+    acc.lo = __builtin_elementwise_fma(u2, x.lo, acc.lo);
+    acc.hi = __builtin_elementwise_fma(u2, x.hi, acc.hi);
+}
+// zero the columns whose 16-bit AND-mask (dropout_mask4) is clear
+__device__ __forceinline__ void quad_mask(Quad& q, uint2 m) {
+    q.lo[0] = __uint_as_float(__float_as_uint(q.lo[0]) & (unsigned)((int)(m.x << 16) >> 31));
+    q.lo[1] = __uint_as_float(__float_as_uint(q.lo[1]) & (unsigned)((int)m.x >> 31));
+    q.hi[0] = __uint_as_float(__float_as_uint(q.hi[0]) & (unsigned)((int)(m.y << 16) >> 31));
+    q.hi[1] = __uint_as_float(__float_as_uint(q.hi[1]) & (unsigned)((int)m.y >> 31));
+}
+__device__ __forceinline__ float4 quad_f4(const Quad& q) { return make_float4(q.lo[0], q.lo[1], q.hi[0], q.hi[1]); }
+
 template <typename HT> __device__ __forceinline__ uint2 f32_to_half4(float4 v) {
     typename H16<HT>::x4 h;
     h[0] = (HT)v.x; h[1] = (HT)v.y; h[2] = (HT)v.z; h[3] = (HT)v.w;
@@ -86,17 +111,15 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const HT* __restrict__ x
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    auto kstep = [&](int ks) __attribute__((always_inline)) {
-        uint4 raw[NS];
-        if (SHARED) {
-            raw[0] = *(const uint4*)(xr + sl.col_off[0] + ks * 16);
-        } else {
+    constexpr int NL = SHARED ? 1 : NS;                           // distinct wide operands
+    auto fetch = [&](uint4 (&raw)[NL], int ks) __attribute__((always_inline)) {
 #pragma unroll
-            for (int s = 0; s < NS; ++s) raw[s] = *(const uint4*)(xr + sl.col_off[s] + ks * 16);
-        }
+        for (int s = 0; s < NL; ++s) raw[s] = *(const uint4*)(xr + sl.col_off[s] + ks * 16);
+    };
+    auto kstep = [&](const uint4 (&raw)[NL], int ks) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            uint4 v = SHARED ? raw[0] : raw[s];
+            uint4 v = raw[SHARED ? 0 : s];
             if (MASK) {
                 const uint2 m0 = dropout_mask4(idx0 + (unsigned)(ks * 16), sl.seed[s], thr_m1);
                 const uint2 m1 = dropout_mask4(idx0 + (unsigned)(ks * 16 + 4), sl.seed[s], thr_m1);
@@ -108,10 +131,18 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const HT* __restrict__ x
     };
     const int ksteps = width / 16;
     int ks = 0;
-    for (; ks + 4 <= ksteps; ks += 4) {                           // four steps = one 128-byte line of every row
-        kstep(ks); kstep(ks + 1); kstep(ks + 2); kstep(ks + 3);
+    for (; ks + LORA_KU <= ksteps; ks += LORA_KU) {               // LORA_KU steps of loads in flight before the first use
+        uint4 raw[LORA_KU][NL];
+#pragma unroll
+        for (int t = 0; t < LORA_KU; ++t) fetch(raw[t], ks + t);
+#pragma unroll
+        for (int t = 0; t < LORA_KU; ++t) kstep(raw[t], ks + t);
     }
-    for (; ks < ksteps; ++ks) kstep(ks);
+    for (; ks < ksteps; ++ks) {
+        uint4 raw[NL];
+        fetch(raw, ks);
+        kstep(raw, ks);
+    }
     if (row0 + j < rows) {
         float* ur = u + (size_t)row * nsr;
 #pragma unroll
@@ -136,37 +167,34 @@ __global__ __launch_bounds__(256) void lora_tn_kernel(const HT* __restrict__ x, 
     if (c >= width) return;
     const int r0 = blockIdx.x * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
-    float4 acc[NS][R];
+    Quad acc[NS][R];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int jj = 0; jj < R; ++jj) acc[s][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 2
-    for (int row = r0; row < r1; ++row) {
-        const float* ur = u + (size_t)row * (NS * R);              // wave-uniform: scalar loads
-        const HT* xr = x + (size_t)row * ldx + c;
-        uint2 raw[NS];
-        if (SHARED) {
-            raw[0] = *(const uint2*)(xr + sl.col_off[0]);
-        } else {
+        for (int jj = 0; jj < R; ++jj) acc[s][jj] = quad_zero();
+    constexpr int NL = SHARED ? 1 : NS;
+    for (int row = r0; row < r1; row += LORA_UN) {                 // LORA_UN rows of loads in flight before the first use
+        uint2 raw[LORA_UN][NL];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) raw[s] = *(const uint2*)(xr + sl.col_off[s]);
+        for (int t = 0; t < LORA_UN; ++t) {
+            const HT* xr = x + (size_t)min(row + t, r1 - 1) * ldx + c;
+#pragma unroll
+            for (int s = 0; s < NL; ++s) raw[t][s] = *(const uint2*)(xr + sl.col_off[s]);
         }
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            uint2 w = SHARED ? raw[0] : raw[s];
-            if (MASK) {
-                const uint2 m = dropout_mask4((unsigned long long)row * (unsigned)width + (unsigned)c, sl.seed[s], thr_m1);
-                w.x &= m.x; w.y &= m.y;
-            }
-            const float4 xv = half4_to_f32<HT>(w);
+        for (int t = 0; t < LORA_UN; ++t) {
+            if (row + t >= r1) break;                              // uniform
+            const float* ur = u + (size_t)(row + t) * (NS * R);    // wave-uniform: scalar loads
 #pragma unroll
-            for (int jj = 0; jj < R; ++jj) {
-                const float uj = ur[s * R + jj];
-                acc[s][jj].x = fmaf(uj, xv.x, acc[s][jj].x);
-                acc[s][jj].y = fmaf(uj, xv.y, acc[s][jj].y);
-                acc[s][jj].z = fmaf(uj, xv.z, acc[s][jj].z);
-                acc[s][jj].w = fmaf(uj, xv.w, acc[s][jj].w);
+            for (int s = 0; s < NS; ++s) {
+                uint2 w = raw[t][SHARED ? 0 : s];
+                if (MASK) {
+                    const uint2 m = dropout_mask4((unsigned long long)(row + t) * (unsigned)width + (unsigned)c, sl.seed[s], thr_m1);
+                    w.x &= m.x; w.y &= m.y;
+                }
+                const Quad xv = quad_of(half4_to_f32<HT>(w), 1.f);
+#pragma unroll
+                for (int jj = 0; jj < R; ++jj) quad_fma(acc[s][jj], ur[s * R + jj], xv);
             }
         }
     }
@@ -174,29 +202,38 @@ __global__ __launch_bounds__(256) void lora_tn_kernel(const HT* __restrict__ x, 
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int jj = 0; jj < R; ++jj) *(float4*)(wp + (size_t)(s * R + jj) * width) = acc[s][jj];
+        for (int jj = 0; jj < R; ++jj) *(float4*)(wp + (size_t)(s * R + jj) * width) = quad_f4(acc[s][jj]);
 }
 
 struct LoraOut { float* p[3]; };
 
+// 32 consecutive elements x 8 interleaved subsets of the chunks per workgroup (a thread per element alone leaves the sum of
+// 1 536 chunks to 48 workgroups: 68 us); the eight partial sums are added in a fixed order.
 __global__ __launch_bounds__(256) void lora_tn_reduce_kernel(const float* __restrict__ ws, LoraOut out, int chunks, int nsr,
                                                              int rank, int width, int transposed, float alpha) {
-    const int t = blockIdx.x * 256 + threadIdx.x;                  // element (sj, c) of the [nsr, width] sum
-    if (t >= nsr * width) return;
-    const int sj = t / width, c = t - sj * width;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                  // four chains: the loop is latency-bound otherwise
-    const size_t stride = (size_t)nsr * width;
-    int k = 0;
-    for (; k + 4 <= chunks; k += 4) {
-        a0 += ws[(size_t)k * stride + t];
-        a1 += ws[(size_t)(k + 1) * stride + t];
-        a2 += ws[(size_t)(k + 2) * stride + t];
-        a3 += ws[(size_t)(k + 3) * stride + t];
+    __shared__ float part[8][32];
+    const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int t = blockIdx.x * 32 + e;                             // element (sj, c) of the [nsr, width] sum
+    const int total = nsr * width;
+    const size_t stride = (size_t)total;
+    float a0 = 0.f, a1 = 0.f;                                      // two chains
+    if (t < total) {
+        int k = g;
+        for (; k + 8 < chunks; k += 16) {
+            a0 += ws[(size_t)k * stride + t];
+            a1 += ws[(size_t)(k + 8) * stride + t];
+        }
+        if (k < chunks) a0 += ws[(size_t)k * stride + t];
     }
-    for (; k < chunks; ++k) a0 += ws[(size_t)k * stride + t];
-    const float v = alpha * ((a0 + a1) + (a2 + a3));
-    const int s = sj / rank, jj = sj - s * rank;
-    out.p[s][transposed ? (size_t)c * rank + jj : (size_t)jj * width + c] = v;
+    part[g][e] = a0 + a1;
+    __syncthreads();
+    if (g == 0 && t < total) {
+        const float v = alpha * (((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) +
+                                 ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e])));
+        const int sj = t / width, c = t - sj * width;
+        const int s = sj / rank, jj = sj - s * rank;
+        out.p[s][transposed ? (size_t)c * rank + jj : (size_t)jj * width + c] = v;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------------
@@ -208,58 +245,117 @@ __global__ __launch_bounds__(256) void lora_up_kernel(const float* __restrict__ 
                                                       unsigned thr_m1, float alpha) {
     const int c = threadIdx.x * 4;
     if (c >= width) return;
-    float4 w[NS][R];
+    Quad w[NS][R];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj)
+            w[s][jj] = quad_of(half4_to_f32<HT>(*(const uint2*)(wt + (size_t)(s * R + jj) * width + c)), alpha);
+    const int r0 = blockIdx.x * rows_per_chunk;
+    const int r1 = min(rows, r0 + rows_per_chunk);
+    constexpr int NL = SAME ? 1 : NS;
+    for (int row = r0; row < r1; row += LORA_UN) {
+        uint2 old[LORA_UN][NL];
+#pragma unroll
+        for (int t = 0; t < LORA_UN; ++t) {
+            const HT* yr = y + (size_t)min(row + t, r1 - 1) * ldy + c;
+#pragma unroll
+            for (int s = 0; s < NL; ++s) old[t][s] = *(const uint2*)(yr + sl.col_off[s]);
+        }
+#pragma unroll
+        for (int t = 0; t < LORA_UN; ++t) {
+            if (row + t >= r1) break;                              // uniform
+            const float* ur = u + (size_t)(row + t) * (NS * R);    // wave-uniform: scalar loads
+            HT* yr = y + (size_t)(row + t) * ldy + c;
+            Quad sum = quad_zero();
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                Quad v = quad_zero();
+#pragma unroll
+                for (int jj = 0; jj < R; ++jj) quad_fma(v, ur[s * R + jj], w[s][jj]);
+                if (MASK)
+                    quad_mask(v, dropout_mask4((unsigned long long)(row + t) * (unsigned)width + (unsigned)c, sl.seed[s], thr_m1));
+                if (SAME) {
+                    sum.lo += v.lo; sum.hi += v.hi;
+                } else {
+                    const Quad o = quad_of(half4_to_f32<HT>(old[t][s]), 1.f);
+                    v.lo += o.lo; v.hi += o.hi;
+                    *(uint2*)(yr + sl.col_off[s]) = f32_to_half4<HT>(quad_f4(v));
+                }
+            }
+            if (SAME) {
+                const Quad o = quad_of(half4_to_f32<HT>(old[t][0]), 1.f);
+                sum.lo += o.lo; sum.hi += o.hi;
+                *(uint2*)(yr + sl.col_off[0]) = f32_to_half4<HT>(quad_f4(sum));
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------------
+// bf_lora_bwd_input = bf_lora_tn (masked, all slots on x) + bf_lora_up (masked, all slots into y) in one walk over the
+// rows: both need mask_s at the same (row, column), both multiply by the same du row, and the hash is what either costs
+// (377 + 357 us as two launches at 368 640 x 768).  ws / reduce: as bf_lora_tn.
+// ----------------------------------------------------------------------------------------------------------------------
+template <typename HT, int R, int NS, bool MASK>
+__global__ __launch_bounds__(256) void lora_bwd_input_kernel(const HT* __restrict__ x, int ldx, const float* __restrict__ du,
+                                                             const HT* __restrict__ wt, HT* __restrict__ y, int ldy,
+                                                             float* __restrict__ ws, int rows, int width, int rows_per_chunk,
+                                                             LoraDev sl, unsigned thr_m1, float alpha) {
+    const int c = threadIdx.x * 4;
+    if (c >= width) return;
+    Quad w[NS][R], acc[NS][R];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int jj = 0; jj < R; ++jj) {
-            const float4 v = half4_to_f32<HT>(*(const uint2*)(wt + (size_t)(s * R + jj) * width + c));
-            w[s][jj] = make_float4(v.x * alpha, v.y * alpha, v.z * alpha, v.w * alpha);
+            w[s][jj] = quad_of(half4_to_f32<HT>(*(const uint2*)(wt + (size_t)(s * R + jj) * width + c)), alpha);
+            acc[s][jj] = quad_zero();
         }
     const int r0 = blockIdx.x * rows_per_chunk;
     const int r1 = min(rows, r0 + rows_per_chunk);
-#pragma unroll 2
-    for (int row = r0; row < r1; ++row) {
-        const float* ur = u + (size_t)row * (NS * R);              // wave-uniform: scalar loads
-        HT* yr = y + (size_t)row * ldy + c;
-        uint2 old[NS];
-        if (SAME) {
-            old[0] = *(const uint2*)(yr + sl.col_off[0]);
-        } else {
+    for (int row = r0; row < r1; row += LORA_UN) {
+        uint2 xin[LORA_UN], old[LORA_UN];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) old[s] = *(const uint2*)(yr + sl.col_off[s]);
+        for (int t = 0; t < LORA_UN; ++t) {
+            const size_t rr = (size_t)min(row + t, r1 - 1);
+            xin[t] = *(const uint2*)(x + rr * ldx + c);
+            old[t] = *(const uint2*)(y + rr * ldy + c);
         }
-        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = 0; t < LORA_UN; ++t) {
+            if (row + t >= r1) break;                              // uniform
+            const float* ur = du + (size_t)(row + t) * (NS * R);   // wave-uniform: scalar loads
+            Quad sum = quad_zero();
 #pragma unroll
-            for (int jj = 0; jj < R; ++jj) {
-                const float uj = ur[s * R + jj];
-                t.x = fmaf(uj, w[s][jj].x, t.x);
-                t.y = fmaf(uj, w[s][jj].y, t.y);
-                t.z = fmaf(uj, w[s][jj].z, t.z);
-                t.w = fmaf(uj, w[s][jj].w, t.w);
+            for (int s = 0; s < NS; ++s) {
+                uint2 xm = xin[t];
+                uint2 m = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (MASK) {
+                    m = dropout_mask4((unsigned long long)(row + t) * (unsigned)width + (unsigned)c, sl.seed[s], thr_m1);
+                    xm.x &= m.x; xm.y &= m.y;
+                }
+                const Quad xv = quad_of(half4_to_f32<HT>(xm), 1.f);
+                Quad v = quad_zero();
+#pragma unroll
+                for (int jj = 0; jj < R; ++jj) {
+                    const float uj = ur[s * R + jj];
+                    quad_fma(acc[s][jj], uj, xv);
+                    quad_fma(v, uj, w[s][jj]);
+                }
+                if (MASK) quad_mask(v, m);
+                sum.lo += v.lo; sum.hi += v.hi;
             }
-            if (MASK) {
-                const uint2 m = dropout_mask4((unsigned long long)row * (unsigned)width + (unsigned)c, sl.seed[s], thr_m1);
-                t.x = __uint_as_float(__float_as_uint(t.x) & (unsigned)((int)(m.x << 16) >> 31));
-                t.y = __uint_as_float(__float_as_uint(t.y) & (unsigned)((int)m.x >> 31));
-                t.z = __uint_as_float(__float_as_uint(t.z) & (unsigned)((int)(m.y << 16) >> 31));
-                t.w = __uint_as_float(__float_as_uint(t.w) & (unsigned)((int)m.y >> 31));
-            }
-            if (SAME) {
-                sum.x += t.x; sum.y += t.y; sum.z += t.z; sum.w += t.w;
-            } else {
-                const float4 o = half4_to_f32<HT>(old[s]);
-                *(uint2*)(yr + sl.col_off[s]) = f32_to_half4<HT>(make_float4(o.x + t.x, o.y + t.y, o.z + t.z, o.w + t.w));
-            }
-        }
-        if (SAME) {
-            const float4 o = half4_to_f32<HT>(old[0]);
-            *(uint2*)(yr + sl.col_off[0]) = f32_to_half4<HT>(make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + sum.w));
+            const Quad o = quad_of(half4_to_f32<HT>(old[t]), 1.f);
+            sum.lo += o.lo; sum.hi += o.hi;
+            *(uint2*)(y + (size_t)(row + t) * ldy + c) = f32_to_half4<HT>(quad_f4(sum));
         }
     }
+    float* wp = ws + (size_t)blockIdx.x * (NS * R) * width + c;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int jj = 0; jj < R; ++jj) *(float4*)(wp + (size_t)(s * R + jj) * width) = quad_f4(acc[s][jj]);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -383,8 +479,45 @@ extern "C" int bf_lora_tn(const void* x, int ldx, const float* u, float* const* 
 #undef LAUNCH
     BF_CHECK_LAUNCH("bf_lora_tn");
     const int nsr = slots->n_slots * slots->rank;
-    hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3(bf_cdiv((long)nsr * width, 256)), dim3(256), 0, s, ws, o, chunks, nsr, slots->rank,
+    hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3(bf_cdiv((long)nsr * width, 32)), dim3(256), 0, s, ws, o, chunks, nsr, slots->rank,
                        width, transposed, alpha);
     BF_CHECK_LAUNCH("bf_lora_tn/reduce");
+    return BF_OK;
+}
+
+extern "C" int bf_lora_bwd_input(const void* x, int ldx, const float* du, const void* wt, void* y, int ldy, float* const* out,
+                                 float* ws, size_t ws_elems, int rows, int width, const bf_lora_slots* slots, float alpha, int cdt,
+                                 bf_stream_t stream) {
+    if (int rc = lora_check("bf_lora_bwd_input", slots, rows, width, cdt, ldx < ldy ? ldx : ldy, false)) return rc;
+    BF_REQUIRE(slots->n_slots * slots->rank <= 16, BF_EINVAL, "bf_lora_bwd_input: n_slots * rank = %d > 16 (use bf_lora_tn + bf_lora_up)",
+               slots->n_slots * slots->rank);
+    BF_REQUIRE(x && du && wt && y && out && ws && bf_aligned16(x) && bf_aligned16(du) && bf_aligned16(wt) && bf_aligned16(y) &&
+               bf_aligned16(ws), BF_EALIGN, "bf_lora_bwd_input: null or unaligned pointer");
+    BF_REQUIRE(ws_elems >= bf_lora_tn_workspace_elems(rows, width, slots), BF_EWORKSPACE,
+               "bf_lora_bwd_input: workspace of %zu elements, %zu needed", ws_elems, bf_lora_tn_workspace_elems(rows, width, slots));
+    LoraOut o;
+    for (int s = 0; s < 3; ++s) {
+        o.p[s] = s < slots->n_slots ? out[s] : nullptr;
+        BF_REQUIRE(s >= slots->n_slots || o.p[s], BF_EINVAL, "bf_lora_bwd_input: out[%d] is null", s);
+    }
+    const LoraDev d = lora_dev(slots);
+    const bool mask = slots->p > 0.f && dropout_threshold(slots->p) > 0;
+    const unsigned thr = dropout_threshold_packed(slots->p);
+    const int rpc = lora_rows_per_chunk(rows), chunks = bf_cdiv(rows, rpc);
+    const dim3 grid(chunks), block(((width / 4) + 63) & ~63);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(HT, R_, NS_, M_) hipLaunchKernelGGL((lora_bwd_input_kernel<HT, R_, NS_, M_>), grid, block, 0, s, (const HT*)x, ldx, du, \
+                                                   (const HT*)wt, (HT*)y, ldy, ws, rows, width, rpc, d, thr, alpha)
+#define BY_MASK(HT, R_, NS_) do { if (mask) LAUNCH(HT, R_, NS_, true); else LAUNCH(HT, R_, NS_, false); } while (0)
+#define BY_SHAPE(HT) do { if (slots->rank == 16) BY_MASK(HT, 16, 1); else if (slots->n_slots == 1) BY_MASK(HT, 8, 1); else BY_MASK(HT, 8, 2); } while (0)
+    if (cdt == BF_F16) BY_SHAPE(f16_t); else BY_SHAPE(bf16_t);
+#undef BY_SHAPE
+#undef BY_MASK
+#undef LAUNCH
+    BF_CHECK_LAUNCH("bf_lora_bwd_input");
+    const int nsr = slots->n_slots * slots->rank;
+    hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3(bf_cdiv((long)nsr * width, 32)), dim3(256), 0, s, ws, o, chunks, nsr, slots->rank,
+                       width, 0, alpha);
+    BF_CHECK_LAUNCH("bf_lora_bwd_input/reduce");
     return BF_OK;
 }

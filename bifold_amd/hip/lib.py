@@ -152,6 +152,8 @@ PROTOTYPES = {
     "bf_lora_tn_workspace_elems": (c_size_t, [c_int, c_int, POINTER(LoraSlots)]),
     "bf_lora_tn": (c_int, [c_void_p, c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_int,
                            POINTER(LoraSlots), c_float, c_int, c_void_p]),
+    "bf_lora_bwd_input": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_void_p), c_void_p, c_size_t,
+                                  c_int, c_int, POINTER(LoraSlots), c_float, c_int, c_void_p]),
     "bf_preprocess_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float),
                                   c_void_p]),
     "bf_resize_normalize_rgb": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

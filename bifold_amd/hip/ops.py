@@ -437,6 +437,30 @@ def lora_tn(x: torch.Tensor, col_off, u: torch.Tensor, outs, rank: int, width: i
                          float(alpha), dtype_code(x), _stream()), "bf_lora_tn")
 
 
+def lora_bwd_input(x: torch.Tensor, du: torch.Tensor, wt: torch.Tensor, y: torch.Tensor, outs, rank: int, width: int,
+                   p: float, seeds, alpha: float = 1.0) -> None:
+    """lora_tn(x, du -> outs) and lora_up(du, wt -> y) of slots that all sit on the same columns, in one pass
+    (n_slots * rank <= 16)."""
+    _dev(x, "x"), _dev(du, "du"), _dev(wt, "wt"), _dev(y, "y")
+    n = len(outs)
+    rows = x.shape[0]
+    if x.dim() != 2 or y.dim() != 2 or x.stride(1) != 1 or y.stride(1) != 1 or y.shape[0] != rows or x.dtype != y.dtype \
+            or wt.dtype != x.dtype or tuple(wt.shape) != (n * rank, width) or not wt.is_contiguous() \
+            or du.dtype != torch.float32 or tuple(du.shape) != (rows, n * rank) or not du.is_contiguous():
+        raise RuntimeError("lora_bwd_input: x, y [rows, ld], du fp32 [rows, S * rank], wt [S * rank, width] expected")
+    ptrs = (C.c_void_p * n)()
+    for s, o in enumerate(outs):
+        _dev(o, "out")
+        if o.dtype != torch.float32 or tuple(o.shape) != (rank, width) or not o.is_contiguous():
+            raise RuntimeError(f"lora_bwd_input: out[{s}] must be a contiguous float32 [{rank}, {width}] tensor")
+        ptrs[s] = o.data_ptr()
+    sl = _lora_slots(n, rank, [0] * n, p, seeds)
+    elems = int(lib.bf_lora_tn_workspace_elems(rows, width, C.byref(sl)))
+    ws = torch.empty(max(elems, 1), dtype=torch.float32, device=x.device)
+    check(lib.bf_lora_bwd_input(_ptr(x), x.stride(0), _ptr(du), _ptr(wt), _ptr(y), y.stride(0), ptrs, _ptr(ws), elems, rows,
+                                width, C.byref(sl), float(alpha), dtype_code(x), _stream()), "bf_lora_bwd_input")
+
+
 def dropout_rows(x: torch.Tensor, add: Optional[torch.Tensor], batch: int, group_rows: int, row0: int, nrows: int,
                  p: float, seed: int) -> torch.Tensor:
     """In place on rows [row0, row0 + nrows) of every group of x [batch * group_rows, cols]: dropout with the mask of the

@@ -517,6 +517,14 @@ size_t bf_lora_tn_workspace_elems(int rows, int width, const bf_lora_slots* slot
 int bf_lora_tn(const void* x, int ldx, const float* u, float* const* out, int transposed, float* ws, size_t ws_elems,
                int rows, int width, const bf_lora_slots* slots, float alpha, int cdt, bf_stream_t stream);
 
+/* The backward's two masked passes in one walk over the rows (n_slots * rank <= 16; every slot on the same columns):
+ *   out[s] (fp32 [rank, width], WRITTEN) = alpha du[:, slot s]^T (mask_s . x)           -- lora_A's gradient
+ *   y += alpha sum_s mask_s . (du[:, slot s] wt[slot s rows])                            -- d(LayerNorm output)
+ * = bf_lora_tn(x, du) followed by bf_lora_up(du, wt, y) with the same slots, at one mask evaluation instead of two. */
+int bf_lora_bwd_input(const void* x, int ldx, const float* du, const void* wt, void* y, int ldy, float* const* out, float* ws,
+                      size_t ws_elems, int rows, int width, const bf_lora_slots* slots, float alpha, int cdt,
+                      bf_stream_t stream);
+
 /* Elementwise cast between fp32 and bf16 (count elements). */
 int bf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, size_t count,
             bf_stream_t stream);

@@ -1304,6 +1304,19 @@ def test_lora_kernels_against_the_masked_matrix_products(ops, gpu, cdt, rows, wi
         for s, (o, m) in enumerate(zip(offs, masks)):
             ref[:, o:o + width] += keep * m * (u[:, s * rank:(s + 1) * rank].double() @ W[s * rank:(s + 1) * rank])
         assert torch.equal(y.float(), ref.to(cdt).float()) or rel_err(y, ref) < (2 ** -7 if cdt == torch.bfloat16 else 2 ** -10)
+        if len(set(offs)) == 1 and n_slots * rank <= 16:
+            # the backward's fused form: lora_tn(x, u) and lora_up(u, wt, y) in one walk; x and y are different tensors
+            x2 = wide[:, :width].contiguous()
+            y2 = wide[:, 8:8 + width].contiguous()
+            y2_before = y2.clone()
+            outs = [torch.full((rank, width), float("nan"), device=gpu) for _ in range(n_slots)]
+            ops.lora_bwd_input(x2, u, wt, y2, outs, rank, width, p, seeds, alpha=keep)
+            ref_y = y2_before.double()
+            for sl_, m in enumerate(masks):
+                us = u[:, sl_ * rank:(sl_ + 1) * rank].double()
+                assert rel_err(outs[sl_], keep * us.t() @ (x2.double() * m)) < 2e-5, ("bwd_input dA", sl_)
+                ref_y += keep * m * (us @ W[sl_ * rank:(sl_ + 1) * rank])
+            assert torch.equal(y2.float(), ref_y.to(cdt).float()) or rel_err(y2, ref_y) < (2 ** -7 if cdt == torch.bfloat16 else 2 ** -10)
         untouched = torch.ones(wide.shape[1], dtype=torch.bool)
         for o in set(offs):
             untouched[o:o + width] = False

@@ -53,12 +53,13 @@ def main():
         ("bwd  tn    dB = dqkv[:, q|v]^T u     ", lambda: ops.lora_tn(qkv, offs, u, gB, r, W, True, alpha=4.0), 2 * wide),
         ("bwd  tn    dA = du^T (D . h1)        ", lambda: ops.lora_tn(h1, zero, u, gA, r, W, False, p, seeds, alpha=1.01), wide),
         ("bwd  up    dh1 += D . (du A)         ", lambda: ops.lora_up(u, A, dh1, zero, r, W, p, seeds, alpha=1.01), 2 * wide),
+        ("bwd  both  the two rows above, one walk ", lambda: ops.lora_bwd_input(h1, u, A, dh1, gA, r, W, p, seeds, alpha=1.01), 3 * wide),
     ]
     total = 0.0
     print(f"# rows {M} width {W} r {r} slots 2 {a.dtype} p {p}")
-    for name, fn, mb in rows:
+    for i, (name, fn, mb) in enumerate(rows):
         us = timed(fn, a.iters)
-        total += us
+        total += us if i not in (4, 5) else 0.0                   # the backward runs the fused row instead of rows 4 + 5
         print(f"{name} {us:8.1f} us   {mb:7.0f} MB   {mb / us:6.2f} TB/s")
     print(f"fused form, one layer forward + backward: {total:8.1f} us")
     # the form of rounds 3 - 5: per projection dropout -> N = r GEMM -> K = r GEMM (+ the backward's five passes)
