@@ -360,18 +360,30 @@ class SiglipTowers(nn.Module):
     def _qkv(self, h1, b: str, i: int, tower: str, cdt, w: int, seeds):
         """Packed QKV projection; with `seeds` (training with lora_dropout > 0) the adapters run unmerged behind their own
         dropout masks: qkv[:, slot] += s (D h1) A^T B^T.  Returns (qkv, {proj letter: (u, seed)} or None)."""
+        pk = self._lora_packed.get(tower) if seeds is not None else None
+        if pk is not None:
+            # the adapter branch of every adapted projection (csrc/lora.hip): u = (D . h1) A^T / (1 - p) from ONE read of
+            # h1, then  qkv[:, slot] += scaling u B^T  -- as a low-rank addend INSIDE the projection's GEMM (one more MFMA
+            # K-step per output tile, bf_gemm_args::lr_u) where the persistent kernel takes the call, else as a
+            # read-modify-write pass over the q / v column blocks (bf_lora_up: the text tower's few rows)
+            p_drop = self.lora["dropout"]
+            sd = [seeds[n] for n in pk["names"]]
+            nsr = len(sd) * pk["r"]
+            ride = pk["bcat"] is not None and ops.gemm_lowrank_ok(h1.shape[0], 3 * w, w, cdt, nsr)
+            if ride:
+                u, u16 = ops.lora_down(h1, [0] * len(sd), pk["a"][i], pk["r"], w, p_drop, sd, alpha=1.0 / (1.0 - p_drop),
+                                       want_half=True)
+                qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"], lr_u=u16,
+                               lr_w=pk["bcat"][i])
+            else:
+                qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
+                u = ops.lora_down(h1, [0] * len(sd), pk["a"][i], pk["r"], w, p_drop, sd, alpha=1.0 / (1.0 - p_drop))
+                ops.lora_up(u, pk["bt"][i], qkv, pk["offs"], pk["r"], w)
+            return qkv, dict(u=u, seeds=sd)
         qkv = ops.gemm(h1, self._packed[b + "self_attn.w"], bias=self._packed[b + "self_attn.b"])
         if seeds is None:
             return qkv, None
         p_drop, scale = self.lora["dropout"], self.lora["alpha"] / self.lora["r"]
-        pk = self._lora_packed.get(tower)
-        if pk is not None:
-            # the adapter branch of every adapted projection in two launches (csrc/lora.hip): u = (D . h1) A^T / (1 - p)
-            # from ONE read of h1, then qkv[:, slot] += scaling u B^T
-            sd = [seeds[n] for n in pk["names"]]
-            u = ops.lora_down(h1, [0] * len(sd), pk["a"][i], pk["r"], w, p_drop, sd, alpha=1.0 / (1.0 - p_drop))
-            ops.lora_up(u, pk["bt"][i], qkv, pk["offs"], pk["r"], w)
-            return qkv, dict(u=u, seeds=sd)
         drop = {}
         for slot, n in enumerate("qkv"):
             if n not in seeds:
@@ -391,6 +403,8 @@ class SiglipTowers(nn.Module):
         w, r = cfg["hidden_size"], self.lora["r"]
         names = [n for n in "qkv" if f"{n}_proj" in self.lora["targets"]]
         self._lora_packed[tower] = None
+        # BIFOLD_LORA_FUSED: 1 (default) these kernels, the up-projection riding in the GEMM where it can; "up": these
+        # kernels with the up-projection always as its own pass; 0: the dropout + GEMM form of rounds 3 - 5
         if os.environ.get("BIFOLD_LORA_FUSED", "1") == "0" or not ops.lora_supported(cdt, w, r, len(names)):
             return
         scale = self.lora["alpha"] / r
@@ -398,7 +412,15 @@ class SiglipTowers(nn.Module):
         pairs = [self.lora_params(tower, i, f"{n}_proj") for i in range(n_layers) for n in names]
         a = torch.cat([la.data for la, _ in pairs]).to(cdt).view(n_layers, len(names) * r, w)
         bt = (torch.cat([lb.data.t() for _, lb in pairs]) * scale).to(cdt).view(n_layers, len(names) * r, w)
-        self._lora_packed[tower] = dict(a=a, bt=bt, names=names, r=r, offs=["qkv".index(n) * w for n in names])
+        offs = ["qkv".index(n) * w for n in names]
+        bcat = None
+        if len(names) * r in (16, 32) and os.environ.get("BIFOLD_LORA_FUSED", "1") != "up":
+            # scaling * lora_B of every adapted projection in the rows (of the packed projection) and columns (of u) that
+            # are its own, zero elsewhere: the lr_w operand of the projection's GEMM
+            bcat = torch.zeros(n_layers, 3 * w, len(names) * r, dtype=cdt, device=a.device)
+            for s_, off in enumerate(offs):
+                bcat[:, off:off + w, s_ * r:(s_ + 1) * r] = bt[:, s_ * r:(s_ + 1) * r, :].transpose(1, 2)
+        self._lora_packed[tower] = dict(a=a, bt=bt, bcat=bcat, names=names, r=r, offs=offs)
 
     def _rematerialize(self, S: Dict, b: str, i: int, tower: str, cfg: Dict, batch: int, seq: int, cdt) -> Dict:
         """Fill in what the forward dropped under the recompute policy, by re-running its kernels on what it kept."""

@@ -41,6 +41,9 @@ struct EpiParams {
     int accumulate;
     float alpha;
     float* colsum;      // fused column sums of the stored result (atomicAdd into a zeroed [n]) or null
+    const void* lr_u;   // low-rank addend (persistent kernel, EPI 5): u [m, lr_k], w [n, lr_k], 16-bit, dense
+    const void* lr_w;
+    int lr_k;
     int store_policy;   // persistent kernel: bit 0 / 1 / 2 = non-temporal (`nt`) output stores in the plain-bf16 /
                         // general / GELU-grad epilogue.  Output tiles are written once and read by a LATER kernel;
                         // stored plainly they push the operand panels out of the XCD's L2 (fusion QKV: 237 MB of
@@ -1459,11 +1462,44 @@ __device__ __forceinline__ void p8_body(
         // retires in order, so loaded after them the first use of the bias waited for the whole first K tile of the
         // next item to arrive (~900 cycles per item in the probe).
         [[maybe_unused]] float4 bj[4];
-        if constexpr (EPI == 1 || EPI == 3) {
+        if constexpr (EPI == 1 || EPI == 3 || EPI == 5) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int n = w.n0 + wn * 64 + j * 16 + (lane_ep >> 4) * 4;
                 bj[j] = (ep.bias && n < ep.n) ? *(const float4*)(ep.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        // EPI 5 = EPI 1 + a low-rank addend (bf_gemm_args::lr_u / lr_w: the LoRA branch of the projection): one more
+        // K-step of MFMAs whose operand fragments come straight from global memory in the fragment layout (row = lane % 16,
+        // eight k values per 16-lane group; groups past lr_k supply zeros).  Issued here, in front of the next item's DMA
+        // pieces like the bias, so that their wait is not queued behind a whole K tile.  A tail tile split along K adds
+        // it in its first chunk only.
+        if constexpr (EPI == 5) {
+            if (w.part <= 0) {
+                typedef typename H16<H>::x8 H8;
+                const H* lu = (const H*)ep.lr_u;
+                const H* lw = (const H*)ep.lr_w;
+                const int kq = (lane_ep >> 4) * 8;
+                const bool kin = kq < ep.lr_k;
+                H8 uf[8], wf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = w.n0 + wn * 64 + j * 16 + (lane_ep & 15);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (kin && n < ep.n) v = *(const uint4*)(lw + (size_t)n * ep.lr_k + kq);
+                    wf[j] = __builtin_bit_cast(H8, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int m = w.m0 + wm * 128 + i * 16 + (lane_ep & 15);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (kin && m < ep.m) v = *(const uint4*)(lu + (size_t)m * ep.lr_k + kq);
+                    uf[i] = __builtin_bit_cast(H8, v);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[j][i] = mfma_16x16x32(wf[j], uf[i], acc[j][i]);
             }
         }
         // next item's first stages go out before this item's epilogue
@@ -1597,7 +1633,7 @@ __device__ __forceinline__ void p8_body(
         // Plain bf16 outputs (alpha / bias / activation only): do the math in the MFMA layout, turn
         // the tile around as bf16 (half the LDS bytes: ds_write runs at ~80 B/clk per CU) in two
         // 64-row halves, and store 8 columns per lane_ep.
-        constexpr bool fast16 = EPI == 1 || EPI == 3;
+        constexpr bool fast16 = EPI == 1 || EPI == 3 || EPI == 5;
         if constexpr (fast16) {
             using AM = ActMath<H>;
             // staging offsets of the lane's four 8-byte pieces of a row (one per 16-column tile j), hoisted: the XOR
@@ -2481,6 +2517,25 @@ extern "C" size_t bf_gemm_tail_workspace_bytes(const bf_gemm_args* g) {
 
 static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_variant);
 
+// Whether gemm_impl's choices below put this call on the persistent kernel's BK = 64 NT loop with the plain 16-bit
+// epilogue -- the one instantiation that carries a low-rank addend (EPI 5).  Same predicates, no side effects.
+static bool gemm_lowrank_ok(const bf_gemm_args* g) {
+    if (!g || !bf_is_half(g->cdt) || g->c_dtype != g->cdt || g->trans_a || g->b_kn) return false;
+    if (g->lr_k != 16 && g->lr_k != 32) return false;
+    if (g->split_k > 1 || g->residual || g->c2 || g->accumulate || g->rows_in != 0 || g->aux) return false;
+    if (g->act == BF_ACT_ERF_GELU_SAVEGRAD || g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_TANH_GELU_GRAD ||
+        g->act == BF_ACT_MUL_AUX) return false;
+    if (g->m <= 0 || g->n <= 0 || g->k <= 0 || (g->k % 64) || (g->n % 8) || (g->ldc % 8)) return false;
+    const BfTuning& T = bf_tuning();
+    const int pipe = T.gemm_pipe.load();
+    if (!(pipe < 0 || pipe == 9) || !T.p8_bk64) return false;     // (8 forces the BK = 32 loop)
+    const int min_tiles = T.p8_min_tiles >= 0 ? T.p8_min_tiles : n_cus() / 2;
+    if (pipe < 0 && !(g->m >= T.p8_min_m && (long)bf_cdiv(g->m, 256) * bf_cdiv(g->n, 256) >= min_tiles)) return false;
+    const size_t a_ext = ((size_t)(g->m - 1) * g->lda + g->k) * 2, b_ext = ((size_t)(g->n - 1) * g->ldb + g->k) * 2;
+    return a_ext + 512ull * (size_t)g->lda < (1ull << 32) && b_ext + 512ull * (size_t)g->ldb < (1ull << 32);
+}
+extern "C" int bf_gemm_lowrank_ok(const bf_gemm_args* g) { return gemm_lowrank_ok(g) ? 1 : 0; }
+
 // Ticket sets of the persistent kernel: 9 counters per launch (8 XCD lanes + finished workgroups), zero at
 // rest (the last workgroup of a launch zeroes its set).  Launches on one stream run in order, so a per-stream
 // ring of sets can never be shared by two running kernels; concurrent streams get rings of their own.
@@ -2726,6 +2781,11 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
     ep.rows_out = g->rows_out; ep.row_off = g->row_off; ep.act = g->act;
     ep.accumulate = g->accumulate; ep.alpha = g->alpha;
     ep.colsum = nullptr;
+    ep.lr_u = g->lr_u; ep.lr_w = g->lr_w; ep.lr_k = g->lr_k;
+    BF_REQUIRE(!g->lr_u || (g->lr_w && bf_aligned16(g->lr_u) && bf_aligned16(g->lr_w)), BF_EALIGN,
+               "bf_gemm: lr_u needs lr_w, both 16-byte aligned");
+    BF_REQUIRE(!g->lr_u || gemm_lowrank_ok(g), BF_EINVAL,
+               "bf_gemm: this call cannot carry a low-rank addend (bf_gemm_lowrank_ok)");
     const BfTuning& T = bf_tuning();
     ep.store_policy = T.p8_nt;      // bit mask, see EpiParams::store_policy (measured in-step: DESIGN.md §6)
     bool colsum_fused = false;
@@ -2801,6 +2861,7 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                a_ext + 512ull * (size_t)g->lda < (1ull << 32) && b_ext + 512ull * (size_t)g->ldb < (1ull << 32);   // 32-bit offsets of the tile rows past M / N
         unsigned* tk8 = variant == 8 ? p8_ticket_set(s) : nullptr;
         if (variant == 8 && !tk8) variant = long_nt ? 0 : 4;
+        BF_REQUIRE(!g->lr_u || variant == 8, BF_EINVAL, "bf_gemm: low-rank addend on a stream without a ticket ring (variant %d)", variant);
         last_variant = 1;   // register-staged fallback unless one of the LDS-DMA kernels below takes it
         if (dma_ok && variant == 8 && (g->k % 32) == 0 && (kps % 32) == 0 && (g->n % 8) == 0 && (g->ldc % 8) == 0 &&
             (!g->aux || (g->ld_aux % 8) == 0)) {
@@ -2842,6 +2903,11 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
                 else if (!g->aux && g->act != BF_ACT_ERF_GELU_GRAD && g->act != BF_ACT_TANH_GELU_GRAD && g->act != BF_ACT_MUL_AUX) epi = 1;
                 else if ((g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->pre) epi = 2;
             }
+            if (g->lr_u) {
+                BF_REQUIRE(epi == 1 && bk64 && !g->trans_a && !g->b_kn, BF_EINVAL,
+                           "bf_gemm: the low-rank addend did not reach the kernel that carries it (epi %d, bk64 %d)", epi, (int)bk64);
+                epi = 5;
+            }
 #define LAUNCH_P8E(AKS, BKS, TC, EPI, H, BKV)                                                       \
     do {                                                                                          \
         static bool lds_ok[P8_TK_DEVICES];  /* > 64 KB of dynamic LDS must be opted into, once per device */ \
@@ -2865,7 +2931,10 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
 #define LAUNCH_P8_H(AKS, BKS, H) LAUNCH_P8_HB(AKS, BKS, H, 32)
 #define LAUNCH_P8_H64(AKS, BKS, H) LAUNCH_P8_HB(AKS, BKS, H, 64)
 #define LAUNCH_P8(AKS, BKS) BY_HALF(LAUNCH_P8_H, AKS, BKS)
-            if (!g->trans_a && !g->b_kn) {
+            if (epi == 5) {                                   // (one instantiation per operand type: NT, BK = 64)
+                if (f16) LAUNCH_P8E(false, false, f16_t, 5, f16_t, 64); else LAUNCH_P8E(false, false, bf16_t, 5, bf16_t, 64);
+            }
+            else if (!g->trans_a && !g->b_kn) {
                 if (bk64) BY_HALF(LAUNCH_P8_H64, false, false); else LAUNCH_P8(false, false);
             }
             else if (!g->trans_a && g->b_kn) {

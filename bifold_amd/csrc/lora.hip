@@ -81,8 +81,8 @@ template <typename HT> __device__ __forceinline__ uint2 f32_to_half4(float4 v) {
 // ----------------------------------------------------------------------------------------------------------------------
 template <typename HT, int NS, bool MASK, bool SHARED>
 __global__ __launch_bounds__(256) void lora_down_kernel(const HT* __restrict__ x, int ldx, const HT* __restrict__ wt,
-                                                        float* __restrict__ u, int rows, int width, int rank, LoraDev sl,
-                                                        unsigned thr_m1, float alpha) {
+                                                        float* __restrict__ u, HT* __restrict__ u_half, int rows, int width,
+                                                        int rank, LoraDev sl, unsigned thr_m1, float alpha) {
     typedef typename H16<HT>::x8 x8;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int nsr = NS * rank;
@@ -148,9 +148,11 @@ __global__ __launch_bounds__(256) void lora_down_kernel(const HT* __restrict__ x
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i0 = 8 * q + 4 * hh;
-            if (i0 < nsr)
-                *(float4*)(ur + i0) = make_float4(acc[4 * q] * alpha, acc[4 * q + 1] * alpha, acc[4 * q + 2] * alpha,
-                                                  acc[4 * q + 3] * alpha);
+            if (i0 < nsr) {
+                const float4 v = make_float4(acc[4 * q] * alpha, acc[4 * q + 1] * alpha, acc[4 * q + 2] * alpha, acc[4 * q + 3] * alpha);
+                *(float4*)(ur + i0) = v;
+                if (u_half) *(uint2*)(u_half + (size_t)row * nsr + i0) = f32_to_half4<HT>(v);
+            }
         }
     }
 }
@@ -395,10 +397,11 @@ int lora_rows_per_chunk(int rows) {
     switch (NSV) { case 1: { constexpr int NS = 1; BODY; } break; case 2: { constexpr int NS = 2; BODY; } break; \
                    default: { constexpr int NS = 3; BODY; } break; }
 
-extern "C" int bf_lora_down(const void* x, int ldx, const void* wt, float* u, int rows, int width, const bf_lora_slots* slots,
-                            float alpha, int cdt, bf_stream_t stream) {
+extern "C" int bf_lora_down(const void* x, int ldx, const void* wt, float* u, void* u_half, int rows, int width,
+                            const bf_lora_slots* slots, float alpha, int cdt, bf_stream_t stream) {
     if (int rc = lora_check("bf_lora_down", slots, rows, width, cdt, ldx, true)) return rc;
-    BF_REQUIRE(x && wt && u && bf_aligned16(x) && bf_aligned16(wt) && bf_aligned16(u), BF_EALIGN, "bf_lora_down: null or unaligned pointer");
+    BF_REQUIRE(x && wt && u && bf_aligned16(x) && bf_aligned16(wt) && bf_aligned16(u) && bf_aligned16(u_half), BF_EALIGN,
+               "bf_lora_down: null or unaligned pointer");
     const int nsr = slots->n_slots * slots->rank;
     const size_t lds = (size_t)(nsr + 1) * (width * 2 + 16);
     BF_REQUIRE(lds <= 64 * 1024, BF_EINVAL, "bf_lora_down: width %d needs %zu bytes of LDS", width, lds);
@@ -408,7 +411,7 @@ extern "C" int bf_lora_down(const void* x, int ldx, const void* wt, float* u, in
     const dim3 grid(bf_cdiv(rows, 128)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(HT, M_, S_) hipLaunchKernelGGL((lora_down_kernel<HT, NS, M_, S_>), grid, block, lds, s, (const HT*)x, ldx, \
-                                              (const HT*)wt, u, rows, width, slots->rank, d, thr, alpha)
+                                              (const HT*)wt, u, (HT*)u_half, rows, width, slots->rank, d, thr, alpha)
 #define BY_FLAGS(HT) do { if (mask) { if (shared) LAUNCH(HT, true, true); else LAUNCH(HT, true, false); } \
                           else { if (shared) LAUNCH(HT, false, true); else LAUNCH(HT, false, false); } } while (0)
     LORA_SWITCH_NS(slots->n_slots, if (cdt == BF_F16) BY_FLAGS(f16_t); else BY_FLAGS(bf16_t));

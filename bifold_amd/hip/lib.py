@@ -52,6 +52,7 @@ class GemmArgs(C.Structure):
         ("split_k", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_size_t),
         ("colsum_out", c_void_p),
+        ("lr_u", c_void_p), ("lr_w", c_void_p), ("lr_k", c_int),
     ]
 
 
@@ -147,7 +148,9 @@ PROTOTYPES = {
     "bf_dropout_mask": (c_int, [c_void_p, c_size_t, c_float, C.c_ulonglong, c_void_p]),
     "bf_dropout_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, C.c_ulonglong,
                                 c_void_p]),
-    "bf_lora_down": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, POINTER(LoraSlots), c_float, c_int, c_void_p]),
+    "bf_lora_down": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(LoraSlots), c_float, c_int,
+                             c_void_p]),
+    "bf_gemm_lowrank_ok": (c_int, [POINTER(GemmArgs)]),
     "bf_lora_up": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(LoraSlots), c_float, c_int, c_void_p]),
     "bf_lora_tn_workspace_elems": (c_size_t, [c_int, c_int, POINTER(LoraSlots)]),
     "bf_lora_tn": (c_int, [c_void_p, c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_int,

@@ -203,9 +203,11 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
          resid_mod: int = 0, out: Optional[torch.Tensor] = None,
          out_dtype: Optional[torch.dtype] = None, rows_in: int = 0, rows_out: int = 0,
          row_off: int = 0, accumulate: bool = False, want_bf16_copy: bool = False,
-         alpha: float = 1.0, split_k: Optional[int] = None, colsum_out: Optional[torch.Tensor] = None):
+         alpha: float = 1.0, split_k: Optional[int] = None, colsum_out: Optional[torch.Tensor] = None,
+         lr_u: Optional[torch.Tensor] = None, lr_w: Optional[torch.Tensor] = None):
     """C = epilogue(alpha * op(A) op(B)); see include/bifold_hip.h for the epilogue order.
-    Returns C, or (C, pre) / (C, copy) when asked for."""
+    Returns C, or (C, pre) / (C, copy) when asked for.  lr_u [m, r] / lr_w [n, r] (r = 16 or 32, the operands' dtype):
+    a low-rank addend of the product, for calls gemm_lowrank_ok accepts."""
     a, ar, ac, lda = _rows2d(a, "A")
     b, br, bc, ldb = _rows2d(b, "B")
     if a.dtype != b.dtype:
@@ -255,6 +257,13 @@ def gemm(a: torch.Tensor, b: torch.Tensor, *, trans_a: bool = False, b_kn: bool 
         if colsum_out.dtype != torch.float32 or colsum_out.numel() != n or not colsum_out.is_contiguous():
             raise RuntimeError("colsum_out must be a contiguous float32 [n] tensor")
         g.colsum_out = colsum_out.data_ptr()
+    if lr_u is not None:
+        if lr_w is None or lr_u.dtype != a.dtype or lr_w.dtype != a.dtype or lr_u.dim() != 2 or lr_w.dim() != 2 \
+                or lr_u.shape[0] != m or lr_w.shape[0] != n or lr_u.shape[1] != lr_w.shape[1] \
+                or not lr_u.is_contiguous() or not lr_w.is_contiguous():
+            raise RuntimeError("low-rank addend: lr_u [m, r] and lr_w [n, r], contiguous, in the operands' dtype")
+        _dev(lr_u, "lr_u"), _dev(lr_w, "lr_w")
+        g.lr_u, g.lr_w, g.lr_k = lr_u.data_ptr(), lr_w.data_ptr(), lr_u.shape[1]
     sk = (pick_split_k(m, n, k, deep_tn=(trans_a and b_kn and a.dtype in HALF))
           if split_k is None else split_k)
     ws = None
@@ -367,6 +376,19 @@ def dropout(x: torch.Tensor, p: float, seed: int, out: Optional[torch.Tensor] = 
     return y
 
 
+def gemm_lowrank_ok(m: int, n: int, k: int, dtype: torch.dtype, lr_k: int, act: int = L.ACT_NONE) -> bool:
+    """Would ops.gemm(a [m, k], b [n, k], bias=..., act=act) in `dtype` carry a low-rank addend of width lr_k?
+    (Dense operands and output; the library evaluates the same predicates as its dispatch.)"""
+    if dtype not in HALF:
+        return False
+    g = L.GemmArgs()
+    g.m, g.n, g.k, g.lda, g.ldb, g.ldc = m, n, k, k, k, n
+    g.cdt = g.c_dtype = L.F16 if dtype == torch.float16 else L.BF16
+    g.alpha, g.act, g.lr_k = 1.0, act, lr_k
+    g.split_k = pick_split_k(m, n, k, deep_tn=False)
+    return bool(lib.bf_gemm_lowrank_ok(C.byref(g)))
+
+
 def _lora_slots(n_slots: int, rank: int, col_off, p: float, seeds) -> "L.LoraSlots":
     sl = L.LoraSlots()
     sl.n_slots, sl.rank, sl.p = int(n_slots), int(rank), float(p)
@@ -383,9 +405,10 @@ def lora_supported(dtype: torch.dtype, width: int, rank: int, n_slots: int) -> b
 
 
 def lora_down(x: torch.Tensor, col_off, wt: torch.Tensor, rank: int, width: int, p: float = 0.0, seeds=None,
-              alpha: float = 1.0) -> torch.Tensor:
+              alpha: float = 1.0, want_half: bool = False):
     """u fp32 [rows, S * rank]: u[:, slot s] = alpha (mask_s . x[:, col_off[s] : col_off[s] + width]) wt[slot s rows]^T.
-    x: 16-bit [rows, ld] (ld = x.shape[1]); wt: same dtype [S * rank, width]."""
+    x: 16-bit [rows, ld] (ld = x.shape[1]); wt: same dtype [S * rank, width].  want_half: also return the same values in
+    x's dtype (the lr_u operand of ops.gemm)."""
     _dev(x, "x"), _dev(wt, "wt")
     n = len(col_off)
     if x.dim() != 2 or wt.dtype != x.dtype or tuple(wt.shape) != (n * rank, width) or not wt.is_contiguous() \
@@ -393,10 +416,11 @@ def lora_down(x: torch.Tensor, col_off, wt: torch.Tensor, rank: int, width: int,
         raise RuntimeError("lora_down: x [rows, ld] and wt [S * rank, width] of one 16-bit type expected")
     rows = x.shape[0]
     u = torch.empty(rows, n * rank, dtype=torch.float32, device=x.device)
+    uh = torch.empty(rows, n * rank, dtype=x.dtype, device=x.device) if want_half else None
     sl = _lora_slots(n, rank, col_off, p, seeds)
-    check(lib.bf_lora_down(_ptr(x), x.stride(0), _ptr(wt), _ptr(u), rows, width, C.byref(sl), float(alpha),
+    check(lib.bf_lora_down(_ptr(x), x.stride(0), _ptr(wt), _ptr(u), _ptr(uh), rows, width, C.byref(sl), float(alpha),
                            dtype_code(x), _stream()), "bf_lora_down")
-    return u
+    return (u, uh) if want_half else u
 
 
 def lora_up(u: torch.Tensor, wt: torch.Tensor, y: torch.Tensor, col_off, rank: int, width: int, p: float = 0.0, seeds=None,

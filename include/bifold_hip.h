@@ -177,9 +177,22 @@ typedef struct bf_gemm_args {
                               * where the kernel can (16-bit GELU-grad path: the fp32 values are summed before they
                               * are rounded for the store), otherwise the stored c is summed by a bf_colsum launch
                               * after the GEMM; needs rows_in == 0 */
+    /* ABI 11: optional LOW-RANK ADDEND of the product, c = epilogue(alpha * (a b^T + lr_u lr_w^T)): lr_u [m, lr_k],
+     * lr_w [n, lr_k], both cdt, row-major and dense, lr_k = 16 or 32.  The LoRA branch of an adapted projection riding
+     * in the projection's GEMM (models/siglip.py:33-40 -> peft: `result + lora_B(lora_A(dropout(x))) * scaling`):
+     * lr_u = the adapters' down-projections side by side (bf_lora_down's 16-bit copy), lr_w = scaling * lora_B placed in
+     * the rows and columns of its projection, zero elsewhere.  One extra MFMA K-step per output tile in front of the
+     * epilogue instead of a read-modify-write pass over c.  Carried by the persistent 256 x 256 kernel's plain 16-bit
+     * epilogue only: bf_gemm_lowrank_ok says whether a call qualifies (large-M NT GEMM, k % 64 == 0, 16-bit c, no
+     * residual / aux / c2 / accumulate / split); bf_gemm refuses lr_u on a call that does not. */
+    const void* lr_u;
+    const void* lr_w;
+    int lr_k;
 } bf_gemm_args;
 
 int bf_gemm(const bf_gemm_args* args, bf_stream_t stream);
+/* 1 when bf_gemm would carry args' low-rank addend (pointers are not looked at; lr_k must be set), else 0. */
+int bf_gemm_lowrank_ok(const bf_gemm_args* args);
 
 /* Tuning hook: force a bf16 kernel variant for every later bf_gemm call of this process
  * (0 = 128x128x64, 4 = 128x128x32 with 4 workgroups per CU, 8 = persistent 256x256 staggered;
@@ -501,9 +514,10 @@ typedef struct bf_lora_slots {
 } bf_lora_slots;
 /* u[:, slot s] = alpha (mask_s . x[:, col_off[s] : col_off[s] + width]) wt[s rank : (s + 1) rank, :]^T
  * forward: x = LayerNorm output, wt = lora_A rows stacked, alpha = 1 / (1 - p);
- * backward: x = d(packed projection output), col_off = the slot's column block, wt = scaling * lora_B^T, p = 0. */
-int bf_lora_down(const void* x, int ldx, const void* wt, float* u, int rows, int width, const bf_lora_slots* slots,
-                 float alpha, int cdt, bf_stream_t stream);
+ * backward: x = d(packed projection output), col_off = the slot's column block, wt = scaling * lora_B^T, p = 0.
+ * u_half (may be NULL): the same values in the compute dtype, [rows, n_slots * rank] -- bf_gemm's lr_u. */
+int bf_lora_down(const void* x, int ldx, const void* wt, float* u, void* u_half, int rows, int width,
+                 const bf_lora_slots* slots, float alpha, int cdt, bf_stream_t stream);
 /* y[:, col_off[s] + c] += alpha mask_s . (u[:, slot s] wt[slot s rows, c]); slots either share col_off (one
  * read-modify-write for all: the backward's d(LayerNorm output), wt = lora_A, alpha = 1 / (1 - p)) or name disjoint column
  * blocks (the forward: y = packed projection output, wt = scaling * lora_B^T, p = 0). */

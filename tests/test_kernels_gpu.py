@@ -1284,9 +1284,10 @@ def test_lora_kernels_against_the_masked_matrix_products(ops, gpu, cdt, rows, wi
     for offs in ([0] * n_slots, [s * width for s in range(n_slots)]):
         xs = [wide[:, o:o + width].double() * m for o, m in zip(offs, masks)]
         # down
-        got = ops.lora_down(wide, offs, wt, rank, width, p, seeds, alpha=keep)
+        got, got16 = ops.lora_down(wide, offs, wt, rank, width, p, seeds, alpha=keep, want_half=True)
         want = torch.cat([keep * x @ W[s * rank:(s + 1) * rank].t() for s, x in enumerate(xs)], dim=1)
         assert rel_err(got, want) < 2e-5, ("down", offs)
+        assert torch.equal(got16, got.to(cdt)) and torch.equal(got, ops.lora_down(wide, offs, wt, rank, width, p, seeds, alpha=keep))
         # tn, both output layouts
         for transposed in (False, True):
             outs = [torch.full((width, rank) if transposed else (rank, width), float("nan"), device=gpu) for _ in xs]
@@ -1333,3 +1334,37 @@ def test_lora_kernels_refuse_what_they_do_not_take(ops, gpu):
         ops.lora_up(u, wt, wide.clone(), [0, 32], 8, 64)
     assert not ops.lora_supported(torch.float32, 768, 8, 2) and ops.lora_supported(torch.float16, 768, 8, 2)
     assert not ops.lora_supported(torch.float16, 768, 4, 2) and not ops.lora_supported(torch.float16, 776, 8, 2)
+
+
+@pytest.mark.parametrize("cdt", HALF)
+@pytest.mark.parametrize("m,n,k,r,act", [(16384, 2304, 768, 16, 0), (20000, 1536, 512, 32, 0), (16640, 768, 768, 16, 4)])
+def test_gemm_low_rank_addend_rides_in_the_persistent_kernel(ops, gpu, cdt, m, n, k, r, act):
+    """bf_gemm_args::lr_u / lr_w (ABI 11): c = act(a b^T + lr_u lr_w^T + bias) with the low-rank product as one more MFMA
+    K-step in front of the epilogue of the persistent kernel (the LoRA up-projection inside the QKV GEMM).  Against the
+    float64 product of the same 16-bit operands; rows that are not a multiple of the 256-row tile; the call is refused
+    where another kernel would run it."""
+    from bifold_amd.hip import lib as L
+    g = torch.Generator().manual_seed(m + n)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(cdt).to(gpu)
+    b = (torch.randn(n, k, generator=g) / math.sqrt(k)).to(cdt).to(gpu)
+    u = torch.randn(m, r, generator=g).to(cdt).to(gpu)
+    wl = (torch.randn(n, r, generator=g) * 0.3).to(cdt).to(gpu)
+    wl[n // 3: 2 * n // 3] = 0                               # the k_proj rows of a packed projection carry no adapter
+    bias = torch.randn(n, generator=g).to(gpu)
+    assert ops.gemm_lowrank_ok(m, n, k, cdt, r, act)
+    got = ops.gemm(a, b, bias=bias, act=act, lr_u=u, lr_w=wl)
+    assert L.lib.bf_gemm_last_variant() == 8
+    plain = ops.gemm(a, b, bias=bias, act=act)
+    ref = a.double() @ b.double().t() + u.double() @ wl.double().t() + bias.double()
+    ref0 = a.double() @ b.double().t() + bias.double()
+    if act == 4:                                             # BF_ACT_TANH_GELU
+        ref, ref0 = F.gelu(ref, approximate="tanh"), F.gelu(ref0, approximate="tanh")
+    tol = 2 ** -7 if cdt == torch.bfloat16 else 2 ** -10
+    assert rel_err(got, ref) < tol and rel_err(plain, ref0) < tol
+    assert rel_err(got, ref0) > 20 * tol                     # the addend is not small here: it was really added
+    # refused where the call runs on another kernel: few rows, fp32 output, a residual
+    assert not ops.gemm_lowrank_ok(4096, n, k, cdt, r) and not ops.gemm_lowrank_ok(m, n, k, cdt, 8)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a[:4096], b, bias=bias, lr_u=u[:4096].contiguous(), lr_w=wl)
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, b, bias=bias, lr_u=u, lr_w=wl, out_dtype=torch.float32)

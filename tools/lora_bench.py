@@ -82,6 +82,18 @@ def main():
             t = ops.gemm(du, a16, b_kn=True)
             ops.dropout(t, p, seeds[s], out=dh1, accumulate=True)
 
+    # the forward's up-projection as a low-rank addend of the packed projection's GEMM instead of the 'fwd up' pass
+    wq = (torch.randn(3 * W, W, device=dev) / 28).to(cdt)
+    bq = torch.randn(3 * W, device=dev)
+    uh = u.to(cdt)
+    bcat = torch.zeros(3 * W, 2 * r, device=dev, dtype=cdt)
+    bcat[:W, :r] = Bt[:r].t()
+    bcat[2 * W:, r:] = Bt[r:].t()
+    if ops.gemm_lowrank_ok(M, 3 * W, W, cdt, 2 * r):
+        g0 = timed(lambda: ops.gemm(h1, wq, bias=bq), a.iters)
+        g1 = timed(lambda: ops.gemm(h1, wq, bias=bq, lr_u=uh, lr_w=bcat), a.iters)
+        g0b = timed(lambda: ops.gemm(h1, wq, bias=bq), a.iters)
+        print(f"packed projection GEMM {M} x {3 * W} x {W}: {g0:8.1f} us plain, {g1:8.1f} us with the low-rank addend, {g0b:8.1f} us plain again")
     f, b = timed(old_fwd, max(2, a.iters // 4)), timed(old_bwd, max(2, a.iters // 4))
     print(f"dropout + GEMM form: forward {f:8.1f} us, backward {b:8.1f} us, together {f + b:8.1f} us")
 
