@@ -17,6 +17,6 @@ cp_if lora_bench.txt r06_lora_bench.txt
 cp_if lora_variants.txt r06_lora_load_depth_variants.txt
 cp_if gemm_vs_hipblaslt_fp16.txt r06_gemm_vs_hipblaslt_fp16.txt
 cp_if observed_parity.jsonl r06_observed_parity.jsonl
-for f in bench_line bench_line_bf16 bench_line_vitl14 bench_line_fp8 bench_line_siglip_seq_frozen bench_line_siglip_seq_lora bench_line_siglip_seq_lora_gemm_form bench_line_siglip_seq_lora_merged; do
+for f in bench_line bench_line_bf16 bench_line_vitl14 bench_line_fp8 bench_line_siglip_seq_frozen bench_line_siglip_seq_lora_ride bench_line_siglip_seq_lora_up_pass bench_line_siglip_seq_lora_gemm_form bench_line_siglip_seq_lora_merged; do
   if [ -s "$src/$f.json" ]; then tail -1 "$src/$f.json" > "profiles/r06_$f.json"; echo "profiles/r06_$f.json"; fi
 done
