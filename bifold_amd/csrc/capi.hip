@@ -39,6 +39,15 @@ BfTuning& bf_tuning() {
 extern "C" int bf_abi_version(void) { return BF_ABI_VERSION; }
 extern "C" const char* bf_last_error(void) { return g_err; }
 extern "C" int bf_last_hip_error(void) { return g_hip_err; }
+// what a binding's mirror of a struct must measure (tests/test_host_logic.py compares hip/lib.py's ctypes structures)
+extern "C" size_t bf_struct_size(int which) {
+    switch (which) {
+        case 0: return sizeof(bf_gemm_args);
+        case 1: return sizeof(bf_gemm_tn_problem);
+        case 2: return sizeof(bf_lora_slots);
+        default: return 0;
+    }
+}
 
 // Test hook: `blocks` workgroups that each hold a whole CU's worth of LDS (a stand-in for a
 // collective's long-running kernels) and spin for `cycles` shader clocks, then exit.  Used by

@@ -151,6 +151,7 @@ PROTOTYPES = {
     "bf_lora_down": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(LoraSlots), c_float, c_int,
                              c_void_p]),
     "bf_gemm_lowrank_ok": (c_int, [POINTER(GemmArgs)]),
+    "bf_struct_size": (c_size_t, [c_int]),
     "bf_lora_up": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(LoraSlots), c_float, c_int, c_void_p]),
     "bf_lora_tn_workspace_elems": (c_size_t, [c_int, c_int, POINTER(LoraSlots)]),
     "bf_lora_tn": (c_int, [c_void_p, c_int, c_void_p, POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_int,

@@ -60,6 +60,9 @@ enum {
 typedef void* bf_stream_t;
 
 int bf_abi_version(void);
+/* sizeof of the structs that cross the boundary (0: bf_gemm_args, 1: bf_gemm_tn_problem, 2: bf_lora_slots; else 0): a
+ * binding checks its mirror against it once. */
+size_t bf_struct_size(int which);
 const char* bf_last_error(void);
 int bf_last_hip_error(void);
 

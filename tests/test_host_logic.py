@@ -50,6 +50,25 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     g.m = g.n = g.k = 64; g.lda = g.ldb = g.ldc = 64; g.cdt, g.c_dtype = L.F16, L.BF16      # 16-bit output of another type
     assert L.lib.bf_gemm(C.byref(g), None) == -1 and b"c_dtype" in L.lib.bf_last_error()
     assert L.lib.bf_bce_parts(256) == 1024 and L.lib.bf_layernorm_bwd_parts(70400) > 0
+    # ABI 11: the LoRA entry points and the GEMM's low-rank addend
+    sl = L.LoraSlots()
+    sl.n_slots, sl.rank = 2, 4
+    assert L.lib.bf_lora_down(None, 64, None, None, None, 8, 64, C.byref(sl), 1.0, L.F16, None) == -1
+    assert b"rank 4" in L.lib.bf_last_error()
+    sl.rank = 8
+    assert L.lib.bf_lora_up(None, None, None, 64, 8, 64, C.byref(sl), 1.0, L.F32, None) == -1 and b"16-bit" in L.lib.bf_last_error()
+    assert L.lib.bf_lora_tn_workspace_elems(1000, 768, C.byref(sl)) == 32 * 16 * 768      # 32 chunks of 32 rows
+    g2 = L.GemmArgs()
+    g2.m, g2.n, g2.k, g2.lda, g2.ldb, g2.ldc, g2.cdt, g2.c_dtype, g2.lr_k = 65536, 2304, 768, 768, 768, 2304, L.F16, L.F16, 8
+    assert L.lib.bf_gemm_lowrank_ok(C.byref(g2)) == 0 and L.lib.bf_gemm_lowrank_ok(None) == 0      # lr_k must be 16 or 32
+
+
+def test_ctypes_structs_measure_what_the_header_declares():
+    from bifold_amd.hip import lib as L
+    assert L.lib.bf_struct_size(0) == C.sizeof(L.GemmArgs)
+    assert L.lib.bf_struct_size(1) == C.sizeof(L.GemmTnProblem)
+    assert L.lib.bf_struct_size(2) == C.sizeof(L.LoraSlots)
+    assert L.lib.bf_struct_size(3) == 0
 
 
 def test_missing_library_fails_loudly(tmp_path):
