@@ -53,6 +53,7 @@ SIGLIP_CONFIGS: Dict[str, Dict] = {
     for s in (224, 256, 384, 512)
 }
 LN_EPS = 1e-6
+_TOWER_GRAD_STREAM16 = True       # the LoRA towers' backward in fp16 mode: residual-stream gradient as fp16 only (see _encoder_bwd)
 
 
 _MERGEABLE = ("q_proj", "k_proj", "v_proj")      # projections folded into the packed in-projection
@@ -458,6 +459,13 @@ class SiglipTowers(nn.Module):
         junk_g = torch.empty(w, dtype=torch.float32, device=dev)       # LayerNorm weight/bias gradients: frozen
         junk_b = torch.empty(w, dtype=torch.float32, device=dev)
         dw = torch.empty(3 * w, w, dtype=torch.float32, device=dev)
+        # fp16 mode: the gradient of the residual stream travels between the blocks' LayerNorm backward passes as fp16 only
+        # (the fusion stack's _GRAD_STREAM16, pickplace.py: every add rounds the running gradient to 11 bits, the loss scale
+        # keeps it in range): a pass reads 2 + 4 + 2 and writes 2 bytes per element instead of 2 + 4 + 4 and 4 + 2 --
+        # 561 -> 350 us per pass at the vision tower's 368 640 x 768, 48 passes per step.  bf16 (8 bits) and fp32 keep fp32.
+        s16 = cdt == torch.float16 and dx_c is not None and _TOWER_GRAD_STREAM16
+        if s16:
+            dx = None
         for i in reversed(range(cfg["num_hidden_layers"])):
             b = f"{tower}.encoder.layers.{i}."
             S = self._rematerialize(saved[i], b, i, tower, cfg, batch, seq, cdt)
@@ -465,8 +473,8 @@ class SiglipTowers(nn.Module):
             # MLP:  xo = xm + gelu_tanh(h2 W1^T + b1) W2^T + b2
             dpre = ops.gemm(op, self._w(b + "mlp.fc2.weight", cdt), b_kn=True, act=L.ACT_TANH_GELU_GRAD, aux=S["pre"])
             dh2 = ops.gemm(dpre, self._w(b + "mlp.fc1.weight", cdt), b_kn=True)
-            dxm, dxm_c = ops.layernorm_bwd(dh2, S["xm"], self._f(b + "layer_norm2.weight"), S["m2"], S["r2"], dx, cdt,
-                                           junk_g, junk_b)
+            dxm, dxm_c = ops.layernorm_bwd(dh2, S["xm"], self._f(b + "layer_norm2.weight"), S["m2"], S["r2"],
+                                           dx_c if s16 else dx, cdt, junk_g, junk_b, stream16=s16)
             del dpre, dh2
             op2 = dxm_c if dxm_c is not None else dxm
             # attention:  xm = x + attn(h1 Wqkv_eff^T + b) Wo^T + bo
@@ -519,8 +527,8 @@ class SiglipTowers(nn.Module):
                     t = ops.gemm(du, la.data.to(cdt), b_kn=True)                                  # [M, w]
                     ops.dropout(t, p_drop, seed, out=dh1, accumulate=True)
                     del hd, t, du
-            dx, dx_c = ops.layernorm_bwd(dh1, S["x"], self._f(b + "layer_norm1.weight"), S["m1"], S["r1"], dxm, cdt,
-                                         junk_g, junk_b)
+            dx, dx_c = ops.layernorm_bwd(dh1, S["x"], self._f(b + "layer_norm1.weight"), S["m1"], S["r1"],
+                                         dxm_c if s16 else dxm, cdt, junk_g, junk_b, stream16=s16)
             saved[i] = None                                # free this block's activations early
         # the embeddings below are frozen: the walk ends here
 
