@@ -81,10 +81,12 @@ def layer_buckets(names: List[str], offsets, depth: int, count: int) -> List[Tup
     # bucket 0 leaves as soon as the LAST fusion layer reports: it may only hold parameters whose gradients
     # the backward has written by then, i.e. the decoders.  Anything else registered behind the fusion layers
     # (a new head, an arena built in another order) goes with the final bucket instead of being averaged stale.
-    late = [n for n in names if marker not in n and offsets[n][0] >= after and "_decoder." not in n]
+    # (the mask head of compute_mask=True is a decoder in this sense: its gradient is written with the heads')
+    is_dec = lambda n: "_decoder." in n or "mask_head." in n   # noqa: E731
+    late = [n for n in names if marker not in n and offsets[n][0] >= after and not is_dec(n)]
     if late:
         after_dec = min(offsets[n][0] for n in late)
-        early = [n for n in names if offsets[n][0] >= after_dec and "_decoder." in n]
+        early = [n for n in names if offsets[n][0] >= after_dec and is_dec(n)]
         if early:
             raise ValueError(f"decoder parameters {early[:2]}... are interleaved with {late[:2]}... behind the "
                              f"fusion layers: cannot bucket the gradient arena in backward order")

@@ -74,10 +74,68 @@ class BCEMask:
     """losses/__init__.py:112-117 (needs a model built with compute_mask=True)."""
 
     def __call__(self, output, sample):
-        return bce_mean(output["mask_heatmap"], sample["mask"].squeeze(1)), {}
+        return bce_mean(output["mask_heatmap"], sample["mask"].squeeze(1).contiguous()), {}
 
     def __init__(self, **kwargs):
         pass
+
+
+class _DiceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, target):
+        prob = prob.contiguous()
+        loss, stats = ops.dice_fwd(prob, target)
+        ctx.save_for_backward(prob, target, stats)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, target, stats = ctx.saved_tensors
+        return ops.dice_bwd(prob, target, stats, g.reshape(1).to(torch.float32).contiguous()), None
+
+
+class DiceLoss:
+    """losses/__init__.py:126-136 on the mask head: per sample 1 - (2 sum(p t) + 1) / (sum p + sum t + 1), summed
+    over the batch (bf_dice_fwd / _bwd)."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __call__(self, output, sample):
+        target = sample["mask"].flatten(1).contiguous()
+        if target.requires_grad:
+            raise RuntimeError("dice targets must not require grad")
+        return _DiceFn.apply(output["mask_heatmap"].flatten(1), target), {}
+
+
+class _FocalFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prob, target, alpha, gamma):
+        prob = prob.contiguous()
+        ctx.save_for_backward(prob, target)
+        ctx.alpha, ctx.gamma = alpha, gamma
+        return ops.focal_fwd(prob, target, alpha, gamma).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, target = ctx.saved_tensors
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        return ops.focal_bwd(prob, target, gs, ctx.alpha, ctx.gamma), None, None, None
+
+
+class FocalLoss:
+    """losses/__init__.py:139-155 on the mask head: alpha_t * BCE * (1 - p_t)^gamma, `.mean(1).sum()`
+    (bf_focal_fwd / _bwd)."""
+
+    def __init__(self, alpha=0.25, gamma=2, **kwargs):
+        self.alpha = alpha
+        self.gamma = gamma
+
+    def __call__(self, output, sample):
+        target = sample["mask"].squeeze(1).contiguous()
+        if target.requires_grad:
+            raise RuntimeError("focal targets must not require grad")
+        return _FocalFn.apply(output["mask_heatmap"], target, float(self.alpha), float(self.gamma)), {}
 
 
 class ComposedLoss:
@@ -99,10 +157,8 @@ class ComposedLoss:
         return total, parts
 
 
-_LOSSES = {"bce_gaussmap": BCEGaussMap, "bce_mask": BCEMask, "composed": ComposedLoss}
-# dice / focal act on the optional mask head (losses/__init__.py:126-155), which no shipped
-# model config enables (compute_mask=False): outside this build's hot path.
-_NOT_BUILT = {"dice", "focal"}
+_LOSSES = {"bce_gaussmap": BCEGaussMap, "bce_mask": BCEMask, "composed": ComposedLoss, "dice": DiceLoss,
+           "focal": FocalLoss}
 
 
 class Losses:
@@ -110,8 +166,6 @@ class Losses:
     def get_by_name(cfg=None, name=None, *args, **kwargs):
         if cfg is not None:
             name = cfg["name"] if isinstance(cfg, dict) else cfg.name
-        if name in _NOT_BUILT:
-            raise NotImplementedError(f"Loss {name} is outside this build's hot path (mask head only)")
         if name not in _LOSSES:
             raise ValueError(f"Loss {name} not recognized")
         if cfg is not None:

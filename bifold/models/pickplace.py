@@ -197,12 +197,16 @@ class ConcatTransformer(nn.Module):
                     bb1=f.fn.net._modules["0"].bias, w2=f.fn.net._modules["3"].weight,
                     bb2=f.fn.net._modules["3"].bias)
 
-    def forward(self, *inputs, modalities=None, attention_masks=None, **kwargs):
+    def forward(self, *inputs, modalities=None, attention_masks=None, return_last_input: bool = False, **kwargs):
         """Standalone use of the component (models/fusion.py:35-64): fp32 CUDA inputs [B, n_i, dim] ->
         (features of the LAST input's tokens [B, n_last, dim], None).  Like the reference the type
         embedding is added to the inputs IN PLACE (fusion.py:52).  The models never call this: RGBOnly /
         SigLip run the same layers inside their fused tail (RGBTailFn / SegmentTailFn), which also fuses
-        the token assembly and the decoders."""
+        the token assembly and the decoders.
+
+        `return_last_input` (not a reference argument; PickPlaceConvDecoder's mask head uses it): the second value is the
+        last input as the layers saw it -- type embedding added -- as a tensor of THIS autograd node, so that a gradient
+        into it reaches the input and the type embedding like the reference's in-place add makes it."""
         if modalities is None:
             modalities = range(len(inputs))
         modalities = [int(m) for m in modalities]
@@ -215,17 +219,19 @@ class ConcatTransformer(nn.Module):
         with torch.no_grad():                              # the reference's in-place `inp += type_embeddings`;
             for mod, inp in zip(modalities, inputs):       # its gradient is produced by _FusionStackFn.backward
                 inp.add_(self.token_type_embeddings.weight[mod].to(inp.dtype))
-        out = _FusionStackFn.apply(self, tuple(modalities), mask, len(inputs), *inputs, *self.parameters())
-        return out[:, -inputs[-1].shape[1]:, :], None
+        out, last_in = _FusionStackFn.apply(self, tuple(modalities), mask, len(inputs), *inputs, *self.parameters())
+        return out[:, -inputs[-1].shape[1]:, :], (last_in if return_last_input else None)
 
 
 class PickPlaceConvDecoder(nn.Module):
     def __init__(self, dim, is_bimanual, fusion_model, num_patches, patch_size, compute_mask=False,
                  detach_mask=False, **kwargs):
         super().__init__()
-        if compute_mask:
-            raise NotImplementedError("compute_mask=True (mask head) is off in every shipped config "
-                                      "and not built on the HIP path")
+        # compute_mask (ref:bifold/models/pickplace.py:25-30): one more ConvDecoder, on the image tokens the fusion model is
+        # HANDED; its sigmoid is `mask_heatmap` and multiplies every pick heatmap (detach_mask: as a constant).  Off in
+        # every shipped model YAML; conf/loss/bce_mask.yaml / composed*.yaml are the losses that read it.
+        self.has_mask = bool(compute_mask)
+        self.detach_mask = bool(detach_mask)
         self.is_bimanual = is_bimanual
         self.dim = dim
         self.num_patches = num_patches
@@ -234,17 +240,26 @@ class PickPlaceConvDecoder(nn.Module):
             raise ValueError("num_patches must be a perfect square")
         self.fusion = Components.get_by_name(fusion_model, dim=dim, **kwargs)
         self.heads_out = head_names(is_bimanual)
+        self.n_pick = len(self.heads_out) // 2              # the pick heads lead (head_names)
+        # every collapsed decoder of the component, in buffer order: the heads, then the mask head
+        self.decoders_all = self.heads_out + (["mask"] if self.has_mask else [])
         chans = [dim, dim // 2, dim // 2, dim // 4, dim // 4, 1]
-        for name in self.heads_out:
+        # registration order = the reference's (fusion, mask_head, the heads): checkpoints index Adam's state by it
+        for name in (["mask"] if self.has_mask else []) + self.heads_out:
+            mod = self._decoder_module(name)
             for j, i in enumerate(DEC_IDX):
                 init = linear_init(chans[j + 1], chans[j])
-                add_param(self, f"{name}_decoder.decoder_net.{i}.weight", init["weight"].view(chans[j + 1], chans[j], 1, 1))
-                add_param(self, f"{name}_decoder.decoder_net.{i}.bias", init["bias"])
+                add_param(self, f"{mod}.decoder_net.{i}.weight", init["weight"].view(chans[j + 1], chans[j], 1, 1))
+                add_param(self, f"{mod}.decoder_net.{i}.bias", init["bias"])
         self._U: Optional[torch.Tensor] = None
         self._collapsed = None
 
+    @staticmethod
+    def _decoder_module(name: str) -> str:
+        return "mask_head" if name == "mask" else f"{name}_decoder"
+
     def decoder_params(self, name: str):
-        net = self._modules[f"{name}_decoder"].decoder_net
+        net = self._modules[self._decoder_module(name)].decoder_net
         ws = [net._modules[str(i)].weight for i in DEC_IDX]
         bs = [net._modules[str(i)].bias for i in DEC_IDX]
         return ws, bs
@@ -261,13 +276,13 @@ class PickPlaceConvDecoder(nn.Module):
         ws0, _ = self.decoder_params(self.heads_out[0])
         dev = ws0[0].device
         main, side = torch.cuda.current_stream(), self._side(dev)
-        dim, nh = self.dim, len(self.heads_out)
+        dim, nh = self.dim, len(self.decoders_all)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
             b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
             rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
-            for h, name in enumerate(self.heads_out):
+            for h, name in enumerate(self.decoders_all):
                 ws, bs = self.decoder_params(name)
                 ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
                                          rows_ws[h])
@@ -285,12 +300,20 @@ class PickPlaceConvDecoder(nn.Module):
         fusion model, the last input's tokens (minus its lead token) feed the decoders.  Returns the
         reference's dict: "attn_weights" (None) and one `[B, S, S]` heatmap per head."""
         component_arena(self)                              # one arena for fusion + decoders, before either runs
-        fused, attn = self.fusion(*inputs, **kwargs)
-        heats = _DecoderHeadsFn.apply(self, fused.contiguous(), *[p for n, p in self.named_parameters()
-                                                                   if "_decoder." in n])
-        out = {"attn_weights": attn}
+        dec_params = [p for n, p in self.named_parameters() if "_decoder." in n or "mask_head." in n]
+        if self.has_mask:
+            # the mask head reads the last input as the fusion model leaves it: type embedding added in place
+            # (models/fusion.py:52, models/pickplace.py:66-69)
+            fused, last_in = self.fusion(*inputs, return_last_input=True, **kwargs)
+            heats = _DecoderHeadsFn.apply(self, fused.contiguous(), last_in, *dec_params)
+        else:
+            fused, _ = self.fusion(*inputs, **kwargs)
+            heats = _DecoderHeadsFn.apply(self, fused.contiguous(), None, *dec_params)
+        out = {"attn_weights": None}
         for name, h in zip(self.heads_out, heats):
             out[f"{name}_heatmap"] = h
+        if self.has_mask:
+            out["mask_heatmap"] = heats[len(self.heads_out)]
         return out
 
 
@@ -507,11 +530,16 @@ def fusion_stack_bwd(fus: "ConcatTransformer", A: ParamArena, cdt, dx, layers, b
     return dx
 
 
-def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride: int, batch: int):
+def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride: int, batch: int,
+                      mask_tok: Optional[torch.Tensor] = None, mask_bstride: int = 0):
     """tok: fp32 view [B, n_patches+1, dim] of the image-modality tokens (batch stride tok_bstride
     elements, used in place) -> heat [n_heads, B, S, S] + (w_eff, rows_ws) for the backward
-    (models/pickplace.py:71-123 with ConvDecoder collapsed, models/modules.py:58-71)."""
-    dim, nh = pp.dim, len(pp.heads_out)
+    (models/pickplace.py:71-123 with ConvDecoder collapsed, models/modules.py:58-71).
+
+    With the mask head (pp.has_mask; models/pickplace.py:66-69,76-98,107-119) `mask_tok` is the same kind of view of the
+    tokens the fusion model was HANDED (type embedding included) and a fourth value comes back: dict(mask=sigmoid of the
+    mask head [B, S, S], pick=heat[:n_pick] * mask, what the pick heads return); `heat` stays the plain sigmoids."""
+    dim, nh, nall = pp.dim, len(pp.heads_out), len(pp.decoders_all)
     dev = tok.device
     pending, pp._collapsed = pp._collapsed, None
     if pending is not None:                                # started by collapse_async on the side stream
@@ -521,29 +549,56 @@ def decoder_heads_fwd(pp: "PickPlaceConvDecoder", tok: torch.Tensor, tok_bstride
         for t in (w_eff, b_eff, rows_ws):
             t.record_stream(main)
     else:
-        w_eff = torch.empty(nh, dim, dtype=torch.float32, device=dev)
-        b_eff = torch.empty(nh, dtype=torch.float32, device=dev)
-        rows_ws = torch.empty(nh, 4 * dim, dtype=torch.float32, device=dev)
-        for h, name in enumerate(pp.heads_out):
+        w_eff = torch.empty(nall, dim, dtype=torch.float32, device=dev)
+        b_eff = torch.empty(nall, dtype=torch.float32, device=dev)
+        rows_ws = torch.empty(nall, 4 * dim, dtype=torch.float32, device=dev)
+        for h, name in enumerate(pp.decoders_all):
             ws, bs = pp.decoder_params(name)
             ops.decoder_collapse_fwd([_w2d(w.data) for w in ws], [b.data for b in bs], w_eff[h], b_eff[h:h + 1],
                                      rows_ws[h])
-    low = ops.decoder_project(tok, tok_bstride, w_eff, b_eff, batch, nh, pp.num_patches, dim)
+    low = ops.decoder_project(tok, tok_bstride, w_eff[:nh], b_eff[:nh], batch, nh, pp.num_patches, dim)
     heat = ops.decoder_upsample_sigmoid(low, pp.upsample_matrix(dev), nh * batch, pp.grid)
     size = pp.grid * 16
-    return heat.view(nh, batch, size, size), w_eff, rows_ws
+    heat = heat.view(nh, batch, size, size)
+    if not pp.has_mask:
+        return heat, w_eff, rows_ws
+    if mask_tok is None:
+        raise RuntimeError("compute_mask=True: the mask head needs the tokens the fusion model was handed")
+    low_m = ops.decoder_project(mask_tok, mask_bstride, w_eff[nh:], b_eff[nh:], batch, 1, pp.num_patches, dim)
+    mask = ops.decoder_upsample_sigmoid(low_m, pp.upsample_matrix(dev), batch, pp.grid).view(batch, size, size)
+    return heat, w_eff, rows_ws, dict(mask=mask, pick=ops.mask_mul_fwd(heat[:pp.n_pick], mask))
+
+
+def decoder_outputs(pp: "PickPlaceConvDecoder", heat, extra):
+    """The component's heatmaps in `pp.heads_out` order (+ `mask_heatmap` last with the mask head)."""
+    if extra is None:
+        return tuple(heat[h] for h in range(len(pp.heads_out)))
+    return (tuple(extra["pick"][h] for h in range(pp.n_pick)) +
+            tuple(heat[h] for h in range(pp.n_pick, len(pp.heads_out))) + (extra["mask"],))
 
 
 def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstride: int, heat, w_eff, rows_ws,
-                      d_heats, d_tok, dtok_bstride: int, batch: int, grad_scale=None):
+                      d_heats, d_tok, dtok_bstride: int, batch: int, grad_scale=None, extra=None, mask_tok=None,
+                      mask_bstride: int = 0):
     """Backward of decoder_heads_fwd: writes d_tok (fp32 view like tok; token 0 gets zeros) and every
     decoder parameter gradient into the arena.  Returns the event after which the decoder gradients are
     complete: the per-head collapse backward runs on the side stream.  `grad_scale` (fp16 mode, models/gradscale.py)
-    multiplies the low-resolution logit gradients, i.e. everything this function and its callers produce."""
+    multiplies the low-resolution logit gradients, i.e. everything this function and its callers produce.
+
+    With the mask head (`extra` of the forward; d_heats then carries d mask_heatmap behind the heads' gradients) the
+    return value is (event, d_mask_tok): the gradient w.r.t. `mask_tok`, fp32 [B, n_patches+1, dim] (token 0 zeros),
+    or None when nothing reaches the mask head (detach_mask and a loss that does not read mask_heatmap)."""
     g = A.grad_view
-    dim, nh = pp.dim, len(pp.heads_out)
+    dim, nh, nall = pp.dim, len(pp.heads_out), len(pp.decoders_all)
     dev = tok.device
     U = pp.upsample_matrix(dev)
+    d_mask = None
+    if extra is not None:
+        d_mask_in = d_heats[nh] if len(d_heats) > nh else None
+        through = not pp.detach_mask and any(d is not None for d in d_heats[:pp.n_pick])
+        d_s, d_mask = ops.mask_mul_bwd(list(d_heats[:pp.n_pick]), heat[:pp.n_pick], extra["mask"], d_mask_in,
+                                       pp.detach_mask, want_d_mask=through or d_mask_in is not None)
+        d_heats = [d_s[h] for h in range(pp.n_pick)] + list(d_heats[pp.n_pick:nh])
     g_low = torch.empty(nh, batch, pp.grid * pp.grid, dtype=torch.float32, device=dev)
     for h in range(nh):
         if d_heats[h] is None:                             # a head the loss ignores
@@ -552,14 +607,26 @@ def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstrid
             ops.decoder_upsample_sigmoid_bwd(heat[h], d_heats[h].contiguous(), U, batch, pp.grid, out=g_low[h])
     if grad_scale is not None:                             # a number or the scaler's device scalar
         ops.scale_check_(g_low, grad_scale)
-    g_w = torch.empty(nh, dim, dtype=torch.float32, device=dev)
-    g_b = torch.empty(nh, dtype=torch.float32, device=dev)
-    ops.decoder_project_bwd(tok, tok_bstride, w_eff, g_low, d_tok, dtok_bstride, g_w, g_b, batch, nh,
+    g_w = torch.empty(nall, dim, dtype=torch.float32, device=dev)
+    g_b = torch.empty(nall, dtype=torch.float32, device=dev)
+    ops.decoder_project_bwd(tok, tok_bstride, w_eff[:nh], g_low, d_tok, dtok_bstride, g_w[:nh], g_b[:nh], batch, nh,
                             pp.num_patches, dim)
+    d_mask_tok = None
+    if extra is not None:
+        if d_mask is None:                                 # nothing reaches the mask head: its gradients are zeros
+            g_w[nh:].zero_()
+            g_b[nh:].zero_()
+        else:
+            g_low_m = ops.decoder_upsample_sigmoid_bwd(extra["mask"], d_mask, U, batch, pp.grid)
+            if grad_scale is not None:
+                ops.scale_check_(g_low_m, grad_scale)
+            d_mask_tok = torch.empty(batch, pp.num_patches + 1, dim, dtype=torch.float32, device=dev)
+            ops.decoder_project_bwd(mask_tok, mask_bstride, w_eff[nh:], g_low_m, d_mask_tok, (pp.num_patches + 1) * dim,
+                                    g_w[nh:], g_b[nh:], batch, 1, pp.num_patches, dim)
     main, side = torch.cuda.current_stream(), pp._side(dev)
     side.wait_stream(main)                                 # g_w / g_b are ready
     with torch.cuda.stream(side):
-        for h, name in enumerate(pp.heads_out):
+        for h, name in enumerate(pp.decoders_all):
             ws, bs = pp.decoder_params(name)
             ops.decoder_collapse_bwd([_w2d(w.data) for w in ws], [b.data for b in bs], rows_ws[h], g_w[h],
                                      g_b[h:h + 1], [_w2d(g(w)) for w in ws], [g(b) for b in bs])
@@ -567,24 +634,31 @@ def decoder_heads_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, tok, tok_bstrid
         done.record(side)
     for t in (g_w, g_b, rows_ws):
         t.record_stream(side)
-    return done
+    return done if extra is None else (done, d_mask_tok)
 
 
 def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch: int, seq: int,
                        mask_mode: int, row_mask, save: bool):
-    """x fp32 [B*seq, dim] (the assembled fusion input) -> heat [n_heads, B, S, S] and what the
-    backward needs.  The LAST n_patches+1 tokens of every sequence are the image modality whose
-    tokens feed the decoders (models/fusion.py:62-63, models/pickplace.py:71)."""
+    """x fp32 [B*seq, dim] (the assembled fusion input) -> the component's heatmaps (decoder_outputs: one [B, S, S] per
+    head, `mask_heatmap` last with the mask head) and what the backward needs.  The LAST n_patches+1 tokens of
+    every sequence are the image modality whose tokens feed the decoders (models/fusion.py:62-63,
+    models/pickplace.py:71); the mask head reads the same rows of x ITSELF (models/pickplace.py:66-69)."""
     dim = pp.dim
+    x_in = x
     x, layers = fusion_stack_fwd(pp.fusion, A, cdt, x, batch, seq, mask_mode, row_mask, save)
     first = seq - (pp.num_patches + 1)
     img_tok = x.view(batch, seq, dim)[:, first:]           # used in place through its batch stride
-    heat, w_eff, rows_ws = decoder_heads_fwd(pp, img_tok, seq * dim, batch)
+    extra = None
+    if pp.has_mask:
+        heat, w_eff, rows_ws, extra = decoder_heads_fwd(pp, img_tok, seq * dim, batch,
+                                                        x_in.view(batch, seq, dim)[:, first:], seq * dim)
+    else:
+        heat, w_eff, rows_ws = decoder_heads_fwd(pp, img_tok, seq * dim, batch)
     saved = None
     if save:
         saved = dict(layers=layers, x_out=x, w_eff=w_eff, rows_ws=rows_ws, heat=heat, batch=batch, seq=seq,
-                     mask_mode=mask_mode, row_mask=row_mask)
-    return heat, saved
+                     mask_mode=mask_mode, row_mask=row_mask, extra=extra, x_in=x_in if pp.has_mask else None)
+    return decoder_outputs(pp, heat, extra), saved
 
 
 def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heats, on_layer_done=None,
@@ -599,8 +673,14 @@ def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heat
     first = seq - (pp.num_patches + 1)
     xv = S["x_out"].view(batch, seq, dim)
     dxv = dx.view(batch, seq, dim)
-    dec_done = decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"], d_heats,
-                                 dxv[:, first:], seq * dim, batch, grad_scale)
+    d_mask_tok = None
+    if S.get("extra") is not None:
+        dec_done, d_mask_tok = decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"],
+                                                 d_heats, dxv[:, first:], seq * dim, batch, grad_scale, S["extra"],
+                                                 S["x_in"].view(batch, seq, dim)[:, first:], seq * dim)
+    else:
+        dec_done = decoder_heads_bwd(pp, A, xv[:, first:], seq * dim, S["heat"], S["w_eff"], S["rows_ws"], d_heats,
+                                     dxv[:, first:], seq * dim, batch, grad_scale)
     joined = []
 
     def layer_done(i):             # the decoders' gradients leave with the first bucket: join before it is reported
@@ -612,6 +692,8 @@ def fusion_decoder_bwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, S, d_heat
     dx = fusion_stack_bwd(pp.fusion, A, cdt, dx, S["layers"], batch, seq, S["mask_mode"], S["row_mask"], layer_done)
     if not joined:
         torch.cuda.current_stream().wait_event(dec_done)
+    if d_mask_tok is not None:     # the mask head read the fusion INPUT's image rows: its token gradient joins dx there
+        ops.rows_accumulate(d_mask_tok, dx.view(batch, seq, dim)[:, first:])
     return dx
 
 
@@ -650,16 +732,19 @@ class _FusionStackFn(torch.autograd.Function):
             c.dtypes = [t.dtype for t in inputs]
             ctx.c = c
         ctx.n_in = n_in
-        return y.view(batch, seq, dim)
+        # second output: the last input as the layers saw it (a copy: x itself is saved for the backward)
+        return y.view(batch, seq, dim), x.view(batch, seq, dim)[:, seq - inputs[-1].shape[1]:].clone()
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_last):
         c: _Ctx = ctx.c
         fus, A = c.fus, c.A
         dim = fus.dim
         dx = fusion_stack_bwd(fus, A, fus.compute_dtype, dy.contiguous().view(-1, dim).float(), c.layers, c.batch,
                               c.seq, c.mode, c.row_mask)
         dxv = dx.view(c.batch, c.seq, dim)
+        if d_last is not None:                             # a reader of the last input beside the layers (the mask head)
+            ops.rows_accumulate(d_last.float().contiguous(), dxv[:, c.seq - c.lens[-1]:])
         d_type = A.grad_view(fus.token_type_embeddings.weight)
         d_type.zero_()
         d_inputs, off = [], 0
@@ -674,20 +759,29 @@ class _FusionStackFn(torch.autograd.Function):
 
 
 class _DecoderHeadsFn(torch.autograd.Function):
-    """The decoders of PickPlaceConvDecoder.forward on their own (models/pickplace.py:71-123)."""
+    """The decoders of PickPlaceConvDecoder.forward on their own (models/pickplace.py:66-123); `last_in` (mask head
+    only): the fusion model's last input, [B, n_patches+1, dim]."""
 
     @staticmethod
-    def forward(ctx, pp, fused, *params):
+    def forward(ctx, pp, fused, last_in, *params):
         batch, n, dim = fused.shape
         if n != pp.num_patches + 1:
             raise RuntimeError(f"expected {pp.num_patches + 1} tokens from the fusion model, got {n}")
         tok = fused.float().contiguous()
-        heat, w_eff, rows_ws = decoder_heads_fwd(pp, tok, n * dim, batch)
+        extra, mtok = None, None
+        if pp.has_mask:
+            if last_in is None or tuple(last_in.shape) != (batch, n, dim):
+                raise RuntimeError("compute_mask=True: the mask head needs the fusion model's last input [B, n, dim]")
+            mtok = last_in.float().contiguous()
+            heat, w_eff, rows_ws, extra = decoder_heads_fwd(pp, tok, n * dim, batch, mtok, n * dim)
+        else:
+            heat, w_eff, rows_ws = decoder_heads_fwd(pp, tok, n * dim, batch)
         if any(ctx.needs_input_grad):
             c = _Ctx()
             c.pp, c.tok, c.heat, c.w_eff, c.rows_ws, c.batch, c.dtype = pp, tok, heat, w_eff, rows_ws, batch, fused.dtype
+            c.extra, c.mtok = extra, mtok
             ctx.c = c
-        return tuple(heat[h] for h in range(len(pp.heads_out)))
+        return decoder_outputs(pp, heat, extra)
 
     @staticmethod
     def backward(ctx, *d_heats):
@@ -696,10 +790,15 @@ class _DecoderHeadsFn(torch.autograd.Function):
         A = component_arena(pp)
         d_tok = torch.empty_like(c.tok)
         n, dim = c.tok.shape[1], c.tok.shape[2]
-        done = decoder_heads_bwd(pp, A, c.tok, n * dim, c.heat, c.w_eff, c.rows_ws, d_heats, d_tok, n * dim, c.batch)
+        d_last = None
+        if c.extra is not None:
+            done, d_last = decoder_heads_bwd(pp, A, c.tok, n * dim, c.heat, c.w_eff, c.rows_ws, d_heats, d_tok, n * dim,
+                                             c.batch, None, c.extra, c.mtok, n * dim)
+        else:
+            done = decoder_heads_bwd(pp, A, c.tok, n * dim, c.heat, c.w_eff, c.rows_ws, d_heats, d_tok, n * dim, c.batch)
         torch.cuda.current_stream().wait_event(done)
         ctx.c = None
-        return (None, d_tok.to(c.dtype)) + tuple(None for _ in range(len(ctx.needs_input_grad) - 2))
+        return (None, d_tok.to(c.dtype), d_last) + tuple(None for _ in range(len(ctx.needs_input_grad) - 3))
 
 
 class RGBTailFn(torch.autograd.Function):
@@ -714,7 +813,7 @@ class RGBTailFn(torch.autograd.Function):
         A: ParamArena = model.trainable_arena()
         cdt = model.compute_dtype
         save = any(ctx.needs_input_grad)      # False under no_grad (inference / get_action)
-        dim, nh = pp.dim, len(pp.heads_out)
+        dim = pp.dim
         n_rgb = pp.num_patches + 1
         batch = vis_feat.shape[0] // n_rgb
         n_text = text_feat.shape[0] // batch
@@ -749,14 +848,14 @@ class RGBTailFn(torch.autograd.Function):
         if emb_drop is not None:
             ops.dropout_rows(x, type_w[0].contiguous(), batch, seq, 0, 1 + n_text, p_t, emb_drop["text"])
             ops.dropout_rows(x, type_w[1].contiguous(), batch, seq, 1 + n_text, n_rgb, p_r, emb_drop["rgb"])
-        heat, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, L.MASK_NONE, None, save)
+        outs, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, L.MASK_NONE, None, save)
         if save:
             c = _Ctx()
             c.model, c.saved, c.vis_feat = model, saved, vis_feat
             c.batch, c.n_text, c.n_rgb = batch, n_text, n_rgb
             c.emb_drop = emb_drop
             ctx.c = c
-        return tuple(heat[h] for h in range(nh))
+        return outs
 
     @staticmethod
     def backward(ctx, *d_heats):
@@ -812,7 +911,7 @@ class SegmentTailFn(torch.autograd.Function):
         A: ParamArena = model.trainable_arena()
         cdt = model.compute_dtype
         save = any(ctx.needs_input_grad)
-        dim, nh = pp.dim, len(pp.heads_out)
+        dim = pp.dim
         batch = segments[0]["batch"]
         seq = sum(1 + sg["n"] for sg in segments)
         dev = segments[0]["src"].device
@@ -829,13 +928,13 @@ class SegmentTailFn(torch.autograd.Function):
             sg["row_off"] = off
             off += 1 + sg["n"]
         mode = L.MASK_QUERY_ROW if row_mask is not None else L.MASK_NONE
-        heat, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, mode, row_mask, save)
+        outs, saved = fusion_decoder_fwd(pp, A, cdt, x, batch, seq, mode, row_mask, save)
         if save:
             c = _Ctx()
             c.model, c.saved, c.batch, c.seq = model, saved, batch, seq
             c.segments = [{k: v for k, v in sg.items() if k != "src"} for sg in segments]
             ctx.c = c
-        return tuple(heat[h] for h in range(nh))
+        return outs
 
     @staticmethod
     def backward(ctx, *d_heats):

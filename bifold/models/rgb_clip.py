@@ -122,4 +122,6 @@ class RGBOnly(BaseModel):
         out = {"attn_weights": None}
         for name, h in zip(self.pick_place.heads_out, heats):
             out[f"{name}_heatmap"] = h
+        if self.pick_place.has_mask:                      # models/pickplace.py:66-69
+            out["mask_heatmap"] = heats[len(self.pick_place.heads_out)]
         return out

@@ -648,3 +648,262 @@ extern "C" int bf_decoder_project_bwd(const float* tok, long tok_bstride, const 
     BF_CHECK_LAUNCH("bf_decoder_project_bwd/2");
     return BF_OK;
 }
+
+// ================================================================== the mask head's product and the mask losses
+// PickPlaceConvDecoder with compute_mask=True (reference models/pickplace.py:66-69,76-98,107-119): a further collapsed
+// ConvDecoder reads the image tokens the fusion model was HANDED (bf_decoder_project / bf_decoder_upsample_sigmoid, one
+// head), and every pick heatmap leaves as sigmoid(pick) * mask_heatmap.  The product and its backward are elementwise.
+__global__ __launch_bounds__(256) void mask_mul_fwd_kernel(const float* __restrict__ s, const float* __restrict__ m,
+                                                           float* __restrict__ out, int n_heads, size_t per4) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per4; i += (size_t)gridDim.x * 256) {
+        const float4 mv = ((const float4*)m)[i];
+        for (int h = 0; h < n_heads; ++h) {
+            const float4 sv = ((const float4*)s)[h * per4 + i];
+            ((float4*)out)[h * per4 + i] = make_float4(sv.x * mv.x, sv.y * mv.y, sv.z * mv.z, sv.w * mv.w);
+        }
+    }
+}
+
+extern "C" int bf_mask_mul_fwd(const float* s, const float* mask, float* out, int n_heads, size_t per_head,
+                               bf_stream_t stream) {
+    BF_REQUIRE(n_heads >= 1 && per_head > 0 && (per_head & 3) == 0, BF_EINVAL,
+               "bf_mask_mul_fwd: per_head must be a positive multiple of 4");
+    BF_REQUIRE(bf_aligned16(s) && bf_aligned16(mask) && bf_aligned16(out), BF_EALIGN, "bf_mask_mul_fwd: unaligned pointer");
+    const size_t per4 = per_head / 4;
+    size_t blocks = (per4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mask_mul_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, mask, out,
+                       n_heads, per4);
+    BF_CHECK_LAUNCH("bf_mask_mul_fwd");
+    return BF_OK;
+}
+
+// d_s[h] = d_out[h] * m;   d_m = d_mask_in + sum_h d_out[h] * s[h]   (the sum only when the mask is not detached;
+// d_out[h] NULL = a head the loss ignores; d_m NULL = nobody wants it)
+struct MaskMulPtrs { const float* d_out[DEC_MAXH]; };
+__global__ __launch_bounds__(256) void mask_mul_bwd_kernel(MaskMulPtrs dp, const float* __restrict__ s,
+                                                           const float* __restrict__ m,
+                                                           const float* __restrict__ d_mask_in,
+                                                           float* __restrict__ d_s, float* __restrict__ d_m,
+                                                           int n_heads, size_t per4, int through) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < per4; i += (size_t)gridDim.x * 256) {
+        const float4 mv = ((const float4*)m)[i];
+        float4 dm = d_mask_in ? ((const float4*)d_mask_in)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int h = 0; h < n_heads; ++h) {
+            float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dp.d_out[h]) go = ((const float4*)dp.d_out[h])[i];
+            ((float4*)d_s)[h * per4 + i] = make_float4(go.x * mv.x, go.y * mv.y, go.z * mv.z, go.w * mv.w);
+            if (through && dp.d_out[h]) {
+                const float4 sv = ((const float4*)s)[h * per4 + i];
+                dm.x = fmaf(go.x, sv.x, dm.x); dm.y = fmaf(go.y, sv.y, dm.y);
+                dm.z = fmaf(go.z, sv.z, dm.z); dm.w = fmaf(go.w, sv.w, dm.w);
+            }
+        }
+        if (d_m) ((float4*)d_m)[i] = dm;
+    }
+}
+
+extern "C" int bf_mask_mul_bwd(const float* const* d_out, const float* s, const float* mask, const float* d_mask_in,
+                               float* d_s, float* d_mask, int n_heads, size_t per_head, int detach,
+                               bf_stream_t stream) {
+    BF_REQUIRE(n_heads >= 1 && n_heads <= DEC_MAXH && per_head > 0 && (per_head & 3) == 0, BF_EINVAL,
+               "bf_mask_mul_bwd: 1..%d heads, per_head a positive multiple of 4", DEC_MAXH);
+    BF_REQUIRE(d_out && s && mask && d_s, BF_EINVAL, "bf_mask_mul_bwd: NULL operand");
+    MaskMulPtrs dp;
+    for (int h = 0; h < DEC_MAXH; ++h) {
+        dp.d_out[h] = h < n_heads ? d_out[h] : nullptr;
+        BF_REQUIRE(bf_aligned16(dp.d_out[h]), BF_EALIGN, "bf_mask_mul_bwd: unaligned d_out[%d]", h);
+    }
+    BF_REQUIRE(bf_aligned16(s) && bf_aligned16(mask) && bf_aligned16(d_mask_in) && bf_aligned16(d_s) &&
+                   bf_aligned16(d_mask), BF_EALIGN, "bf_mask_mul_bwd: unaligned pointer");
+    const size_t per4 = per_head / 4;
+    size_t blocks = (per4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(mask_mul_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dp, s, mask,
+                       d_mask_in, d_s, d_mask, n_heads, per4, detach ? 0 : 1);
+    BF_CHECK_LAUNCH("bf_mask_mul_bwd");
+    return BF_OK;
+}
+
+// dst[b, i] += src[b, i], i < row_elems: the mask head's token gradient joins the gradient of the fusion INPUT's image
+// rows (fp32, or the fp16 gradient stream of fp16 mode)
+template <typename TD>
+__global__ __launch_bounds__(256) void rows_accumulate_kernel(const float* __restrict__ src, TD* __restrict__ dst,
+                                                              long src_bstride, long dst_bstride, int batch,
+                                                              long row4) {
+    const size_t total = (size_t)batch * row4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / row4, q = i - b * row4;
+        const float4 a = *(const float4*)(src + b * src_bstride + q * 4);
+        TD* d = dst + b * dst_bstride + q * 4;
+        const float4 c = Vec4<TD>::load(d);
+        Vec4<TD>::store(d, make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w));
+    }
+}
+
+extern "C" int bf_rows_accumulate(const float* src, long src_bstride, void* dst, int dst_dtype, long dst_bstride,
+                                  int batch, long row_elems, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && row_elems > 0 && (row_elems & 3) == 0, BF_EINVAL, "bf_rows_accumulate: bad shape");
+    BF_REQUIRE(dst_dtype == BF_F32 || dst_dtype == BF_F16, BF_EINVAL, "bf_rows_accumulate: dst is fp32 or fp16, got %d",
+               dst_dtype);
+    BF_REQUIRE(bf_aligned16(src) && (src_bstride & 3) == 0 && (dst_bstride & 3) == 0 &&
+                   (((uintptr_t)dst) & (dst_dtype == BF_F32 ? 15u : 7u)) == 0,
+               BF_EALIGN, "bf_rows_accumulate: unaligned pointer or stride");
+    const long row4 = row_elems / 4;
+    size_t blocks = ((size_t)batch * row4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (dst_dtype == BF_F16)
+        hipLaunchKernelGGL((rows_accumulate_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           (f16_t*)dst, src_bstride, dst_bstride, batch, row4);
+    else
+        hipLaunchKernelGGL((rows_accumulate_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src,
+                           (float*)dst, src_bstride, dst_bstride, batch, row4);
+    BF_CHECK_LAUNCH("bf_rows_accumulate");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ DiceLoss (reference losses/__init__.py:126-136)
+// per sample b: A = 2 sum(p t) + 1, D = sum p + sum t + 1, loss = sum_b (1 - A / D).  stats[b] = {sum p t, sum p, sum t, 0}
+__global__ __launch_bounds__(256) void dice_stats_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                         float* __restrict__ stats, int pixels) {
+    __shared__ float red[4][3];
+    const int b = blockIdx.x;
+    const float4* pp = (const float4*)(p + (size_t)b * pixels);
+    const float4* tp = (const float4*)(t + (size_t)b * pixels);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < (pixels >> 2); i += 256) {
+        const float4 a = pp[i], c = tp[i];
+        s0 += (a.x * c.x + a.y * c.y) + (a.z * c.z + a.w * c.w);
+        s1 += (a.x + a.y) + (a.z + a.w);
+        s2 += (c.x + c.y) + (c.z + c.w);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s0; red[threadIdx.x >> 6][1] = s1; red[threadIdx.x >> 6][2] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        stats[(size_t)b * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 3) stats[(size_t)b * 4 + 3] = 0.f;
+}
+__global__ __launch_bounds__(64) void dice_finish_kernel(const float* __restrict__ stats, float* __restrict__ loss, int batch) {
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < batch; b += 64) {
+        const float A = 2.0f * stats[(size_t)b * 4] + 1.0f, D = stats[(size_t)b * 4 + 1] + stats[(size_t)b * 4 + 2] + 1.0f;
+        acc += 1.0f - A / D;
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[0] = acc;
+}
+
+extern "C" int bf_dice_fwd(const float* prob, const float* target, float* stats, float* loss, int batch, int pixels,
+                           bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && pixels > 0 && (pixels & 3) == 0, BF_EINVAL, "bf_dice_fwd: bad shape");
+    BF_REQUIRE(bf_aligned16(prob) && bf_aligned16(target) && stats && loss, BF_EALIGN, "bf_dice_fwd: unaligned / NULL pointer");
+    hipLaunchKernelGGL(dice_stats_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, prob, target, stats, pixels);
+    BF_CHECK_LAUNCH("bf_dice_fwd/1");
+    hipLaunchKernelGGL(dice_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, stats, loss, batch);
+    BF_CHECK_LAUNCH("bf_dice_fwd/2");
+    return BF_OK;
+}
+
+// d loss / d p[b, j] = -(2 t_j D_b - A_b) / D_b^2
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float* __restrict__ t, const float* __restrict__ stats,
+                                                       const float* __restrict__ gscale, float* __restrict__ d_p,
+                                                       int pixels) {
+    const int b = blockIdx.y;
+    const float A = 2.0f * stats[(size_t)b * 4] + 1.0f, D = stats[(size_t)b * 4 + 1] + stats[(size_t)b * 4 + 2] + 1.0f;
+    const float g = gscale[0], c1 = -2.0f * g / D, c0 = g * A / (D * D);
+    const float4* tp = (const float4*)(t + (size_t)b * pixels);
+    float4* dp = (float4*)(d_p + (size_t)b * pixels);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < (pixels >> 2); i += gridDim.x * 256) {
+        const float4 c = tp[i];
+        dp[i] = make_float4(fmaf(c1, c.x, c0), fmaf(c1, c.y, c0), fmaf(c1, c.z, c0), fmaf(c1, c.w, c0));
+    }
+}
+
+extern "C" int bf_dice_bwd(const float* target, const float* stats, const float* gscale, float* d_prob, int batch,
+                           int pixels, bf_stream_t stream) {
+    BF_REQUIRE(batch > 0 && pixels > 0 && (pixels & 3) == 0, BF_EINVAL, "bf_dice_bwd: bad shape");
+    BF_REQUIRE(bf_aligned16(target) && bf_aligned16(d_prob) && stats && gscale, BF_EALIGN,
+               "bf_dice_bwd: unaligned / NULL pointer");
+    int bx = bf_cdiv(pixels >> 2, 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(dice_bwd_kernel, dim3(bx, batch), dim3(256), 0, (hipStream_t)stream, target, stats, gscale, d_prob,
+                       pixels);
+    BF_CHECK_LAUNCH("bf_dice_bwd");
+    return BF_OK;
+}
+
+// ------------------------------------------------------------------ FocalLoss (reference losses/__init__.py:139-155)
+// f = alpha_t * ce * (1 - p_t)^gamma,  ce = BCE with torch's -100 clamp of each log,  p_t = p t + (1 - p)(1 - t),
+// alpha_t = alpha t + (1 - alpha)(1 - t) (alpha < 0: no weighting);  loss = sum f / rows  (`.mean(1).sum()` on [B, S, S])
+__device__ __forceinline__ float focal_pow(float q, float gamma) {
+    return gamma == 2.0f ? q * q : (gamma == 1.0f ? q : (gamma == 0.0f ? 1.0f : powf(q, gamma)));
+}
+__device__ __forceinline__ float focal_term(float p, float t, float alpha, float gamma) {
+    const float ce = -(t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - p), -100.0f));
+    const float q = 1.0f - (p * t + (1.0f - p) * (1.0f - t));
+    float f = ce * focal_pow(q, gamma);
+    if (alpha >= 0.0f) f *= alpha * t + (1.0f - alpha) * (1.0f - t);
+    return f;
+}
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                        float* __restrict__ part, size_t n4, float alpha, float gamma) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 a = ((const float4*)p)[i], c = ((const float4*)t)[i];
+        acc += (focal_term(a.x, c.x, alpha, gamma) + focal_term(a.y, c.y, alpha, gamma)) +
+               (focal_term(a.z, c.z, alpha, gamma) + focal_term(a.w, c.w, alpha, gamma));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int bf_focal_fwd(const float* prob, const float* target, float* loss_part, float* loss, size_t count,
+                            int n_part, float inv_rows, float alpha, float gamma, bf_stream_t stream) {
+    BF_REQUIRE(count > 0 && (count & 3) == 0 && n_part >= 1 && n_part <= 1024, BF_EINVAL, "bf_focal_fwd: bad shape");
+    BF_REQUIRE(bf_aligned16(prob) && bf_aligned16(target) && loss_part && loss, BF_EALIGN,
+               "bf_focal_fwd: unaligned / NULL pointer");
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3(n_part), dim3(256), 0, (hipStream_t)stream, prob, target, loss_part,
+                       count / 4, alpha, gamma);
+    BF_CHECK_LAUNCH("bf_focal_fwd");
+    return bf_bce_finish(loss_part, loss, 1, n_part, inv_rows, stream);
+}
+
+// d f / d p = alpha_t [ ce' q^gamma + ce gamma q^(gamma-1) (1 - 2 t) ],  ce' = (p - t) / max(p (1 - p), 1e-12) (torch's
+// binary_cross_entropy backward),  q = 1 - p_t,  d q / d p = 1 - 2 t
+__device__ __forceinline__ float focal_grad(float p, float t, float alpha, float gamma) {
+    const float ce = -(t * fmaxf(logf(p), -100.0f) + (1.0f - t) * fmaxf(logf(1.0f - p), -100.0f));
+    const float dce = (p - t) / fmaxf(p * (1.0f - p), 1e-12f);
+    const float q = 1.0f - (p * t + (1.0f - p) * (1.0f - t));
+    const float dq = gamma == 0.0f ? 0.0f : gamma * focal_pow(q, gamma - 1.0f);
+    float d = dce * focal_pow(q, gamma) + ce * dq * (1.0f - 2.0f * t);
+    if (alpha >= 0.0f) d *= alpha * t + (1.0f - alpha) * (1.0f - t);
+    return d;
+}
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                        const float* __restrict__ gscale, float* __restrict__ d_p,
+                                                        size_t n4, float inv_rows, float alpha, float gamma) {
+    const float gs = gscale[0] * inv_rows;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 a = ((const float4*)p)[i], c = ((const float4*)t)[i];
+        ((float4*)d_p)[i] = make_float4(gs * focal_grad(a.x, c.x, alpha, gamma), gs * focal_grad(a.y, c.y, alpha, gamma),
+                                        gs * focal_grad(a.z, c.z, alpha, gamma), gs * focal_grad(a.w, c.w, alpha, gamma));
+    }
+}
+
+extern "C" int bf_focal_bwd(const float* prob, const float* target, const float* gscale, float* d_prob, size_t count,
+                            float inv_rows, float alpha, float gamma, bf_stream_t stream) {
+    BF_REQUIRE(count > 0 && (count & 3) == 0, BF_EINVAL, "bf_focal_bwd: count must be a positive multiple of 4");
+    BF_REQUIRE(bf_aligned16(prob) && bf_aligned16(target) && bf_aligned16(d_prob) && gscale, BF_EALIGN,
+               "bf_focal_bwd: unaligned / NULL pointer");
+    const size_t n4 = count / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, prob, target, gscale,
+                       d_prob, n4, inv_rows, alpha, gamma);
+    BF_CHECK_LAUNCH("bf_focal_bwd");
+    return BF_OK;
+}

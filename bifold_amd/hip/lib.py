@@ -19,7 +19,7 @@ ACT_NONE, ACT_QUICK_GELU, ACT_ERF_GELU, ACT_ERF_GELU_GRAD, ACT_TANH_GELU, ACT_TA
 ACT_ERF_GELU_SAVEGRAD, ACT_MUL_AUX = 6, 7
 MASK_NONE, MASK_CAUSAL, MASK_QUERY_ROW = 0, 1, 2
 TARGETS_FIRST, TARGETS_GMM, TARGETS_FIT, MAX_TARGET_POINTS = 0, 1, 2, 16
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get(
@@ -128,6 +128,15 @@ PROTOTYPES = {
     "bf_decoder_project_bwd_ws": (c_size_t, [c_int, c_int, c_int]),
     "bf_decoder_project_bwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "bf_mask_mul_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_size_t, c_void_p]),
+    "bf_mask_mul_bwd": (c_int, [POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_size_t,
+                                c_int, c_void_p]),
+    "bf_rows_accumulate": (c_int, [c_void_p, c_long, c_void_p, c_int, c_long, c_int, c_long, c_void_p]),
+    "bf_dice_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bf_dice_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bf_focal_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_float, c_float, c_float,
+                             c_void_p]),
+    "bf_focal_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_void_p]),
     "bf_scale_check": (c_int, [c_void_p, c_size_t, c_float, c_void_p, c_void_p]),
     "bf_depth_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "bf_depth_standardize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -727,6 +727,99 @@ def bce_mean_bwd(heat, target, gscale: torch.Tensor):
     return d
 
 
+# ----------------------------------------------------------------------------- mask head (compute_mask=True)
+def _mask_pair(prob: torch.Tensor, target: torch.Tensor, what: str):
+    _dev(prob, what + " probabilities"); _dev(target, what + " target")
+    if prob.numel() != target.numel() or prob.dtype != torch.float32 or target.dtype != torch.float32:
+        raise RuntimeError(f"{what} needs float32 tensors of one size, got {tuple(prob.shape)} {prob.dtype} vs "
+                           f"{tuple(target.shape)} {target.dtype}")
+    if prob.shape[0] != target.shape[0]:
+        raise RuntimeError(f"{what}: batch sizes differ ({prob.shape[0]} vs {target.shape[0]})")
+
+
+def mask_mul_fwd(s: torch.Tensor, mask: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """s fp32 [n_heads, B, S, S] (sigmoids of the pick heads) * mask fp32 [B, S, S] -> out like s."""
+    _dev(s, "pick heatmaps"); _dev(mask, "mask heatmap")
+    if s.dtype != torch.float32 or mask.dtype != torch.float32 or s.shape[1:] != mask.shape:
+        raise RuntimeError(f"mask_mul_fwd: fp32 [n, ...] and [...] expected, got {tuple(s.shape)} / {tuple(mask.shape)}")
+    out = torch.empty_like(s) if out is None else out
+    check(lib.bf_mask_mul_fwd(_ptr(s), _ptr(mask), _ptr(out), s.shape[0], mask.numel(), _stream()), "bf_mask_mul_fwd")
+    return out
+
+
+def mask_mul_bwd(d_outs, s: torch.Tensor, mask: torch.Tensor, d_mask_in: Optional[torch.Tensor], detach: bool,
+                 want_d_mask: bool = True):
+    """Backward of mask_mul_fwd: (d_s like s, d_mask like mask or None).  `d_outs`: one gradient (or None) per head."""
+    n = s.shape[0]
+    if len(d_outs) != n:
+        raise RuntimeError(f"mask_mul_bwd: {n} heads, {len(d_outs)} gradients")
+    keep = []
+    arr = (C.c_void_p * n)()
+    for i, d in enumerate(d_outs):
+        if d is not None:
+            d = d.contiguous()
+            if d.dtype != torch.float32 or d.shape != mask.shape:
+                raise RuntimeError(f"mask_mul_bwd: gradient {i} is {tuple(d.shape)} {d.dtype}")
+            keep.append(d)
+            arr[i] = d.data_ptr()
+    if d_mask_in is not None:
+        d_mask_in = d_mask_in.contiguous()
+    d_s = torch.empty_like(s)
+    d_mask = torch.empty_like(mask) if want_d_mask else None
+    check(lib.bf_mask_mul_bwd(arr, _ptr(s), _ptr(mask), _ptr(d_mask_in), _ptr(d_s), _ptr(d_mask), n, mask.numel(),
+                              1 if detach else 0, _stream()), "bf_mask_mul_bwd")
+    return d_s, d_mask
+
+
+def rows_accumulate(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[b] += src[b]: src fp32 [B, n, D] contiguous, dst a [B, n, D] view (rows contiguous, any batch stride)."""
+    if src.dtype != torch.float32 or not src.is_contiguous() or src.shape != dst.shape or src.dim() != 3:
+        raise RuntimeError(f"rows_accumulate: fp32 contiguous [B, n, D] source expected, got {tuple(src.shape)} {src.dtype}")
+    if dst.stride(2) != 1 or dst.stride(1) != dst.shape[2]:
+        raise RuntimeError("rows_accumulate: the destination's rows must be contiguous")
+    check(lib.bf_rows_accumulate(_ptr(src), src.stride(0), _ptr(dst), dtype_code(dst), dst.stride(0), src.shape[0],
+                                 src.shape[1] * src.shape[2], _stream()), "bf_rows_accumulate")
+
+
+def dice_fwd(prob: torch.Tensor, target: torch.Tensor):
+    """DiceLoss forward: (loss [1], stats [B, 4] for the backward)."""
+    _mask_pair(prob, target, "dice")
+    batch = prob.shape[0]
+    stats = torch.empty(batch, 4, dtype=torch.float32, device=prob.device)
+    loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+    check(lib.bf_dice_fwd(_ptr(prob), _ptr(target), _ptr(stats), _ptr(loss), batch, prob.numel() // batch, _stream()),
+          "bf_dice_fwd")
+    return loss, stats
+
+
+def dice_bwd(prob_like: torch.Tensor, target: torch.Tensor, stats: torch.Tensor, gscale: torch.Tensor):
+    d = torch.empty_like(prob_like)
+    batch = prob_like.shape[0]
+    check(lib.bf_dice_bwd(_ptr(target), _ptr(stats), _ptr(gscale), _ptr(d), batch, prob_like.numel() // batch, _stream()),
+          "bf_dice_bwd")
+    return d
+
+
+def focal_fwd(prob: torch.Tensor, target: torch.Tensor, alpha: float, gamma: float) -> torch.Tensor:
+    """FocalLoss forward on [B, rows, cols]: sum / rows.  Returns a 1-element tensor."""
+    _mask_pair(prob, target, "focal")
+    if prob.dim() != 3:
+        raise RuntimeError(f"focal: [B, S, S] probabilities expected, got {tuple(prob.shape)}")
+    nparts = lib.bf_bce_parts(prob.shape[0])
+    parts = torch.empty(nparts, dtype=torch.float32, device=prob.device)
+    loss = torch.empty(1, dtype=torch.float32, device=prob.device)
+    check(lib.bf_focal_fwd(_ptr(prob), _ptr(target), _ptr(parts), _ptr(loss), prob.numel(), nparts, 1.0 / prob.shape[1],
+                           float(alpha), float(gamma), _stream()), "bf_focal_fwd")
+    return loss
+
+
+def focal_bwd(prob: torch.Tensor, target: torch.Tensor, gscale: torch.Tensor, alpha: float, gamma: float):
+    d = torch.empty_like(prob)
+    check(lib.bf_focal_bwd(_ptr(prob), _ptr(target), _ptr(gscale), _ptr(d), prob.numel(), 1.0 / prob.shape[1], float(alpha),
+                           float(gamma), _stream()), "bf_focal_bwd")
+    return d
+
+
 # ----------------------------------------------------------------------------- optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, shadow, step, lr, beta1, beta2, eps, weight_decay,
               decoupled, grad_scale=None, skip_flag=None, skipped=None, skipped_known: float = 0.0):

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define BF_ABI_VERSION 11
+#define BF_ABI_VERSION 12
 
 enum { BF_F32 = 0, BF_BF16 = 1, BF_F16 = 2 };
 
@@ -429,6 +429,43 @@ int bf_decoder_project_bwd(const float* tok, long tok_bstride, const float* w_ef
                            void* d_tok, int dtok_dtype, long dtok_bstride, float* g_w_eff, float* g_b_eff,
                            float* part_ws, int batch, int n_heads, int n_patch, int dim,
                            bf_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * The mask head (PickPlaceConvDecoder(compute_mask=True), models/pickplace.py:25-30,66-69,76-98,107-119; ABI 12).
+ * The head itself is one more collapsed ConvDecoder: bf_decoder_collapse_fwd / bf_decoder_project /
+ * bf_decoder_upsample_sigmoid with n_heads = 1 over the image tokens the fusion model was handed (type embedding
+ * included: models/fusion.py:52 adds it in place).  What is new is the product and the losses on `mask_heatmap`.
+ *
+ * bf_mask_mul_fwd: out[h, i] = s[h, i] * mask[i], h < n_heads (the pick heads), i < per_head (= B * S * S); fp32.
+ * bf_mask_mul_bwd: d_s[h] = d_out[h] * mask (zeros where d_out[h] == NULL: a head the loss ignores);
+ *   d_mask = d_mask_in (NULL = 0: the loss does not read mask_heatmap) + sum_h d_out[h] * s[h] -- the sum is left
+ *   out with detach != 0 (models/pickplace.py:79-87,110-114: `.detach()`); d_mask NULL = not wanted.
+ *   d_out: host array of n_heads device pointers (n_heads <= 4). */
+int bf_mask_mul_fwd(const float* s, const float* mask, float* out, int n_heads, size_t per_head, bf_stream_t stream);
+int bf_mask_mul_bwd(const float* const* d_out, const float* s, const float* mask, const float* d_mask_in, float* d_s,
+                    float* d_mask, int n_heads, size_t per_head, int detach, bf_stream_t stream);
+/* dst[b, i] += src[b, i] for b < batch, i < row_elems (batch strides in elements; dst fp32 or fp16): the mask head's
+ * token gradient added to the gradient of the fusion INPUT's image rows. */
+int bf_rows_accumulate(const float* src, long src_bstride, void* dst, int dst_dtype, long dst_bstride, int batch,
+                       long row_elems, bf_stream_t stream);
+/* DiceLoss (losses/__init__.py:126-136): prob / target fp32 [batch, pixels];
+ *   stats fp32 [batch, 4] <- {sum p t, sum p, sum t, 0} per sample (kept for the backward),
+ *   loss[0] = sum_b 1 - (2 stats0 + 1) / (stats1 + stats2 + 1).
+ * bf_dice_bwd: d_prob[b, j] = gscale[0] * -(2 t_j D_b - A_b) / D_b^2 with A, D the numerator / denominator above. */
+int bf_dice_fwd(const float* prob, const float* target, float* stats, float* loss, int batch, int pixels,
+                bf_stream_t stream);
+int bf_dice_bwd(const float* target, const float* stats, const float* gscale, float* d_prob, int batch, int pixels,
+                bf_stream_t stream);
+/* FocalLoss (losses/__init__.py:139-155) on fp32 [count] probabilities / targets:
+ *   f = alpha_t * BCE(p, t) * (1 - p_t)^gamma (BCE with torch's -100 clamp of each log; alpha < 0: no alpha_t),
+ *   loss[0] = inv_rows * sum f   (`.mean(1).sum()` on [B, S, S]: inv_rows = 1 / S);
+ *   loss_part: fp32 scratch of n_part (<= 1024) floats.
+ * bf_focal_bwd: d_prob = gscale[0] * inv_rows * d f / d p, the BCE factor differentiated as torch does
+ *   ((p - t) / max(p (1 - p), 1e-12)). */
+int bf_focal_fwd(const float* prob, const float* target, float* loss_part, float* loss, size_t count, int n_part,
+                 float inv_rows, float alpha, float gamma, bf_stream_t stream);
+int bf_focal_bwd(const float* prob, const float* target, const float* gscale, float* d_prob, size_t count,
+                 float inv_rows, float alpha, float gamma, bf_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Optimiser (optim/__init__.py:4-14 -> torch.optim.Adam / AdamW) over a flat fp32

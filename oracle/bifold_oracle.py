@@ -258,19 +258,37 @@ def decoder_heads(is_bimanual: bool):
 
 
 def pick_place_convdecoder(state: State, inputs: Sequence[torch.Tensor], heads: int,
-                           is_bimanual: bool, pfx: str = "pick_place.", **fusion_kw):
-    """PickPlaceConvDecoder.forward with compute_mask=False
-    (models/pickplace.py:59-124): fuse, drop token 0, view tokens as a row-major
-    g x g grid -> [B,D,g,g], one ConvDecoder per head, squeeze, sigmoid."""
+                           is_bimanual: bool, pfx: str = "pick_place.", compute_mask: Optional[bool] = None,
+                           detach_mask: bool = False, **fusion_kw):
+    """PickPlaceConvDecoder.forward (models/pickplace.py:59-124): fuse, drop token 0, view tokens as a row-major
+    g x g grid -> [B,D,g,g], one ConvDecoder per head, squeeze, sigmoid.
+
+    compute_mask (default: whether the state holds a `mask_head`; models/pickplace.py:25-30,66-69,76-98,107-119):
+    a further ConvDecoder reads the LAST input's tokens (minus token 0) -- as the fusion model left them, i.e. WITH the
+    type embedding its forward added in place (models/fusion.py:52: `inp += type_embeddings`) -- and its sigmoid is
+    `mask_heatmap`; every pick heatmap is multiplied by it (by its detached value with detach_mask)."""
+    if compute_mask is None:
+        compute_mask = f"{pfx}mask_head.decoder_net.0.weight" in state
     fused = concat_transformer(state, inputs, heads, pfx=pfx + "fusion.", **fusion_kw)
     tok = fused[:, 1:, :]
     b, n, d = tok.shape
     g = int(math.isqrt(n))
     feat = tok.reshape(b, g, g, d).permute(0, 3, 1, 2)
     out: Dict[str, Optional[torch.Tensor]] = {"attn_weights": None}
+    mask = None
+    if compute_mask:
+        mods = fusion_kw.get("modalities")
+        last_mod = list(mods)[-1] if mods is not None else len(inputs) - 1
+        raw = inputs[-1] + state[pfx + "fusion.token_type_embeddings.weight"][last_mod]
+        mfeat = raw[:, 1:, :].reshape(b, g, g, d).permute(0, 3, 1, 2)
+        mask = torch.sigmoid(conv_decoder_logits(state, f"{pfx}mask_head.", mfeat).squeeze(1))
+        out["mask_heatmap"] = mask
     for name in decoder_heads(is_bimanual):
         logits = conv_decoder_logits(state, f"{pfx}{name}_decoder.", feat)
-        out[f"{name}_heatmap"] = torch.sigmoid(logits.squeeze(1))
+        heat = torch.sigmoid(logits.squeeze(1))
+        if mask is not None and name.endswith("pick"):
+            heat = heat * (mask.detach() if detach_mask else mask)
+        out[f"{name}_heatmap"] = heat
     return out
 
 
@@ -304,7 +322,7 @@ def collapse_decoder(state: State, pfx: str):
 # model, loss, optimiser
 # --------------------------------------------------------------------------
 def rgb_clip_forward(state: State, sample: Mapping[str, torch.Tensor], heads: int,
-                     is_bimanual: bool = False, dropout=None):
+                     is_bimanual: bool = False, dropout=None, detach_mask: bool = False):
     """RGBOnly.forward (models/rgb_clip.py:52-73).  `dropout` (training with p > 0, GIVEN masks):
     dict(text=(p, keep [B,78,D]), rgb=(p, keep [B,n+1,D]), layers=[(p, {attn, out, act, ff})...])."""
     t = clip_text_tokens(state, sample["instruction"])
@@ -315,7 +333,7 @@ def rgb_clip_forward(state: State, sample: Mapping[str, torch.Tensor], heads: in
     v = clip_vision_tokens(state, sample["rgb"])
     x_rgb = _drop(F.linear(v, state["project.weight"], state["project.bias"]) + state["rgb_pos_embedding"], dr.get("rgb"))
     kw = dict(layer_drop=dr["layers"]) if dr.get("layers") is not None else {}
-    return pick_place_convdecoder(state, [x_text, x_rgb], heads, is_bimanual, **kw)
+    return pick_place_convdecoder(state, [x_text, x_rgb], heads, is_bimanual, detach_mask=detach_mask, **kw)
 
 
 def _prepend(token: torch.Tensor, feats: torch.Tensor):
@@ -323,16 +341,16 @@ def _prepend(token: torch.Tensor, feats: torch.Tensor):
 
 
 def siglip_forward(state: State, sample: Mapping[str, torch.Tensor], tower_heads: int, fusion_heads: int,
-                   is_bimanual: bool):
+                   is_bimanual: bool, detach_mask: bool = False):
     """SigLip.forward (models/siglip.py:56-70): prepend the learned image / text tokens to the
     towers' last hidden states and hand both to the pick/place head."""
     img = _prepend(state["image_token"], siglip_vision_tokens(state, sample["rgb"], tower_heads))
     txt = _prepend(state["text_token"], siglip_text_tokens(state, sample["instruction"], tower_heads))
-    return pick_place_convdecoder(state, [txt, img], fusion_heads, is_bimanual)
+    return pick_place_convdecoder(state, [txt, img], fusion_heads, is_bimanual, detach_mask=detach_mask)
 
 
 def siglip_sequential_forward(state: State, sample: Mapping[str, torch.Tensor], tower_heads: int,
-                              fusion_heads: int, is_bimanual: bool):
+                              fusion_heads: int, is_bimanual: bool, detach_mask: bool = False):
     """SiglipSequential.forward (models/siglip.py:85-137): the vision tower also encodes the T
     context frames; each gets the image token prepended, frames are concatenated and
     `context_pos_embedding` added; the fusion mask is [ones | ctx_mask repeated n+1 | ones] and
@@ -347,7 +365,7 @@ def siglip_sequential_forward(state: State, sample: Mapping[str, torch.Tensor], 
     mask = torch.cat([torch.ones(b, txt.shape[1]),
                       sample["context_attention_mask"].float().repeat_interleave(n, dim=1),
                       torch.ones(b, n)], dim=1)
-    return pick_place_convdecoder(state, [txt, cf, img], fusion_heads, is_bimanual,
+    return pick_place_convdecoder(state, [txt, cf, img], fusion_heads, is_bimanual, detach_mask=detach_mask,
                                   modalities=[0, 1, 1], attention_masks=mask)
 
 
@@ -373,6 +391,51 @@ def bce_gaussmap(output: Mapping[str, torch.Tensor], sample: Mapping[str, torch.
         cur = bce_mean(output[f"{n}_heatmap"], tgt)
         parts[n] = cur
         total = cur if total is None else total + cur
+    return total, parts
+
+
+def bce_mask(output: Mapping[str, torch.Tensor], sample: Mapping[str, torch.Tensor]):
+    """BCEMask (losses/__init__.py:112-117): mean BCE of the mask head against sample["mask"] [B,1,S,S]."""
+    return bce_mean(output["mask_heatmap"], sample["mask"].squeeze(1)), {}
+
+
+def dice_loss(output: Mapping[str, torch.Tensor], sample: Mapping[str, torch.Tensor]):
+    """DiceLoss (losses/__init__.py:126-136): per sample 1 - (2 sum(p t) + 1) / (sum p + sum t + 1), summed."""
+    p = output["mask_heatmap"].flatten(1)
+    t = sample["mask"].flatten(1)
+    num = 2.0 * (p * t).sum(1)
+    den = p.sum(-1) + t.sum(-1)
+    return (1.0 - (num + 1.0) / (den + 1.0)).sum(), {}
+
+
+def focal_loss(output: Mapping[str, torch.Tensor], sample: Mapping[str, torch.Tensor], alpha: float = 0.25,
+               gamma: float = 2):
+    """FocalLoss (losses/__init__.py:139-155): alpha_t * BCE * (1 - p_t)^gamma per pixel; `.mean(1).sum()` on
+    [B,S,S] = the sum over everything divided by the number of ROWS."""
+    p = output["mask_heatmap"]
+    t = sample["mask"].squeeze(1)
+    ce = F.binary_cross_entropy(p, t, reduction="none")      # the reference's call: its backward is torch's own formula
+    p_t = p * t + (1.0 - p) * (1.0 - t)
+    loss = ce * ((1.0 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * t + (1.0 - alpha) * (1.0 - t)) * loss
+    return loss.mean(1).sum(), {}
+
+
+def composed_loss(output, sample, loss_names: Sequence[str], weights: Sequence[float], is_bimanual: bool,
+                  mask_pick_heatmap: bool = False, **kw):
+    """ComposedLoss (losses/__init__.py:30-51): the weighted sum of named losses; the parts dict carries each loss
+    under its name and its own parts under "name part"."""
+    fns = {"bce_gaussmap": lambda o, s: bce_gaussmap(o, s, is_bimanual, mask_pick_heatmap),
+           "bce_mask": bce_mask, "dice": dice_loss,
+           "focal": lambda o, s: focal_loss(o, s, **{k: v for k, v in kw.items() if k in ("alpha", "gamma")})}
+    total, parts = None, {}
+    for n, w in zip(loss_names, weights):
+        cur, sub = fns[n](output, sample)
+        total = cur * w if total is None else total + cur * w
+        parts[n] = cur
+        for k, v in sub.items():
+            parts[f"{n} {k}"] = v
     return total, parts
 
 

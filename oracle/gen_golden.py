@@ -249,6 +249,117 @@ def tiny_end_to_end(is_bimanual: bool, fname: str, seed: int, patch: int = 16):
     print(f"  wrote {fname}")
 
 
+# --------------------------------------------------------------------------
+def mask_head_fixture(is_bimanual: bool, detach_mask: bool, loss_cfg: dict, fname: str, seed: int):
+    """The reference's RGBOnly with `compute_mask=True` (models/pickplace.py:25-30,66-69,76-119) trained for three
+    steps under one of the reference's own composed losses (conf/loss/composed.yaml, composed_dice_focal.yaml:
+    losses/__init__.py:30-51,112-155) -- and every single loss evaluated on the first step's output."""
+    print(f"== mask head, bimanual={is_bimanual}, detach_mask={detach_mask}, loss={loss_cfg['loss_names']}")
+    mk = dict(TINY_MODEL, is_bimanual=is_bimanual, compute_mask=True, detach_mask=detach_mask)
+    model = build_ref_rgbonly(dict(TINY_CLIP), mk, seed)
+    assert model.pick_place.mask_head is not None
+    state0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    gen = torch.Generator().manual_seed(seed + 7)
+    sample = O.synthetic_sample(3, gen, size=64, vocab=512, is_bimanual=is_bimanual, heat_size=64)
+    # a binary cloth mask [B, 1, S, S] (what the datasets hand over): a thresholded smooth field, one sample all zero
+    field = torch.nn.functional.interpolate(torch.randn(3, 1, 8, 8, generator=gen), size=64, mode="bilinear")
+    sample["mask"] = (field > 0.1).float()
+    sample["mask"][2] = 0.0
+    ref_loss = RefLosses.get_by_name(cfg=Cfg(name="composed", is_bimanual=is_bimanual, **loss_cfg))
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = RefOptimizers.get_by_name(cfg=Cfg(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
+                                    params=params)
+    model.train()
+    rec = {"losses": []}
+    for it in range(3):
+        out = model({k: v.clone() for k, v in sample.items()})
+        loss, parts = ref_loss(out, sample)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            rec["out"] = {k: v.detach().clone() for k, v in out.items() if v is not None}
+            rec["loss"] = loss.detach().clone()
+            rec["parts"] = {k: v.detach().clone() for k, v in parts.items()}
+            rec["grads"] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+            with torch.no_grad():
+                rec["single"] = {n: RefLosses.get_by_name(name=n, is_bimanual=is_bimanual,
+                                                          mask_pick_heatmap=loss_cfg["mask_pick_heatmap"])(out, sample)[0]
+                                 .detach().clone() for n in ("bce_gaussmap", "bce_mask", "dice", "focal")}
+        rec["losses"].append(float(loss))
+        opt.step()
+    rec["params_after"] = {k: p.detach().clone() for k, p in model.named_parameters() if p.requires_grad}
+
+    # the restatement against the run
+    state = {k: v.clone() for k, v in state0.items()}
+    train_keys = [k for k in state if O.is_trainable_key(k)]
+    m = {k: torch.zeros_like(state[k]) for k in train_keys}
+    v = {k: torch.zeros_like(state[k]) for k in train_keys}
+    for it in range(3):
+        for k in train_keys:
+            state[k] = state[k].detach().requires_grad_(True)
+        out = O.rgb_clip_forward(state, sample, mk["heads"], is_bimanual, detach_mask=detach_mask)
+        loss, parts = O.composed_loss(out, sample, is_bimanual=is_bimanual, **loss_cfg)
+        grads = torch.autograd.grad(loss, [state[k] for k in train_keys], allow_unused=True)
+        if it == 0:
+            for k, t in rec["out"].items():
+                check(f"out[{k}]", out[k].detach(), t)
+            check("loss", loss.detach(), rec["loss"], rtol=1e-6)
+            for k, t in rec["parts"].items():
+                check(f"part[{k}]", parts[k].detach(), t, rtol=1e-6)
+            single = {"bce_gaussmap": O.bce_gaussmap(out, sample, is_bimanual, loss_cfg["mask_pick_heatmap"])[0],
+                      "bce_mask": O.bce_mask(out, sample)[0], "dice": O.dice_loss(out, sample)[0],
+                      "focal": O.focal_loss(out, sample)[0]}
+            for k, t in rec["single"].items():
+                check(f"single[{k}]", single[k].detach(), t, rtol=1e-6)
+            for k, g in zip(train_keys, grads):
+                check(f"grad[{k}]", torch.zeros_like(state[k]) if g is None else g, rec["grads"][k], rtol=1e-4, atol=1e-7)
+        assert abs(float(loss) - rec["losses"][it]) <= 1e-5 * abs(rec["losses"][it])
+        with torch.no_grad():
+            for k, g in zip(train_keys, grads):
+                g = torch.zeros_like(state[k]) if g is None else g
+                state[k], m[k], v[k] = O.adam_update(state[k].detach(), g, m[k], v[k], it + 1, 1e-4)
+    # (atol: an element whose gradient is of the size of Adam's eps = 1e-8 moves by lr * g / (|g| + eps) -- fp32 noise
+    # of 1e-9 in such a gradient is 5e-6 of movement at lr = 1e-4; the all-zero mask of sample 2 makes such elements)
+    for k, p_ in rec["params_after"].items():
+        check(f"param3[{k}]", state[k].detach(), p_, rtol=1e-5, atol=2e-5)
+
+    blob = {}
+    for k, t in np_state(state0).items():
+        blob["state/" + k] = t
+    for k, t in sample.items():
+        blob["sample/" + k] = t.numpy()
+    for k, t in rec["out"].items():
+        blob["out/" + k] = t.numpy()
+    blob["loss"] = rec["loss"].numpy()
+    blob["losses3"] = np.array(rec["losses"], dtype=np.float64)
+    for k, t in rec["parts"].items():
+        blob["loss_part/" + k] = t.numpy()
+    for k, t in rec["single"].items():
+        blob["single/" + k] = t.numpy()
+    for k, t in rec["grads"].items():
+        blob["grad/" + k] = t.numpy()
+    for k, t in rec["params_after"].items():
+        blob["param3/" + k] = t.numpy()
+    blob["meta/heads"] = np.array(mk["heads"])
+    blob["meta/is_bimanual"] = np.array(int(is_bimanual))
+    blob["meta/detach_mask"] = np.array(int(detach_mask))
+    blob["meta/loss_names"] = np.array(loss_cfg["loss_names"])
+    blob["meta/weights"] = np.array(loss_cfg["weights"], dtype=np.float64)
+    blob["meta/mask_pick_heatmap"] = np.array(int(loss_cfg["mask_pick_heatmap"]))
+    np.savez_compressed(os.path.join(GOLD, fname), **blob)
+    print(f"  wrote {fname}")
+
+
+MASK_LOSS_DICE_FOCAL = dict(loss_names=["bce_gaussmap", "focal", "dice"], weights=[40, 20, 1], mask_pick_heatmap=True)
+MASK_LOSS_BCE = dict(loss_names=["bce_gaussmap", "bce_mask"], weights=[2, 1], mask_pick_heatmap=True)
+
+
+def mask_head_fixtures():
+    mask_head_fixture(False, False, MASK_LOSS_DICE_FOCAL, "tiny_mask_head.npz", seed=3417)
+    mask_head_fixture(True, True, MASK_LOSS_BCE, "tiny_mask_head_bimanual_detached.npz", seed=3418)
+
+
+
 def masked_fusion_fixture(seed: int):
     """PickPlaceConvDecoder driven the way SiglipSequential drives it
     (models/siglip.py:118-137): three inputs, modalities [0,1,1], a query-row
@@ -740,11 +851,15 @@ def main():
     ap.add_argument("--only-lora", action="store_true")
     ap.add_argument("--only-postproc", action="store_true")
     ap.add_argument("--only-patch14", action="store_true")
+    ap.add_argument("--only-mask-head", action="store_true")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     if args.only_patch14:
         tiny_end_to_end(False, "tiny_patch14.npz", seed=3414, patch=14)
+        return
+    if args.only_mask_head:
+        mask_head_fixtures()
         return
     if args.only_lora:
         siglip_lora_fixture(False, "tiny_siglip_lora.npz", seed=3415)
@@ -764,6 +879,7 @@ def main():
     tiny_end_to_end(True, "tiny_bimanual.npz", seed=3408)
     masked_fusion_fixture(seed=3409)
     per_op_fixture(seed=3410)
+    mask_head_fixtures()
     if not args.skip_full:
         full_size_summary(seed=3407, batch=2)
 

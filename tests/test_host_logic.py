@@ -34,7 +34,7 @@ def test_header_symbols_are_exported_and_bound():
     assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
     for name in declared:
         assert hasattr(L.lib, name)
-    assert L.lib.bf_abi_version() == L.ABI_VERSION == 11
+    assert L.lib.bf_abi_version() == L.ABI_VERSION == 12
 
 
 def test_c_abi_rejects_bad_arguments_before_launching():
@@ -58,6 +58,14 @@ def test_c_abi_rejects_bad_arguments_before_launching():
     sl.rank = 8
     assert L.lib.bf_lora_up(None, None, None, 64, 8, 64, C.byref(sl), 1.0, L.F32, None) == -1 and b"16-bit" in L.lib.bf_last_error()
     assert L.lib.bf_lora_tn_workspace_elems(1000, 768, C.byref(sl)) == 32 * 16 * 768      # 32 chunks of 32 rows
+    # ABI 12: the mask head's product and the mask losses
+    assert L.lib.bf_mask_mul_fwd(None, None, None, 2, 6, None) == -1 and b"multiple of 4" in L.lib.bf_last_error()
+    assert L.lib.bf_mask_mul_bwd(None, None, None, None, None, None, 5, 8, 0, None) == -1 and b"heads" in L.lib.bf_last_error()
+    assert L.lib.bf_rows_accumulate(None, 0, None, L.BF16, 0, 1, 8, None) == -1 and b"fp32 or fp16" in L.lib.bf_last_error()
+    assert L.lib.bf_dice_fwd(None, None, None, None, 0, 64, None) == -1
+    assert L.lib.bf_dice_bwd(None, None, None, None, 2, 6, None) == -1
+    assert L.lib.bf_focal_fwd(None, None, None, None, 64, 2000, 1.0, 0.25, 2.0, None) == -1
+    assert L.lib.bf_focal_bwd(None, None, None, None, 6, 1.0, 0.25, 2.0, None) == -1 and b"multiple of 4" in L.lib.bf_last_error()
     g2 = L.GemmArgs()
     g2.m, g2.n, g2.k, g2.lda, g2.ldb, g2.ldc, g2.cdt, g2.c_dtype, g2.lr_k = 65536, 2304, 768, 768, 768, 2304, L.F16, L.F16, 8
     assert L.lib.bf_gemm_lowrank_ok(C.byref(g2)) == 0 and L.lib.bf_gemm_lowrank_ok(None) == 0      # lr_k must be 16 or 32
@@ -114,6 +122,16 @@ def test_factories_and_error_behaviour():
         Models.get_by_name(tiny_cfg(dropout=1.0), device=torch.device("cpu"))
     loss = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=True, mask_pick_heatmap=False))
     assert loss.heads() == ["left_pick", "left_place", "right_pick", "right_place"]
+    # round 6: the mask head and its losses (conf/loss/bce_mask.yaml, composed.yaml, composed_dice_focal.yaml)
+    comp = Losses.get_by_name(cfg=dict(name="composed", loss_names=["bce_gaussmap", "focal", "dice"], weights=[40, 20, 1],
+                                       is_bimanual=False, mask_pick_heatmap=True))
+    assert list(comp.loss_dict) == ["bce_gaussmap", "focal", "dice"] and comp.weights["focal"] == 20
+    assert comp.loss_dict["focal"].alpha == 0.25 and comp.loss_dict["focal"].gamma == 2
+    assert comp.loss_dict["bce_gaussmap"].mask_pick_heatmap is True
+    mm = Models.get_by_name(tiny_cfg(compute_mask=True, detach_mask=True), device=torch.device("cpu"))
+    keys = [n for n, _ in mm.named_parameters() if n.startswith("pick_place.") and "fusion" not in n]
+    assert keys[0] == "pick_place.mask_head.decoder_net.0.weight" and keys[10] == "pick_place.pick_decoder.decoder_net.0.weight"
+    assert mm.pick_place.has_mask and mm.pick_place.detach_mask and mm.pick_place.decoders_all == ["pick", "place", "mask"]
 
 
 @pytest.mark.parametrize("fixture,bim", [("tiny_unimanual.npz", False), ("tiny_bimanual.npz", True)])
@@ -254,6 +272,13 @@ def test_layer_buckets_tile_the_arena():
     covered = sorted(b)
     assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(4)) and covered[-1][1] == off
     assert b[1] == (offsets[names[6]][0], b[0][0])             # layer 2 comes right after the decoders
+    # the mask head (compute_mask=True) is registered BETWEEN the fusion layers and the heads, like the reference's, and its
+    # gradient is written with the heads': it rides in the decoders' bucket
+    names3, offsets3, off3 = names[:-1], {k: v for k, v in offsets.items() if k != names[-1]}, offsets[names[-1]][0]
+    for n, cnt in (("pick_place.mask_head.decoder_net.0.weight", 500), ("pick_place.pick_decoder.decoder_net.0.weight", 500)):
+        names3.append(n); offsets3[n] = (off3, cnt); off3 += (cnt + 63) // 64 * 64
+    b3 = layer_buckets(names3, offsets3, 3, off3)
+    assert len(b3) == 5 and b3[0] == (offsets3["pick_place.mask_head.decoder_net.0.weight"][0], off3)
 
 
 @pytest.mark.parametrize("name,fixture,extra", [("siglip", "tiny_siglip.npz", {}),

@@ -1368,3 +1368,79 @@ def test_gemm_low_rank_addend_rides_in_the_persistent_kernel(ops, gpu, cdt, m, n
         ops.gemm(a[:4096], b, bias=bias, lr_u=u[:4096].contiguous(), lr_w=wl)
     with pytest.raises(RuntimeError):
         ops.gemm(a, b, bias=bias, lr_u=u, lr_w=wl, out_dtype=torch.float32)
+
+
+# ---- the mask head's product and the mask losses (csrc/decoder.hip, ABI 12) ---------------------------------------------
+@pytest.mark.parametrize("heads,detach,with_dmask,skip_head", [(1, False, True, False), (2, False, False, False),
+                                                               (2, True, True, False), (2, False, True, True)])
+def test_mask_mul_fwd_bwd(ops, gpu, heads, detach, with_dmask, skip_head):
+    """out[h] = s[h] * m and its backward against autograd (models/pickplace.py:76-98,107-119: the pick heatmaps times
+    the mask heatmap, detached or not; a head the loss ignores hands None)."""
+    g = torch.Generator().manual_seed(heads * 7 + detach)
+    B, S = 3, 32
+    s = torch.rand(heads, B, S, S, generator=g).requires_grad_(True)
+    m = torch.rand(B, S, S, generator=g).requires_grad_(True)
+    out = s * (m.detach() if detach else m)
+    got = ops.mask_mul_fwd(s.detach().to(gpu), m.detach().to(gpu))
+    assert torch.equal(got.cpu(), out.detach())
+    d_out = torch.randn(heads, B, S, S, generator=g)
+    d_mask_in = torch.randn(B, S, S, generator=g) if with_dmask else None
+    if skip_head:
+        d_out[1] = 0.0
+    total = (out * d_out).sum() + ((m * d_mask_in).sum() if with_dmask else 0.0)
+    total.backward()
+    d_list = [None if (skip_head and h == 1) else d_out[h].to(gpu) for h in range(heads)]
+    d_s, d_m = ops.mask_mul_bwd(d_list, s.detach().to(gpu), m.detach().to(gpu),
+                                d_mask_in.to(gpu) if with_dmask else None, detach)
+    assert rel_err(d_s, s.grad) < 1e-6
+    ref_dm = m.grad if m.grad is not None else torch.zeros_like(m)
+    assert (d_m.cpu() - ref_dm).abs().max().item() <= 1e-6 * max(1.0, ref_dm.abs().max().item())
+    with pytest.raises(RuntimeError, match="heads"):
+        ops.mask_mul_bwd([None] * (heads + 1), s.detach().to(gpu), m.detach().to(gpu), None, detach)
+
+
+@pytest.mark.parametrize("dst_dtype", [torch.float32, torch.float16])
+def test_rows_accumulate(ops, gpu, dst_dtype):
+    g = torch.Generator().manual_seed(5)
+    B, seq, n, D = 3, 11, 5, 64
+    src = torch.randn(B, n, D, generator=g)
+    dst = torch.randn(B, seq, D, generator=g).to(dst_dtype)
+    ref = dst.float().clone()
+    ref[:, seq - n:] += src
+    d = dst.to(gpu)
+    ops.rows_accumulate(src.to(gpu), d[:, seq - n:])
+    assert torch.equal(d[:, :seq - n].cpu(), dst[:, :seq - n])
+    assert rel_err(d.float(), ref.to(dst_dtype).float()) < (1e-7 if dst_dtype == torch.float32 else 1e-3)
+    with pytest.raises(RuntimeError, match="contiguous"):       # rows two elements apart
+        ops.rows_accumulate(src.to(gpu), d.as_strided((B, n, D), (seq * D, 2 * D, 1)))
+
+
+@pytest.mark.parametrize("B,S", [(3, 64), (5, 224)])
+def test_dice_and_focal_losses(ops, gpu, B, S):
+    """bf_dice_* / bf_focal_* against the reference's formulas under autograd (losses/__init__.py:126-155), with the
+    probabilities at the edges torch's BCE clamps (p = 0, p = 1), an empty mask, and other alpha / gamma than the defaults."""
+    from oracle import bifold_oracle as O
+    g = torch.Generator().manual_seed(B * S)
+    p = torch.rand(B, S, S, generator=g)
+    p[0, 0, :4] = torch.tensor([0.0, 1.0, 1e-30, 1.0 - 1e-7])
+    t = (torch.rand(B, 1, S, S, generator=g) > 0.6).float()
+    t[1] = 0.0
+    pl = p.clone().requires_grad_(True)
+    ref, _ = O.dice_loss({"mask_heatmap": pl}, {"mask": t})
+    ref.backward()
+    loss, stats = ops.dice_fwd(p.flatten(1).to(gpu), t.flatten(1).to(gpu))
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    gs = torch.full((1,), 0.5, device=gpu)
+    d = ops.dice_bwd(p.flatten(1).to(gpu), t.flatten(1).to(gpu), stats, gs)
+    assert rel_err(d.view(B, S, S), 0.5 * pl.grad) < 1e-5
+    for alpha, gamma in ((0.25, 2.0), (-1.0, 2.0), (0.6, 1.5), (0.25, 0.0), (0.25, 1.0)):
+        pl = p.clone().requires_grad_(True)
+        ref, _ = O.focal_loss({"mask_heatmap": pl}, {"mask": t}, alpha=alpha, gamma=gamma)
+        ref.backward()
+        got = ops.focal_fwd(p.to(gpu), t.squeeze(1).to(gpu), alpha, gamma)
+        assert abs(got.item() - ref.item()) < 2e-5 * abs(ref.item()), (alpha, gamma)
+        d = ops.focal_bwd(p.to(gpu), t.squeeze(1).contiguous().to(gpu), gs, alpha, gamma)
+        want = 0.5 * pl.grad
+        finite = torch.isfinite(want)
+        # (at p = 0 with t = 1 torch's own chain 0 * inf is nan for gamma < 1; everywhere else the values agree)
+        assert rel_err(torch.where(finite, d.cpu(), torch.zeros_like(want)), torch.where(finite, want, torch.zeros_like(want))) < 2e-5, (alpha, gamma)

@@ -14,7 +14,7 @@ def load(golden_dir, name):
     groups = {}
     for k in z.files:
         head, _, rest = k.partition("/")
-        groups.setdefault(head, {})[rest] = torch.from_numpy(z[k])
+        groups.setdefault(head, {})[rest] = z[k] if z[k].dtype.kind in "US" else torch.from_numpy(z[k])
     return groups
 
 
@@ -59,6 +59,37 @@ def test_end_to_end_step_matches_reference(golden_dir, fixture):
     assert np.allclose(losses, fx["losses3"][""].numpy(), rtol=1e-5)
     for k, ref in fx["param3"].items():
         assert close(state[k].detach(), ref, rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.parametrize("fixture", ["tiny_mask_head.npz", "tiny_mask_head_bimanual_detached.npz"])
+def test_mask_head_and_mask_losses_match_reference(golden_dir, fixture):
+    """compute_mask=True (models/pickplace.py:25-30,66-119) under the reference's composed losses and each of
+    bce_gaussmap / bce_mask / dice / focal on its own (losses/__init__.py:30-51,112-155): runs of the reference."""
+    fx = load(golden_dir, fixture)
+    meta = fx["meta"]
+    bim, detach = bool(int(meta["is_bimanual"])), bool(int(meta["detach_mask"]))
+    names = [str(n) for n in meta["loss_names"]]
+    cfg = dict(loss_names=names, weights=[float(w) for w in meta["weights"]], mask_pick_heatmap=bool(int(meta["mask_pick_heatmap"])))
+    state, sample = dict(fx["state"]), fx["sample"]
+    keys = [k for k in state if O.is_trainable_key(k)]
+    assert set(keys) == set(fx["grad"]) and any("mask_head" in k for k in keys)
+    for k in keys:
+        state[k] = state[k].detach().requires_grad_(True)
+    out = O.rgb_clip_forward(state, sample, int(meta["heads"]), bim, detach_mask=detach)
+    loss, parts = O.composed_loss(out, sample, is_bimanual=bim, **cfg)
+    grads = torch.autograd.grad(loss, [state[k] for k in keys], allow_unused=True)
+    for k, ref in fx["out"].items():
+        assert close(out[k].detach(), ref), k
+    assert close(loss.detach(), fx["loss"][""], rtol=1e-6)
+    assert set(parts) == set(fx["loss_part"])
+    for k, ref in fx["loss_part"].items():
+        assert close(parts[k].detach(), ref, rtol=1e-6), k
+    single = {"bce_gaussmap": O.bce_gaussmap(out, sample, bim, cfg["mask_pick_heatmap"])[0], "bce_mask": O.bce_mask(out, sample)[0],
+              "dice": O.dice_loss(out, sample)[0], "focal": O.focal_loss(out, sample)[0]}
+    for k, ref in fx["single"].items():
+        assert close(single[k].detach(), ref, rtol=1e-6), k
+    for k, g in zip(keys, grads):
+        assert close(torch.zeros_like(state[k]) if g is None else g, fx["grad"][k], rtol=1e-4, atol=1e-7), k
 
 
 def test_masked_three_input_fusion_matches_reference(golden_dir):

@@ -293,6 +293,41 @@ def test_masked_three_input_component_call_matches_reference(gpu, golden_dir, ob
     assert attn is None and feats.shape == (2, 10, 96)
 
 
+@pytest.mark.parametrize("detach", [False, True])
+def test_standalone_component_with_the_mask_head_matches_the_oracle(gpu, observed, detach):
+    """Components.get_by_name("pick_place_convdecoder", compute_mask=True) called on its own (models/pickplace.py:59-124):
+    outputs, the gradients of both inputs and of every parameter -- the mask head's token gradient reaches the last input
+    AND the type embedding the fusion model added to it in place (models/fusion.py:52) -- against the pinned restatement
+    under autograd.  fp32 mode."""
+    from oracle import bifold_oracle as O
+    from bifold.models import Components
+    torch.manual_seed(11 + detach)
+    pp = Components.get_by_name("pick_place_convdecoder", dim=96, is_bimanual=True, fusion_model="concat_transformer",
+                                num_patches=9, patch_size=16, heads=4, depth=2, dropout=0.0, mlp_ratio=4,
+                                compute_mask=True, detach_mask=detach)
+    state = {"pick_place." + k: v.detach().clone().requires_grad_(True) for k, v in pp.state_dict().items()}
+    pp = pp.to(gpu)
+    pp.fusion.compute_dtype = torch.float32
+    g = torch.Generator().manual_seed(3)
+    cpu_ins = [torch.randn(2, 5, 96, generator=g).requires_grad_(True), torch.randn(2, 10, 96, generator=g).requires_grad_(True)]
+    ins = [t.detach().to(gpu).requires_grad_(True) for t in cpu_ins]
+    out = pp(*[t.clone() for t in ins])
+    ref = O.pick_place_convdecoder(state, cpu_ins, heads=4, is_bimanual=True, detach_mask=detach)
+    keys = [k for k in ref if ref[k] is not None]
+    assert set(keys) == {k for k in out if out[k] is not None} and "mask_heatmap" in keys
+    worst = max(rel(out[k], ref[k].detach()) for k in keys)
+    assert worst < 1e-4
+    wts = {k: torch.randn(ref[k].shape, generator=g) for k in keys}
+    sum((ref[k] * wts[k]).sum() for k in keys).backward()
+    sum((out[k] * wts[k].to(gpu)).sum() for k in keys).backward()
+    seen = dict(out=worst, d_in=max(rel(a.grad, b.grad) for a, b in zip(ins, cpu_ins)))
+    named = dict(pp.named_parameters())
+    seen["d_param"] = max(rel(named[k[len("pick_place."):]].grad, v.grad) for k, v in state.items())
+    observed(f"standalone_mask_head_detach{int(detach)}", **seen)
+    assert seen["d_in"] < 2e-4 and seen["d_param"] < 2e-4
+    assert rel(named["fusion.token_type_embeddings.weight"].grad, state["pick_place.fusion.token_type_embeddings.weight"].grad) < 2e-4
+
+
 def _fusion_stack_both_ways(gpu, knob, cdt):
     """Outputs and every gradient of a 3-block, 256-wide fusion stack with pickplace.<knob> = 0 and = 1."""
     from bifold.models import Components
