@@ -91,24 +91,36 @@ class _WeightGradSide:
             for dy, x, _ in todo:
                 self.held += [dy, x]
 
-    def ready(self):
-        """Event on the main stream: everything queued so far (the operands of the next dW GEMM) is produced."""
+    def prepare(self, rows: int, dtype) -> None:
+        """Decide once per backward whether the grouped launch takes this token count (every layer has the same)."""
+        if self.group is not None and self.qualifies is None:
+            self.qualifies = ops.gemm_tn_grouped_qualifies(rows, dtype)
+            if not self.qualifies:
+                self.group = None
+
+    def ready(self, last: bool = False):
+        """Event on the main stream: everything queued so far (the operands of the next dW GEMM) is produced.
+        A layer whose dW GEMMs leave as ONE grouped launch needs only the event behind the LAST operand (`last`): an
+        event record between two dependent kernels is a 7 us bubble on the main stream (profiles/r06_step_gaps.txt:
+        three of the four records of a layer were never waited for), so the others are not recorded.  (The device's idle
+        time in the backward fell from 255 to 117 us per step and the step did not move -- 7 926 vs 7 925 samples/s over
+        four interleaved pairs: the part is at its power cap, an idle gap is not lost time.)"""
         if not self.on:
+            return None
+        if self.group is not None and self.qualifies and not last:
             return None
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         return ev
 
     def gemm(self, dy, x, out, after=None):
-        if self.group is not None and self.qualifies is None:
-            # decided once per backward (every layer has the same token count): a layer whose weight gradients the
-            # grouped launch would refuse (few tokens, an odd count) keeps the per-GEMM issue order and lifetimes
-            self.qualifies = ops.gemm_tn_grouped_qualifies(dy.shape[0], dy.dtype)
-            if not self.qualifies:
-                self.group = None
+        # decided once per backward (every layer has the same token count): a layer whose weight gradients the
+        # grouped launch would refuse (few tokens, an odd count) keeps the per-GEMM issue order and lifetimes
+        self.prepare(dy.shape[0], dy.dtype)
         if self.group is not None and dy.dtype in ops.HALF:
             self.group.append((dy, x, out))
-            self.group_after = after
+            if after is not None:
+                self.group_after = after
             return
         if not self.on:
             ops.gemm(dy, x, trans_a=True, b_kn=True, out=out)
@@ -420,6 +432,7 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
         wg.on, wg.side, wg.group, wg.group_after, wg.qualifies, wg.held, wg.marked = False, None, None, None, None, [], []
     g = A.grad_view
     op3 = dx3_c if dx3_c is not None else dx3
+    wg.prepare(op3.shape[0], op3.dtype)
     drop = S.get("drop")
     pd, sd = drop if drop is not None else (0.0, {})
     if drop is not None:
@@ -462,7 +475,7 @@ def fusion_layer_bwd(dx3, dx3_c, S, P, A: ParamArena, cdt, batch, seq, heads, ma
         wg.gemm(op2, S["o"], g(P["wo"]), e2)
     dqkv = ops.attention_bwd(S["qkv"], S["o"], do, S["lse"], batch, seq, heads, d, d ** -0.5, mask_mode, row_mask,
                              dropout=pd, seed=sd.get("attn", 0))
-    e_qkv = wg.ready()
+    e_qkv = wg.ready(last=True)
     if not _DW_ORDER:
         wg.gemm(dqkv, S["h1"], g(P["wqkv"]), e_qkv)
     dh1 = ops.gemm(dqkv, A.operand(P["wqkv"], cdt), b_kn=True)

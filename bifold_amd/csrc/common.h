@@ -39,6 +39,21 @@ void bf_set_error(int hip_code, const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// Zero `n` floats in stream order with a kernel of this library instead of hipMemsetAsync: the runtime's fill leaves the
+// device idle for ~12 us between the two kernels it sits between (profiles/r06_step_gaps.txt: eight of them on the
+// backward's dependent chain); an ordinary launch does not.  (A template so that every translation unit may hold it.)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void bf_zero_f32_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+static inline hipError_t bf_zero_f32_async(float* p, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(bf_zero_f32_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+    return hipGetLastError();
+}
+
 static inline bool bf_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int bf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t bf_dtype_size(int dt) { return (dt == BF_BF16 || dt == BF_F16) ? 2 : 4; }

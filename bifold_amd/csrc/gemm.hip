@@ -2869,8 +2869,8 @@ static int gemm_impl(const bf_gemm_args* g, bf_stream_t stream, int force_varian
             // column sums fused into the bf16 GELU-grad epilogue (same predicate as the kernel's `fastgrad`)
             if (g->colsum_out && !slabs && !f32out && (g->act == BF_ACT_ERF_GELU_GRAD || g->act == BF_ACT_MUL_AUX) && !g->bias && !g->residual &&
                 !g->c2 && !g->pre && !g->accumulate && g->rows_in == 0) {   // == the EPI 2 instantiation below
-                BF_REQUIRE(hipMemsetAsync(g->colsum_out, 0, (size_t)g->n * sizeof(float), s) == hipSuccess, BF_ELAUNCH,
-                           "bf_gemm: memset of colsum_out failed");
+                BF_REQUIRE(bf_zero_f32_async(g->colsum_out, (size_t)g->n, s) == hipSuccess, BF_ELAUNCH,
+                           "bf_gemm: zeroing colsum_out failed");
                 ep.colsum = g->colsum_out;
                 colsum_fused = true;
             }

@@ -648,8 +648,8 @@ extern "C" int bf_colsum(const void* x, int x_dtype, float* out, int rows, int c
     BF_REQUIRE(bf_aligned16(x) && bf_aligned16(out), BF_EALIGN, "bf_colsum: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), s);
-        BF_REQUIRE(e == hipSuccess, BF_ELAUNCH, "bf_colsum: memset failed");
+        hipError_t e = bf_zero_f32_async(out, (size_t)cols, s);
+        BF_REQUIRE(e == hipSuccess, BF_ELAUNCH, "bf_colsum: zeroing the sums failed");
     }
     const int col_tiles = bf_cdiv(cols, 256);
     int row_chunks = bf_cdiv(2048, col_tiles);
@@ -1192,9 +1192,9 @@ extern "C" int bf_fusion_assemble_bwd(const void* dx, int dx_dtype, void* d_rgb_
                    bf_aligned16(d_rgb_pos), BF_EALIGN, "bf_fusion_assemble_bwd: unaligned pointer");
     hipStream_t s = (hipStream_t)stream;
     const int L = 1 + n_text + n_rgb;
-    BF_REQUIRE(hipMemsetAsync(d_text_pos, 0, (size_t)(1 + n_text) * dim * sizeof(float), s) == hipSuccess &&
-                   hipMemsetAsync(d_rgb_pos, 0, (size_t)n_rgb * dim * sizeof(float), s) == hipSuccess,
-               BF_ELAUNCH, "bf_fusion_assemble_bwd: memset failed");
+    BF_REQUIRE(bf_zero_f32_async(d_text_pos, (size_t)(1 + n_text) * dim, s) == hipSuccess &&
+                   bf_zero_f32_async(d_rgb_pos, (size_t)n_rgb * dim, s) == hipSuccess,
+               BF_ELAUNCH, "bf_fusion_assemble_bwd: zeroing the position gradients failed");
     int chunks = batch >= 64 ? 16 : (batch >= 8 ? 4 : 1);
     const int per_chunk = bf_cdiv(batch, chunks);
     chunks = bf_cdiv(batch, per_chunk);

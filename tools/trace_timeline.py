@@ -107,6 +107,15 @@ def main(path, skip=2, steps=2):
     print(f"# device idle gaps: {len(gaps) / steps:.0f} per step, total {sum(g[0] for g in gaps) / 1e6 / steps:.3f} ms/step; largest:")
     for g, a, b in gaps[:25]:
         print(f"#   {g / 1e3:8.1f} us  after {short(a)[:50]:<50} before {short(b)[:50]}")
+    # the same gaps by the pair of kernels on either side
+    pairs = defaultdict(lambda: [0, 0])
+    for g, a, b in gaps:
+        k = (short(a)[:44], short(b)[:44])
+        pairs[k][0] += g
+        pairs[k][1] += 1
+    print("# idle gaps by (kernel before, kernel after): us/step, count/step")
+    for (a, b), (g, c) in sorted(pairs.items(), key=lambda kv: -kv[1][0])[:30]:
+        print(f"#   {g / 1e3 / steps:8.1f} {c / steps:5.1f}  {a:<44} -> {b}")
 
 
 if __name__ == "__main__":
