@@ -12,7 +12,8 @@ slice is reported to the gradient-ready hooks (data-parallel all-reduce, clippin
 shows a scaled value to them (with no hook registered -- one process -- the whole arena is un-scaled in one pass at
 the end of the backward).  S is a power of two (no rounding of its own); it starts at 64 x (elements of one head's
 heatmaps) rounded up: measured on config A's gradients that puts the largest 16-bit gradient element at ~1e2 and the
-1 % quantile at ~6e-3 (binary16: max 65 504, smallest normal 6e-5).  `loss_scale: <number>` overrides the start.
+1 % quantile at ~6e-3 (binary16: max 65 504, smallest normal 6e-5) -- or lower, where the first backward's largest logit
+gradient says so (sum-type / weighted losses on the mask head: dice, focal, composed).  `loss_scale: <number>` overrides the start.
 
 Round 4: S and the step's fate live ON THE DEVICE (`state`, `nonfinite`), nothing is read back per step:
   * bf_scale_check counts the non-finite results of the un-scaling in `nonfinite` (under data parallelism the
@@ -77,12 +78,56 @@ class DynamicGradScale:
             arena.grad_scaler = self                       # where FusedAdam.step finds the guard
         return arena
 
-    def _init_state(self, d_heats) -> None:
+    @staticmethod
+    def _peak_logit_gradient(d_heats, saved) -> Optional[float]:
+        """max |d loss / d logit| over every decoder of the first backward (the quantity the scale multiplies): for a plain
+        head d_heat * p (1 - p); with the mask head (models/pickplace.py:76-98) the pick heads' d_out * mask * s (1 - s) and
+        the mask's own (d_mask + sum d_out * s) * m (1 - m).  Torch glue, ONE host read, first backward of a run only."""
+        if not saved or saved.get("heat") is None:
+            return None
+        heat, extra = saved["heat"], saved.get("extra")
+        nh = heat.shape[0]
+        n_pick = nh // 2
+        peak = heat.new_zeros(())
+        d_mask = None
+        for h in range(nh):
+            d = d_heats[h] if h < len(d_heats) else None
+            if d is None:
+                continue
+            s = heat[h]
+            if extra is not None and h < n_pick:
+                d_mask = d * s if d_mask is None else d_mask + d * s
+                d = d * extra["mask"]
+            peak = torch.maximum(peak, (d * s * (1.0 - s)).abs().max())
+        if extra is not None:
+            m = extra["mask"]
+            d_in = d_heats[nh] if len(d_heats) > nh else None
+            if d_mask is None or saved.get("detach_mask"):
+                d_mask = d_in
+            elif d_in is not None:
+                d_mask = d_mask + d_in
+            if d_mask is not None:
+                peak = torch.maximum(peak, (d_mask * m * (1.0 - m)).abs().max())
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            t = peak.detach().reshape(1).clone()
+            if torch.distributed.get_backend() == "gloo":
+                t = t.cpu()
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)     # every rank starts at the same scale
+            return float(t.item())
+        return float(peak.item())
+
+    def _init_state(self, d_heats, saved=None) -> None:
         if self.setting is not None:
             s0 = self.setting
         else:
             n = max((t.numel() for t in d_heats if t is not None), default=1)
             s0 = 2.0 ** (math.ceil(math.log2(max(n, 1))) + 6)
+            # 64 x elements is sized for nn.BCELoss's mean (logit gradients <= 1 / elements).  A loss that is a SUM, or
+            # weighted (dice / focal / composed on the mask head), has larger ones: start where the largest scaled
+            # logit gradient is ~64, like the BCE case -- never above the BCE start, which stays what it was
+            peak = self._peak_logit_gradient(d_heats, saved)
+            if peak is not None and math.isfinite(peak) and peak > 0.0:
+                s0 = max(min(s0, 2.0 ** math.ceil(math.log2(64.0 / peak))), self.min_scale)
         self.start_scale = float(s0)
         st = torch.zeros(8, dtype=torch.float32)
         st[_S], st[_INV] = s0, 1.0 / s0
@@ -94,8 +139,9 @@ class DynamicGradScale:
         return float(self.state[_S].item()) if self.state is not None else 1.0
 
     # ------------------------------------------------------------------ the backward's two ends
-    def begin(self, d_heats) -> torch.Tensor:
-        """Called at the top of the tail's backward; returns S as a device scalar."""
+    def begin(self, d_heats, saved=None) -> torch.Tensor:
+        """Called at the top of the tail's backward (`saved`: what fusion_decoder_fwd kept -- the heads' sigmoids, the
+        mask head's -- for the start of the scale); returns S as a device scalar."""
         arena = self._plan()
         if self.state is None:
             # a checkpoint loaded before the scaler existed left its scale on the arena (FusedAdam.load_state_dict): the
@@ -107,7 +153,7 @@ class DynamicGradScale:
                 self.load_state_dict(pending)
                 arena.pending_grad_scaler_sd = None
             else:
-                self._init_state(d_heats)
+                self._init_state(d_heats, saved)
         return self.state[_S:_S + 1]
 
     def ready(self, layer: int) -> None:

@@ -670,7 +670,8 @@ def fusion_decoder_fwd(pp: "PickPlaceConvDecoder", A: ParamArena, cdt, x, batch:
     saved = None
     if save:
         saved = dict(layers=layers, x_out=x, w_eff=w_eff, rows_ws=rows_ws, heat=heat, batch=batch, seq=seq,
-                     mask_mode=mask_mode, row_mask=row_mask, extra=extra, x_in=x_in if pp.has_mask else None)
+                     mask_mode=mask_mode, row_mask=row_mask, extra=extra, x_in=x_in if pp.has_mask else None,
+                     detach_mask=pp.detach_mask)
     return decoder_outputs(pp, heat, extra), saved
 
 
@@ -882,7 +883,7 @@ class RGBTailFn(torch.autograd.Function):
         dim = pp.dim
         gs = scaler_of(model)                                  # fp16: loss scale (models/gradscale.py)
         ready = gs.ready if gs is not None else model._grad_ready
-        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else None)
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats, c.saved) if gs is not None else None)
         g_type = g(pp.fusion.token_type_embeddings.weight)
         type_true = None
         if c.emb_drop is not None:
@@ -961,7 +962,7 @@ class SegmentTailFn(torch.autograd.Function):
         dim = pp.dim
         gs = scaler_of(model)                                  # fp16: loss scale (models/gradscale.py)
         ready = gs.ready if gs is not None else model._grad_ready
-        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats) if gs is not None else None)
+        dx = fusion_decoder_bwd(pp, A, cdt, c.saved, d_heats, ready, gs.begin(d_heats, c.saved) if gs is not None else None)
         if dx.dtype != torch.float32:                          # fp16 mode's 16-bit gradient stream: the segment kernels
             dx = ops.cast(dx, torch.float32)                   # and the towers' backward take fp32
         d_type = g(pp.fusion.token_type_embeddings.weight)
