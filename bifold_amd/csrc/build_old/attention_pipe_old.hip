@@ -767,17 +767,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv_pipe_kernel(
     };
     // p = exp2(S' c), dS = p dP', both packed for the products above
     auto v_phase = [&](const f32x16& sX, const f32x16& pX, x8 (&pp)[2], x8 (&ds)[2]) __attribute__((always_inline)) {
-        // the two multiplies per score as packed fp32 pairs (v_pk_mul_f32: two elements per issue slot; same products)
-        const f32x2 sl22 = {sl2, sl2};
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const f32x2 t = (f32x2){sX[8 * u + e], sX[8 * u + e + 1]} * sl22;
-                const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                const f32x2 d = p * (f32x2){pX[8 * u + e], pX[8 * u + e + 1]};
-                pp[u][e] = (HT)p[0]; pp[u][e + 1] = (HT)p[1];
-                ds[u][e] = (HT)d[0]; ds[u][e + 1] = (HT)d[1];
+            for (int e = 0; e < 8; ++e) {
+                const float p = __builtin_amdgcn_exp2f(sX[8 * u + e] * sl2);
+                pp[u][e] = (HT)p;
+                ds[u][e] = (HT)(p * pX[8 * u + e]);
             }
     };
 
@@ -1076,16 +1072,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_q_pipe_kernel(
             }
     };
     auto v_phase = [&](const f32x16& sX, const f32x16& pX, float cl, x8 (&ds)[2]) __attribute__((always_inline)) {
-        // the FMA of the exponent and the product with dP as packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32: same values)
-        const f32x2 sl22 = {sl2, sl2}, cl2 = {cl, cl};
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const f32x2 t = __builtin_elementwise_fma((f32x2){sX[8 * u + e], sX[8 * u + e + 1]}, sl22, cl2);
-                const f32x2 p = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
-                const f32x2 d = p * (f32x2){pX[8 * u + e], pX[8 * u + e + 1]};
-                ds[u][e] = (HT)d[0]; ds[u][e + 1] = (HT)d[1];
+            for (int e = 0; e < 8; ++e) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sX[8 * u + e], sl2, cl));
+                ds[u][e] = (HT)(p * pX[8 * u + e]);
             }
     };
 
