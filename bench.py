@@ -298,6 +298,10 @@ def main():
     ap.add_argument("--lora-recompute", default="none", choices=["none", "mlp", "full"],
                     help="siglip_seq --lora: what the towers' backward re-makes instead of keeping (none 198 samples/s at "
                          "181 GiB, mlp 190 at 147 GiB, full 179 at 109 GiB; B = 128)")
+    ap.add_argument("--mask-head", action="store_true",
+                    help="diagnostic (configs a / vitl14): PickPlaceConvDecoder(compute_mask=True) under the reference's "
+                         "conf/loss/composed_dice_focal.yaml (bce_gaussmap x 40 with mask_pick_heatmap, focal x 20, dice x 1) "
+                         "and a synthetic binary cloth mask in the sample; never the headline")
     ap.add_argument("--no-parity", action="store_true", help="skip the 4-sample oracle check of the timed batch")
     args = ap.parse_args()
 
@@ -342,11 +346,19 @@ def main():
                        text_encoder=None, pick_place_model="pick_place_convdecoder", fusion_model="concat_transformer",
                        depth=8, heads=16, mlp_ratio=4, dropout=0.0, dtype=dtype, context_length=4,
                        lora_recompute=args.lora_recompute)
+        if args.mask_head:
+            if seq or fp8:
+                raise SystemExit("--mask-head goes with --config a / vitl14")
+            cfg.update(compute_mask=True, detach_mask=False)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")       # random-init CLIP (no network for weights)
             mdl = Models.get_by_name(cfg, device=dev).to(dev)
         mdl.train()
-        lfn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=seq, mask_pick_heatmap=False))
+        if args.mask_head:                        # ref:bifold/conf/loss/composed_dice_focal.yaml
+            lfn = Losses.get_by_name(cfg=dict(name="composed", loss_names=["bce_gaussmap", "focal", "dice"],
+                                              weights=[40, 20, 1], is_bimanual=False, mask_pick_heatmap=True))
+        else:
+            lfn = Losses.get_by_name(cfg=dict(name="bce_gaussmap", is_bimanual=seq, mask_pick_heatmap=False))
         optim = Optimizers.get_by_name(cfg=dict(name="adam", lr=1e-4, betas=[0.9, 0.999], eps=1e-8, weight_decay=0),
                                        params=[p for p in mdl.parameters() if p.requires_grad])
         return mdl, lfn, optim
@@ -357,6 +369,12 @@ def main():
     else:
         sample = synthetic_batch(args.batch, dev, seed=3407 + rank, size=336 if big else 224,
                                  heat_size=384 if big else 0)
+        if args.mask_head:                        # a binary cloth mask [B, 1, S, S]: a thresholded smooth field
+            hs = 384 if big else 224
+            gm = torch.Generator(device=dev).manual_seed(4001 + rank)
+            field = torch.nn.functional.interpolate(torch.randn(args.batch, 1, 7, 7, generator=gm, device=dev), size=hs,
+                                                    mode="bilinear")
+            sample["mask"] = (field > 0.0).float().contiguous()
 
     sync = None
     if world > 1 or os.environ.get("BIFOLD_FORCE_PG") == "1":
@@ -539,7 +557,10 @@ def main():
                                     if fp8 else
                                     "BASELINE configs[1]: rgb_clip ViT-B/16@224 + CLIP text (77 tok, 32 real) + "
                                     "fusion 8x512 (16 heads) + 2 conv decoders, BCE, Adam; frozen encoders; "
-                                    "random-init weights"), "per_gpu_batch": args.batch,
+                                    "random-init weights") +
+                                   ("; DIAGNOSTIC --mask-head: compute_mask=True, composed loss bce_gaussmap x 40 "
+                                    "(mask_pick_heatmap) + focal x 20 + dice x 1" if args.mask_head else ""),
+                       "per_gpu_batch": args.batch,
                        "global_batch": global_batch, "parallelism": f"dp{world}", "final_loss": final_loss,
                        "collective": (f"RCCL all-reduce(AVG) of the gradient arena over {torch.distributed.get_world_size()} "
                                       f"ranks, {len(sync.plan) + 1} bucketed launches per step on a side stream"
